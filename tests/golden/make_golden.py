@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in tests/golden/ by IMPORTING the reference (dev container only).
+
+    python tests/golden/make_golden.py [--full]
+
+The reference at /root/reference is imported, never copied.  Two throw-away stub modules are written to a
+temp dir so the import succeeds in this image:
+  * ``torchaudio``       -- imported by the reference but never used on this path;
+  * ``cqt_nsgt_pytorch`` -- the un-vendored CQT package; the stub exposes ``CQT_nsgt`` = our oracle
+                            NSGT-CQT (oracle/nsgt_cqt.py), so whole-network goldens = reference U-Net
+                            body + our CQT definition (CQT parity itself is unpinned, see oracle/__init__.py).
+Weights come from the seeded counter-based initialiser (audio-inpainting-diffusion_amd/init.py) with O(1)
+gates, loaded into the reference modules through ``load_state_dict``.
+
+Fixtures written (inputs + reference outputs only -- data, not code):
+  ops_small.npz      per-op: BiasFreeGroupNorm, UpDownResample up/down, RFF_MLP_Block, TimeAttentionBlock,
+                     ResnetBlock in the five structural variants the U-Net uses
+  unet_small_a.npz / unet_small_b.npz   whole network (reduced widths): input + output + state_dict key/shape list
+                     (weights are regenerated from the seeded initialiser, seed stored)
+  edm_schedule.npz   create_schedule / get_gamma for T in {35,36,70,128} with the tester parameters
+  sampler_toy.npz    full sampler trajectories (reference Sampler + EDM driving a toy denoiser)
+  unet_full_cfgA.npz (--full) full-size 22.05 kHz network output for the seeded weights/input (B=1)
+"""
+import argparse
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+def _setup_imports():
+    stub = tempfile.mkdtemp(prefix="aid_stubs_")
+    os.makedirs(os.path.join(stub, "torchaudio"))
+    open(os.path.join(stub, "torchaudio", "__init__.py"), "w").close()
+    os.makedirs(os.path.join(stub, "cqt_nsgt_pytorch"))
+    with open(os.path.join(stub, "cqt_nsgt_pytorch", "__init__.py"), "w") as f:
+        f.write("from oracle.nsgt_cqt import OracleCQT as CQT_nsgt\n")
+    for p in (stub, REF, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _np(sd):
+    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def _seed_module(mod, seed, gate_scale=10.0, affine_scale=10.0):
+    from audio_inpainting_diffusion_amd.init import seeded_init_
+    return seeded_init_(mod, seed, gate_scale, affine_scale)
+
+
+def gen_ops(out):
+    import networks.unet_cqt_oct_with_projattention_adaLN_2 as R
+    from audio_inpainting_diffusion_amd.config import Cfg
+    from audio_inpainting_diffusion_amd.init import seeded_normal
+    d = {}
+    rnd = lambda stream, *shape: torch.from_numpy(seeded_normal(1234, stream, int(np.prod(shape)))).reshape(*shape)
+    init = dict(init_mode="kaiming_uniform", init_weight=np.sqrt(1 / 3))
+    init_zero = dict(init_mode="kaiming_uniform", init_weight=1e-7)
+    attn = Cfg(num_heads=8, attn_dropout=0.0, bias_qkv=False, N=0, rel_pos_num_buckets=32,
+               rel_pos_max_distance=64, use_rel_pos=False, Nproj=8)
+    with torch.no_grad():
+        # group norm
+        gn = R.BiasFreeGroupNorm(16, 8)
+        gn.gamma.copy_(1.0 + 0.3 * rnd(1, 1, 16, 1, 1))
+        x = rnd(2, 2, 16, 5, 12) * 3.0 + 0.5
+        d["gn.x"], d["gn.gamma"], d["gn.y"] = x.numpy(), gn.gamma.numpy(), gn(x).numpy()
+        # resamplers
+        x = rnd(3, 2, 3, 4, 16)
+        d["rs.x"] = x.numpy()
+        d["rs.down"] = R.UpDownResample(down=True, mode_resample="T")(x).numpy()
+        d["rs.up"] = R.UpDownResample(up=True, mode_resample="T")(x).numpy()
+        # embedding
+        emb = _seed_module(R.RFF_MLP_Block(emb_dim=32, init=init), 5)
+        sig = torch.tensor([[-2.1], [-0.3], [0.0]])
+        for k, v in _np(emb.state_dict()).items():
+            d["emb.sd.embedding." + k] = v
+        d["emb.sigma"], d["emb.y"] = sig.numpy(), emb(sig).numpy()
+        # attention block alone
+        ta = _seed_module(R.TimeAttentionBlock(16, attn, init, init_zero, 12), 6)
+        x = rnd(4, 2, 16, 12, 8)
+        for k, v in _np(ta.state_dict()).items():
+            d["ta.sd." + k] = v
+        d["ta.x"], d["ta.y"] = x.numpy(), ta(x).numpy()
+        # resnet block variants: (tag, dim, dim_out, num_dils, kernel, proj_place, attention, F, T)
+        variants = [("rb_plain", 16, 16, 3, (5, 3), "before", False, 24, 16),
+                    ("rb_attn", 8, 16, 2, (5, 3), "before", True, 12, 8),
+                    ("rb_out", 16, 2, 1, (1, 1), "after", False, 10, 8),
+                    ("rb_init", 2, 8, 1, (1, 1), "before", False, 8, 32),
+                    ("rb_dec", 32, 16, 4, (5, 3), "before", True, 20, 4)]
+        for si, (tag, dim, dout, nd, ks, pp, at, Fd, T) in enumerate(variants):
+            rb = R.ResnetBlock(dim, dout, True, num_dils=nd, bias=False, kernel_size=ks, emb_dim=32,
+                               proj_place=pp, init=init, init_zero=init_zero,
+                               attention_dict=attn if at else None, Fdim=Fd)
+            _seed_module(rb, 10 + si)
+            x = rnd(20 + si, 2, dim, Fd, T)
+            e = torch.relu(rnd(40 + si, 2, 32)) * 0.2
+            for k, v in _np(rb.state_dict()).items():
+                d[f"{tag}.sd.{k}"] = v
+            d[f"{tag}.x"], d[f"{tag}.emb"], d[f"{tag}.y"] = x.numpy(), e.numpy(), rb(x, e).numpy()
+    np.savez_compressed(os.path.join(out, "ops_small.npz"), **d)
+    print("ops_small.npz", len(d), "arrays")
+
+
+def gen_unet_small(out):
+    import networks.unet_cqt_oct_with_projattention_adaLN_2 as R
+    from audio_inpainting_diffusion_amd.config import small_args
+    from audio_inpainting_diffusion_amd.init import seeded_normal
+    cfgs = {
+        "a": dict(num_octs=4, bins_per_oct=8, Ns=(8, 8, 16, 16), num_dils=(1, 2, 2, 3), attention=(0, 0, 1, 1, 1),
+                  audio_len=4096, fs=22050, emb_dim=32),
+        "b": dict(num_octs=7, bins_per_oct=8, Ns=(8, 8, 16, 16, 16, 32, 32), num_dils=(2, 3, 4, 5, 6, 7, 7),
+                  attention=(0, 0, 0, 0, 1, 1, 1, 1), audio_len=16384, fs=22050, emb_dim=64),
+    }
+    for tag, kw in cfgs.items():
+        args = small_args(**kw)
+        net = R.Unet_CQT_oct_with_attention(args, torch.device("cpu"))
+        _seed_module(net, 100 + ord(tag))
+        L = kw["audio_len"]
+        x = torch.from_numpy(seeded_normal(77, ord(tag), 2 * L)).reshape(2, L) * 0.5
+        cn = torch.tensor([[-0.9], [0.2]])
+        with torch.no_grad():
+            y = net(x, cn)
+        # weights are NOT stored: both sides regenerate them with seeded_init_(seed, gate_scale=10, affine_scale=10)
+        d = dict(x=x.numpy(), cnoise=cn.numpy(), y=y.numpy(), cfg=np.array(repr(kw)), seed=np.array(100 + ord(tag)),
+                 keys=np.array(list(net.state_dict().keys())),
+                 shapes=np.array([repr(tuple(v.shape)) for v in net.state_dict().values()]))
+        np.savez_compressed(os.path.join(out, f"unet_small_{tag}.npz"), **d)
+        print(f"unet_small_{tag}.npz  y rms {float(y.pow(2).mean().sqrt()):.4g}  x rms {float(x.pow(2).mean().sqrt()):.4g}")
+
+
+def gen_edm(out):
+    import diff_params.edm as E
+    from audio_inpainting_diffusion_amd.config import make_args
+    args = make_args()
+    edm = E.EDM(args)
+    tp = args.tester.diff_params
+    edm.sigma_min, edm.sigma_max, edm.ro, edm.sigma_data = tp.sigma_min, tp.sigma_max, tp.ro, tp.sigma_data
+    edm.Schurn, edm.Stmin, edm.Stmax, edm.Snoise = tp.Schurn, tp.Stmin, tp.Stmax, tp.Snoise
+    d = {}
+    for T in (35, 36, 70, 128):
+        t = edm.create_schedule(T)
+        d[f"t{T}"], d[f"gamma{T}"] = t.numpy(), edm.get_gamma(t).numpy()
+    s = torch.tensor([[1.2], [0.5], [1e-3]])
+    d["sigma"] = s.numpy()
+    for n in ("cskip", "cout", "cin", "cnoise"):
+        d[n] = getattr(edm, n)(s).numpy()
+    np.savez_compressed(os.path.join(out, "edm_schedule.npz"), **d)
+    print("edm_schedule.npz t35[:3]", d["t35"][:3], "gamma35", d["gamma35"][0], "gamma36", d["gamma36"][0])
+
+
+class _ToyNet(torch.nn.Module):
+    """Differentiable stand-in denoiser: fixed 9-tap conv times tanh(cnoise); owns an oracle CQT for apply_hpf_DC."""
+
+    def __init__(self, L):
+        super().__init__()
+        from oracle.nsgt_cqt import OracleCQT
+        self.CQTransform = OracleCQT(3, 8, "oct", ("kaiser", 1), 22050, L)
+        k = torch.tensor([0.02, -0.05, 0.1, 0.25, 0.4, 0.25, 0.1, -0.05, 0.02])
+        self.register_buffer("k", k.view(1, 1, 9))
+
+    def forward(self, x, cnoise):
+        y = torch.nn.functional.conv1d(x.unsqueeze(1), self.k, padding=4).squeeze(1)
+        return y * torch.tanh(cnoise) + 0.1 * torch.sin(3.0 * x)
+
+
+def gen_sampler(out):
+    import diff_params.edm as E
+    import testing.edm_sampler_inpainting as S
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.init import seeded_normal
+    L, T = 2048, 6
+    d = {"L": np.array(L), "T": np.array(T)}
+    net = _ToyNet(L)
+    cases = [("g_s0", 0.25, 1, True, 0), ("g_s1", 0.25, 1, True, 1), ("g_s2_nosmooth", 0.25, 1, False, 2),
+             ("r_s0", 0.0, 1, True, 0), ("r_b2_s1", 0.0, 2, True, 1), ("r_b2_nosmooth", 0.0, 2, False, 2)]
+    for tag, xi, B, smooth, seed in cases:
+        args = make_args(audio_len=L, T=T, xi=xi)
+        args.tester.data_consistency.smooth = smooth
+        args.tester.data_consistency.hann_size = 20
+        edm = E.EDM(args)
+        smp = S.Sampler(model=net, diff_params=edm, args=args, rid=False)
+        y = torch.from_numpy(seeded_normal(5, seed, B * L)).reshape(B, L) * 0.063
+        mask = torch.ones(1, L)
+        mask[:, 900:1150] = 0
+        torch.manual_seed(seed)
+        x = smp.predict_inpainting(y * mask, mask)
+        d[f"{tag}.y"], d[f"{tag}.mask"], d[f"{tag}.out"] = (y * mask).numpy(), mask.numpy(), x.numpy()
+        d[f"{tag}.meta"] = np.array([xi, B, int(smooth), seed], dtype=np.float64)
+        print("sampler", tag, "out rms", float(x.pow(2).mean().sqrt()))
+    np.savez_compressed(os.path.join(out, "sampler_toy.npz"), **d)
+
+
+def gen_full(out):
+    import networks.unet_cqt_oct_with_projattention_adaLN_2 as R
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.init import seeded_normal
+    args = make_args("maestro22k")
+    t0 = time.time()
+    net = R.Unet_CQT_oct_with_attention(args, torch.device("cpu"))
+    _seed_module(net, 0)
+    L = args.exp.audio_len
+    x = torch.from_numpy(seeded_normal(2024, 0, L)).reshape(1, L) * 0.5
+    cn = torch.tensor([[-0.35]])
+    with torch.no_grad():
+        y = net(x, cn)
+    print("full cfgA forward done in %.1fs, y rms %.4g" % (time.time() - t0, float(y.pow(2).mean().sqrt())))
+    np.savez_compressed(os.path.join(out, "unet_full_cfgA.npz"), y=y.numpy().astype(np.float32), cnoise=cn.numpy(),
+                        recipe=np.array("weights: seeded_init_(seed=0, gate_scale=10, affine_scale=10); "
+                                        "x = 0.5*seeded_normal(2024, 0, L)"))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    _setup_imports()
+    torch.set_grad_enabled(True)
+    todo = a.only.split(",") if a.only else ["ops", "unet", "edm", "sampler"] + (["full"] if a.full else [])
+    if "ops" in todo: gen_ops(HERE)
+    if "unet" in todo: gen_unet_small(HERE)
+    if "edm" in todo: gen_edm(HERE)
+    if "sampler" in todo: gen_sampler(HERE)
+    if "full" in todo: gen_full(HERE)

@@ -1,0 +1,232 @@
+"""ctypes binding of libaid_hip.so (the C ABI in include/aid_kernels.h).
+
+There is deliberately NO fallback: if the shared library is missing or a launcher returns an error code,
+``AidError`` is raised.  Tensors are passed as raw device pointers + element strides; the stream is torch's
+current HIP stream, so kernels order naturally with torch allocations/copies and can be graph-captured.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaid_hip.so")
+AID_CQT_MAX_OCT = 12
+AID_STATS_SPLIT = 32
+
+
+class AidError(RuntimeError):
+    pass
+
+
+class View(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("sB", C.c_int64), ("sC", C.c_int64), ("sF", C.c_int64)]
+
+
+class GroupStatsParams(C.Structure):
+    _fields_ = [("x", View), ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("groups", C.c_int),
+                ("gamma", C.c_void_p), ("mod", C.c_void_p), ("mod_ld", C.c_int64), ("eps", C.c_float),
+                ("scale", C.c_void_p), ("stats", C.c_void_p), ("ws", C.c_void_p)]
+
+
+class Conv2dParams(C.Structure):
+    _fields_ = [("x", View), ("y", View), ("res", View), ("aux", View),
+                ("wp", C.c_void_p),
+                ("in_scale", C.c_void_p), ("in_scale_ld", C.c_int64),
+                ("out_scale", C.c_void_p), ("out_scale_ld", C.c_int64),
+                ("aux_scale", C.c_void_p), ("aux_scale_ld", C.c_int64),
+                ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("F", C.c_int), ("T", C.c_int),
+                ("Cin_pad", C.c_int), ("Cout_pad", C.c_int),
+                ("KH", C.c_int), ("KW", C.c_int), ("dilF", C.c_int),
+                ("act", C.c_int), ("epi", C.c_int),
+                ("alpha", C.c_float), ("res_scale", C.c_float)]
+
+
+class ResampleParams(C.Structure):
+    _fields_ = [("x", View), ("y", View), ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int),
+                ("up", C.c_int), ("adjoint", C.c_int)]
+
+
+class AttentionParams(C.Structure):
+    _fields_ = [("qk", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p), ("probs", C.c_void_p),
+                ("B", C.c_int), ("H", C.c_int), ("F", C.c_int), ("T", C.c_int), ("scale", C.c_float)]
+
+
+class EmbedParams(C.Structure):
+    _fields_ = [("sigma", C.c_void_p), ("rff_freq", C.c_void_p), ("w0", C.c_void_p), ("b0", C.c_void_p),
+                ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("emb", C.c_void_p),
+                ("B", C.c_int), ("rff", C.c_int), ("h0", C.c_int), ("h1", C.c_int), ("E", C.c_int)]
+
+
+class ModulationParams(C.Structure):
+    _fields_ = [("emb", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("mod", C.c_void_p),
+                ("B", C.c_int), ("E", C.c_int), ("N", C.c_int)]
+
+
+class CqtTables(C.Structure):
+    _fields_ = [("n_oct", C.c_int), ("bins", C.c_int), ("rc", C.c_void_p), ("Lg", C.c_void_p), ("goff", C.c_void_p),
+                ("g", C.c_void_p), ("T_oct", C.c_void_p), ("twiddle", C.c_void_p), ("Tmax", C.c_int)]
+
+
+class CqtParams(C.Structure):
+    _fields_ = [("tab", CqtTables), ("T_host", C.c_int * AID_CQT_MAX_OCT), ("oct", View * AID_CQT_MAX_OCT),
+                ("spec", C.c_void_p), ("band_ws", C.c_void_p), ("in_scale", C.c_void_p), ("B", C.c_int), ("Lh", C.c_int)]
+
+
+class CqtGatherParams(C.Structure):
+    _fields_ = [("band_ws", C.c_void_p), ("kfirst", C.c_void_p), ("kcount", C.c_void_p),
+                ("rc", C.c_void_p), ("Lg", C.c_void_p), ("goff", C.c_void_p), ("woff", C.c_void_p), ("Tk", C.c_void_p),
+                ("gdM", C.c_void_p), ("X", C.c_void_p), ("cskip", C.c_void_p), ("cout", C.c_void_p), ("hpf", C.c_void_p),
+                ("Y", C.c_void_p), ("B", C.c_int), ("Lh", C.c_int), ("ws_per_b", C.c_int64)]
+
+
+class AxpbyParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("out", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p),
+                ("B", C.c_int), ("L", C.c_int64)]
+
+
+class ScoreStepParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("xhat", C.c_void_p), ("yobs", C.c_void_p), ("smask", C.c_void_p),
+                ("smask_sB", C.c_int64), ("x0", C.c_void_p), ("d0", C.c_void_p), ("t", C.c_void_p), ("h", C.c_void_p),
+                ("xnext", C.c_void_p), ("dout", C.c_void_p), ("xh_out", C.c_void_p),
+                ("B", C.c_int), ("L", C.c_int64), ("mode", C.c_int)]
+
+
+class Add2Params(C.Structure):
+    _fields_ = [("u", View), ("v", View), ("y", View), ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int),
+                ("a", C.c_float), ("b", C.c_float)]
+
+
+EXPORTS = ["aid_abi_version", "aid_last_error", "aid_group_stats", "aid_conv2d", "aid_conv2d_pack_dims", "aid_resample",
+           "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
+           "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2"]
+
+_lib = None
+
+
+def lib():
+    """Load libaid_hip.so (built by ``__graft_entry__.build()`` / ``build.py``).  Raises if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AidError(f"{LIB_PATH} not found: build the HIP extension first (python __graft_entry__.py). "
+                           "There is no CPU / eager fallback on the product path.")
+        L = C.CDLL(LIB_PATH)
+        L.aid_last_error.restype = C.c_char_p
+        L.aid_abi_version.restype = C.c_int
+        for name in EXPORTS:
+            if not hasattr(L, name):
+                raise AidError(f"libaid_hip.so does not export {name}")
+        L.aid_conv2d_pack_dims.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.aid_conv2d_pack_dims.restype = None
+        for name in EXPORTS[2:]:
+            if name != "aid_conv2d_pack_dims":
+                getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
+                getattr(L, name).restype = C.c_int
+        if L.aid_abi_version() != 1:
+            raise AidError("ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, params) -> None:
+    rc = getattr(lib(), name)(C.addressof(params), _stream())
+    if rc != 0:
+        raise AidError(f"{name} failed rc={rc}: {lib().aid_last_error().decode()}")
+
+
+def call_on(fn, params_addr: int, stream: int, name: str = "") -> None:
+    rc = fn(params_addr, stream)
+    if rc != 0:
+        raise AidError(f"{name} failed rc={rc}: {lib().aid_last_error().decode()}")
+
+
+def _req(t: torch.Tensor):
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise AidError("HIP kernels need float32 tensors on the GPU (no CPU fallback)")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def view4(t: Optional[torch.Tensor]) -> View:
+    """[B,C,F,T] tensor (any strides with T contiguous) -> aid_view."""
+    if t is None:
+        return View(None, 0, 0, 0)
+    _req(t)
+    assert t.dim() == 4 and (t.stride(3) == 1 or t.shape[3] == 1), "T must be contiguous"
+    return View(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+
+
+def pack_dims(cin: int, cout: int):
+    a, b = C.c_int(0), C.c_int(0)
+    lib().aid_conv2d_pack_dims(cin, cout, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def pack_conv_weight(w: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+    """[Cout,Cin,KH,KW] (or [Cout,Cin,1] / [Cout,Cin]) -> packed [KH*KW, Cin_pad, Cout_pad] (cout contiguous).
+
+    transpose=True packs the input-gradient operator instead: taps flipped, roles of Cin/Cout swapped."""
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    elif w.dim() == 3:
+        w = w[:, :, None, :]  # Conv1d [O,I,k] -> [O,I,1,k]
+    w = w.detach().float()
+    if transpose:
+        w = w.flip(2, 3).permute(1, 0, 2, 3)
+    co, ci, kh, kw = w.shape
+    cip, cop = pack_dims(ci, co)
+    out = torch.zeros(kh * kw, cip, cop, device=w.device, dtype=torch.float32)
+    out[:, :ci, :co] = w.permute(2, 3, 1, 0).reshape(kh * kw, ci, co)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CQT launch helpers (used by cqt.CQTransform)
+# ---------------------------------------------------------------------------------------------------------
+def _cqt_params(tr, tab, octs: Sequence[torch.Tensor]) -> CqtParams:
+    P = tr.plan
+    p = CqtParams()
+    p.tab = CqtTables(P.numocts, P.binsoct, ptr(tab["rc"]), ptr(tab["Lg"]), ptr(tab["goff"]), ptr(tab["g"]),
+                      ptr(tab["T_oct"]), ptr(tab["twiddle"]), P.Tmax)
+    for o in range(P.numocts):
+        p.T_host[o] = int(P.T_oct[o])
+        t = octs[o]
+        _req(t)
+        assert t.shape[1] == 2 and t.shape[2] == P.binsoct and t.shape[3] == P.T_oct[o] and t.stride(3) == 1
+        p.oct[o] = View(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+    p.B = octs[0].shape[0]
+    p.Lh = P.Lh
+    return p
+
+
+def cqt_analysis(tr, tab, spec_ri: torch.Tensor, octs, in_scale=None):
+    _req(spec_ri)
+    assert spec_ri.is_contiguous()
+    p = _cqt_params(tr, tab, octs)
+    p.spec = spec_ri.data_ptr()
+    p.in_scale = ptr(in_scale)
+    call("aid_cqt_analysis", p)
+
+
+def cqt_synthesis(tr, tab, octs, ws: torch.Tensor):
+    p = _cqt_params(tr, tab, octs)
+    p.band_ws = ws.data_ptr()
+    call("aid_cqt_synthesis", p)
+
+
+def cqt_gather(tr, tab, ws, Y, X=None, cskip=None, cout=None, hpf=None):
+    P = tr.plan
+    p = CqtGatherParams(ptr(ws), ptr(tab["kfirst"]), ptr(tab["kcount"]), ptr(tab["rc"]), ptr(tab["Lg"]),
+                        ptr(tab["goff"]), ptr(tab["woff"]), ptr(tab["Tk"]), ptr(tab["gdM"]), ptr(X), ptr(cskip),
+                        ptr(cout), ptr(hpf), Y.data_ptr(), Y.shape[0], P.Lh, P.ws_per_b)
+    call("aid_cqt_gather", p)

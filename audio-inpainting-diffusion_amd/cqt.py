@@ -1,0 +1,174 @@
+"""Octave-mode NSGT constant-Q transform for MI355X: host-side plan + device transform object.
+
+Replaces the external ``cqt_nsgt_pytorch.CQT_nsgt`` the reference instantiates at
+networks/unet_cqt_oct_with_projattention_adaLN_2.py:620 (mode="oct", Kaiser window) and calls at :743 (fwd),
+:841 (bwd) and testing/edm_sampler_inpainting.py:63,123 (apply_hpf_DC).  The transform definition is ours
+(the package's source is not available -- see DESIGN.md "CQT: parity unpinned"); the frame design is stated in
+``CQTPlan`` and restated independently, band by band, in oracle/nsgt_cqt.py.
+
+``CQTPlan``      pure numpy (float64) design: window lengths, centres, Kaiser windows, octave lengths, dual
+                 frame, DC/Nyquist projector, gather tables.  No GPU needed (unit-tested on CPU).
+``CQTransform``  device object with the reference call surface (``fwd``, ``bwd``, ``apply_hpf_DC``) running
+                 the HIP kernels ``aid_cqt_analysis / aid_cqt_synthesis / aid_cqt_gather``; coefficients live
+                 in planar ``[B, 2, bins, T_o]`` tensors (what the U-Net kernels consume) and are converted to
+                 the reference's complex list only at the public boundary.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+def _next_pow2(n: int) -> int:
+    return 1 << (int(n) - 1).bit_length()
+
+
+class CQTPlan:
+    def __init__(self, numocts: int, binsoct: int, fs: float, audio_len: int, window=("kaiser", 1.0)):
+        L = int(audio_len)
+        if L % 2:
+            raise ValueError("audio_len must be even")
+        self.numocts, self.binsoct, self.fs, self.L = int(numocts), int(binsoct), float(fs), L
+        self.Lh = L // 2 + 1
+        K = self.K = self.numocts * self.binsoct
+        k = np.arange(K, dtype=np.float64)
+        b = (self.fs / 2.0) / 2.0 ** self.numocts * 2.0 ** (k / self.binsoct) * L / self.fs
+        centre = np.concatenate(([0.0], b, [L / 2.0]))
+        ratio = 2.0 ** (1.0 / self.binsoct) - 2.0 ** (-1.0 / self.binsoct)
+        Lg = np.empty(K + 2, dtype=np.int64)
+        Lg[0] = np.round(2.0 * b[0])
+        Lg[1] = np.round(b[0] * ratio)
+        Lg[2:K + 1] = np.round(centre[3:K + 2] - centre[1:K])
+        Lg[K + 1] = np.round(2.0 * (L / 2.0 - b[K - 1]))
+        Lg = np.maximum(Lg, 4)
+        rc = np.round(centre).astype(np.int64)
+        self.Lg_all, self.rc_all = Lg, rc
+
+        if isinstance(window, (tuple, list)) and window[0] == "kaiser":
+            beta = float(window[1])
+        elif window == "hann":
+            beta = None
+        else:
+            raise NotImplementedError(f"window {window!r}")
+
+        # one concatenated offset axis j for all bands
+        off = np.concatenate([np.arange(-(m // 2), m - m // 2) for m in Lg])
+        band = np.repeat(np.arange(K + 2), Lg)
+        r = 2.0 * off / Lg[band]
+        if beta is not None:
+            g = np.i0(beta * np.sqrt(np.clip(1.0 - r * r, 0.0, None))) / np.i0(beta)
+        else:
+            g = 0.5 + 0.5 * np.cos(np.pi * r)
+        T_oct = [_next_pow2(int(Lg[1 + o * self.binsoct: 1 + (o + 1) * self.binsoct].max())) for o in range(self.numocts)]
+        M = Lg.astype(np.float64).copy()
+        M[1:K + 1] = np.repeat(np.array(T_oct, dtype=np.float64), self.binsoct)
+        self.T_oct = T_oct
+
+        # frame-operator diagonal over the whole DFT circle (positive bands, DC, Nyquist, mirrored bands)
+        S = np.zeros(L, dtype=np.float64)
+        w = M[band] * g * g
+        np.add.at(S, (rc[band] + off) % L, w)
+        inner = (band >= 1) & (band <= K)
+        np.add.at(S, (-rc[band[inner]] - off[inner]) % L, w[inner])
+        gd = g / S[(rc[band] + off) % L]
+        Hl = np.zeros(L, dtype=np.float64)
+        edge = ~inner
+        np.add.at(Hl, (rc[band[edge]] + off[edge]) % L, M[band[edge]] * g[edge] * gd[edge])
+        self.hpf = (1.0 - Hl[: self.Lh]).astype(np.float32)
+        self.S = S
+
+        # ---- device tables for the K emitted bands ----------------------------------------------------
+        sel = inner
+        self.Lg = Lg[1:K + 1].astype(np.int32)
+        self.rc = rc[1:K + 1].astype(np.int32)
+        self.goff = (np.concatenate(([0], np.cumsum(Lg[1:K + 1])))[:-1]).astype(np.int32)
+        self.g = g[sel].astype(np.float32)
+        self.gdM = (gd[sel] * M[band[sel]]).astype(np.float32)
+        self.Tk = np.repeat(np.array(T_oct, dtype=np.int32), self.binsoct)
+        self.woff = (np.concatenate(([0], np.cumsum(self.Tk.astype(np.int64))))[:-1]).astype(np.int32)
+        self.ws_per_b = int(self.Tk.astype(np.int64).sum())
+        lo = self.rc.astype(np.int64) - self.Lg // 2
+        hi = lo + self.Lg - 1
+        assert np.all(np.diff(lo) >= 0) and np.all(np.diff(hi) >= 0), "band edges must be monotone"
+        assert lo[0] > 0 and hi[-1] < L // 2, "emitted bands must stay inside (0, L/2)"
+        assert np.all(self.Lg <= self.Tk), "painless condition violated"
+        v = np.arange(self.Lh)
+        kfirst = np.searchsorted(hi, v, side="left")
+        kend = np.searchsorted(lo, v, side="right")
+        self.kfirst = kfirst.astype(np.int32)
+        self.kcount = np.maximum(kend - kfirst, 0).astype(np.int32)
+        self.Tmax = int(max(T_oct))
+        m = np.arange(self.Tmax // 2, dtype=np.float64)
+        tw = np.exp(-2j * np.pi * m / self.Tmax)
+        self.twiddle = np.stack([tw.real, tw.imag], axis=-1).astype(np.float32).reshape(-1)
+
+
+class CQTransform:
+    """Device transform with the call surface of the reference's ``CQT_nsgt`` (mode="oct")."""
+
+    def __init__(self, numocts, binsoct, mode="oct", window=("kaiser", 1.0), fs=44100, audio_len=44100,
+                 dtype=torch.float32, device="cuda"):
+        assert mode == "oct" and dtype == torch.float32
+        self.plan = CQTPlan(numocts, binsoct, fs, audio_len, window)
+        self.device = torch.device(device)
+        self.numocts, self.binsoct, self.Ls = int(numocts), int(binsoct), int(audio_len)
+        self.size_per_oct = list(self.plan.T_oct)
+        self._dev = None
+
+    # device tables are created lazily so that the plan can be built (and unit-tested) without a GPU
+    def _tables(self, device):
+        if self._dev is None or self._dev["device"] != device:
+            P = self.plan
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+            self._dev = dict(device=device, rc=t(P.rc), Lg=t(P.Lg), goff=t(P.goff), g=t(P.g), gdM=t(P.gdM), Tk=t(P.Tk),
+                             woff=t(P.woff), kfirst=t(P.kfirst), kcount=t(P.kcount), twiddle=t(P.twiddle), hpf=t(P.hpf),
+                             T_oct=t(np.array(P.T_oct, dtype=np.int32)))
+        return self._dev
+
+    # ---- planar API used by the network ----------------------------------------------------------------
+    def alloc_octaves(self, B, device) -> List[torch.Tensor]:
+        return [torch.empty(B, 2, self.binsoct, T, device=device, dtype=torch.float32) for T in self.plan.T_oct]
+
+    def analysis(self, x: torch.Tensor, outs: Sequence[torch.Tensor], in_scale: Optional[torch.Tensor] = None,
+                 spec_out: Optional[list] = None):
+        """x[B,L] -> fills the planar octave views ``outs`` (low octave first); returns rfft(x) [B,Lh] complex."""
+        from . import _lib
+        assert x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == self.Ls
+        tab = self._tables(x.device)
+        spec = torch.fft.rfft(x, dim=-1)
+        _lib.cqt_analysis(self, tab, torch.view_as_real(spec), outs, in_scale)
+        return spec
+
+    def synthesis_spectrum(self, octs: Sequence[torch.Tensor], X=None, cskip=None, cout=None, hpf=False):
+        """planar octave views -> Y[B,Lh] complex = hpf * (cskip*X + cout * overlap-add of the dual-windowed bands)."""
+        from . import _lib
+        B = octs[0].shape[0]
+        dev = octs[0].device
+        tab = self._tables(dev)
+        ws = torch.empty(B, self.plan.ws_per_b, 2, device=dev, dtype=torch.float32)
+        _lib.cqt_synthesis(self, tab, octs, ws)
+        Y = torch.empty(B, self.plan.Lh, 2, device=dev, dtype=torch.float32)
+        _lib.cqt_gather(self, tab, ws, Y, None if X is None else torch.view_as_real(X), cskip, cout, tab["hpf"] if hpf else None)
+        return torch.view_as_complex(Y)
+
+    # ---- reference call surface --------------------------------------------------------------------------
+    def fwd(self, x: torch.Tensor) -> List[torch.Tensor]:
+        """x[B,1,L] -> list (lowest octave first) of complex64 [B,1,bins,T_o]   (unet...py:743)"""
+        B = x.shape[0]
+        outs = self.alloc_octaves(B, x.device)
+        self.analysis(x.reshape(B, self.Ls).contiguous().float(), outs)
+        return [torch.complex(o[:, 0], o[:, 1]).unsqueeze(1) for o in outs]
+
+    def bwd(self, c: Sequence[torch.Tensor]) -> torch.Tensor:
+        """list of complex [B,1,bins,T_o] -> [B,1,L]   (unet...py:841)"""
+        octs = [torch.stack((ci.squeeze(1).real, ci.squeeze(1).imag), dim=1).contiguous().float() for ci in c]
+        Y = self.synthesis_spectrum(octs)
+        return torch.fft.irfft(Y, n=self.Ls, dim=-1).unsqueeze(1)
+
+    def apply_hpf_DC(self, x: torch.Tensor) -> torch.Tensor:
+        """x[B,L] minus its DC- and Nyquist-band frame components (edm_sampler_inpainting.py:63,123)."""
+        tab = self._tables(x.device)
+        return torch.fft.irfft(torch.fft.rfft(x, dim=-1) * tab["hpf"], n=self.Ls, dim=-1)

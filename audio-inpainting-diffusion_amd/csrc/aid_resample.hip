@@ -1,0 +1,130 @@
+// aid_resample: 2:1 cubic FIR resampling along T (reflect padding) and the exact adjoints of both maps.
+// HBM-bound; each thread produces 4 consecutive outputs (one float4 store), inputs come through L1/L2.
+#include "aid_common.h"
+
+__constant__ float c_h[8] = {-0.01171875f, -0.03515625f, 0.11328125f, 0.43359375f,
+                             0.43359375f, 0.11328125f, -0.03515625f, -0.01171875f};
+
+struct ResDev {
+    aid_resample_params p;
+    int Tout, lpr_log2, nrows, tiles;   // tiles = thread-tiles per row
+};
+
+__device__ __forceinline__ int refl(int i, int T) {
+    if (i < 0) i = -i;
+    if (i >= T) i = 2 * (T - 1) - i;
+    return i;
+}
+
+// ---- forward maps ------------------------------------------------------------------------------------
+__device__ __forceinline__ float down_at(const float* x, int T, int j) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += c_h[k] * x[refl(2 * j + k - 3, T)];
+    return s;
+}
+__device__ __forceinline__ float up_at(const float* x, int T, int n) {
+    const int m = n >> 1;
+    if ((n & 1) == 0)
+        return c_h[7] * x[refl(m - 2, T)] + c_h[5] * x[refl(m - 1, T)] + c_h[3] * x[refl(m, T)] + c_h[1] * x[refl(m + 1, T)];
+    return c_h[6] * x[refl(m - 1, T)] + c_h[4] * x[refl(m, T)] + c_h[2] * x[refl(m + 1, T)] + c_h[0] * x[refl(m + 2, T)];
+}
+// ---- adjoints: gather over the (up to 3) padded-domain pre-images of input index i --------------------
+// down: y[j] = sum_k h[k] xp[2j+k-3]           T = length of x (the down input), g has T/2 entries
+__device__ __forceinline__ float down_adj_virtual(const float* g, int T, int ip) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int num = ip + 3 - k;
+        if ((num & 1) == 0) {
+            const int j = num >> 1;   // arithmetic shift: negative stays negative
+            if (j >= 0 && j < (T >> 1)) s += c_h[k] * g[j];
+        }
+    }
+    return s;
+}
+__device__ __forceinline__ float down_adj_at(const float* g, int T, int i) {
+    float s = down_adj_virtual(g, T, i);
+    if (i >= 1 && i <= 3) s += down_adj_virtual(g, T, -i);
+    if (i >= T - 4 && i <= T - 2) s += down_adj_virtual(g, T, 2 * (T - 1) - i);
+    return s;
+}
+// up: y[2m] = sum_q h[7-2q] xp[m-2+q], y[2m+1] = sum_q h[6-2q] xp[m-1+q]     T = length of x, g has 2T entries
+__device__ __forceinline__ float up_adj_virtual(const float* g, int T, int ip) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int m = ip + 2 - q;
+        if (m >= 0 && m < T) s += c_h[7 - 2 * q] * g[2 * m];
+        m = ip + 1 - q;
+        if (m >= 0 && m < T) s += c_h[6 - 2 * q] * g[2 * m + 1];
+    }
+    return s;
+}
+__device__ __forceinline__ float up_adj_at(const float* g, int T, int i) {
+    float s = up_adj_virtual(g, T, i);
+    if (i >= 1 && i <= 2) s += up_adj_virtual(g, T, -i);
+    if (i >= T - 3 && i <= T - 2) s += up_adj_virtual(g, T, 2 * (T - 1) - i);
+    return s;
+}
+
+// MODE: 0 down, 1 up, 2 down-adjoint (in T/2 -> out T), 3 up-adjoint (in 2T -> out T)
+template <int MODE>
+__global__ __launch_bounds__(256) void resample_kernel(const ResDev a) {
+    const aid_resample_params& p = a.p;
+    const int tid = threadIdx.x;
+    const int lpr = 1 << a.lpr_log2;
+    const int sub = tid >> a.lpr_log2, lq = tid & (lpr - 1);
+    const int rpb = 256 >> a.lpr_log2;
+    const int tile = blockIdx.x % a.tiles;
+    const int row = (blockIdx.x / a.tiles) * rpb + sub;
+    if (row >= a.nrows) return;
+    const int o4 = (tile * lpr + lq) * 4;
+    if (o4 >= a.Tout) return;
+    const int f = row % p.F;
+    const int bc = row / p.F;
+    const int c = bc % p.C;
+    const int b = bc / p.C;
+    const float* x = p.x.p + (int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)f * p.x.sF;
+    float* y = p.y.p + (int64_t)b * p.y.sB + (int64_t)c * p.y.sC + (int64_t)f * p.y.sF;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int o = o4 + e;
+        if (MODE == 0) v[e] = down_at(x, p.T, o);
+        else if (MODE == 1) v[e] = up_at(x, p.T, o);
+        else if (MODE == 2) v[e] = down_adj_at(x, a.Tout, o);   // x holds g (T/2 entries), Tout = T of the down input
+        else v[e] = up_adj_at(x, a.Tout, o);                     // x holds g (2T entries), Tout = T of the up input
+    }
+    *reinterpret_cast<float4*>(y + o4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+extern "C" int aid_resample(const aid_resample_params* p, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    AID_REQUIRE(p && p->x.p && p->y.p, "aid_resample: null pointer");
+    ResDev a;
+    a.p = *p;
+    int mode;
+    if (!p->adjoint) { mode = p->up ? 1 : 0; a.Tout = p->up ? 2 * p->T : p->T / 2; }
+    else             { mode = p->up ? 3 : 2; a.Tout = p->up ? p->T / 2 : 2 * p->T; }   // T = length of the incoming gradient
+    AID_REQUIRE(a.Tout >= 4 && (a.Tout % 4) == 0, "aid_resample: output length must be a multiple of 4");
+    AID_REQUIRE((p->y.sB % 4) == 0 && (p->y.sC % 4) == 0 && (p->y.sF % 4) == 0 && (((uintptr_t)p->y.p) & 15) == 0,
+                "aid_resample: output view must be float4-addressable");
+    const int min_in = (mode == 0) ? 4 : (mode == 1 ? 3 : 0);
+    AID_REQUIRE(p->T >= min_in, "aid_resample: input too short for reflect padding");
+    int lpr = aid_pow2ceil(a.Tout / 4);
+    if (lpr > 256) lpr = 256;
+    a.lpr_log2 = aid_ilog2(lpr);
+    a.nrows = p->B * p->C * p->F;
+    a.tiles = aid_cdiv(a.Tout / 4, lpr);
+    const int rpb = 256 / lpr;
+    dim3 grid((unsigned)(aid_cdiv(a.nrows, rpb) * a.tiles));
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(resample_kernel<0>, grid, dim3(256), 0, st, a); break;
+        case 1: hipLaunchKernelGGL(resample_kernel<1>, grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(resample_kernel<2>, grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL(resample_kernel<3>, grid, dim3(256), 0, st, a); break;
+    }
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}

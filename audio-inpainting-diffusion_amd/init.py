@@ -4,7 +4,7 @@ The reference draws its random-init weights from torch's global RNG at construct
 (networks/unet_cqt_oct_with_projattention_adaLN_2.py:20-34,599-600); those bits depend on the torch build.
 Benchmarks and parity fixtures need identical weights in the dev container, on the GPU box and inside the
 imported reference, so weights are produced by a counter-based generator (splitmix64 on
-``(seed, tensor index, element index)``) with the reference's distribution family:
+``(seed, crc32(state_dict key), element index)``) with the reference's distribution family:
 
   * conv / linear ``weight``  : U(-1,1) * sqrt(3/fan_in) * sqrt(1/3)        (kaiming_uniform, init_weight sqrt(1/3), :599)
   * ``gate*.weight``          : U(-1,1) * sqrt(3/fan_in) * gate_scale        (reference gate_scale = 1e-7, :600)
@@ -18,6 +18,7 @@ O(1) to the output (with the reference's 1e-7 gates a broken kernel would be inv
 from __future__ import annotations
 
 import math
+import zlib
 from typing import Dict, Iterable, Tuple
 
 import numpy as np
@@ -87,13 +88,14 @@ def seeded_tensor(name: str, shape: Tuple[int, ...], index: int, seed: int, gate
 
 def seeded_state_dict(shapes: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 0, gate_scale: float = 1e-7,
                       affine_scale: float = 1.0) -> Dict[str, torch.Tensor]:
-    """shapes: (key, shape) pairs in state_dict order -> {key: tensor}."""
-    return {k: seeded_tensor(k, tuple(s), i, seed, gate_scale, affine_scale) for i, (k, s) in enumerate(shapes)}
+    """shapes: (key, shape) pairs -> {key: tensor}.  The per-tensor stream is crc32(key), so the result does not
+    depend on the order in which a module happens to register its parameters."""
+    return {k: seeded_tensor(k, tuple(s), zlib.crc32(k.encode()), seed, gate_scale, affine_scale) for k, s in shapes}
 
 
 @torch.no_grad()
 def seeded_init_(module: torch.nn.Module, seed: int = 0, gate_scale: float = 1e-7, affine_scale: float = 1.0):
-    """Fill ``module`` in place (state_dict order defines the per-tensor stream index)."""
+    """Fill ``module`` in place (each tensor's stream is derived from its state_dict key)."""
     sd = module.state_dict()
     new = seeded_state_dict([(k, tuple(v.shape)) for k, v in sd.items()], seed, gate_scale, affine_scale)
     module.load_state_dict(new, strict=True)

@@ -1,0 +1,202 @@
+"""EDM inpainting sampler on MI355X -- drop-in for ``testing.edm_sampler_inpainting.Sampler``.
+
+Call surface kept from the reference (testing/edm_sampler_inpainting.py): ``Sampler(model, diff_params, args,
+rid=False)`` (:10), public attributes ``xi / nb_steps / order`` (:19-32), ``predict_inpainting(y_masked, mask)``
+(:327), ``predict_unconditional(shape, device)`` (:155), ``update_diff_params`` (:43).  The loop (:178-262) stays
+in Python but is sync-free: the schedule, gamma and every per-step scalar live on the host (float32 torch
+arithmetic identical to the reference), noise is drawn from the CPU generator in the reference's order and
+copied asynchronously, and each step costs two fused element-wise launches besides the denoiser evaluations.
+
+Batch semantics (new; the reference only ever runs B=1 and its guided branch raises for B>1, :75-:78): every
+reduction the reference takes over the whole batch -- the guidance norm (:75), ``normguide`` (:83) and the mask
+row used for smoothing (:307) -- is taken PER ITEM, so item b of a batch reproduces the reference's B=1 run.
+``seeds=[...]`` gives every item its own CPU generator (prior draw, then one draw per churned step), making
+results independent of batch composition and of how segments are sharded over GPUs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def prepare_smooth_mask(mask: torch.Tensor, size: int) -> torch.Tensor:
+    """Hann cross-fade of the mask edges, row by row (vectorised form of :302-325; the reference walks all L
+    samples of row 0 in a Python loop and re-uses the result for every item)."""
+    hann = torch.hann_window(size * 2)
+    left, right = hann[0:size], hann[size:]
+    m = mask.detach().to("cpu", torch.float32)
+    out = m.clone()
+    for r in range(m.shape[0]):
+        row = m[r].numpy()
+        prev = np.concatenate(([1.0], row[:-1]))
+        for i in np.nonzero(row != prev)[0]:
+            if row[i] == 0:
+                out[r, i - size:i] = right
+            if row[i] == 1:
+                out[r, i:i + size] = left
+    return out
+
+
+class Sampler:
+    def __init__(self, model, diff_params, args, rid=False):
+        self.model = model
+        self.diff_params = diff_params
+        self.args = args
+        if not self.args.tester.diff_params.same_as_training:
+            self.update_diff_params()
+        self.order = self.args.tester.order
+        self.xi = self.args.tester.posterior_sampling.xi
+        dc = self.args.tester.data_consistency
+        self.data_consistency = dc.use and dc.type == "always"
+        self.data_consistency_end = dc.use and dc.type == "end"
+        if self.data_consistency or self.data_consistency_end:
+            self.smooth = bool(dc.smooth)
+        self.nb_steps = self.args.tester.T
+        self.rid = rid
+        if rid:
+            raise NotImplementedError("rid=True debug buffers are not built (SURVEY.md section 2, row 4)")
+        self.seeds: Optional[List[int]] = None      # per-item RNG seeds; None -> global torch CPU generator
+        self.trace = None                           # set to [] to record every projected x_hat (tests)
+        self.n_evals = 0
+
+    def update_diff_params(self):
+        dp, tp = self.diff_params, self.args.tester.diff_params
+        dp.sigma_min, dp.sigma_max, dp.ro, dp.sigma_data = tp.sigma_min, tp.sigma_max, tp.ro, tp.sigma_data
+        dp.Schurn, dp.Stmin, dp.Stmax, dp.Snoise = tp.Schurn, tp.Stmin, tp.Stmax, tp.Snoise
+
+    # ---------------------------------------------------------------------------------------------------
+    def _fast(self) -> bool:
+        return hasattr(self.model, "denoise")
+
+    def _randn(self, shape):
+        if self.seeds is None:
+            n = torch.randn(shape)
+        else:
+            n = torch.cat([torch.randn([1, shape[1]], generator=g) for g in self._gens], dim=0)
+        return n
+
+    def _to_dev(self, cpu_tensor, device):
+        return cpu_tensor.pin_memory().to(device, non_blocking=True) if device.type == "cuda" else cpu_tensor.to(device)
+
+    def _vec(self, value, B, device):
+        """host scalar (0-d float32 tensor or float) -> device [B]"""
+        return torch.full((B,), float(value), dtype=torch.float32, device=device)
+
+    # ---- one denoiser evaluation -> projected x_hat --------------------------------------------------------
+    def _denoise(self, x, t_i):
+        """x_hat = D(x; t_i) [+ guidance step] ; data-consistency projection is applied by the caller's fused
+        step kernel.  t_i: 0-d float32 CPU tensor."""
+        B = x.shape[0]
+        dp = self.diff_params
+        self.n_evals += B
+        if self.y is not None and self.xi > 0:
+            return self._denoise_guided(x, t_i)
+        hpf = bool(self.y is None and self.args.tester.filter_out_cqt_DC_Nyq)   # (:122-123) unconditional only
+        if self._fast():
+            s = t_i.reshape(1)
+            return self.model.denoise(x, self._vec(dp.cnoise(s), B, x.device), self._vec(dp.cin(s), B, x.device),
+                                      self._vec(dp.cskip(s), B, x.device), self._vec(dp.cout(s), B, x.device), hpf)
+        with torch.no_grad():
+            x_hat = dp.denoiser(x, self.model, t_i.reshape(1).to(x.device).unsqueeze(-1))
+            if hpf:
+                x_hat = self.model.CQTransform.apply_hpf_DC(x_hat)
+        return x_hat
+
+    def _denoise_guided(self, x, t_i):
+        """Reconstruction guidance (:57-105), per item.  Differentiates through the network with torch.autograd;
+        the MI355X network supplies its own input-VJP (autograd.py)."""
+        dp = self.diff_params
+        B, L = x.shape
+        x = x.detach().requires_grad_()
+        sig = t_i.reshape(1, 1).to(x.device).expand(B, 1)
+        with torch.enable_grad():
+            x_hat = dp.denoiser(x, self.model, sig)
+            if self.args.tester.filter_out_cqt_DC_Nyq:
+                x_hat = self.model.CQTransform.apply_hpf_DC(x_hat)
+            den_rec = self.mask * x_hat
+            nrm = self.args.tester.posterior_sampling.norm
+            if nrm == "smoothl1":
+                norm = torch.nn.functional.smooth_l1_loss(self.y, den_rec, reduction="none",
+                                                          beta=self.args.tester.posterior_sampling.smoothl1_beta).sum(dim=1)
+            else:
+                norm = torch.linalg.norm(self.y - den_rec, dim=1, ord=nrm)
+            rec_grads = torch.autograd.grad(outputs=norm.sum(), inputs=x)[0]
+        normguide = torch.linalg.norm(rec_grads, dim=1, keepdim=True) / self.args.exp.audio_len ** 0.5
+        s = float(t_i) * self.xi / (normguide + 1e-6)
+        return (x_hat.detach() - s * rec_grads).detach()
+
+    def _score_step(self, x, x_hat, t_i, h, mode, x0=None, d0=None):
+        """fused: projection (:343) + d = -t*score (:105,:230) + Euler proposal (:240) or Heun combine (:247)."""
+        B, L = x.shape
+        xnext = torch.empty_like(x)
+        dout = torch.empty_like(x) if mode == 0 else None
+        proj = self.data_consistency and self.y is not None
+        xh_out = torch.empty_like(x) if self.trace is not None else None
+        tv, hv = self._vec(t_i, B, x.device), self._vec(h, B, x.device)   # keep alive until after the launch
+        p = _lib.ScoreStepParams(x.data_ptr(), x_hat.data_ptr(), _lib.ptr(self.y) if proj else None,
+                                 _lib.ptr(self.smask) if proj else None, (self.smask.stride(0) if self.smask.shape[0] > 1 else 0) if proj else 0,
+                                 _lib.ptr(x0), _lib.ptr(d0), tv.data_ptr(), hv.data_ptr(),
+                                 xnext.data_ptr(), _lib.ptr(dout), _lib.ptr(xh_out), B, L, mode)
+        _lib.call("aid_score_step", p)
+        del tv, hv
+        if self.trace is not None:
+            self.trace.append(xh_out)
+        return xnext, dout
+
+    # ---------------------------------------------------------------------------------------------------
+    def predict_unconditional(self, shape, device):
+        self.y = None
+        self.mask = self.smask = None
+        return self.predict(shape, device)
+
+    def predict(self, shape, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise _lib.AidError("the MI355X sampler runs on the GPU only (no CPU fallback)")
+        dp = self.diff_params
+        B, L = shape
+        self._gens = None if self.seeds is None else [torch.Generator().manual_seed(int(s)) for s in self.seeds]
+        t = dp.create_schedule(self.nb_steps)                 # host, float32
+        gamma = dp.get_gamma(t)
+        x = self._to_dev(self._randn(shape) * t[0], device)   # prior (edm.py:94)
+        for i in range(self.nb_steps):
+            if gamma[i] == 0:
+                t_hat = t[i]
+            else:
+                t_hat = t[i] + gamma[i] * t[i]
+                eps = self._to_dev(self._randn(shape) * dp.Snoise, device)
+                coef = (t_hat ** 2 - t[i] ** 2) ** (1 / 2)
+                xn = torch.empty_like(x)
+                cv = self._vec(coef, B, device)
+                p = _lib.AxpbyParams(x.data_ptr(), eps.data_ptr(), xn.data_ptr(), None, cv.data_ptr(), B, L)
+                _lib.call("aid_axpby", p)                      # x + sqrt(t_hat^2 - t_i^2) * eps   (:214)
+                del cv
+                x = xn
+            x_hat = self._denoise(x, t_hat)
+            h = t[i + 1] - t_hat
+            x_prime, d = self._score_step(x, x_hat, t_hat, h, mode=0)
+            if t[i + 1] != 0 and self.order == 2:
+                x_hat2 = self._denoise(x_prime, t[i + 1])
+                x, _ = self._score_step(x_prime, x_hat2, t[i + 1], h, mode=1, x0=x, d0=d)
+            else:
+                x = x_prime
+        if self.data_consistency_end and self.y is not None:
+            x = self.smask * self.y + (1 - self.smask) * x
+        return x.detach()
+
+    def predict_inpainting(self, y_masked, mask):
+        """y_masked[B,L], mask[1|B,L] -> inpainted [B,L] on y_masked.device   (:327-346)"""
+        self.mask = mask.to(y_masked.device)
+        self.y = y_masked.contiguous().float()
+        if self.data_consistency or self.data_consistency_end:
+            sm = prepare_smooth_mask(mask, self.args.tester.data_consistency.hann_size) if self.smooth else mask.float()
+            self.smask = sm.to(y_masked.device).contiguous()
+        return self.predict(self.y.shape, self.y.device)
+
+    def predict_spectrogram_inpainting(self, y_masked, mask):
+        raise NotImplementedError("spectrogram inpainting (STFT-domain mask) is SURVEY.md section 8f item 1 -- next")

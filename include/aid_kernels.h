@@ -1,0 +1,248 @@
+/*
+ * aid_kernels.h -- C ABI of libaid_hip.so: the MI355X (gfx950) kernels behind the EDM inpainting hot path.
+ *
+ * Boundary contract (last row):
+ *   - plain C: raw device pointers, sizes, strides in ELEMENTS, a hipStream_t passed as void*;
+ *   - every entry point returns 0 on success or a negative AID_E_* code; nothing throws, nothing allocates
+ *     (workspaces are passed in), nothing synchronises the device;
+ *   - all tensors are fp32, laid out [B, C, F, T] with T contiguous (stride 1); sB/sC/sF strides let a
+ *     producer write straight into a slice of a concatenation buffer (replaces the reference's torch.cat /
+ *     slicing copies, networks/unet_cqt_oct_with_projattention_adaLN_2.py:769-774,814,821-822);
+ *   - complex CQT coefficients cross this boundary in PLANAR form [B, 2(re,im), bins, T] (replaces
+ *     view_as_real/permute/contiguous, unet...py:752-753,826-827).
+ *
+ * The reference has no FFI: it is pure PyTorch.  Each entry point therefore cites the torch call site(s) in
+ * /root/reference it replaces.  The Python binding a maintainer would add is shown in INTEGRATION.md and
+ * implemented in audio-inpainting-diffusion_amd/_lib.py (ctypes).
+ */
+#ifndef AID_KERNELS_H
+#define AID_KERNELS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AID_OK 0
+#define AID_E_BADARG (-1)   /* unsupported shape / null pointer / misaligned stride */
+#define AID_E_LAUNCH (-2)   /* hipLaunchKernel reported an error                    */
+
+#define AID_ABI_VERSION 1
+int aid_abi_version(void);
+/* last HIP error string seen by a launcher in this process (never NULL) */
+const char* aid_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * 4-D fp32 view: element (b,c,f,t) lives at p[b*sB + c*sC + f*sF + t].
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    float* p;
+    int64_t sB, sC, sF;
+} aid_view;
+
+/* ---------------------------------------------------------------------------------------------------
+ * aid_group_stats -- BiasFreeGroupNorm statistics + adaLN modulation folded into ONE per-(b,c) scale.
+ *   replaces: BiasFreeGroupNorm.forward (unet...py:147-163) and the `x*(gamma+1)` that follows it
+ *             (unet...py:465,479).
+ *   computes, per sample b and group g (C/groups consecutive channels, all F*T positions):
+ *       mean, std (unbiased, centred)                                  -> stats[b][g] = {mean, 1/(std+eps)}
+ *       scale[b][c] = gamma[c] * (1 + mod[b*mod_ld + c]) / (std + eps)   (mod may be NULL -> 1)
+ *   so that norm(x)*gamma*(1+mod) == x * scale[b][c].
+ *   ws: >= B*groups*AID_STATS_SPLIT*2 doubles of scratch.
+ * ------------------------------------------------------------------------------------------------- */
+#define AID_STATS_SPLIT 32
+typedef struct {
+    aid_view x;
+    int B, C, F, T, groups;
+    const float* gamma;        /* [C]            */
+    const float* mod;          /* [B, mod_ld] or NULL */
+    int64_t mod_ld;
+    float eps;
+    float* scale;              /* [B, C]   out   */
+    float* stats;              /* [B, groups, 2] out (mean, 1/(std+eps)) */
+    double* ws;
+} aid_group_stats_params;
+int aid_group_stats(const aid_group_stats_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * aid_conv2d -- fused dilated dense convolution as fp32-MFMA implicit GEMM (the 99 %-of-FLOPs kernel).
+ *   replaces: Conv2d.forward / F.conv2d(padding="same", dilation=(d,1)) (unet...py:79-88) together with the
+ *             elementwise work around it in ResnetBlock.forward (unet...py:472-482, 456, 488-491),
+ *             the pyramid projection + combine (unet...py:794), the 1x1 channel projections, and (with
+ *             F=1, KH=KW=1) the qk Conv1d of TimeAttentionBlock (unet...py:355).
+ *       xin  = act( x[b,ci,f',t'] * in_scale[b,ci] )            act: 0 none, 1 erf-GELU; in_scale may be NULL
+ *       acc  = sum_{ci,kh,kw} w[co,ci,kh,kw] * xin[b,ci,f+(kh-KH/2)*dilF, t+(kw-KW/2)]   (zero 'same' padding)
+ *       y    = alpha * ( res_scale * res[b,co,f,t] + acc * out_scale[b*out_scale_ld + co] )
+ *              (res may be NULL -> 0 ; out_scale may be NULL -> 1)
+ *   epilogue extension for the input-VJP (guidance branch), selected by `epi`:
+ *       epi = 0 : as above
+ *       epi = 1 : y = alpha * acc * out_scale * gelu'(aux[b,co,f,t] * aux_scale[b,co])   (dGELU epilogue)
+ *   weights are PRE-PACKED by the host: wp[KH*KW][Cin_pad][Cout_pad], cout contiguous, zero padded
+ *   (Cin_pad % 32 == 0, Cout_pad a multiple of the M tile the launcher picks for Cout) -- see aid_conv2d_pack_dims.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    aid_view x, y, res, aux;
+    const float* wp;
+    const float* in_scale;   int64_t in_scale_ld;
+    const float* out_scale;  int64_t out_scale_ld;
+    const float* aux_scale;  int64_t aux_scale_ld;
+    int B, Cin, Cout, F, T;
+    int Cin_pad, Cout_pad;
+    int KH, KW, dilF;
+    int act, epi;
+    float alpha, res_scale;
+} aid_conv2d_params;
+int aid_conv2d(const aid_conv2d_params* p, void* stream);
+/* padded dims the packed weight buffer must have for a given (Cin, Cout) */
+void aid_conv2d_pack_dims(int Cin, int Cout, int* Cin_pad, int* Cout_pad);
+
+/* ---------------------------------------------------------------------------------------------------
+ * aid_resample -- 8-tap cubic FIR 2:1 resampling along T with reflect padding.
+ *   replaces: UpDownResample.forward (unet...py:549-580; taps :514-515).  The reference runs this as a
+ *             dense conv with a diagonal [F,F,8] weight; here it is the 16-FLOP/output FIR.
+ *   up = 0: y[..., j] = sum_k h[k] * xr[2j + k - 3]                    T_out = T/2
+ *   up = 1: transposed conv, stride 2, crop 7 (no x2 gain)              T_out = 2T
+ *   adjoint = 1 computes the exact transpose of the selected map (used by the input-VJP).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    aid_view x, y;
+    int B, C, F, T;        /* T = input length */
+    int up, adjoint;
+} aid_resample_params;
+int aid_resample(const aid_resample_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * aid_time_attention -- softmax(q k^T * F^-1/2) v over the time axis, per (sample, head).
+ *   replaces: the einsum/softmax/einsum core of TimeAttentionBlock.forward (unet...py:358-374).
+ *   qk : [B, H*2F, T]  (rows h*2F .. h*2F+F-1 = q of head h, next F rows = k)   -- output of the qk GEMM
+ *   v  : [B, H, F, T]  (the projected input itself, unet...py:353)
+ *   out: [B, H, F, T]
+ *   T <= 128.  If `probs` is non-NULL the softmax matrix [B,H,T,T] is also written (saved for the VJP).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* qk; const float* v; float* out; float* probs;
+    int B, H, F, T;
+    float scale;
+} aid_attention_params;
+int aid_time_attention(const aid_attention_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * aid_embed -- RFF noise-level embedding + 3-layer ReLU MLP.
+ *   replaces: RFF_MLP_Block.forward (unet...py:184-211).   sigma[B] -> emb[B, emb_dim]
+ * aid_modulation -- every affine/gate Linear of the network as ONE batched product.
+ *   replaces: the ~194 `affine(sigma)` / `gate(sigma)` Linear calls per evaluation (unet...py:461-462,476-477).
+ *   mod[b, j] = sum_e emb[b,e] * W[j,e] + bias[j],  W = all affine/gate weights stacked row-wise [N, E].
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* sigma;                /* [B] (the c_noise value)            */
+    const float* rff_freq;             /* [rff]                              */
+    const float* w0; const float* b0;  /* [h0, 2*rff], [h0]                   */
+    const float* w1; const float* b1;  /* [h1, h0]                            */
+    const float* w2; const float* b2;  /* [E, h1]                             */
+    float* emb;                        /* [B, E]                              */
+    int B, rff, h0, h1, E;
+} aid_embed_params;
+int aid_embed(const aid_embed_params* p, void* stream);
+
+typedef struct {
+    const float* emb; const float* W; const float* bias; float* mod;
+    int B, E, N;
+} aid_modulation_params;
+int aid_modulation(const aid_modulation_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * CQT (octave-mode NSGT).  replaces the external cqt_nsgt_pytorch calls CQT_nsgt.fwd / .bwd /
+ * .apply_hpf_DC (call sites unet...py:743,841; testing/edm_sampler_inpainting.py:63,123).
+ * The length-L real FFTs on either side are done by the caller (rocFFT through torch.fft in round 1).
+ *
+ * Band table (device, built once by the host from audio-inpainting-diffusion_amd/cqt.py):
+ *   band k of octave o:  centre bin rc[k], window length Lg[k], window samples g[goff[k] .. goff[k]+Lg[k])
+ *   (analysis window) or the dual window times M_k (synthesis), sampled at offsets j = -Lg/2 .. Lg-Lg/2-1.
+ *
+ * aid_cqt_analysis : spec[B, Lh] complex (interleaved re,im; Lh = L/2+1)  ->  coef octave tensors.
+ *     c_k[t] = IFFT_T( wrap_T( spec[rc_k + j] * g_k[j] ) ) * in_scale[b]
+ *     written to out[b, 0/1, bin, t] of the octave's planar view.
+ * aid_cqt_synthesis: coef octave views -> band spectra ws[b][k][T_o] = FFT_T(c_k)[.] (complex interleaved)
+ * aid_cqt_gather   : Y[b][v] = hpf[v] * ( cskip[b] * X[b][v] + cout[b] * sum_k ws[b][k][(v-rc_k) mod T_o] * gdM_k[v-rc_k] )
+ *     (X, cskip, cout, hpf optional) -- deterministic overlap-add, no atomics.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int n_oct, bins;                 /* octaves, bins per octave                       */
+    const int* rc;                   /* [n_oct*bins] centre bins                        */
+    const int* Lg;                   /* [n_oct*bins] window lengths                     */
+    const int* goff;                 /* [n_oct*bins] offsets into g                     */
+    const float* g;                  /* concatenated windows                            */
+    const int* T_oct;                /* [n_oct] host-side copy is passed in T_host      */
+    const float* twiddle;            /* [Tmax/2] complex interleaved exp(-2 pi i m/Tmax) */
+    int Tmax;
+} aid_cqt_tables;
+
+#define AID_CQT_MAX_OCT 12
+typedef struct {
+    aid_cqt_tables tab;
+    int T_host[AID_CQT_MAX_OCT];     /* octave lengths (host copy)                      */
+    aid_view oct[AID_CQT_MAX_OCT];   /* per-octave planar views [B,2,bins,T_o] (sC = stride between re/im planes) */
+    const float* spec;               /* analysis: in  [B, Lh, 2]                         */
+    float* band_ws;                  /* synthesis: out [B, sum_o bins*T_o, 2]            */
+    const float* in_scale;           /* analysis: per-sample scale [B] or NULL          */
+    int B, Lh;
+} aid_cqt_params;
+int aid_cqt_analysis(const aid_cqt_params* p, void* stream);
+int aid_cqt_synthesis(const aid_cqt_params* p, void* stream);
+
+typedef struct {
+    const float* band_ws;            /* [B, sum_o bins*T_o, 2]                           */
+    const int* kfirst; const int* kcount;   /* [Lh] first covering band and count        */
+    const int* rc; const int* Lg; const int* goff; const int* woff; const int* Tk;  /* per band; woff = offset of band in band_ws (complex elems) */
+    const float* gdM;                /* concatenated dual windows times M_k              */
+    const float* X;                  /* [B, Lh, 2] or NULL                               */
+    const float* cskip; const float* cout;  /* [B] or NULL (-> 0 / 1)                    */
+    const float* hpf;                /* [Lh] or NULL                                     */
+    float* Y;                        /* [B, Lh, 2]                                       */
+    int B, Lh; int64_t ws_per_b;
+} aid_cqt_gather_params;
+int aid_cqt_gather(const aid_cqt_gather_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Sampler element-wise kernels (replace the tensor expressions of Sampler.predict / get_score,
+ * testing/edm_sampler_inpainting.py:141-147, 204-251, 343).  All arrays [B, L]; per-sample scalars [B].
+ *
+ * aid_axpby   : out = a[b]*x + b_[b]*y                       (churn add :214; generic)
+ * aid_score_step : data-consistency projection + ODE direction + Euler proposal in one pass
+ *       xh  = smask*yobs + (1-smask)*xhat                     (:343)      (smask NULL -> xh = xhat)
+ *       d   = (x - xh) / t[b]                                 (:105,:230  d = -t*score)
+ *       mode 0:  xnext = x + h[b]*d ;  dout = d               (Euler proposal :240 / final step :251)
+ *       mode 1:  xnext = x0 + h[b]*0.5*(d0 + d)               (Heun combine :247; x0,d0 from the first eval)
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* x; const float* y; float* out;
+    const float* a; const float* b;   /* per-sample [B] */
+    int B; int64_t L;
+} aid_axpby_params;
+int aid_axpby(const aid_axpby_params* p, void* stream);
+
+typedef struct {
+    const float* x; const float* xhat; const float* yobs; const float* smask; int64_t smask_sB;
+    const float* x0; const float* d0;
+    const float* t; const float* h;   /* per-sample [B] */
+    float* xnext; float* dout; float* xh_out;
+    int B; int64_t L; int mode;
+} aid_score_step_params;
+int aid_score_step(const aid_score_step_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * aid_add2 -- y = a*u + b*v on [B,C,F,T] views (the `(x + res)/sqrt(2)` skip combine of a ResnetBlock whose
+ *   input and output widths agree, unet...py:491 with res_conv = Identity; also gradient accumulation).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    aid_view u, v, y;
+    int B, C, F, T;
+    float a, b;
+} aid_add2_params;
+int aid_add2(const aid_add2_params* p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AID_KERNELS_H */

@@ -1,0 +1,256 @@
+"""GPU parity, kernel by kernel: every C-ABI entry point of libaid_hip.so against the CPU oracle (oracle/) or
+the plain torch-CPU fp32 form of the same op, on the same seeded inputs.
+
+Tolerances (fp32 path, stated per test): 2e-6 rel-L2 for pure data movement / FIR, 1e-5 for reductions and
+GEMM-shaped kernels (summation order differs from oneDNN), well inside BASELINE.json's 1e-4 budget.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def L():
+    from audio_inpainting_diffusion_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 16, 5, 12), (3, 64, 7, 256), (1, 96, 128, 1024), (2, 8, 3, 4)])
+def test_group_stats(L, shape):
+    from oracle.unet import group_std_norm
+    B, Cc, Fd, T = shape
+    x = _rand(*shape, seed=1, scale=3.0) + 0.5
+    gamma = 1.0 + 0.3 * _rand(Cc, seed=2)
+    mod = 0.5 * _rand(B, Cc + 5, seed=3)
+    xd = x.to(DEV)
+    scale = torch.empty(B, Cc, device=DEV)
+    stats = torch.empty(B, 8, 2, device=DEV)
+    ws = torch.empty(B * 8 * L.AID_STATS_SPLIT * 2, device=DEV, dtype=torch.float64)
+    gd, md = gamma.to(DEV), mod.to(DEV)
+    p = L.GroupStatsParams(L.view4(xd), B, Cc, Fd, T, 8, gd.data_ptr(), md[:, 3:].data_ptr(), md.stride(0), 1e-7,
+                           scale.data_ptr(), stats.data_ptr(), ws.data_ptr())
+    L.call("aid_group_stats", p)
+    ref = group_std_norm(x, gamma.view(1, -1, 1, 1)) * (1 + mod[:, 3:3 + Cc])[:, :, None, None]
+    got = xd * scale[:, :, None, None]
+    assert rel_l2(got.cpu(), ref) < 1e-5
+    xg = x.reshape(B, 8, -1)
+    assert rel_l2(stats[:, :, 0].cpu(), xg.mean(-1)) < 1e-4 + 1e-5
+    assert rel_l2(stats[:, :, 1].cpu(), 1.0 / (xg.std(-1) + 1e-7)) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------
+def _conv_ref(x, w, dil, in_scale, act, out_scale, res, res_scale, alpha):
+    h = x
+    if in_scale is not None:
+        h = h * in_scale[:, :, None, None]
+    if act:
+        h = F.gelu(h)
+    kh = w.shape[2]
+    y = F.conv2d(h, w, padding="same", dilation=(dil, 1) if kh > 1 else 1)
+    if out_scale is not None:
+        y = y * out_scale[:, :, None, None]
+    if res is not None:
+        y = y + res_scale * res
+    return alpha * y
+
+
+CONV_CASES = [
+    # B, Cin, Cout, F, T, KH, KW, dil, prologue, epilogue
+    (2, 16, 16, 24, 16, 5, 3, 1, True, True),
+    (2, 16, 16, 24, 16, 5, 3, 4, True, True),
+    (1, 64, 64, 64, 512, 5, 3, 2, True, True),       # level-0 shape class (M=64 config, TT=256)
+    (1, 96, 96, 20, 256, 5, 3, 8, True, True),       # M=96 config
+    (1, 128, 128, 40, 128, 5, 3, 16, True, True),    # M=128 config, ROWS=2
+    (2, 256, 256, 24, 32, 5, 3, 64, True, True),     # two M tiles, ROWS=8, dilation larger than F
+    (2, 2, 64, 16, 64, 5, 3, 1, False, True),        # pyramid projection 2 -> C
+    (2, 2, 8, 8, 32, 1, 1, 1, False, False),         # init-block proj_in
+    (2, 48, 2, 10, 8, 1, 1, 1, False, True),         # out-block projection C -> 2
+    (2, 24, 8, 12, 8, 1, 1, 1, True, False),         # attention proj_in (scale prologue, no GELU)
+    (2, 8, 24, 12, 8, 1, 1, 1, False, True),         # attention proj_out
+    (2, 96, 192, 1, 8, 1, 1, 1, False, False),       # qk GEMM, F = 1
+    (1, 320, 640, 1, 128, 1, 1, 1, False, False),    # qk GEMM, larger K
+    (3, 40, 40, 9, 12, 5, 3, 2, True, True),         # ragged: T not a power of two, odd row count
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(L, case):
+    B, Cin, Cout, Fd, T, KH, KW, dil, pro, epi = case
+    x = _rand(B, Cin, Fd, T, seed=10)
+    w = _rand(Cout, Cin, KH, KW, seed=11, scale=1.0 / math.sqrt(Cin * KH * KW))
+    in_scale = (1.0 + 0.5 * _rand(B, Cin, seed=12)) if pro else None
+    act = 1 if (pro and KH > 1) else 0
+    out_scale = _rand(B, Cout + 3, seed=13) if epi else None
+    res = _rand(B, Cout, Fd, T, seed=14) if epi else None
+    alpha, res_scale = (1 / math.sqrt(2), 1.5) if epi else (1.0, 1.0)
+    ref = _conv_ref(x, w, dil, in_scale, act, None if out_scale is None else out_scale[:, 1:1 + Cout], res, res_scale, alpha)
+
+    xd, wd = x.to(DEV), w.to(DEV)
+    wp = L.pack_conv_weight(wd)
+    # write into a channel slice of a larger buffer to exercise the strided-view path
+    ybig = torch.full((B, Cout + 4, Fd, T), 7.0, device=DEV)
+    y = ybig[:, 2:2 + Cout]
+    p = L.Conv2dParams()
+    resd = None if res is None else res.to(DEV)
+    isd = None if in_scale is None else in_scale.to(DEV)
+    osd = None if out_scale is None else out_scale.to(DEV)
+    p.x, p.y, p.res, p.aux = L.view4(xd), L.view4(y), L.view4(resd), L.view4(None)
+    p.wp = wp.data_ptr()
+    p.in_scale, p.in_scale_ld = L.ptr(isd), (0 if isd is None else isd.stride(0))
+    p.out_scale, p.out_scale_ld = (None if osd is None else osd[:, 1:].data_ptr()), (0 if osd is None else osd.stride(0))
+    p.B, p.Cin, p.Cout, p.F, p.T = B, Cin, Cout, Fd, T
+    p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
+    p.KH, p.KW, p.dilF, p.act, p.epi = KH, KW, dil, act, 0
+    p.alpha, p.res_scale = alpha, res_scale
+    L.call("aid_conv2d", p)
+    torch.cuda.synchronize()
+    assert rel_l2(y.cpu(), ref) < 1e-5
+    assert float(ybig[:, :2].min()) == 7.0 and float(ybig[:, 2 + Cout:].min()) == 7.0, "wrote outside its channel slice"
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 3, 4, 16), (1, 2, 5, 8), (2, 4, 3, 256), (1, 1, 2, 2048)])
+def test_resample_and_adjoints(L, shape):
+    from oracle.unet import resample_down, resample_up
+    B, Cc, Fd, T = shape
+    x = _rand(*shape, seed=20)
+    xd = x.to(DEV)
+
+    def run(inp, Tout, up, adjoint):
+        out = torch.empty(B, Cc, Fd, Tout, device=DEV)
+        p = L.ResampleParams(L.view4(inp), L.view4(out), B, Cc, Fd, inp.shape[-1], up, adjoint)
+        L.call("aid_resample", p)
+        return out
+
+    dn = run(xd, T // 2, 0, 0)
+    up = run(xd, 2 * T, 1, 0)
+    assert rel_l2(dn.cpu(), resample_down(x)) < 2e-6
+    assert rel_l2(up.cpu(), resample_up(x)) < 2e-6
+    # adjoints: <A x, g> == <x, A^T g>
+    g1 = _rand(B, Cc, Fd, T // 2, seed=21).to(DEV)
+    g2 = _rand(B, Cc, Fd, 2 * T, seed=22).to(DEV)
+    a1 = run(g1, T, 0, 1)
+    a2 = run(g2, T, 1, 1)
+    assert abs(float((dn.double() * g1.double()).sum() - (xd.double() * a1.double()).sum())) < 1e-4 * float(dn.norm() * g1.norm())
+    assert abs(float((up.double() * g2.double()).sum() - (xd.double() * a2.double()).sum())) < 1e-4 * float(up.norm() * g2.norm())
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 8, 12, 8), (1, 8, 40, 32), (2, 8, 320, 128), (1, 4, 56, 64), (1, 8, 9, 4)])
+def test_time_attention(L, shape):
+    B, H, Fd, T = shape
+    qk = _rand(B, H * 2 * Fd, T, seed=30, scale=2.0)
+    v = _rand(B, H, Fd, T, seed=31)
+    q4 = qk.reshape(B, H, 2 * Fd, T).permute(0, 1, 3, 2)
+    q, k = q4[..., :Fd], q4[..., Fd:]
+    sim = torch.einsum("bhnd,bhmd->bhnm", q, k) * (float(Fd) ** -0.5)
+    attn = sim.softmax(-1)
+    ref = torch.einsum("bhnm,bhmd->bhnd", attn, v.permute(0, 1, 3, 2)).permute(0, 1, 3, 2)
+    qd, vd = qk.to(DEV), v.to(DEV)
+    out = torch.empty(B, H, Fd, T, device=DEV)
+    probs = torch.empty(B, H, T, T, device=DEV)
+    p = L.AttentionParams(qd.data_ptr(), vd.data_ptr(), out.data_ptr(), probs.data_ptr(), B, H, Fd, T, float(Fd) ** -0.5)
+    L.call("aid_time_attention", p)
+    assert rel_l2(probs.cpu(), attn) < 1e-5
+    assert rel_l2(out.cpu(), ref) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------
+def test_embed_and_modulation(L):
+    from oracle.unet import embed
+    E, B = 48, 5
+    sd = {"embedding.RFF_freq": 16 * _rand(1, 32, seed=40)}
+    dims = [(128, 64), (256, 128), (E, 256)]
+    for i, (o, ii) in enumerate(dims):
+        sd[f"embedding.MLP.{i}.weight"] = _rand(o, ii, seed=41 + i, scale=1 / math.sqrt(ii))
+        sd[f"embedding.MLP.{i}.bias"] = 0.1 * _rand(o, seed=45 + i)
+    sig = torch.tensor([[-2.1], [-0.3], [0.0], [-1.0], [0.4]])
+    ref = embed(sd, sig)
+    d = {k: v.to(DEV).contiguous() for k, v in sd.items()}
+    sg = sig.reshape(-1).to(DEV).contiguous()
+    emb = torch.empty(B, E, device=DEV)
+    p = L.EmbedParams(sg.data_ptr(), d["embedding.RFF_freq"].data_ptr(),
+                      d["embedding.MLP.0.weight"].data_ptr(), d["embedding.MLP.0.bias"].data_ptr(),
+                      d["embedding.MLP.1.weight"].data_ptr(), d["embedding.MLP.1.bias"].data_ptr(),
+                      d["embedding.MLP.2.weight"].data_ptr(), d["embedding.MLP.2.bias"].data_ptr(),
+                      emb.data_ptr(), B, 32, 128, 256, E)
+    L.call("aid_embed", p)
+    assert rel_l2(emb.cpu(), ref) < 2e-5     # sin/cos of ~1e2 rad arguments: device vs host libm
+    N = 1000
+    Wm, bm = _rand(N, E, seed=50), _rand(N, seed=51)
+    Wd, bd_ = Wm.to(DEV), bm.to(DEV)
+    for Bm in (5, 19):
+        e = _rand(Bm, E, seed=52).to(DEV)
+        mod = torch.empty(Bm, N, device=DEV)
+        L.call("aid_modulation", L.ModulationParams(e.data_ptr(), Wd.data_ptr(), bd_.data_ptr(), mod.data_ptr(), Bm, E, N))
+        assert rel_l2(mod.cpu(), e.cpu() @ Wm.t() + bm) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [(3, 8, 22050, 2048), (7, 8, 22050, 16384), (4, 8, 16000, 4096), (7, 64, 22050, 184184)])
+def test_cqt_against_oracle(L, cfg):
+    from audio_inpainting_diffusion_amd.cqt import CQTransform
+    from oracle.nsgt_cqt import OracleCQT
+    no, bpo, fs, Ls = cfg
+    orc = OracleCQT(no, bpo, "oct", ("kaiser", 1), fs, Ls)
+    tr = CQTransform(no, bpo, "oct", ("kaiser", 1.0), fs, Ls, device=DEV)
+    x = _rand(2, Ls, seed=60, scale=0.063)
+    c_ref = orc.fwd(x[:, None])
+    c = tr.fwd(x[:, None].to(DEV))
+    for a, b in zip(c, c_ref):
+        assert a.shape == b.shape and a.dtype == torch.complex64
+        assert rel_l2(torch.view_as_real(a.cpu()), torch.view_as_real(b)) < 1e-5
+    # synthesis of ARBITRARY coefficients (not in the range of fwd)
+    cr = [torch.complex(_rand(*ci.shape, seed=61 + i), _rand(*ci.shape, seed=71 + i)) for i, ci in enumerate(c_ref)]
+    y_ref = orc.bwd(cr)
+    y = tr.bwd([ci.to(DEV) for ci in cr])
+    assert rel_l2(y.cpu(), y_ref) < 1e-5
+    # perfect reconstruction up to the DC/Nyquist projector (BASELINE's "CQT round-trip", <= 1e-5)
+    rt = tr.bwd(c)[:, 0]
+    hp = tr.apply_hpf_DC(x.to(DEV))
+    assert rel_l2(hp.cpu(), orc.apply_hpf_DC(x)) < 1e-5
+    assert rel_l2(rt.cpu(), hp.cpu()) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------
+def test_sampler_elementwise(L):
+    B, Ls = 3, 1000
+    x, xh, y = _rand(B, Ls, seed=80), _rand(B, Ls, seed=81), _rand(B, Ls, seed=82)
+    sm = torch.rand(B, Ls, generator=torch.Generator().manual_seed(83))
+    t, h = torch.tensor([0.5, 0.7, 0.9]), torch.tensor([-0.1, -0.2, -0.3])
+    xd, xhd, yd, smd, td, hd = (a.to(DEV) for a in (x, xh, y, sm, t, h))
+    xn, dd, xo = torch.empty_like(xd), torch.empty_like(xd), torch.empty_like(xd)
+    p = L.ScoreStepParams(xd.data_ptr(), xhd.data_ptr(), yd.data_ptr(), smd.data_ptr(), smd.stride(0), None, None,
+                          td.data_ptr(), hd.data_ptr(), xn.data_ptr(), dd.data_ptr(), xo.data_ptr(), B, Ls, 0)
+    L.call("aid_score_step", p)
+    xp = sm * y + (1 - sm) * xh
+    score = (xp - x) / t[:, None] ** 2
+    d = -t[:, None] * score
+    assert rel_l2(xo.cpu(), xp) < 2e-6 and rel_l2(dd.cpu(), d) < 2e-6 and rel_l2(xn.cpu(), x + h[:, None] * d) < 2e-6
+    # Heun combine
+    x2 = torch.empty_like(xd)
+    p = L.ScoreStepParams(xn.data_ptr(), xhd.data_ptr(), yd.data_ptr(), smd.data_ptr(), smd.stride(0), xd.data_ptr(), dd.data_ptr(),
+                          td.data_ptr(), hd.data_ptr(), x2.data_ptr(), None, None, B, Ls, 1)
+    L.call("aid_score_step", p)
+    xpr = x + h[:, None] * d
+    d2 = -(t[:, None]) * ((xp - xpr) / t[:, None] ** 2)
+    assert rel_l2(x2.cpu(), x + h[:, None] * (0.5 * d + 0.5 * d2)) < 2e-6
+    out = torch.empty_like(xd)
+    L.call("aid_axpby", L.AxpbyParams(xd.data_ptr(), yd.data_ptr(), out.data_ptr(), None, td.data_ptr(), B, Ls))
+    assert rel_l2(out.cpu(), x + t[:, None] * y) < 2e-6

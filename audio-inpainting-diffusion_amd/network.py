@@ -120,20 +120,30 @@ class _Plan:
     """Flat list of (C function, params struct) pairs executed in order on the current stream."""
 
     def __init__(self):
-        self.ops = []          # (fn, addr, name)
+        self.ops = []          # (fn, addr, name, flops)
         self.keep = []         # structs + tensors referenced by raw pointers
         self.flops = 0
+        self.timing = None     # set to a list to bracket every conv launch with HIP events (bench.py roofline)
 
-    def add(self, name, params, *tensors):
+    def add(self, name, params, *tensors, flops=0):
         fn = getattr(_lib.lib(), name)
-        self.ops.append((fn, C.addressof(params), name))
+        self.ops.append((fn, C.addressof(params), name, flops))
         self.keep.append(params)
         self.keep.extend(t for t in tensors if t is not None)
+        self.flops += flops
 
     def run(self):
         stream = torch.cuda.current_stream().cuda_stream
-        for fn, addr, name in self.ops:
-            rc = fn(addr, stream)
+        timing = self.timing
+        for fn, addr, name, flops in self.ops:
+            if timing is not None and flops > 0 and name == "aid_conv2d":
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(addr, stream)
+                e1.record()
+                timing.append((e0, e1, flops))
+            else:
+                rc = fn(addr, stream)
             if rc != 0:
                 raise _lib.AidError(f"{name} failed rc={rc}: {_lib.lib().aid_last_error().decode()}")
 
@@ -174,8 +184,7 @@ class _Builder:
         p.KH, p.KW, p.dilF, p.act, p.epi = kh, kw, dil, act, 0
         p.alpha, p.res_scale = alpha, res_scale
         assert wp.shape[0] == kh * kw
-        self.plan.add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale)
-        self.plan.flops += 2 * B * F * T * cin * cout * kh * kw
+        self.plan.add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale, flops=2 * B * F * T * cin * cout * kh * kw)
 
     def add2(self, u, v, y, a, b):
         B, Cc, F, T = u.shape
@@ -190,8 +199,7 @@ class _Builder:
     def attention(self, qk, v, out, heads, F, T, probs=None):
         B = v.shape[0]
         p = _lib.AttentionParams(qk.data_ptr(), v.data_ptr(), out.data_ptr(), _lib.ptr(probs), B, heads, F, T, float(F) ** -0.5)
-        self.plan.add("aid_time_attention", p, qk, v, out, probs)
-        self.plan.flops += 4 * B * heads * T * T * F
+        self.plan.add("aid_time_attention", p, qk, v, out, probs, flops=4 * B * heads * T * T * F)
 
 
 # =========================================================================================================

@@ -154,37 +154,51 @@ class Sampler:
         self.mask = self.smask = None
         return self.predict(shape, device)
 
-    def predict(self, shape, device):
+    def begin(self, shape, device):
+        """Draw the prior and set up the schedule; returns the loop state consumed by ``step``."""
         device = torch.device(device)
         if device.type != "cuda":
             raise _lib.AidError("the MI355X sampler runs on the GPU only (no CPU fallback)")
         dp = self.diff_params
-        B, L = shape
         self._gens = None if self.seeds is None else [torch.Generator().manual_seed(int(s)) for s in self.seeds]
         t = dp.create_schedule(self.nb_steps)                 # host, float32
         gamma = dp.get_gamma(t)
         x = self._to_dev(self._randn(shape) * t[0], device)   # prior (edm.py:94)
+        return dict(x=x, t=t, gamma=gamma, shape=tuple(shape), device=device)
+
+    def step(self, state, i: int):
+        """One iteration of the sampling loop (:201-251): churn, denoiser evaluation, Heun correction."""
+        dp = self.diff_params
+        t, gamma, x, shape, device = state["t"], state["gamma"], state["x"], state["shape"], state["device"]
+        B, L = shape
+        if gamma[i] == 0:
+            t_hat = t[i]
+        else:
+            t_hat = t[i] + gamma[i] * t[i]
+            eps = self._to_dev(self._randn(shape) * dp.Snoise, device)
+            coef = (t_hat ** 2 - t[i] ** 2) ** (1 / 2)
+            xn = torch.empty_like(x)
+            cv = self._vec(coef, B, device)
+            p = _lib.AxpbyParams(x.data_ptr(), eps.data_ptr(), xn.data_ptr(), None, cv.data_ptr(), B, L)
+            _lib.call("aid_axpby", p)                      # x + sqrt(t_hat^2 - t_i^2) * eps   (:214)
+            del cv
+            x = xn
+        x_hat = self._denoise(x, t_hat)
+        h = t[i + 1] - t_hat
+        x_prime, d = self._score_step(x, x_hat, t_hat, h, mode=0)
+        if t[i + 1] != 0 and self.order == 2:
+            x_hat2 = self._denoise(x_prime, t[i + 1])
+            x, _ = self._score_step(x_prime, x_hat2, t[i + 1], h, mode=1, x0=x, d0=d)
+        else:
+            x = x_prime
+        state["x"] = x
+        return state
+
+    def predict(self, shape, device):
+        state = self.begin(shape, device)
         for i in range(self.nb_steps):
-            if gamma[i] == 0:
-                t_hat = t[i]
-            else:
-                t_hat = t[i] + gamma[i] * t[i]
-                eps = self._to_dev(self._randn(shape) * dp.Snoise, device)
-                coef = (t_hat ** 2 - t[i] ** 2) ** (1 / 2)
-                xn = torch.empty_like(x)
-                cv = self._vec(coef, B, device)
-                p = _lib.AxpbyParams(x.data_ptr(), eps.data_ptr(), xn.data_ptr(), None, cv.data_ptr(), B, L)
-                _lib.call("aid_axpby", p)                      # x + sqrt(t_hat^2 - t_i^2) * eps   (:214)
-                del cv
-                x = xn
-            x_hat = self._denoise(x, t_hat)
-            h = t[i + 1] - t_hat
-            x_prime, d = self._score_step(x, x_hat, t_hat, h, mode=0)
-            if t[i + 1] != 0 and self.order == 2:
-                x_hat2 = self._denoise(x_prime, t[i + 1])
-                x, _ = self._score_step(x_prime, x_hat2, t[i + 1], h, mode=1, x0=x, d0=d)
-            else:
-                x = x_prime
+            self.step(state, i)
+        x = state["x"]
         if self.data_consistency_end and self.y is not None:
             x = self.smask * self.y + (1 - self.smask) * x
         return x.detach()

@@ -1,0 +1,153 @@
+#!/usr/bin/env python
+"""Benchmark of the EDM inpainting sampling hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--xi 0|0.25] [--batch 8]
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "Config 2"): batch 8 x 22.05 kHz MAESTRO-shape
+segments (L=184184) per GPU, centred 300 ms gap, tester parameters of conf/tester/inpainting_tester.yaml with
+T=36, random-init (seeded) full-size network (186 M parameters), synthetic waveforms 0.063*N(0,1).
+One "step" = one iteration of the sampling loop = stochastic churn + TWO denoiser evaluations (Heun) +
+data-consistency projection for all 8 segments.  W untimed warm-up steps, then exactly K steps timed between
+barrier+synchronize pairs; MAX over ranks.  value = denoiser evaluations per second over the whole job
+(= n_gpus * 8 segments * 2 evaluations * K / wall); ms_per_step = wall / K.  Weak scaling: every GPU owns 8
+segments; the only collective is the start-up weight broadcast (not timed).
+
+roofline: the dominant kernel is conv_mfma_kernel (aid_conv2d, fp32 MFMA implicit GEMM, 99 % of the FLOPs).
+Every conv launch inside the timed region is bracketed by HIP events on the launch stream;
+achieved = sum of algorithmic conv FLOPs / sum of conv kernel time, peak = 157.3 TFLOP/s (fp32 MFMA dense).
+cpu_baseline: the CPU oracle (torch-CPU restatement of the reference path, oracle/) timed on this host's cores
+for the same network at B=1 (rank 0, N=1 only): 1 warm-up + 2 timed forward evaluations.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def cpu_baseline(net, args, n_timed=2):
+    from oracle.nsgt_cqt import OracleCQT
+    from oracle.unet import OracleUnet
+    from oracle.edm import OracleEDM
+    from audio_inpainting_diffusion_amd.init import seeded_normal
+    n, bpo = args.network.cqt.num_octs, args.network.cqt.bins_per_oct
+    L = args.exp.audio_len
+    cores = torch.get_num_threads()
+    orc = OracleUnet(n, bpo, OracleCQT(n, bpo, "oct", ("kaiser", 1), args.exp.sample_rate, L)).load_state_dict(net.state_dict())
+    edm = OracleEDM()
+    x = torch.from_numpy(seeded_normal(1, 0, L)).reshape(1, L) * 0.5
+    s = torch.full((1, 1), 0.5)
+    with torch.no_grad():
+        edm.denoiser(x, orc, s)
+        t0 = time.time()
+        for _ in range(n_timed):
+            edm.denoiser(x, orc, s)
+        dt = (time.time() - t0) / n_timed
+    return {"value": round(1.0 / dt, 4), "unit": "denoiser-evals/s", "cores": cores, "kind": "port",
+            "sample": f"B=1 full-size 22.05 kHz network, forward-only (xi=0) evaluations: 1 warm-up + {n_timed} timed, "
+                      f"{dt:.2f} s each, torch {torch.__version__} CPU fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="segments per GPU")
+    ap.add_argument("--xi", type=float, default=0.0, help="0 = replacement branch (forward only); 0.25 = guided (reference default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    from audio_inpainting_diffusion_amd import dist as D
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    from audio_inpainting_diffusion_amd.sampler import Sampler
+
+    rank, local, world = D.init_distributed()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    T = 36
+    assert a.warmup + a.steps <= T - 1, "timed steps must be Heun steps (the last step of the schedule is Euler)"
+    args = make_args("maestro22k", audio_len=184184, T=T, gap_ms=300.0, xi=a.xi)
+    L, B = args.exp.audio_len, a.batch
+
+    net = Unet_CQT_oct_with_attention(args, dev)
+    if rank == 0:
+        seeded_init_(net, 0)                       # reference-scale gates (1e-7), like a fresh reference network
+    t0 = time.time()
+    nbytes = D.broadcast_parameters(net, src=0)    # RCCL broadcast of the flat fp32 weight buffer over xGMI
+    torch.cuda.synchronize()
+    t_bcast = time.time() - t0
+    net.prepare()
+
+    lo, hi = D.shard_range(world * B, rank, world)
+    y = torch.stack([torch.from_numpy(seeded_normal(7, g, L)) for g in range(lo, hi)]) * 0.063
+    gap = int(300.0 * args.exp.sample_rate / 1000)
+    start = L // 2 - gap // 2                       # tester_inpainting.py:231-254
+    mask = torch.ones(1, L)
+    mask[:, start:start + gap] = 0
+    smp = Sampler(model=net, diff_params=EDM(args), args=args)
+    smp.seeds = D.item_seeds(1234, lo, hi)
+    smp.mask = mask.to(dev)
+    smp.y = (y * mask).to(dev).contiguous()
+    from audio_inpainting_diffusion_amd.sampler import prepare_smooth_mask
+    smp.smask = prepare_smooth_mask(mask, args.tester.data_consistency.hann_size).to(dev).contiguous()
+
+    state = smp.begin((B, L), dev)
+    for i in range(a.warmup):
+        smp.step(state, i)
+    st = net._state(B)
+    timing = []
+    st["plan_body"].timing = timing
+    torch.cuda.synchronize()
+    D.barrier()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, a.warmup + a.steps):
+        smp.step(state, i)
+    torch.cuda.synchronize()
+    D.barrier()
+    wall = time.perf_counter() - t0
+    st["plan_body"].timing = None
+    wall = D.max_over_ranks(wall, dev)
+    assert torch.isfinite(state["x"]).all()
+
+    conv_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in timing)
+    conv_flops = sum(f for _, _, f in timing)
+    evals = world * B * 2 * a.steps
+    if rank == 0:
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        out = {
+            "metric": "denoiser-steps/sec", "value": round(evals / wall, 3), "unit": "denoiser evaluations (one segment each) per second, whole job",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * wall / a.steps, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: batch 8 x 22.05 kHz MAESTRO-shape segments (L=184184) per GPU, 300 ms gap, "
+                                   "T=36 EDM schedule, Heun steps %d..%d" % (a.warmup, a.warmup + a.steps - 1),
+                       "branch": "xi=%g (%s)" % (a.xi, "reconstruction guidance: forward + input-VJP" if a.xi > 0 else "replacement / data-consistency: forward only"),
+                       "segments_per_gpu": B, "evals_per_step": 2, "network": "unet_cqt_oct_with_attention 22 kHz, 186.3 M params, random-init (seeded)",
+                       "parallelism": "segments sharded %d-way, one process per GPU, weights broadcast once (%.0f MB in %.3f s), no collective in the loop" % (world, nbytes / 1e6, t_bcast)},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (aid_conv2d, fp32 v_mfma_f32_32x32x2_f32)",
+                         "achieved": round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 4),
+                         "traffic": None, "launches": len(timing), "avg_launch_us": round(1e3 * conv_ms / max(1, len(timing)), 1),
+                         "algorithmic_gflop_per_launch": round(conv_flops / max(1, len(timing)) / 1e9, 2),
+                         "conv_time_fraction_of_wall": round(conv_ms * 1e-3 / wall, 3)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(net, args)
+            out["cpu_baseline"]["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    D.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -47,7 +47,7 @@ class Conv2dParams(C.Structure):
 
 class ResampleParams(C.Structure):
     _fields_ = [("x", View), ("y", View), ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int),
-                ("up", C.c_int), ("adjoint", C.c_int)]
+                ("up", C.c_int), ("adjoint", C.c_int), ("accumulate", C.c_int)]
 
 
 class AttentionParams(C.Structure):
@@ -73,14 +73,15 @@ class CqtTables(C.Structure):
 
 class CqtParams(C.Structure):
     _fields_ = [("tab", CqtTables), ("T_host", C.c_int * AID_CQT_MAX_OCT), ("oct", View * AID_CQT_MAX_OCT),
-                ("spec", C.c_void_p), ("band_ws", C.c_void_p), ("in_scale", C.c_void_p), ("B", C.c_int), ("Lh", C.c_int)]
+                ("spec", C.c_void_p), ("band_ws", C.c_void_p), ("in_scale", C.c_void_p), ("B", C.c_int), ("Lh", C.c_int),
+                ("unnormalized", C.c_int)]
 
 
 class CqtGatherParams(C.Structure):
     _fields_ = [("band_ws", C.c_void_p), ("kfirst", C.c_void_p), ("kcount", C.c_void_p),
                 ("rc", C.c_void_p), ("Lg", C.c_void_p), ("goff", C.c_void_p), ("woff", C.c_void_p), ("Tk", C.c_void_p),
                 ("gdM", C.c_void_p), ("X", C.c_void_p), ("cskip", C.c_void_p), ("cout", C.c_void_p), ("hpf", C.c_void_p),
-                ("Y", C.c_void_p), ("B", C.c_int), ("Lh", C.c_int), ("ws_per_b", C.c_int64)]
+                ("Y", C.c_void_p), ("B", C.c_int), ("Lh", C.c_int), ("ws_per_b", C.c_int64), ("band_scale", C.c_void_p)]
 
 
 class AxpbyParams(C.Structure):
@@ -100,9 +101,36 @@ class Add2Params(C.Structure):
                 ("a", C.c_float), ("b", C.c_float)]
 
 
+class GroupDotParams(C.Structure):
+    _fields_ = [("u", View), ("v", View), ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("groups", C.c_int),
+                ("ws", C.c_void_p)]
+
+
+class NormBwdParams(C.Structure):
+    _fields_ = [("gd", View), ("x", View), ("gy", View), ("out", View),
+                ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("groups", C.c_int),
+                ("stats", C.c_void_p), ("ws", C.c_void_p), ("eps", C.c_float), ("a", C.c_float), ("accumulate", C.c_int)]
+
+
+class AttentionBwdParams(C.Structure):
+    _fields_ = [("qk", C.c_void_p), ("v", C.c_void_p), ("probs", C.c_void_p), ("gout", C.c_void_p),
+                ("gqk", C.c_void_p), ("gv", C.c_void_p), ("B", C.c_int), ("H", C.c_int), ("F", C.c_int), ("T", C.c_int),
+                ("scale", C.c_float), ("accumulate_gv", C.c_int)]
+
+
+class GuidanceSeedParams(C.Structure):
+    _fields_ = [("xhat", C.c_void_p), ("y", C.c_void_p), ("mask", C.c_void_p), ("mask_sB", C.c_int64),
+                ("g", C.c_void_p), ("norm", C.c_void_p), ("B", C.c_int), ("L", C.c_int64)]
+
+
+class RowNormParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("B", C.c_int), ("L", C.c_int64)]
+
+
 EXPORTS = ["aid_abi_version", "aid_last_error", "aid_group_stats", "aid_conv2d", "aid_conv2d_pack_dims", "aid_resample",
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
-           "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2"]
+           "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
+           "aid_time_attention_bwd", "aid_guidance_seed", "aid_row_norm"]
 
 _lib = None
 
@@ -193,11 +221,11 @@ def pack_conv_weight(w: torch.Tensor, transpose: bool = False) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------------------
 # CQT launch helpers (used by cqt.CQTransform)
 # ---------------------------------------------------------------------------------------------------------
-def _cqt_params(tr, tab, octs: Sequence[torch.Tensor]) -> CqtParams:
+def _cqt_params(tr, tab, octs: Sequence[torch.Tensor], window: Optional[torch.Tensor] = None) -> CqtParams:
     P = tr.plan
     p = CqtParams()
-    p.tab = CqtTables(P.numocts, P.binsoct, ptr(tab["rc"]), ptr(tab["Lg"]), ptr(tab["goff"]), ptr(tab["g"]),
-                      ptr(tab["T_oct"]), ptr(tab["twiddle"]), P.Tmax)
+    p.tab = CqtTables(P.numocts, P.binsoct, ptr(tab["rc"]), ptr(tab["Lg"]), ptr(tab["goff"]),
+                      ptr(tab["g"] if window is None else window), ptr(tab["T_oct"]), ptr(tab["twiddle"]), P.Tmax)
     for o in range(P.numocts):
         p.T_host[o] = int(P.T_oct[o])
         t = octs[o]
@@ -206,15 +234,19 @@ def _cqt_params(tr, tab, octs: Sequence[torch.Tensor]) -> CqtParams:
         p.oct[o] = View(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
     p.B = octs[0].shape[0]
     p.Lh = P.Lh
+    p.unnormalized = 0
     return p
 
 
-def cqt_analysis(tr, tab, spec_ri: torch.Tensor, octs, in_scale=None):
+def cqt_analysis(tr, tab, spec_ri: torch.Tensor, octs, in_scale=None, window=None, unnormalized=False):
+    """spec [B,Lh,2] -> planar octave views.  window=None: analysis windows g (forward transform);
+    window=gdM + unnormalized: exact adjoint of synthesis+gather (input-VJP)."""
     _req(spec_ri)
     assert spec_ri.is_contiguous()
-    p = _cqt_params(tr, tab, octs)
+    p = _cqt_params(tr, tab, octs, window)
     p.spec = spec_ri.data_ptr()
     p.in_scale = ptr(in_scale)
+    p.unnormalized = int(unnormalized)
     call("aid_cqt_analysis", p)
 
 
@@ -224,9 +256,11 @@ def cqt_synthesis(tr, tab, octs, ws: torch.Tensor):
     call("aid_cqt_synthesis", p)
 
 
-def cqt_gather(tr, tab, ws, Y, X=None, cskip=None, cout=None, hpf=None):
+def cqt_gather(tr, tab, ws, Y, X=None, cskip=None, cout=None, hpf=None, window=None, band_scale=None):
+    """Y = hpf * (cskip*X + cout * band_scale * sum_k ws_k * window_k).  window=None: dual windows gdM (forward
+    synthesis); window = g/T_k: adjoint of the analysis."""
     P = tr.plan
     p = CqtGatherParams(ptr(ws), ptr(tab["kfirst"]), ptr(tab["kcount"]), ptr(tab["rc"]), ptr(tab["Lg"]),
-                        ptr(tab["goff"]), ptr(tab["woff"]), ptr(tab["Tk"]), ptr(tab["gdM"]), ptr(X), ptr(cskip),
-                        ptr(cout), ptr(hpf), Y.data_ptr(), Y.shape[0], P.Lh, P.ws_per_b)
+                        ptr(tab["goff"]), ptr(tab["woff"]), ptr(tab["Tk"]), ptr(tab["gdM"] if window is None else window),
+                        ptr(X), ptr(cskip), ptr(cout), ptr(hpf), Y.data_ptr(), Y.shape[0], P.Lh, P.ws_per_b, ptr(band_scale))
     call("aid_cqt_gather", p)

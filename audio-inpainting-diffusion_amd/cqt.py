@@ -100,6 +100,12 @@ class CQTPlan:
         kend = np.searchsorted(lo, v, side="right")
         self.kfirst = kfirst.astype(np.int32)
         self.kcount = np.maximum(kend - kfirst, 0).astype(np.int32)
+        # adjoint-path tables (input-VJP): analysis adjoint uses g/T_k in the gather; rfft/irfft adjoint weights
+        self.g_over_T = (self.g / np.repeat(self.Tk.astype(np.float64), self.Lg)).astype(np.float32)
+        wv = np.full(self.Lh, 2.0)
+        wv[0] = wv[-1] = 1.0
+        self.w_over_L = (wv / L).astype(np.float32)      # d irfft / dY_v  (real inner product)  = w_v/L * rfft(g)_v
+        self.L_over_w = (L / wv).astype(np.float32)      # adjoint of rfft expressed through irfft
         self.Tmax = int(max(T_oct))
         m = np.arange(self.Tmax // 2, dtype=np.float64)
         tw = np.exp(-2j * np.pi * m / self.Tmax)
@@ -125,6 +131,7 @@ class CQTransform:
             t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
             self._dev = dict(device=device, rc=t(P.rc), Lg=t(P.Lg), goff=t(P.goff), g=t(P.g), gdM=t(P.gdM), Tk=t(P.Tk),
                              woff=t(P.woff), kfirst=t(P.kfirst), kcount=t(P.kcount), twiddle=t(P.twiddle), hpf=t(P.hpf),
+                             g_over_T=t(P.g_over_T), w_over_L=t(P.w_over_L), L_over_w=t(P.L_over_w),
                              T_oct=t(np.array(P.T_oct, dtype=np.int32)))
         return self._dev
 
@@ -154,6 +161,35 @@ class CQTransform:
         _lib.cqt_gather(self, tab, ws, Y, None if X is None else torch.view_as_real(X), cskip, cout, tab["hpf"] if hpf else None)
         return torch.view_as_complex(Y)
 
+    # ---- exact adjoints (input-VJP of the guidance branch) -------------------------------------------------
+    def synthesis_adjoint(self, gY: torch.Tensor, gouts: Sequence[torch.Tensor]):
+        """gY[B,Lh] complex = gradient w.r.t. the band-sum spectrum (real inner product) -> WRITES the gradients
+        w.r.t. the planar octave tensors into ``gouts``.  (= analysis kernel with the dual windows, no 1/T.)"""
+        from . import _lib
+        tab = self._tables(gY.device)
+        _lib.cqt_analysis(self, tab, torch.view_as_real(gY.contiguous()), gouts, None, window=tab["gdM"], unnormalized=True)
+
+    def analysis_adjoint(self, gocts: Sequence[torch.Tensor], in_scale=None, X=None, cskip=None):
+        """gradients w.r.t. the planar octave tensors -> S[B,Lh] complex with irfft(S) = gradient w.r.t. the
+        time-domain input of ``analysis`` (times in_scale), plus cskip*X if given."""
+        from . import _lib
+        B, dev = gocts[0].shape[0], gocts[0].device
+        tab = self._tables(dev)
+        ws = torch.empty(B, self.plan.ws_per_b, 2, device=dev, dtype=torch.float32)
+        _lib.cqt_synthesis(self, tab, gocts, ws)
+        S = torch.empty(B, self.plan.Lh, 2, device=dev, dtype=torch.float32)
+        _lib.cqt_gather(self, tab, ws, S, None if X is None else torch.view_as_real(X.contiguous()), cskip, in_scale, None,
+                        window=tab["g_over_T"], band_scale=tab["L_over_w"])
+        return torch.view_as_complex(S)
+
+    def spectrum_scale(self, X: torch.Tensor, table: Optional[torch.Tensor], per_item=None) -> torch.Tensor:
+        """Y = table[v] * per_item[b] * X  (either factor optional) through the gather kernel."""
+        from . import _lib
+        tab = self._tables(X.device)
+        Y = torch.empty(X.shape[0], self.plan.Lh, 2, device=X.device, dtype=torch.float32)
+        _lib.cqt_gather(self, tab, None, Y, torch.view_as_real(X.contiguous()), per_item, None, table)
+        return torch.view_as_complex(Y)
+
     # ---- reference call surface --------------------------------------------------------------------------
     def fwd(self, x: torch.Tensor) -> List[torch.Tensor]:
         """x[B,1,L] -> list (lowest octave first) of complex64 [B,1,bins,T_o]   (unet...py:743)"""
@@ -169,6 +205,24 @@ class CQTransform:
         return torch.fft.irfft(Y, n=self.Ls, dim=-1).unsqueeze(1)
 
     def apply_hpf_DC(self, x: torch.Tensor) -> torch.Tensor:
-        """x[B,L] minus its DC- and Nyquist-band frame components (edm_sampler_inpainting.py:63,123)."""
+        """x[B,L] minus its DC- and Nyquist-band frame components (edm_sampler_inpainting.py:63,123).
+        Differentiable: the projector is a real symmetric spectral multiplier, hence self-adjoint."""
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _HpfFn.apply(x, self)
+        return self._hpf(x)
+
+    def _hpf(self, x):
         tab = self._tables(x.device)
-        return torch.fft.irfft(torch.fft.rfft(x, dim=-1) * tab["hpf"], n=self.Ls, dim=-1)
+        X = torch.fft.rfft(x.detach().float().contiguous(), dim=-1)
+        return torch.fft.irfft(self.spectrum_scale(X, tab["hpf"]), n=self.Ls, dim=-1)
+
+
+class _HpfFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, tr):
+        ctx.tr = tr
+        return tr._hpf(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.tr._hpf(g), None

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(CQT_THREADS) void cqt_analysis_kernel(const aid_cqt
     }
     __syncthreads();
     float2* R = lds_fft(A, Bf, T, p.tab.Tmax, reinterpret_cast<const float2*>(p.tab.twiddle), +1.f);
-    float sc = 1.0f / (float)T;
+    float sc = p.unnormalized ? 1.0f : 1.0f / (float)T;
     if (p.in_scale) sc *= p.in_scale[b];
     const aid_view& v = p.oct[o];
     float* re = v.p + (int64_t)b * v.sB + (int64_t)bin * v.sF;
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void cqt_gather_kernel(const aid_cqt_gather_pa
             acc.y += c.y * w;
         }
         if (p.cout) { const float co = p.cout[b]; acc.x *= co; acc.y *= co; }
+        if (p.band_scale) { const float bs = p.band_scale[v]; acc.x *= bs; acc.y *= bs; }
     }
     if (p.X) {
         const float2 x = reinterpret_cast<const float2*>(p.X)[(int64_t)b * p.Lh + v];

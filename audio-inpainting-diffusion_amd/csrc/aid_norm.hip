@@ -93,3 +93,122 @@ extern "C" int aid_group_stats(const aid_group_stats_params* p, void* stream) {
     AID_CHECK_LAUNCH();
     return AID_OK;
 }
+
+// =====================================================================================================
+// Input-VJP side: <u,v> per (sample, group) and the normalisation backward.
+// =====================================================================================================
+struct DotDev { aid_group_dot_params p; int cg, nrows, lpr_log2; };
+
+__global__ __launch_bounds__(256) void group_dot_partial(const DotDev a) {
+    const aid_group_dot_params& p = a.p;
+    const int bg = blockIdx.x, split = blockIdx.y;
+    const int b = bg / p.groups, g = bg - b * p.groups;
+    const int tid = threadIdx.x;
+    const int lpr = 1 << a.lpr_log2;
+    const int sub = tid >> a.lpr_log2, lq = tid & (lpr - 1);
+    const int rpp = 256 >> a.lpr_log2;
+    const int r_begin = (int)(((int64_t)a.nrows * split) / AID_STATS_SPLIT);
+    const int r_end = (int)(((int64_t)a.nrows * (split + 1)) / AID_STATS_SPLIT);
+    const int tq = p.T >> 2;
+    double s = 0.0;
+    for (int r = r_begin + sub; r < r_end; r += rpp) {
+        const int c = g * a.cg + r / p.F;
+        const int f = r % p.F;
+        const float* ru = p.u.p + (int64_t)b * p.u.sB + (int64_t)c * p.u.sC + (int64_t)f * p.u.sF;
+        const float* rv = p.v.p + (int64_t)b * p.v.sB + (int64_t)c * p.v.sC + (int64_t)f * p.v.sF;
+        for (int q = lq; q < tq; q += lpr) {
+            const float4 x = *reinterpret_cast<const float4*>(ru + 4 * q);
+            const float4 y = *reinterpret_cast<const float4*>(rv + 4 * q);
+            s += (double)x.x * y.x + (double)x.y * y.y + (double)x.z * y.z + (double)x.w * y.w;
+        }
+    }
+    __shared__ double red[4];
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) p.ws[(int64_t)bg * AID_STATS_SPLIT + split] = red[0] + red[1] + red[2] + red[3];
+}
+
+extern "C" int aid_group_dot(const aid_group_dot_params* p, void* stream) {
+    AID_REQUIRE(p && p->u.p && p->v.p && p->ws, "aid_group_dot: null pointer");
+    AID_REQUIRE(p->groups > 0 && p->C % p->groups == 0 && (p->T % 4) == 0, "aid_group_dot: bad shape");
+    DotDev a;
+    a.p = *p;
+    a.cg = p->C / p->groups;
+    a.nrows = a.cg * p->F;
+    int lpr = aid_pow2ceil(p->T / 4);
+    if (lpr > 256) lpr = 256;
+    a.lpr_log2 = aid_ilog2(lpr);
+    hipLaunchKernelGGL(group_dot_partial, dim3(p->B * p->groups, AID_STATS_SPLIT), dim3(256), 0, (hipStream_t)stream, a);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}
+
+struct NbDev { aid_norm_bwd_params p; int cg, lpr_log2, nrows, tiles; float* coef; };
+
+// coef[b,g] = <gd,x>_g * inv / ((n-1) * std)   (written into the tail of the ws buffer as floats)
+__global__ void norm_bwd_coef(const NbDev a) {
+    const aid_norm_bwd_params& p = a.p;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.B * p.groups) return;
+    double d = 0.0;
+    for (int k = 0; k < AID_STATS_SPLIT; ++k) d += p.ws[(int64_t)i * AID_STATS_SPLIT + k];
+    const double inv = (double)p.stats[2 * i + 1];
+    const double sd = 1.0 / inv - (double)p.eps;
+    const double n = (double)a.cg * p.F * p.T;
+    a.coef[i] = (sd > 0.0) ? (float)(d * inv / ((n - 1.0) * sd)) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const NbDev a) {
+    const aid_norm_bwd_params& p = a.p;
+    const int tid = threadIdx.x;
+    const int lpr = 1 << a.lpr_log2;
+    const int sub = tid >> a.lpr_log2, lq = tid & (lpr - 1);
+    const int rpb = 256 >> a.lpr_log2;
+    const int tile = blockIdx.x % a.tiles;
+    const int row = (blockIdx.x / a.tiles) * rpb + sub;
+    if (row >= a.nrows) return;
+    const int o4 = (tile * lpr + lq) * 4;
+    if (o4 >= p.T) return;
+    const int f = row % p.F;
+    const int bc = row / p.F;
+    const int c = bc % p.C;
+    const int b = bc / p.C;
+    const int bg = b * p.groups + c / a.cg;
+    const float coef = a.coef[bg];
+    const float mean = p.stats[2 * bg];
+    const float4 gd = *reinterpret_cast<const float4*>(p.gd.p + (int64_t)b * p.gd.sB + (int64_t)c * p.gd.sC + (int64_t)f * p.gd.sF + o4);
+    const float4 x = *reinterpret_cast<const float4*>(p.x.p + (int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)f * p.x.sF + o4);
+    float4 r = make_float4(gd.x - coef * (x.x - mean), gd.y - coef * (x.y - mean), gd.z - coef * (x.z - mean), gd.w - coef * (x.w - mean));
+    if (p.gy.p) {
+        const float4 gy = *reinterpret_cast<const float4*>(p.gy.p + (int64_t)b * p.gy.sB + (int64_t)c * p.gy.sC + (int64_t)f * p.gy.sF + o4);
+        r.x += p.a * gy.x; r.y += p.a * gy.y; r.z += p.a * gy.z; r.w += p.a * gy.w;
+    }
+    float* o = p.out.p + (int64_t)b * p.out.sB + (int64_t)c * p.out.sC + (int64_t)f * p.out.sF + o4;
+    if (p.accumulate) {
+        const float4 old = *reinterpret_cast<const float4*>(o);
+        r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w;
+    }
+    *reinterpret_cast<float4*>(o) = r;
+}
+
+extern "C" int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream) {
+    AID_REQUIRE(p && p->gd.p && p->x.p && p->out.p && p->stats && p->ws, "aid_norm_bwd: null pointer");
+    AID_REQUIRE(p->groups > 0 && p->C % p->groups == 0 && (p->T % 4) == 0, "aid_norm_bwd: bad shape");
+    NbDev a;
+    a.p = *p;
+    a.cg = p->C / p->groups;
+    // coefficients live right behind the dot partials in the caller's scratch (ws holds B*groups*SPLIT*2 doubles)
+    a.coef = reinterpret_cast<float*>(const_cast<double*>(p->ws) + (int64_t)p->B * p->groups * AID_STATS_SPLIT);
+    int lpr = aid_pow2ceil(p->T / 4);
+    if (lpr > 256) lpr = 256;
+    a.lpr_log2 = aid_ilog2(lpr);
+    a.nrows = p->B * p->C * p->F;
+    a.tiles = aid_cdiv(p->T / 4, lpr);
+    const int rpb = 256 / lpr;
+    hipLaunchKernelGGL(norm_bwd_coef, dim3(aid_cdiv(p->B * p->groups, 64)), dim3(64), 0, (hipStream_t)stream, a);
+    AID_CHECK_LAUNCH();
+    hipLaunchKernelGGL(norm_bwd_kernel, dim3((unsigned)(aid_cdiv(a.nrows, rpb) * a.tiles)), dim3(256), 0, (hipStream_t)stream, a);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}

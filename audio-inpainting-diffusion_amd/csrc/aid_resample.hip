@@ -96,7 +96,12 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResDev a) {
         else if (MODE == 2) v[e] = down_adj_at(x, a.Tout, o);   // x holds g (T/2 entries), Tout = T of the down input
         else v[e] = up_adj_at(x, a.Tout, o);                     // x holds g (2T entries), Tout = T of the up input
     }
-    *reinterpret_cast<float4*>(y + o4) = make_float4(v[0], v[1], v[2], v[3]);
+    float4 r = make_float4(v[0], v[1], v[2], v[3]);
+    if (p.accumulate) {
+        const float4 o = *reinterpret_cast<const float4*>(y + o4);
+        r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+    }
+    *reinterpret_cast<float4*>(y + o4) = r;
 }
 
 extern "C" int aid_resample(const aid_resample_params* p, void* stream) {

@@ -94,3 +94,59 @@ extern "C" int aid_add2(const aid_add2_params* p, void* stream) {
     AID_CHECK_LAUNCH();
     return AID_OK;
 }
+
+// ---- per-item L2 norms and the analytic seed of the reconstruction-guidance gradient --------------------
+__device__ __forceinline__ double block_sum_1024(double v) {
+    __shared__ double red[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) { for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i]; red[0] = t; }
+    __syncthreads();
+    t = red[0];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void row_norm_kernel(const aid_row_norm_params p) {
+    const int b = blockIdx.x;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < p.L; i += 1024) { const double v = p.x[(int64_t)b * p.L + i]; s += v * v; }
+    s = block_sum_1024(s);
+    if (threadIdx.x == 0) p.out[b] = (float)sqrt(s);
+}
+
+extern "C" int aid_row_norm(const aid_row_norm_params* p, void* stream) {
+    AID_REQUIRE(p && p->x && p->out, "aid_row_norm: null pointer");
+    hipLaunchKernelGGL(row_norm_kernel, dim3(p->B), dim3(1024), 0, (hipStream_t)stream, *p);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}
+
+__global__ __launch_bounds__(1024) void guidance_seed_kernel(const aid_guidance_seed_params p) {
+    const int b = blockIdx.x;
+    const float* m = p.mask + (int64_t)b * p.mask_sB;
+    const int64_t base = (int64_t)b * p.L;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < p.L; i += 1024) {
+        const double r = (double)p.y[base + i] - (double)(m[i] * p.xhat[base + i]);
+        s += r * r;
+    }
+    s = block_sum_1024(s);
+    const float nrm = (float)sqrt(s);
+    if (threadIdx.x == 0) p.norm[b] = nrm;
+    const float inv = nrm > 0.f ? 1.0f / nrm : 0.f;
+    for (int64_t i = threadIdx.x; i < p.L; i += 1024) {
+        const float mi = m[i];
+        p.g[base + i] = -mi * (p.y[base + i] - mi * p.xhat[base + i]) * inv;
+    }
+}
+
+extern "C" int aid_guidance_seed(const aid_guidance_seed_params* p, void* stream) {
+    AID_REQUIRE(p && p->xhat && p->y && p->mask && p->g && p->norm, "aid_guidance_seed: null pointer");
+    hipLaunchKernelGGL(guidance_seed_kernel, dim3(p->B), dim3(1024), 0, (hipStream_t)stream, *p);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}

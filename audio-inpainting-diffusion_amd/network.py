@@ -154,7 +154,33 @@ class _Builder:
         self.plan = _Plan()
         self.nbytes = 0
         self.stats_ws = torch.empty(B * 8 * _lib.AID_STATS_SPLIT * 2, device=device, dtype=torch.float64)
-        self.saved = []   # per fused step: dict with what the input-VJP needs
+        self.bwd = []          # closures emitting the VJP ops of each forward op (run in reverse by finish_backward)
+        self.bplan = None
+        self.gmap = {}         # storage data_ptr -> flat gradient storage of the same size
+        self.scratch = {}      # shape -> scratch tensor for dgrad outputs awaiting the normalisation backward
+
+    # ---- gradient storage: one flat buffer per activation storage, views share strides/offsets ------------
+    def G(self, t):
+        st = t.untyped_storage()
+        g = self.gmap.get(st.data_ptr())
+        if g is None:
+            g = self.gmap[st.data_ptr()] = torch.zeros(st.nbytes() // 4, device=self.device, dtype=torch.float32)
+            self.nbytes += g.numel() * 4
+        return g.as_strided(t.size(), t.stride(), t.storage_offset())
+
+    def _scratch(self, shape):
+        t = self.scratch.get(tuple(shape))
+        if t is None:
+            t = self.scratch[tuple(shape)] = self.buf(*shape)
+        return t
+
+    def finish_backward(self):
+        """Emit the reverse sweep (input-VJP) into ``self.bplan``."""
+        fwd_plan, self.plan = self.plan, _Plan()
+        for emit in reversed(self.bwd):
+            emit()
+        self.bplan, self.plan = self.plan, fwd_plan
+        return self.bplan
 
     def buf(self, *shape):
         t = torch.empty(*shape, device=self.device, dtype=torch.float32)
@@ -163,43 +189,99 @@ class _Builder:
 
     # ---- op emitters ---------------------------------------------------------------------------------
     def stats(self, x, gamma, mod, scale, stats=None):
+        """group statistics of x -> per-(b,c) scale (+ saved mean / inverse std for the VJP)."""
         B, Cc, F, T = x.shape
         p = _lib.GroupStatsParams(_lib.view4(x), B, Cc, F, T, 8, gamma.data_ptr(), _lib.ptr(mod),
                                   0 if mod is None else mod.stride(0), 1e-7, scale.data_ptr(), _lib.ptr(stats),
                                   self.stats_ws.data_ptr())
         self.plan.add("aid_group_stats", p, x, gamma, mod, scale, stats)
 
-    def conv(self, x, y, wp, cin, cout, kh=1, kw=1, dil=1, in_scale=None, act=0, out_scale=None, res=None,
-             res_scale=1.0, alpha=1.0):
+    def _conv_raw(self, x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha, epi=0,
+                  aux=None, aux_scale=None):
         B, _, F, T = x.shape
         assert x.shape[1] == cin and y.shape[1] == cout and y.shape[0] == B and y.shape[2] == F and y.shape[3] == T
         p = _lib.Conv2dParams()
-        p.x, p.y, p.res, p.aux = _lib.view4(x), _lib.view4(y), _lib.view4(res), _lib.view4(None)
+        p.x, p.y, p.res, p.aux = _lib.view4(x), _lib.view4(y), _lib.view4(res), _lib.view4(aux)
         p.wp = wp.data_ptr()
         p.in_scale, p.in_scale_ld = _lib.ptr(in_scale), (0 if in_scale is None else in_scale.stride(0))
         p.out_scale, p.out_scale_ld = _lib.ptr(out_scale), (0 if out_scale is None else out_scale.stride(0))
-        p.aux_scale, p.aux_scale_ld = None, 0
+        p.aux_scale, p.aux_scale_ld = _lib.ptr(aux_scale), (0 if aux_scale is None else aux_scale.stride(0))
         p.B, p.Cin, p.Cout, p.F, p.T = B, cin, cout, F, T
         p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
-        p.KH, p.KW, p.dilF, p.act, p.epi = kh, kw, dil, act, 0
+        p.KH, p.KW, p.dilF, p.act, p.epi = kh, kw, dil, act, epi
         p.alpha, p.res_scale = alpha, res_scale
         assert wp.shape[0] == kh * kw
-        self.plan.add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale, flops=2 * B * F * T * cin * cout * kh * kw)
+        self.plan.add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale, aux, aux_scale, flops=2 * B * F * T * cin * cout * kh * kw)
 
-    def add2(self, u, v, y, a, b):
+    def conv(self, x, y, wp, cin, cout, kh=1, kw=1, dil=1, in_scale=None, act=0, out_scale=None, res=None,
+             res_scale=1.0, alpha=1.0, wpT=None, norm_stats=None):
+        """Forward conv + registration of its input-VJP.  ``norm_stats``: the (mean, 1/(std+eps)) buffer when
+        ``in_scale`` was produced by ``stats`` from this same ``x`` (the scale then depends on x)."""
+        self._conv_raw(x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha)
+        if wpT is None:
+            return
+
+        def bw():
+            gy = self.G(y)
+            B, _, F, T = x.shape
+            fused_res = (norm_stats is not None) and (res is x)
+            if res is not None and not fused_res:
+                gr = self.G(res)
+                self.add2_raw(gr, gy, gr, 1.0, alpha * res_scale)
+            if norm_stats is not None:
+                gd = self._scratch(x.shape)
+                self._conv_raw(gy, gd, wpT, cout, cin, kh, kw, dil, out_scale, 0, in_scale, None, 1.0, alpha,
+                               epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None)
+                dp = _lib.GroupDotParams(_lib.view4(gd), _lib.view4(x), B, cin, F, T, 8, self.stats_ws.data_ptr())
+                self.plan.add("aid_group_dot", dp, gd, x)
+                npar = _lib.NormBwdParams(_lib.view4(gd), _lib.view4(x), _lib.view4(gy if fused_res else None), _lib.view4(self.G(x)),
+                                          B, cin, F, T, 8, norm_stats.data_ptr(), self.stats_ws.data_ptr(), 1e-7,
+                                          alpha * res_scale, 1)
+                self.plan.add("aid_norm_bwd", npar, gd, x, gy, norm_stats)
+            else:
+                gx = self.G(x)
+                self._conv_raw(gy, gx, wpT, cout, cin, kh, kw, dil, out_scale, 0, in_scale, gx, 1.0 / alpha, alpha,
+                               epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None)
+        self.bwd.append(bw)
+
+
+    def add2_raw(self, u, v, y, a, b):
         B, Cc, F, T = u.shape
         p = _lib.Add2Params(_lib.view4(u), _lib.view4(v), _lib.view4(y), B, Cc, F, T, a, b)
         self.plan.add("aid_add2", p, u, v, y)
 
-    def resample(self, x, y, up, adjoint=0):
+    def add2(self, u, v, y, a, b):
+        self.add2_raw(u, v, y, a, b)
+
+        def bw():
+            gy, gu, gv = self.G(y), self.G(u), self.G(v)
+            self.add2_raw(gu, gy, gu, 1.0, a)
+            self.add2_raw(gv, gy, gv, 1.0, b)
+        self.bwd.append(bw)
+
+    def _resample_raw(self, x, y, up, adjoint=0, accumulate=0):
         B, Cc, F, T = x.shape
-        p = _lib.ResampleParams(_lib.view4(x), _lib.view4(y), B, Cc, F, T, int(up), int(adjoint))
+        p = _lib.ResampleParams(_lib.view4(x), _lib.view4(y), B, Cc, F, T, int(up), int(adjoint), int(accumulate))
         self.plan.add("aid_resample", p, x, y)
 
-    def attention(self, qk, v, out, heads, F, T, probs=None):
+    def resample(self, x, y, up):
+        self._resample_raw(x, y, up)
+        self.bwd.append(lambda: self._resample_raw(self.G(y), self.G(x), up, adjoint=1, accumulate=1))
+
+    def attention(self, qk, v, out, heads, F, T):
         B = v.shape[0]
-        p = _lib.AttentionParams(qk.data_ptr(), v.data_ptr(), out.data_ptr(), _lib.ptr(probs), B, heads, F, T, float(F) ** -0.5)
+        probs = self.buf(B, heads, T, T)
+        scale = float(F) ** -0.5
+        p = _lib.AttentionParams(qk.data_ptr(), v.data_ptr(), out.data_ptr(), probs.data_ptr(), B, heads, F, T, scale)
         self.plan.add("aid_time_attention", p, qk, v, out, probs, flops=4 * B * heads * T * T * F)
+
+        def bw():
+            gq, gv, go = self.G(qk), self.G(v), self.G(out)
+            assert gq.is_contiguous() and gv.is_contiguous() and go.is_contiguous()
+            bp = _lib.AttentionBwdParams(qk.data_ptr(), v.data_ptr(), probs.data_ptr(), go.data_ptr(), gq.data_ptr(), gv.data_ptr(),
+                                         B, heads, F, T, scale, 1)
+            self.plan.add("aid_time_attention_bwd", bp, qk, v, probs, go, gq, gv, flops=10 * B * heads * T * T * F)
+        self.bwd.append(bw)
 
 
 # =========================================================================================================
@@ -337,42 +419,47 @@ class Unet_CQT_oct_with_attention(nn.Module):
         x = xin
         if hasattr(blk, "proj_in"):
             x = bd.buf(B, N, F, T)
-            bd.conv(xin, x, W[pfx + "proj_in.weight"], blk.dim, N)
+            bd.conv(xin, x, W[pfx + "proj_in.weight"], blk.dim, N, wpT=W[pfx + "proj_in.weight#T"])
         if blk.has_attn:
             H = blk.heads
             assert F == blk.fdim, "attention block built for a different number of frequency rows"
-            sc = bd.buf(B, N)
-            bd.stats(x, W[pfx + "norm2.gamma"], self._mod(st, pfx + "affine2"), sc)
+            sc, stb = bd.buf(B, N), bd.buf(B, 8, 2)
+            bd.stats(x, W[pfx + "norm2.gamma"], self._mod(st, pfx + "affine2"), sc, stb)
             xp = bd.buf(B, H, F, T)
-            bd.conv(x, xp, W[pfx + "attn_block.proj_in.weight"], N, H, in_scale=sc)
+            bd.conv(x, xp, W[pfx + "attn_block.proj_in.weight"], N, H, in_scale=sc, wpT=W[pfx + "attn_block.proj_in.weight#T"],
+                    norm_stats=stb)
             qk = bd.buf(B, 2 * H * F, 1, T)
-            bd.conv(xp.view(B, H * F, 1, T), qk, W[pfx + "attn_block.qk.weight"], H * F, 2 * H * F)
+            bd.conv(xp.view(B, H * F, 1, T), qk, W[pfx + "attn_block.qk.weight"], H * F, 2 * H * F,
+                    wpT=W[pfx + "attn_block.qk.weight#T"])
             att = bd.buf(B, H, F, T)
             bd.attention(qk, xp, att, H, F, T)
             x1 = bd.buf(B, N, F, T)
             bd.conv(att, x1, W[pfx + "attn_block.proj_out.weight"], H, N, out_scale=self._mod(st, pfx + "gate2"), res=x,
-                    alpha=RSQRT2)
+                    alpha=RSQRT2, wpT=W[pfx + "attn_block.proj_out.weight#T"])
             x = x1
         kh, kw = blk.ks
         for k in range(blk.num_dils):
-            sc = bd.buf(B, N)
-            bd.stats(x, W[pfx + f"norm.{k}.gamma"], self._mod(st, pfx + f"affine.{k}"), sc)
+            sc, stb = bd.buf(B, N), bd.buf(B, 8, 2)
+            bd.stats(x, W[pfx + f"norm.{k}.gamma"], self._mod(st, pfx + f"affine.{k}"), sc, stb)
             xn = bd.buf(B, N, F, T)
             bd.conv(x, xn, W[pfx + f"H.{k}.weight"], N, N, kh, kw, dil=(2 ** k if kh > 1 else 1), in_scale=sc, act=1,
-                    out_scale=self._mod(st, pfx + f"gate.{k}"), res=x, alpha=RSQRT2)
+                    out_scale=self._mod(st, pfx + f"gate.{k}"), res=x, alpha=RSQRT2, wpT=W[pfx + f"H.{k}.weight#T"],
+                    norm_stats=stb)
             x = xn
         if blk.proj_place == "after":
             assert hasattr(blk, "proj_out") and hasattr(blk, "res_conv")
             t1 = bd.buf(B, blk.dim_out, F, T)
             if prev_out is not None:   # (Xout + OutBlock(X))/sqrt2 folded in (unet...py:817)
-                bd.conv(xin, t1, W[pfx + "res_conv.weight"], blk.dim, blk.dim_out, res=prev_out, res_scale=SQRT2)
+                bd.conv(xin, t1, W[pfx + "res_conv.weight"], blk.dim, blk.dim_out, res=prev_out, res_scale=SQRT2,
+                        wpT=W[pfx + "res_conv.weight#T"])
                 a2 = 0.5
             else:
-                bd.conv(xin, t1, W[pfx + "res_conv.weight"], blk.dim, blk.dim_out)
+                bd.conv(xin, t1, W[pfx + "res_conv.weight"], blk.dim, blk.dim_out, wpT=W[pfx + "res_conv.weight#T"])
                 a2 = RSQRT2
-            bd.conv(x, yout, W[pfx + "proj_out.weight"], N, blk.dim_out, res=t1, alpha=a2)
+            bd.conv(x, yout, W[pfx + "proj_out.weight"], N, blk.dim_out, res=t1, alpha=a2, wpT=W[pfx + "proj_out.weight#T"])
         elif hasattr(blk, "res_conv"):
-            bd.conv(xin, yout, W[pfx + "res_conv.weight"], blk.dim, blk.dim_out, res=x, alpha=RSQRT2)
+            bd.conv(xin, yout, W[pfx + "res_conv.weight"], blk.dim, blk.dim_out, res=x, alpha=RSQRT2,
+                    wpT=W[pfx + "res_conv.weight#T"])
         else:
             bd.add2(x, xin, yout, RSQRT2, RSQRT2)
 
@@ -423,14 +510,14 @@ class Unet_CQT_oct_with_attention(nn.Module):
                 pyr = pyrL
             hs = D[i][:, Ns[i]:, :, :]
             self._emit_resblock(bd, st, f"downs.{i}.2.", self.downs[i][2], Xb[i], hs)
-            wpyr = W[f"downs.{i}.1.weight"]
+            wpyr, wpyrT = W[f"downs.{i}.1.weight"], W[f"downs.{i}.1.weight#T"]
             if i < n - 1:
                 Xd = bd.buf(B, Ns[i], Fl[i], Tl[i] // 2)
                 bd.resample(hs, Xd, up=0)
-                bd.conv(pyr, Xb[i + 1][:, :, bpo:, :], wpyr, 2, Ns[i], 5, 3, dil=1, res=Xd, alpha=RSQRT2)      # (:794)
+                bd.conv(pyr, Xb[i + 1][:, :, bpo:, :], wpyr, 2, Ns[i], 5, 3, dil=1, res=Xd, alpha=RSQRT2, wpT=wpyrT)   # (:794)
             else:
                 Xmid = bd.buf(B, Ns[i], Fl[i], Tl[i])
-                bd.conv(pyr, Xmid, wpyr, 2, Ns[i], 5, 3, dil=1, res=hs, alpha=RSQRT2)
+                bd.conv(pyr, Xmid, wpyr, 2, Ns[i], 5, 3, dil=1, res=hs, alpha=RSQRT2, wpT=wpyrT)
             pyr_prev = pyr
         # -- bottleneck (:800-804) --------------------------------------------------------------------------------
         Xcur = Xmid
@@ -460,6 +547,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
         st["nbytes"] = bd.nbytes
         st["flops"] = bd.plan.flops
         st["keep"] = (pyrL, D, Xb, bd.stats_ws)
+        st["builder"] = bd            # the input-VJP plan is emitted lazily (first guided evaluation)
         return st
 
     def _state(self, B: int):
@@ -513,6 +601,68 @@ class Unet_CQT_oct_with_attention(nn.Module):
         self._run_body(st, cnoise)
         Y = self.CQTransform.synthesis_spectrum(st["octs_out"], X=X, cskip=cskip, cout=cout, hpf=hpf)
         return torch.fft.irfft(Y, n=L, dim=-1)
+
+    # ---------------------------------------------------------------------------------------------------
+    # input-VJP (reconstruction guidance, testing/edm_sampler_inpainting.py:57-105)
+    # ---------------------------------------------------------------------------------------------------
+    def _bwd_plan(self, st):
+        if "plan_bwd" not in st:
+            bd = st["builder"]
+            st["plan_bwd"] = bd.finish_backward()
+            st["gin"] = [bd.G(t) for t in st["octs_in"]]
+            st["gout"] = [bd.G(t) for t in st["octs_out"]]
+            st["gzero"] = list(bd.gmap.values())
+            st["nbytes"] = bd.nbytes
+        return st["plan_bwd"]
+
+    @torch.no_grad()
+    def _body_vjp(self, st, gYsum):
+        """gYsum[B,Lh] complex: gradient w.r.t. the synthesis band-sum spectrum of the LAST forward of this batch
+        size -> fills the gradients of the analysis octave tensors (st['gin'])."""
+        plan = self._bwd_plan(st)
+        for g in st["gzero"]:
+            g.zero_()
+        self.CQTransform.synthesis_adjoint(gYsum, st["gout"])
+        plan.run()
+
+    @torch.no_grad()
+    def vjp(self, g_pred: torch.Tensor) -> torch.Tensor:
+        """d<g_pred, forward(inputs, sigma)>/d inputs for the most recent ``forward`` of this batch size."""
+        B, L = g_pred.shape
+        st = self._state(B)
+        tr = self.CQTransform
+        tab = tr._tables(g_pred.device)
+        G = torch.fft.rfft(g_pred.detach().float().contiguous(), dim=-1)
+        self._body_vjp(st, tr.spectrum_scale(G, tab["w_over_L"]))
+        S = tr.analysis_adjoint(st["gin"])
+        return torch.fft.irfft(S, n=L, dim=-1)
+
+    @torch.no_grad()
+    def denoise_guided(self, x, cnoise, cin, cskip, cout, hpf: bool, y, mask):
+        """Fused guided evaluation: x_hat = [hpf](cskip*x + cout*F(cin*x)) and
+        rec_grads = d/dx || y - mask*x_hat ||_2 (per item, edm_sampler_inpainting.py:60-81), computed with the
+        hand-written input-VJP instead of torch.autograd.  Returns (x_hat, rec_grads, norm[B])."""
+        self._check_input(x)
+        B, L = x.shape
+        st = self._state(B)
+        tr = self.CQTransform
+        tab = tr._tables(x.device)
+        X = tr.analysis(x.contiguous(), st["octs_in"], in_scale=cin)
+        self._run_body(st, cnoise)
+        Y = tr.synthesis_spectrum(st["octs_out"], X=X, cskip=cskip, cout=cout, hpf=hpf)
+        x_hat = torch.fft.irfft(Y, n=L, dim=-1)
+        g = torch.empty_like(x_hat)
+        norm = torch.empty(B, device=x.device, dtype=torch.float32)
+        m = mask if mask.dim() == 2 else mask.reshape(1, -1)
+        sp = _lib.GuidanceSeedParams(x_hat.data_ptr(), y.data_ptr(), m.data_ptr(), m.stride(0) if m.shape[0] > 1 else 0,
+                                     g.data_ptr(), norm.data_ptr(), B, L)
+        _lib.call("aid_guidance_seed", sp)
+        Gh = torch.fft.rfft(g, dim=-1)
+        if hpf:
+            Gh = tr.spectrum_scale(Gh, tab["hpf"])                       # the projector is self-adjoint
+        self._body_vjp(st, tr.spectrum_scale(Gh, tab["w_over_L"], per_item=cout))
+        S = tr.analysis_adjoint(st["gin"], in_scale=cin, X=Gh, cskip=cskip)
+        return x_hat, torch.fft.irfft(S, n=L, dim=-1), norm
 
     def flops_per_eval(self, B: int = 1) -> int:
         """Algorithmic conv/GEMM/attention FLOPs of one forward evaluation at batch B (2*MACs)."""

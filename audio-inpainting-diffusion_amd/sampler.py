@@ -108,18 +108,31 @@ class Sampler:
         return x_hat
 
     def _denoise_guided(self, x, t_i):
-        """Reconstruction guidance (:57-105), per item.  Differentiates through the network with torch.autograd;
-        the MI355X network supplies its own input-VJP (autograd.py)."""
+        """Reconstruction guidance (:57-105), per item.  With the MI355X network the gradient comes from its
+        hand-written input-VJP (network.denoise_guided); any other model goes through torch.autograd."""
         dp = self.diff_params
         B, L = x.shape
+        nrm = self.args.tester.posterior_sampling.norm
+        hpf = bool(self.args.tester.filter_out_cqt_DC_Nyq)
+        if self._fast() and hasattr(self.model, "denoise_guided") and nrm == 2:
+            s1 = t_i.reshape(1)
+            x_hat, rec_grads, _ = self.model.denoise_guided(
+                x, self._vec(dp.cnoise(s1), B, x.device), self._vec(dp.cin(s1), B, x.device), self._vec(dp.cskip(s1), B, x.device),
+                self._vec(dp.cout(s1), B, x.device), hpf, self.y, self.mask)
+            gn = torch.empty(B, device=x.device, dtype=torch.float32)
+            _lib.call("aid_row_norm", _lib.RowNormParams(rec_grads.data_ptr(), gn.data_ptr(), B, L))
+            normguide = gn / self.args.exp.audio_len ** 0.5                      # (:83) per item
+            s = -(float(t_i) * self.xi) / (normguide + 1e-6)                     # (:87), sign folded for the axpy
+            out = torch.empty_like(x_hat)
+            _lib.call("aid_axpby", _lib.AxpbyParams(x_hat.data_ptr(), rec_grads.data_ptr(), out.data_ptr(), None, s.data_ptr(), B, L))
+            return out                                                           # x_hat - s*rec_grads (:97)
         x = x.detach().requires_grad_()
         sig = t_i.reshape(1, 1).to(x.device).expand(B, 1)
         with torch.enable_grad():
             x_hat = dp.denoiser(x, self.model, sig)
-            if self.args.tester.filter_out_cqt_DC_Nyq:
+            if hpf:
                 x_hat = self.model.CQTransform.apply_hpf_DC(x_hat)
             den_rec = self.mask * x_hat
-            nrm = self.args.tester.posterior_sampling.norm
             if nrm == "smoothl1":
                 norm = torch.nn.functional.smooth_l1_loss(self.y, den_rec, reduction="none",
                                                           beta=self.args.tester.posterior_sampling.smoothl1_beta).sum(dim=1)

@@ -107,8 +107,9 @@ void aid_conv2d_pack_dims(int Cin, int Cout, int* Cin_pad, int* Cout_pad);
  * ------------------------------------------------------------------------------------------------- */
 typedef struct {
     aid_view x, y;
-    int B, C, F, T;        /* T = input length */
+    int B, C, F, T;        /* T = length of the tensor passed as x (for adjoint=1: the incoming gradient) */
     int up, adjoint;
+    int accumulate;        /* 1: y += result (gradient accumulation), 0: y = result */
 } aid_resample_params;
 int aid_resample(const aid_resample_params* p, void* stream);
 
@@ -166,6 +167,10 @@ int aid_modulation(const aid_modulation_params* p, void* stream);
  * aid_cqt_synthesis: coef octave views -> band spectra ws[b][k][T_o] = FFT_T(c_k)[.] (complex interleaved)
  * aid_cqt_gather   : Y[b][v] = hpf[v] * ( cskip[b] * X[b][v] + cout[b] * sum_k ws[b][k][(v-rc_k) mod T_o] * gdM_k[v-rc_k] )
  *     (X, cskip, cout, hpf optional) -- deterministic overlap-add, no atomics.
+ *
+ * The exact adjoints needed by the input-VJP re-use the same three kernels with other window tables:
+ *   adjoint(synthesis+gather) = aid_cqt_analysis with g := gdM and unnormalized = 1;
+ *   adjoint(analysis)         = aid_cqt_synthesis + aid_cqt_gather with gdM := g / T_k.
  * ------------------------------------------------------------------------------------------------- */
 typedef struct {
     int n_oct, bins;                 /* octaves, bins per octave                       */
@@ -187,6 +192,7 @@ typedef struct {
     float* band_ws;                  /* synthesis: out [B, sum_o bins*T_o, 2]            */
     const float* in_scale;           /* analysis: per-sample scale [B] or NULL          */
     int B, Lh;
+    int unnormalized;                /* analysis: 1 = skip the 1/T of the inverse FFT (adjoint of the synthesis FFT) */
 } aid_cqt_params;
 int aid_cqt_analysis(const aid_cqt_params* p, void* stream);
 int aid_cqt_synthesis(const aid_cqt_params* p, void* stream);
@@ -198,9 +204,10 @@ typedef struct {
     const float* gdM;                /* concatenated dual windows times M_k              */
     const float* X;                  /* [B, Lh, 2] or NULL                               */
     const float* cskip; const float* cout;  /* [B] or NULL (-> 0 / 1)                    */
-    const float* hpf;                /* [Lh] or NULL                                     */
+    const float* hpf;                /* [Lh] or NULL  (any real per-bin multiplier)      */
     float* Y;                        /* [B, Lh, 2]                                       */
     int B, Lh; int64_t ws_per_b;
+    const float* band_scale;         /* [Lh] or NULL: extra per-bin multiplier of the band sum only (adjoint paths) */
 } aid_cqt_gather_params;
 int aid_cqt_gather(const aid_cqt_gather_params* p, void* stream);
 
@@ -230,6 +237,55 @@ typedef struct {
     int B; int64_t L; int mode;
 } aid_score_step_params;
 int aid_score_step(const aid_score_step_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Input-VJP helpers (reconstruction-guidance branch: torch.autograd.grad(norm, x) at
+ * testing/edm_sampler_inpainting.py:78-81 walks back through the whole denoiser).
+ *
+ * aid_group_dot  : partial sums of <u, v> per (sample, channel group) into ws (same layout as aid_group_stats).
+ * aid_norm_bwd   : backward of the group-std normalisation feeding a conv (x -> x*scale[b,c], scale ~ 1/(std+eps)):
+ *       out (+)= gd - coef[b,g] * (x - mean[b,g]) + a * gy
+ *       coef = <gd, x>_group * inv / ((n-1) * std),  inv = 1/(std+eps) from aid_group_stats' `stats`,
+ *       gd = dgrad conv output (already times scale and GELU'), gy optional skip-path gradient.
+ * aid_time_attention_bwd : gradients of aid_time_attention w.r.t. qk and v given d(out) and the saved probs.
+ * aid_guidance_seed : g = d/dxhat || y - mask*xhat ||_2 = -mask * (y - mask*xhat) / norm[b]   (per item; :65-75)
+ * aid_row_norm   : out[b] = || x[b,:] ||_2                                                   (:83)
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    aid_view u, v;
+    int B, C, F, T, groups;
+    double* ws;
+} aid_group_dot_params;
+int aid_group_dot(const aid_group_dot_params* p, void* stream);
+
+typedef struct {
+    aid_view gd, x, gy, out;      /* gy.p may be NULL */
+    int B, C, F, T, groups;
+    const float* stats;           /* [B, groups, 2] (mean, 1/(std+eps)) from the forward aid_group_stats */
+    const double* ws;             /* partial dots from aid_group_dot */
+    float eps, a;
+    int accumulate;
+} aid_norm_bwd_params;
+int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream);
+
+typedef struct {
+    const float* qk; const float* v; const float* probs; const float* gout;
+    float* gqk; float* gv;        /* gqk written; gv accumulated (+=) when accumulate_gv != 0 */
+    int B, H, F, T;
+    float scale;
+    int accumulate_gv;
+} aid_attention_bwd_params;
+int aid_time_attention_bwd(const aid_attention_bwd_params* p, void* stream);
+
+typedef struct {
+    const float* xhat; const float* y; const float* mask; int64_t mask_sB;
+    float* g; float* norm;        /* g [B,L], norm [B] */
+    int B; int64_t L;
+} aid_guidance_seed_params;
+int aid_guidance_seed(const aid_guidance_seed_params* p, void* stream);
+
+typedef struct { const float* x; float* out; int B; int64_t L; } aid_row_norm_params;
+int aid_row_norm(const aid_row_norm_params* p, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * aid_add2 -- y = a*u + b*v on [B,C,F,T] views (the `(x + res)/sqrt(2)` skip combine of a ResnetBlock whose

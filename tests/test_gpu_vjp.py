@@ -1,0 +1,166 @@
+"""GPU parity of the input-VJP (reconstruction-guidance branch, reference testing/edm_sampler_inpainting.py:57-105):
+the hand-written backward kernels against torch.autograd over the CPU oracle."""
+import ast
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def L():
+    from audio_inpainting_diffusion_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize("case", [(2, 16, 24, 16, 5, 3, 2), (1, 64, 20, 256, 5, 3, 8), (2, 32, 12, 8, 1, 1, 1), (2, 128, 16, 32, 5, 3, 4)])
+def test_fused_step_vjp(L, case):
+    """One ResnetBlock step  y = (x + conv(gelu(norm(x)*(1+g))) * s)/sqrt2  (unet...py:472-482): dgrad conv with
+    dGELU epilogue + group-dot + normalisation backward vs torch.autograd."""
+    from oracle.unet import group_std_norm
+    B, N, Fd, T, KH, KW, dil = case
+    x = _rand(B, N, Fd, T, seed=1, scale=2.0) + 0.3
+    w = _rand(N, N, KH, KW, seed=2, scale=1 / math.sqrt(N * KH * KW))
+    gamma, g, s = 1 + 0.3 * _rand(N, seed=3), 0.4 * _rand(B, N, seed=4), _rand(B, N, seed=5)
+    gy = _rand(B, N, Fd, T, seed=6)
+    xr = x.clone().requires_grad_()
+    h = group_std_norm(xr, gamma.view(1, -1, 1, 1)) * (1 + g)[:, :, None, None]
+    y = (xr + F.conv2d(F.gelu(h), w, padding="same", dilation=(dil, 1) if KH > 1 else 1) * s[:, :, None, None]) / math.sqrt(2)
+    ref = torch.autograd.grad((y * gy).sum(), xr)[0]
+
+    xd, gyd, gd_, gam, gm, sd = (t.to(DEV).contiguous() for t in (x, gy, torch.zeros_like(x), gamma, g, s))
+    scale, stats = torch.empty(B, N, device=DEV), torch.empty(B, 8, 2, device=DEV)
+    ws = torch.empty(B * 8 * L.AID_STATS_SPLIT * 2, device=DEV, dtype=torch.float64)
+    L.call("aid_group_stats", L.GroupStatsParams(L.view4(xd), B, N, Fd, T, 8, gam.data_ptr(), gm.data_ptr(), gm.stride(0), 1e-7,
+                                                 scale.data_ptr(), stats.data_ptr(), ws.data_ptr()))
+    wT = L.pack_conv_weight(w.to(DEV), transpose=True)
+    p = L.Conv2dParams()
+    p.x, p.y, p.res, p.aux = L.view4(gyd), L.view4(gd_), L.view4(None), L.view4(xd)
+    p.wp = wT.data_ptr()
+    p.in_scale, p.in_scale_ld = sd.data_ptr(), sd.stride(0)
+    p.out_scale, p.out_scale_ld = scale.data_ptr(), scale.stride(0)
+    p.aux_scale, p.aux_scale_ld = scale.data_ptr(), scale.stride(0)
+    p.B, p.Cin, p.Cout, p.F, p.T = B, N, N, Fd, T
+    p.Cin_pad, p.Cout_pad = wT.shape[1], wT.shape[2]
+    p.KH, p.KW, p.dilF, p.act, p.epi = KH, KW, dil, 0, 1
+    p.alpha, p.res_scale = 1 / math.sqrt(2), 1.0
+    L.call("aid_conv2d", p)
+    L.call("aid_group_dot", L.GroupDotParams(L.view4(gd_), L.view4(xd), B, N, Fd, T, 8, ws.data_ptr()))
+    out = torch.full_like(xd, 0.25)      # accumulate on top of an existing gradient
+    L.call("aid_norm_bwd", L.NormBwdParams(L.view4(gd_), L.view4(xd), L.view4(gyd), L.view4(out), B, N, Fd, T, 8, stats.data_ptr(),
+                                           ws.data_ptr(), 1e-7, 1 / math.sqrt(2), 1))
+    assert rel_l2(out.cpu() - 0.25, ref) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 12, 8), (1, 8, 40, 32), (1, 8, 320, 128), (1, 4, 56, 64)])
+def test_attention_bwd(L, shape):
+    B, H, Fd, T = shape
+    qk = _rand(B, H * 2 * Fd, T, seed=30, scale=1.5).requires_grad_()
+    v = _rand(B, H, Fd, T, seed=31).requires_grad_()
+    go = _rand(B, H, Fd, T, seed=32)
+    q4 = qk.reshape(B, H, 2 * Fd, T).permute(0, 1, 3, 2)
+    sim = torch.einsum("bhnd,bhmd->bhnm", q4[..., :Fd], q4[..., Fd:]) * (float(Fd) ** -0.5)
+    out = torch.einsum("bhnm,bhmd->bhnd", sim.softmax(-1), v.permute(0, 1, 3, 2)).permute(0, 1, 3, 2)
+    gq_ref, gv_ref = torch.autograd.grad((out * go).sum(), (qk, v))
+    qd, vd, god = qk.detach().to(DEV), v.detach().to(DEV), go.to(DEV)
+    o = torch.empty(B, H, Fd, T, device=DEV)
+    probs = torch.empty(B, H, T, T, device=DEV)
+    sc = float(Fd) ** -0.5
+    L.call("aid_time_attention", L.AttentionParams(qd.data_ptr(), vd.data_ptr(), o.data_ptr(), probs.data_ptr(), B, H, Fd, T, sc))
+    gq = torch.empty_like(qd)
+    gv = torch.full_like(vd, 0.5)
+    L.call("aid_time_attention_bwd", L.AttentionBwdParams(qd.data_ptr(), vd.data_ptr(), probs.data_ptr(), god.data_ptr(), gq.data_ptr(),
+                                                          gv.data_ptr(), B, H, Fd, T, sc, 1))
+    assert rel_l2(gq.cpu(), gq_ref) < 2e-5
+    assert rel_l2(gv.cpu() - 0.5, gv_ref) < 2e-5
+
+
+def test_cqt_adjoints(L):
+    """<A x, c> == <x, A^H c> for analysis and synthesis (real inner products), via the device kernels."""
+    from audio_inpainting_diffusion_amd.cqt import CQTransform
+    no, bpo, fs, Ls = 4, 8, 22050, 4096
+    tr = CQTransform(no, bpo, "oct", ("kaiser", 1.0), fs, Ls, device=DEV)
+    tab = tr._tables(torch.device(DEV))
+    x = _rand(2, Ls, seed=1).to(DEV)
+    outs = tr.alloc_octaves(2, DEV)
+    tr.analysis(x, outs)
+    gc = [_rand(*o.shape, seed=10 + i).to(DEV) for i, o in enumerate(outs)]
+    lhs = sum(float((a.double() * b.double()).sum()) for a, b in zip(outs, gc))
+    gx = torch.fft.irfft(tr.analysis_adjoint(gc), n=Ls)
+    rhs = float((x.double() * gx.double()).sum())
+    assert abs(lhs - rhs) < 1e-5 * max(1.0, abs(lhs))
+    # synthesis: c -> y = irfft(gather(...)) ;  adjoint: g_y -> g_c
+    c = [_rand(*o.shape, seed=20 + i).to(DEV) for i, o in enumerate(outs)]
+    y = torch.fft.irfft(tr.synthesis_spectrum(c), n=Ls)
+    gy = _rand(2, Ls, seed=30).to(DEV)
+    gco = [torch.empty_like(o) for o in outs]
+    tr.synthesis_adjoint(tr.spectrum_scale(torch.fft.rfft(gy), tab["w_over_L"]), gco)
+    lhs = float((y.double() * gy.double()).sum())
+    rhs = sum(float((a.double() * b.double()).sum()) for a, b in zip(c, gco))
+    assert abs(lhs - rhs) < 1e-5 * max(1.0, abs(lhs))
+
+
+def _setup(tag="a"):
+    from audio_inpainting_diffusion_amd.config import small_args
+    from audio_inpainting_diffusion_amd.init import seeded_init_
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    from oracle.nsgt_cqt import OracleCQT
+    from oracle.unet import OracleUnet
+    z = np.load(os.path.join(GOLDEN, f"unet_small_{tag}.npz"))
+    kw = ast.literal_eval(str(z["cfg"]))
+    args = small_args(**kw)
+    net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(DEV)), int(z["seed"]), gate_scale=10.0, affine_scale=10.0)
+    cqt = OracleCQT(kw["num_octs"], kw["bins_per_oct"], "oct", ("kaiser", 1), kw["fs"], kw["audio_len"])
+    orc = OracleUnet(kw["num_octs"], kw["bins_per_oct"], cqt).load_state_dict(net.state_dict())
+    return net, orc, z, kw, args
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_network_vjp_vs_oracle_autograd(tag):
+    """torch.autograd.grad through the drop-in network (autograd bridge -> hand-written VJP plan) vs the oracle."""
+    net, orc, z, kw, _ = _setup(tag)
+    x, cn = torch.from_numpy(z["x"]), torch.from_numpy(z["cnoise"])
+    g = _rand(*x.shape, seed=3)
+    xr = x.clone().requires_grad_()
+    ref = torch.autograd.grad((orc(xr, cn) * g).sum(), xr)[0]
+    xd = x.to(DEV).requires_grad_()
+    y = net(xd, cn.to(DEV))
+    got = torch.autograd.grad((y * g.to(DEV)).sum(), xd)[0]
+    e = rel_l2(got.cpu(), ref)
+    print(f"network input-VJP ({tag}): rel-L2 vs oracle autograd = {e:.3e}")
+    assert e < 1e-4
+
+
+def test_guided_evaluation_and_sampler_vs_oracle():
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.sampler import Sampler
+    from oracle.edm import OracleEDM
+    from oracle.sampler import OracleSampler
+    net, orc, z, kw, args = _setup("a")
+    Ls = kw["audio_len"]
+    args.tester.T, args.tester.posterior_sampling.xi = 3, 0.25
+    args.tester.data_consistency.hann_size = 20
+    y = torch.from_numpy(z["x"]) * 0.126
+    mask = torch.ones(1, Ls)
+    mask[:, 1800:2300] = 0
+    smp = Sampler(model=net, diff_params=EDM(args), args=args)
+    smp.seeds, smp.trace = [5, 6], []
+    out = smp.predict_inpainting((y * mask).to(DEV), mask.to(DEV))
+    osmp = OracleSampler(orc, OracleEDM(), T=3, xi=0.25, hann_size=20, audio_len=Ls)
+    ref = osmp.predict_inpainting(y * mask, mask, seeds=[5, 6], record=True)
+    errs = [rel_l2(a.cpu(), b) for a, b in zip(smp.trace, osmp.trace)]
+    print("guided per-evaluation x_hat rel-L2:", ["%.2e" % e for e in errs], " final:", "%.2e" % rel_l2(out.cpu(), ref))
+    assert len(errs) == 5 and errs[0] < 1e-4 and max(errs) < 5e-4

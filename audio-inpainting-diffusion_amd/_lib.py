@@ -101,6 +101,11 @@ class Add2Params(C.Structure):
                 ("a", C.c_float), ("b", C.c_float)]
 
 
+class ScaleActParams(C.Structure):
+    _fields_ = [("x", View), ("y", View), ("scale", C.c_void_p), ("scale_ld", C.c_int64),
+                ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("act", C.c_int)]
+
+
 class GroupDotParams(C.Structure):
     _fields_ = [("u", View), ("v", View), ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("groups", C.c_int),
                 ("ws", C.c_void_p)]
@@ -130,7 +135,7 @@ class RowNormParams(C.Structure):
 EXPORTS = ["aid_abi_version", "aid_last_error", "aid_group_stats", "aid_conv2d", "aid_conv2d_pack_dims", "aid_resample",
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
-           "aid_time_attention_bwd", "aid_guidance_seed", "aid_row_norm"]
+           "aid_time_attention_bwd", "aid_guidance_seed", "aid_row_norm", "aid_scale_act"]
 
 _lib = None
 

@@ -1,20 +1,26 @@
 // aid_conv2d: fused dilated dense convolution as an fp32-MFMA implicit GEMM for gfx950.
 //
 //   GEMM view:  M = Cout, N = (b, f, t) output positions, K = (ci, kh, kw).
-//   One workgroup computes an M_BLK x N_BLK tile; its N tile is ROWS consecutive (b,f) rows times TT
-//   consecutive t (TT = min(N_BLK, pow2ceil(T)), ROWS = N_BLK/TT), so the three kw taps of a row are
-//   served from one LDS strip with a 1-sample halo each side and the five kh taps are five dilated
-//   input rows.  K is walked in chunks of KC input channels:
-//     stage  x-strips  [KC][ROWS][KH][TT+8]  global -> (scale, GELU) -> LDS   (prologue fused in staging:
-//                                                     each element is transformed once per block, not per tap)
-//     stage  weights   [KH*KW][KC][M_BLK]     pre-packed, cout-contiguous, float4 copies
-//     MFMA   v_mfma_f32_32x32x2_f32: A = W[32 cout][2 ci], B = X[2 ci][32 t]; both operands are
-//            conflict-free ds_read_b32 (lanes 0-31 consecutive floats, the two half-waves hit different ci).
-//   Epilogue (registers -> global): y = alpha * (res_scale*res + acc*out_scale[b,co])   (or the dGELU form).
+//   One workgroup (4 waves, one per SIMD) computes an M_BLK x N_BLK tile; its N tile is ROWS consecutive (b,f)
+//   rows times TT consecutive t (TT = min(N_BLK, pow2ceil(T)), ROWS = N_BLK/TT), so the three kw taps of a row
+//   come from one LDS strip with a 1-sample halo each side and the five kh taps are five dilated input rows.
+//   K is walked in chunks of KC input channels through a DOUBLE-BUFFERED LDS tile:
+//     x strips  [KC][ROWS][KH][TT+8]   global -> registers -> (scale, GELU) -> LDS
+//     weights   [KH*KW][KC][M_BLK]     pre-packed (cout contiguous), float4 copies
+//   Software pipeline (round 1, v2): the global loads of chunk c+1 are issued into registers BEFORE the MFMA
+//   loop of chunk c; their transform + ds_write into the other LDS buffer is interleaved slot by slot with
+//   the MFMAs (VALU / LDS-write issue next to the matrix pipe), and ONE barrier closes the chunk.  All
+//   per-thread staging addresses are computed once, outside the K loop.  (v1 staged synchronously with
+//   runtime-trip-count loops: one load in flight per wave, ~20 k cycles of exposed latency per chunk = 41 %
+//   of the fp32 MFMA peak; see profiles/r01_*.)
+//   MFMA: v_mfma_f32_32x32x2_f32, A = W[32 cout][2 ci], B = X[2 ci][32 t]; both operands are conflict-free
+//   ds_read_b32 (lanes 0-31 consecutive floats; the two half-waves read different ci).
+//   Epilogue (registers -> global): y = alpha * (res_scale*res + acc*out_scale[b,co])  or the dGELU form (epi=1).
 //
-//   fp32 MFMA is exact fp32 FMA arithmetic (guide: cdna_hip_programming.md section 3), so parity with the
-//   reference's F.conv2d is limited only by summation order.
+//   fp32 MFMA is exact fp32 FMA arithmetic (cdna_hip_programming.md section 3), so parity with the reference's
+//   F.conv2d is limited only by summation order.
 #include "aid_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -27,23 +33,41 @@ struct ConvDev {
     int nchunks;      // ceil(Cin / KC)
 };
 
+__device__ __forceinline__ float4 xform4(float4 v, float sc, int act) {
+    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+    if (act == 1) { v.x = aid_gelu(v.x); v.y = aid_gelu(v.y); v.z = aid_gelu(v.z); v.w = aid_gelu(v.w); }
+    return v;
+}
+
 template <int KH, int KW, int MT, int NT, int WGM, int WGN, int KC>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_mfma_kernel(const ConvDev a) {
     constexpr int NTHREADS = 64 * WGM * WGN;
     constexpr int M_BLK = 32 * MT * WGM;
     constexpr int N_BLK = 32 * NT * WGN;
     constexpr int TAPS = KH * KW;
-    constexpr int XOFF = 4 - KW / 2;   // LDS strip: [3]=left halo, [4..4+TT) core, [4+TT]=right halo
+    constexpr int PADL = (KW > 1) ? 4 : 0;                   // strip: [3]=left halo, [4..4+TT) core, [4+TT]=right halo
+    constexpr int XOFF = PADL - KW / 2;
+    constexpr int XQ_TOTAL = KC * KH * (N_BLK / 4);
+    constexpr int XQ = (XQ_TOTAL + NTHREADS - 1) / NTHREADS; // x float4s per thread per chunk
+    constexpr int MQ = M_BLK / 4;
+    constexpr int WQ_TOTAL = TAPS * KC * MQ;
+    constexpr int WQ = (WQ_TOTAL + NTHREADS - 1) / NTHREADS; // weight float4s per thread per chunk
+    constexpr int HQ = 2;                                    // halo elements per thread per chunk (fast path)
+    constexpr int KSTEPS = TAPS * (KC / 2);
+    constexpr int NSLOT = (KH > 1) ? KH : (KSTEPS >= 4 ? 4 : KSTEPS);
+    constexpr int KS_PER_SLOT = KSTEPS / NSLOT;
+    static_assert(KSTEPS % NSLOT == 0 && NSLOT >= 2, "k-steps must split evenly into >= 2 slots");
 
     const aid_conv2d_params& p = a.p;
     const int TT = 1 << a.tt_log2;
     const int ROWS = 1 << a.rows_log2;
-    const int TTP = TT + 8;
+    const int TTP = TT + 2 * PADL;
+    const int XSZ = KC * ROWS * KH * TTP;
+    constexpr int WSZ = TAPS * KC * M_BLK;
+    const int BUFSZ = XSZ + WSZ;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem;                                   // [KC][ROWS][KH][TTP]
-    float* Ws = smem + KC * ROWS * KH * TTP;            // [TAPS][KC][M_BLK]
-    int* rowinfo = (int*)(Ws + TAPS * KC * M_BLK);      // [ROWS][2] = (b, f) or b = -1
+    int* rowinfo = (int*)(smem + 2 * BUFSZ);                 // [ROWS][2] = (b, f) or b = -1
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -66,13 +90,67 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_mfma_kernel(const ConvDev
     }
     __syncthreads();
 
-    f32x16 acc[MT][NT];
+    // ---- per-thread staging descriptors (constant over the K loop) ------------------------------------------
+    const int tq_log2 = a.tt_log2 - 2;
+    int64_t xg[XQ];      // global element offset without the channel term, -1 = out of range
+    int xlds[XQ];        // LDS float offset inside the X tile
+    int xci[XQ];         // channel within the chunk
+    int xsc[XQ];         // in_scale row offset b * in_scale_ld
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < XQ; ++i) {
+        const int q = tid + i * NTHREADS;
+        const int tq = q & ((1 << tq_log2) - 1);
+        const int s = q >> tq_log2;
+        const int kh = s % KH;
+        const int s2 = s / KH;
+        const int rr = s2 & (ROWS - 1);
+        const int ci = s2 >> a.rows_log2;
+        const int b = rowinfo[2 * rr];
+        const int fi = rowinfo[2 * rr + 1] + (kh - KH / 2) * p.dilF;
+        const int t = t0 + 4 * tq;
+        const bool ok = b >= 0 && fi >= 0 && fi < p.F && t < p.T && q < XQ_TOTAL;
+        xg[i] = ok ? ((int64_t)b * p.x.sB + (int64_t)fi * p.x.sF + t) : -1;
+        xlds[i] = (q < XQ_TOTAL) ? (s * TTP + PADL + 4 * tq) : -1;
+        xci[i] = ci;
+        xsc[i] = ok ? (int)(b * p.in_scale_ld) : 0;
+    }
+    const int nstrips = KC * ROWS * KH;
+    const bool halo_fast = (KW > 1) && (2 * nstrips <= HQ * NTHREADS);
+    int64_t hg[HQ];
+    int hlds[HQ], hci[HQ], hsc[HQ];
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+    for (int i = 0; i < HQ; ++i) {
+        hg[i] = -1; hlds[i] = -1; hci[i] = 0; hsc[i] = 0;
+        const int h = tid + i * NTHREADS;
+        if (KW > 1 && halo_fast && h < 2 * nstrips) {
+            const int s = h >> 1, side = h & 1;
+            const int kh = s % KH;
+            const int s2 = s / KH;
+            const int rr = s2 & (ROWS - 1);
+            const int ci = s2 >> a.rows_log2;
+            const int b = rowinfo[2 * rr];
+            const int fi = rowinfo[2 * rr + 1] + (kh - KH / 2) * p.dilF;
+            const int t = side ? (t0 + TT) : (t0 - 1);
+            const bool ok = b >= 0 && fi >= 0 && fi < p.F && t >= 0 && t < p.T;
+            hg[i] = ok ? ((int64_t)b * p.x.sB + (int64_t)fi * p.x.sF + t) : -1;
+            hlds[i] = s * TTP + (side ? 4 + TT : 3);
+            hci[i] = ci;
+            hsc[i] = ok ? (int)(b * p.in_scale_ld) : 0;
+        }
+    }
+    int wg[WQ], wlds[WQ];    // weight source offset (without chunk / m0 terms) and LDS offset; -1 = idle slot
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int i = 0; i < WQ; ++i) {
+        const int q = tid + i * NTHREADS;
+        if (q < WQ_TOTAL) {
+            const int m4 = q % MQ;
+            const int ci = (q / MQ) % KC;
+            const int tap = q / (MQ * KC);
+            wg[i] = (tap * p.Cin_pad + ci) * p.Cout_pad + 4 * m4;
+            wlds[i] = (tap * KC + ci) * M_BLK + 4 * m4;
+        } else { wg[i] = -1; wlds[i] = -1; }
+    }
+    const float* wbase = p.wp + m0;
 
     // per-n-tile LDS offsets of this lane's B element (without the ci / kh / kw terms)
     int xoff[NT];
@@ -84,101 +162,127 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_mfma_kernel(const ConvDev
         xoff[j] = rr * KH * TTP + tt + XOFF;
     }
     const int ci_lane = lane >> 5;
-    const int strip_ci = ROWS * KH * TTP;   // LDS stride between input channels
+    const int strip_ci = ROWS * KH * TTP;
 
-    const int tq_log2 = a.tt_log2 - 2;      // quads per strip = TT/4
-    const int nquads = (KC * ROWS * KH) << tq_log2;
-    const int nstrips = KC * ROWS * KH;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    for (int ch = 0; ch < a.nchunks; ++ch) {
-        const int c0 = ch * KC;
-        // ---- stage x strips ---------------------------------------------------------------------
-        for (int q = tid; q < nquads; q += NTHREADS) {
-            const int tq = q & ((1 << tq_log2) - 1);
-            const int s = q >> tq_log2;
+    float4 xv[XQ];
+    float xs[XQ];
+    float hv[HQ];
+    float4 wv[WQ];
+
+    auto issue_loads = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < XQ; ++i) {
+            const int c = c0 + xci[i];
+            const bool ok = xg[i] >= 0 && c < p.Cin;
+            xv[i] = ok ? *reinterpret_cast<const float4*>(p.x.p + xg[i] + (int64_t)c * p.x.sC) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xs[i] = (ok && p.in_scale) ? p.in_scale[xsc[i] + c] : 1.f;
+        }
+        if (KW > 1) {
+#pragma unroll
+            for (int i = 0; i < HQ; ++i) {
+                const int c = c0 + hci[i];
+                const bool ok = hg[i] >= 0 && c < p.Cin;
+                float v = ok ? p.x.p[hg[i] + (int64_t)c * p.x.sC] : 0.f;
+                if (ok && p.in_scale) v *= p.in_scale[hsc[i] + c];
+                hv[i] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WQ; ++i)
+            wv[i] = (wg[i] >= 0) ? *reinterpret_cast<const float4*>(wbase + wg[i] + (int64_t)c0 * p.Cout_pad)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    // write the register-staged chunk into LDS buffer `Xs/Ws`; `slot` < 0 writes everything
+    auto write_slot = [&](float* Xs, float* Ws, int slot) {
+#pragma unroll
+        for (int i = 0; i < XQ; ++i)
+            if ((slot < 0 || (i % (NSLOT - 1)) == slot) && (XQ_TOTAL % NTHREADS == 0 || xlds[i] >= 0))
+                *reinterpret_cast<float4*>(Xs + xlds[i]) = xform4(xv[i], xs[i], p.act);
+#pragma unroll
+        for (int i = 0; i < WQ; ++i)
+            if ((slot < 0 || (i % (NSLOT - 1)) == slot) && wlds[i] >= 0)
+                *reinterpret_cast<float4*>(Ws + wlds[i]) = wv[i];
+        if (KW > 1 && (slot < 0 || slot == NSLOT - 2)) {
+#pragma unroll
+            for (int i = 0; i < HQ; ++i)
+                if (hlds[i] >= 0) Xs[hlds[i]] = (p.act == 1) ? aid_gelu(hv[i]) : hv[i];
+        }
+    };
+    // slow path for the halos of very short rows (only tiny test shapes): synchronous
+    auto halo_slow = [&](float* Xs, int c0) {
+        for (int h = tid; h < 2 * nstrips; h += NTHREADS) {
+            const int s = h >> 1, side = h & 1;
             const int kh = s % KH;
             const int s2 = s / KH;
             const int rr = s2 & (ROWS - 1);
             const int ci = s2 >> a.rows_log2;
             const int b = rowinfo[2 * rr];
             const int fi = rowinfo[2 * rr + 1] + (kh - KH / 2) * p.dilF;
-            const int t = t0 + 4 * tq;
+            const int t = side ? (t0 + TT) : (t0 - 1);
             const int c = c0 + ci;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b >= 0 && fi >= 0 && fi < p.F && c < p.Cin && t < p.T) {
-                const float* src = p.x.p + (int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)fi * p.x.sF + t;
-                v = *reinterpret_cast<const float4*>(src);
-                if (p.in_scale) {
-                    const float sc = p.in_scale[(int64_t)b * p.in_scale_ld + c];
-                    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
-                }
-                if (p.act == 1) { v.x = aid_gelu(v.x); v.y = aid_gelu(v.y); v.z = aid_gelu(v.z); v.w = aid_gelu(v.w); }
+            float v = 0.f;
+            if (b >= 0 && fi >= 0 && fi < p.F && c < p.Cin && t >= 0 && t < p.T) {
+                v = p.x.p[(int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)fi * p.x.sF + t];
+                if (p.in_scale) v *= p.in_scale[(int64_t)b * p.in_scale_ld + c];
+                if (p.act == 1) v = aid_gelu(v);
             }
-            *reinterpret_cast<float4*>(Xs + s * TTP + 4 + 4 * tq) = v;
+            Xs[s * TTP + (side ? 4 + TT : 3)] = v;
         }
-        if (KW > 1) {
-            for (int h = tid; h < 2 * nstrips; h += NTHREADS) {
-                const int s = h >> 1;
-                const int side = h & 1;
-                const int kh = s % KH;
-                const int s2 = s / KH;
-                const int rr = s2 & (ROWS - 1);
-                const int ci = s2 >> a.rows_log2;
-                const int b = rowinfo[2 * rr];
-                const int fi = rowinfo[2 * rr + 1] + (kh - KH / 2) * p.dilF;
-                const int t = side ? (t0 + TT) : (t0 - 1);
-                const int c = c0 + ci;
-                float v = 0.f;
-                if (b >= 0 && fi >= 0 && fi < p.F && c < p.Cin && t >= 0 && t < p.T) {
-                    v = p.x.p[(int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)fi * p.x.sF + t];
-                    if (p.in_scale) v *= p.in_scale[(int64_t)b * p.in_scale_ld + c];
-                    if (p.act == 1) v = aid_gelu(v);
-                }
-                Xs[s * TTP + (side ? 4 + TT : 3)] = v;
-            }
-        }
-        // ---- stage weights ------------------------------------------------------------------------
-        {
-            constexpr int MQ = M_BLK / 4;
-            constexpr int WQ = TAPS * KC * MQ;
-            for (int q = tid; q < WQ; q += NTHREADS) {
-                const int m4 = q % MQ;
-                const int ci = (q / MQ) % KC;
-                const int tap = q / (MQ * KC);
-                const float* src = p.wp + ((int64_t)tap * p.Cin_pad + c0 + ci) * p.Cout_pad + m0 + 4 * m4;
-                *reinterpret_cast<float4*>(Ws + (tap * KC + ci) * M_BLK + 4 * m4) =
-                    *reinterpret_cast<const float4*>(src);
-            }
-        }
-        __syncthreads();
-        // ---- MFMA over the chunk -------------------------------------------------------------------
-#pragma unroll 1
-        for (int kh = 0; kh < KH; ++kh) {
+    };
+
+    // ---- prologue: chunk 0 -> buffer 0 -----------------------------------------------------------------------
+    issue_loads(0);
+    write_slot(smem, smem + XSZ, -1);
+    if (KW > 1 && !halo_fast) halo_slow(smem, 0);
+    __syncthreads();
+
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+        const int cur = ch & 1;
+        const float* Xs = smem + cur * BUFSZ;
+        const float* Ws = Xs + XSZ;
+        float* Xn = smem + (cur ^ 1) * BUFSZ;
+        float* Wn = Xn + XSZ;
+        const bool more = (ch + 1) < a.nchunks;
 #pragma unroll
-            for (int kw = 0; kw < KW; ++kw) {
-                const int tap = kh * KW + kw;
+        for (int slot = 0; slot < NSLOT; ++slot) {
 #pragma unroll
-                for (int cp = 0; cp < KC / 2; ++cp) {
-                    const int ci = 2 * cp + ci_lane;
-                    float av[MT], bv[NT];
+            for (int k = 0; k < KS_PER_SLOT; ++k) {
+                const int ks = slot * KS_PER_SLOT + k;          // k-step index: (tap, cp) with cp fastest
+                const int tap = ks / (KC / 2);
+                const int cp = ks % (KC / 2);
+                const int kh = tap / KW, kw = tap % KW;
+                const int ci = 2 * cp + ci_lane;
+                float av[MT], bv[NT];
 #pragma unroll
-                    for (int i = 0; i < MT; ++i)
-                        av[i] = Ws[(tap * KC + ci) * M_BLK + (wm * MT + i) * 32 + (lane & 31)];
+                for (int i = 0; i < MT; ++i)
+                    av[i] = Ws[(tap * KC + ci) * M_BLK + (wm * MT + i) * 32 + (lane & 31)];
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    bv[j] = Xs[ci * strip_ci + kh * TTP + xoff[j] + kw];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        bv[j] = Xs[ci * strip_ci + kh * TTP + xoff[j] + kw];
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-                }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                // the next chunk's global loads are issued BEHIND the first MFMAs of this chunk, so the matrix
+                // pipe is already busy while the wave spends its issue slots on address arithmetic / VMEM
+                if (slot == 0 && k == 0 && more) issue_loads((ch + 1) * KC);
             }
+            if (more && slot > 0) write_slot(Xn, Wn, slot - 1);
         }
+        if (more && KW > 1 && !halo_fast) halo_slow(Xn, (ch + 1) * KC);
         __syncthreads();
     }
 
-    // ---- epilogue --------------------------------------------------------------------------------------
+    // ---- epilogue --------------------------------------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = (wn * NT + j) * 32 + (lane & 31);
@@ -236,7 +340,7 @@ static int launch_cfg(const aid_conv2d_params* p, hipStream_t st) {
     a.nchunks = aid_cdiv(p->Cin, KC);
     const int rgroups = aid_cdiv(a.nrows, ROWS);
     dim3 grid((unsigned)(rgroups * a.tiles_t), (unsigned)(p->Cout_pad / M_BLK));
-    const size_t lds = sizeof(float) * ((size_t)KC * ROWS * KH * (TT + 8) + (size_t)KH * KW * KC * M_BLK) +
+    const size_t lds = sizeof(float) * 2 * ((size_t)KC * ROWS * KH * (TT + (KW > 1 ? 8 : 0)) + (size_t)KH * KW * KC * M_BLK) +
                        sizeof(int) * 2 * ROWS;
     AID_REQUIRE(lds <= 160 * 1024, "aid_conv2d: LDS tile too large");
     auto kern = conv_mfma_kernel<KH, KW, MT, NT, WGM, WGN, KC>;
@@ -252,11 +356,32 @@ static int launch_cfg(const aid_conv2d_params* p, hipStream_t st) {
 
 template <int KH, int KW, int KC>
 static int launch_m(const aid_conv2d_params* p, hipStream_t st) {
-    switch (pick_mblk(p->Cout)) {
+    int mb = pick_mblk(p->Cout);
+    if (mb == 128) {
+        // grid-starved GEMMs (qk projections: N = B*T columns only): trade tile height for more workgroups
+        const int64_t npos = (int64_t)p->B * p->F * p->T;
+        const int64_t ntiles = (npos + 255) / 256;
+        if (ntiles * (p->Cout_pad / 128) < 192) mb = (ntiles * (p->Cout_pad / 64) < 192) ? 32 : 64;
+    }
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("AID_CONV_CFG"); dbg = e ? atoi(e) : 0; }
+    if (KH == 5 && mb == 128 && dbg == 1) return launch_cfg<KH, KW, 1, 2, 4, 4, KC>(p, st);   // 16 waves, 128x256
+    if (KH == 5 && mb == 128 && dbg == 2) return launch_cfg<KH, KW, 2, 4, 2, 4, KC>(p, st);   // 8 waves, 128x512
+    if (KH == 5 && mb == 128 && dbg == 3) return launch_cfg<KH, KW, 2, 4, 2, 2, KC>(p, st);   // 4 waves, 128x256
+    if (KH == 5 && mb == 128 && dbg == 4) return launch_cfg<KH, KW, 2, 1, 2, 4, KC>(p, st);   // 8 waves, 128x128
+    if (KH == 5 && mb == 64 && dbg == 1) return launch_cfg<KH, KW, 2, 1, 1, 8, KC>(p, st);    // 8 waves, 64x256
+    if (KH == 5 && mb == 64 && dbg == 2) return launch_cfg<KH, KW, 1, 1, 2, 8, KC>(p, st);    // 16 waves, 64x256
+    if (KH == 5 && mb == 64 && dbg == 3) return launch_cfg<KH, KW, 1, 2, 2, 8, KC>(p, st);    // 16 waves, 64x512
+    if (KH == 5 && mb == 96 && dbg == 1) return launch_cfg<KH, KW, 1, 2, 3, 4, KC>(p, st);    // 12 waves, 96x256
+    if (KH == 5 && mb == 96 && dbg == 2) return launch_cfg<KH, KW, 3, 2, 1, 4, KC>(p, st);    // 4 waves, 96x256
+    if (KH == 5 && mb == 96 && dbg == 3) return launch_cfg<KH, KW, 3, 2, 1, 8, KC>(p, st);    // 8 waves, 96x512
+    switch (mb) {
         case 32: return launch_cfg<KH, KW, 1, 2, 1, 4, KC>(p, st);
         case 64: return launch_cfg<KH, KW, 2, 2, 1, 4, KC>(p, st);
-        case 96: return launch_cfg<KH, KW, 3, 2, 1, 4, KC>(p, st);
-        default: return launch_cfg<KH, KW, 2, 4, 2, 2, KC>(p, st);
+        case 96: return launch_cfg<KH, KW, 3, 1, 1, 8, KC>(p, st);
+        default:
+            if (KH == 5) return launch_cfg<KH, KW, 1, 2, 4, 4, KC>(p, st);     // 16 waves (4 per SIMD), 128x256
+            return launch_cfg<KH, KW, 2, 2, 2, 4, KC>(p, st);
     }
 }
 
@@ -271,6 +396,7 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     aid_conv2d_pack_dims(p->Cin, p->Cout, &cip, &cop);
     AID_REQUIRE(p->Cin_pad == cip && p->Cout_pad == cop, "aid_conv2d: packed weight dims mismatch (use aid_conv2d_pack_dims)");
     AID_REQUIRE(p->epi == 0 || (p->epi == 1 && p->aux.p && p->aux_scale), "aid_conv2d: epi=1 needs aux + aux_scale");
+    AID_REQUIRE((int64_t)p->B * p->in_scale_ld < (1LL << 31), "aid_conv2d: in_scale too large");
     if (p->KH == 5 && p->KW == 3) return launch_m<5, 3, 4>(p, st);
     if (p->KH == 1 && p->KW == 1) {
         if (p->Cin <= 8) return launch_m<1, 1, 8>(p, st);

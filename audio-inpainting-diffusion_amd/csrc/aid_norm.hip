@@ -212,3 +212,46 @@ extern "C" int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream) {
     AID_CHECK_LAUNCH();
     return AID_OK;
 }
+
+// =====================================================================================================
+// h = act(x * scale[b,c])  (one pass, float4, HBM-bound)
+// =====================================================================================================
+struct SaDev { aid_scale_act_params p; int lpr_log2, nrows, tiles; };
+
+__global__ __launch_bounds__(256) void scale_act_kernel(const SaDev a) {
+    const aid_scale_act_params& p = a.p;
+    const int tid = threadIdx.x;
+    const int lpr = 1 << a.lpr_log2;
+    const int sub = tid >> a.lpr_log2, lq = tid & (lpr - 1);
+    const int rpb = 256 >> a.lpr_log2;
+    const int tile = blockIdx.x % a.tiles;
+    const int row = (blockIdx.x / a.tiles) * rpb + sub;
+    if (row >= a.nrows) return;
+    const int o4 = (tile * lpr + lq) * 4;
+    if (o4 >= p.T) return;
+    const int f = row % p.F;
+    const int bc = row / p.F;
+    const int c = bc % p.C;
+    const int b = bc / p.C;
+    const float sc = p.scale ? p.scale[(int64_t)b * p.scale_ld + c] : 1.f;
+    float4 v = *reinterpret_cast<const float4*>(p.x.p + (int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)f * p.x.sF + o4);
+    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+    if (p.act == 1) { v.x = aid_gelu(v.x); v.y = aid_gelu(v.y); v.z = aid_gelu(v.z); v.w = aid_gelu(v.w); }
+    *reinterpret_cast<float4*>(p.y.p + (int64_t)b * p.y.sB + (int64_t)c * p.y.sC + (int64_t)f * p.y.sF + o4) = v;
+}
+
+extern "C" int aid_scale_act(const aid_scale_act_params* p, void* stream) {
+    AID_REQUIRE(p && p->x.p && p->y.p, "aid_scale_act: null pointer");
+    AID_REQUIRE((p->T % 4) == 0, "aid_scale_act: T must be a multiple of 4");
+    SaDev a;
+    a.p = *p;
+    int lpr = aid_pow2ceil(p->T / 4);
+    if (lpr > 256) lpr = 256;
+    a.lpr_log2 = aid_ilog2(lpr);
+    a.nrows = p->B * p->C * p->F;
+    a.tiles = aid_cdiv(p->T / 4, lpr);
+    const int rpb = 256 / lpr;
+    hipLaunchKernelGGL(scale_act_kernel, dim3((unsigned)(aid_cdiv(a.nrows, rpb) * a.tiles)), dim3(256), 0, (hipStream_t)stream, a);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}

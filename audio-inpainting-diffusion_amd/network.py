@@ -128,9 +128,20 @@ class _Plan:
     def add(self, name, params, *tensors, flops=0):
         fn = getattr(_lib.lib(), name)
         self.ops.append((fn, C.addressof(params), name, flops))
+        self.descr = getattr(self, "descr", [])
+        if name == "aid_conv2d":
+            q = params
+            self.descr.append("conv %dx%d d%-3d Cin%-4d Cout%-4d F%-3d T%-4d act%d epi%d" % (q.KH, q.KW, q.dilF, q.Cin, q.Cout, q.F, q.T, q.act, q.epi))
+        else:
+            self.descr.append(name)
         self.keep.append(params)
         self.keep.extend(t for t in tensors if t is not None)
         self.flops += flops
+
+    def _cur_descr(self, fn, addr):
+        if not hasattr(self, "_dmap"):
+            self._dmap = {o[1]: d for o, d in zip(self.ops, self.descr)}
+        return self._dmap.get(addr, "?")
 
     def run(self):
         stream = torch.cuda.current_stream().cuda_stream
@@ -141,7 +152,7 @@ class _Plan:
                 e0.record()
                 rc = fn(addr, stream)
                 e1.record()
-                timing.append((e0, e1, flops))
+                timing.append((e0, e1, flops, self.descr[len(timing) % 1] if False else self._cur_descr(fn, addr)))
             else:
                 rc = fn(addr, stream)
             if rc != 0:
@@ -169,9 +180,10 @@ class _Builder:
         return g.as_strided(t.size(), t.stride(), t.storage_offset())
 
     def _scratch(self, shape):
-        t = self.scratch.get(tuple(shape))
+        key = tuple(shape)
+        t = self.scratch.get(key)
         if t is None:
-            t = self.scratch[tuple(shape)] = self.buf(*shape)
+            t = self.scratch[key] = self.buf(*[d for d in key if not isinstance(d, str)])
         return t
 
     def finish_backward(self):
@@ -217,7 +229,15 @@ class _Builder:
              res_scale=1.0, alpha=1.0, wpT=None, norm_stats=None):
         """Forward conv + registration of its input-VJP.  ``norm_stats``: the (mean, 1/(std+eps)) buffer when
         ``in_scale`` was produced by ``stats`` from this same ``x`` (the scale then depends on x)."""
-        self._conv_raw(x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha)
+        if act and kh > 1:
+            # evaluate norm*mod -> GELU once per element into a scratch tensor; the conv stages plain copies
+            hbuf = self._scratch(("h",) + tuple(x.shape))
+            sp = _lib.ScaleActParams(_lib.view4(x), _lib.view4(hbuf), in_scale.data_ptr(), in_scale.stride(0), x.shape[0], cin,
+                                     x.shape[2], x.shape[3], 1)
+            self.plan.add("aid_scale_act", sp, x, hbuf, in_scale)
+            self._conv_raw(hbuf, y, wp, cin, cout, kh, kw, dil, None, 0, out_scale, res, res_scale, alpha)
+        else:
+            self._conv_raw(x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha)
         if wpT is None:
             return
 

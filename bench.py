@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="segments per GPU")
     ap.add_argument("--xi", type=float, default=0.0, help="0 = replacement branch (forward only); 0.25 = guided (reference default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-table", action="store_true", help="print per-shape conv kernel times (stderr)")
     a = ap.parse_args()
 
     from audio_inpainting_diffusion_amd import dist as D
@@ -108,6 +109,8 @@ def main():
     st = net._state(B)
     timing = []
     st["plan_body"].timing = timing
+    if a.xi > 0:
+        net._bwd_plan(st).timing = timing
     torch.cuda.synchronize()
     D.barrier()
     t0 = time.perf_counter()
@@ -117,11 +120,20 @@ def main():
     D.barrier()
     wall = time.perf_counter() - t0
     st["plan_body"].timing = None
+    if a.xi > 0:
+        net._bwd_plan(st).timing = None
     wall = D.max_over_ranks(wall, dev)
     assert torch.isfinite(state["x"]).all()
 
-    conv_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in timing)
-    conv_flops = sum(f for _, _, f in timing)
+    conv_ms = sum(t[0].elapsed_time(t[1]) for t in timing)
+    conv_flops = sum(t[2] for t in timing)
+    if a.conv_table and rank == 0:
+        agg = {}
+        for e0, e1, f, d in timing:
+            r = agg.setdefault(d, [0, 0.0, 0])
+            r[0] += 1; r[1] += e0.elapsed_time(e1); r[2] += f
+        for d, (n, ms, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            print("%-62s n=%3d  %8.3f ms/launch  %6.1f TF/s  %5.1f%% of conv time" % (d, n, ms / n, f / ms / 1e9, 100 * ms / conv_ms), file=sys.stderr)
     evals = world * B * 2 * a.steps
     if rank == 0:
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0

@@ -288,6 +288,19 @@ typedef struct { const float* x; float* out; int B; int64_t L; } aid_row_norm_pa
 int aid_row_norm(const aid_row_norm_params* p, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * aid_scale_act -- h = act(x * scale[b,c]) on [B,C,F,T] views (act: 0 none, 1 erf-GELU).
+ *   The normalise -> modulate -> GELU prologue of a dilated step (unet...py:475-482) evaluated ONCE per element
+ *   into a scratch tensor; the 5x3 conv then stages plain copies (inside the conv's LDS staging the same GELU
+ *   would be re-evaluated for each of the 5 dilated rows and each Cout tile).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    aid_view x, y;
+    const float* scale; int64_t scale_ld;
+    int B, C, F, T, act;
+} aid_scale_act_params;
+int aid_scale_act(const aid_scale_act_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * aid_add2 -- y = a*u + b*v on [B,C,F,T] views (the `(x + res)/sqrt(2)` skip combine of a ResnetBlock whose
  *   input and output widths agree, unet...py:491 with res_conv = Identity; also gradient accumulation).
  * ------------------------------------------------------------------------------------------------- */

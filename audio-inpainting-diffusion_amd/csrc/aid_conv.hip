@@ -251,27 +251,33 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_mfma_kernel(const ConvDev
         float* Xn = smem + (cur ^ 1) * BUFSZ;
         float* Wn = Xn + XSZ;
         const bool more = (ch + 1) < a.nchunks;
+        // operand fragments are fetched one k-step AHEAD of the MFMAs that consume them (explicit register
+        // double buffer), so every ds_read has a full k-step of matrix work to land behind
+        float av[2][MT], bv[2][NT];
+        auto load_frags = [&](int ks, int buf) {
+            const int tap = ks / (KC / 2);
+            const int cp = ks % (KC / 2);
+            const int kh = tap / KW, kw = tap % KW;
+            const int ci = 2 * cp + ci_lane;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                av[buf][i] = Ws[(tap * KC + ci) * M_BLK + (wm * MT + i) * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                bv[buf][j] = Xs[ci * strip_ci + kh * TTP + xoff[j] + kw];
+        };
+        load_frags(0, 0);
 #pragma unroll
         for (int slot = 0; slot < NSLOT; ++slot) {
 #pragma unroll
             for (int k = 0; k < KS_PER_SLOT; ++k) {
                 const int ks = slot * KS_PER_SLOT + k;          // k-step index: (tap, cp) with cp fastest
-                const int tap = ks / (KC / 2);
-                const int cp = ks % (KC / 2);
-                const int kh = tap / KW, kw = tap % KW;
-                const int ci = 2 * cp + ci_lane;
-                float av[MT], bv[NT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    av[i] = Ws[(tap * KC + ci) * M_BLK + (wm * MT + i) * 32 + (lane & 31)];
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    bv[j] = Xs[ci * strip_ci + kh * TTP + xoff[j] + kw];
+                if (ks + 1 < KSTEPS) load_frags(ks + 1, (ks + 1) & 1);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][i], bv[ks & 1][j], acc[i][j], 0, 0, 0);
                 // the next chunk's global loads are issued BEHIND the first MFMAs of this chunk, so the matrix
                 // pipe is already busy while the wave spends its issue slots on address arithmetic / VMEM
                 if (slot == 0 && k == 0 && more) issue_loads((ch + 1) * KC);
@@ -363,6 +369,7 @@ static int launch_m(const aid_conv2d_params* p, hipStream_t st) {
         const int64_t ntiles = (npos + 255) / 256;
         if (ntiles * (p->Cout_pad / 128) < 192) mb = (ntiles * (p->Cout_pad / 64) < 192) ? 32 : 64;
     }
+    // AID_CONV_CFG=n selects alternative tile / wave-count configurations (tuning experiments only)
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("AID_CONV_CFG"); dbg = e ? atoi(e) : 0; }
     if (KH == 5 && mb == 128 && dbg == 1) return launch_cfg<KH, KW, 1, 2, 4, 4, KC>(p, st);   // 16 waves, 128x256
@@ -377,8 +384,12 @@ static int launch_m(const aid_conv2d_params* p, hipStream_t st) {
     if (KH == 5 && mb == 96 && dbg == 3) return launch_cfg<KH, KW, 3, 2, 1, 8, KC>(p, st);    // 8 waves, 96x512
     switch (mb) {
         case 32: return launch_cfg<KH, KW, 1, 2, 1, 4, KC>(p, st);
-        case 64: return launch_cfg<KH, KW, 2, 2, 1, 4, KC>(p, st);
-        case 96: return launch_cfg<KH, KW, 3, 1, 1, 8, KC>(p, st);
+        case 64:
+            if (KH == 5) return launch_cfg<KH, KW, 1, 2, 2, 8, KC>(p, st);     // 16 waves, 64x512
+            return launch_cfg<KH, KW, 2, 2, 1, 4, KC>(p, st);
+        case 96:
+            if (KH == 5) return launch_cfg<KH, KW, 1, 2, 3, 4, KC>(p, st);     // 12 waves, 96x256
+            return launch_cfg<KH, KW, 3, 1, 1, 8, KC>(p, st);
         default:
             if (KH == 5) return launch_cfg<KH, KW, 1, 2, 4, 4, KC>(p, st);     // 16 waves (4 per SIMD), 128x256
             return launch_cfg<KH, KW, 2, 2, 2, 4, KC>(p, st);

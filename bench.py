@@ -13,11 +13,16 @@ barrier+synchronize pairs; MAX over ranks.  value = denoiser evaluations per sec
 (= n_gpus * 8 segments * 2 evaluations * K / wall); ms_per_step = wall / K.  Weak scaling: every GPU owns 8
 segments; the only collective is the start-up weight broadcast (not timed).
 
+Default branch: xi=0.25 = reconstruction guidance, the reference tester's shipped setting: every evaluation is a
+forward pass PLUS the input-VJP through the whole denoiser (--xi 0 times the forward-only replacement branch).
+
 roofline: the dominant kernel is conv_mfma_kernel (aid_conv2d, fp32 MFMA implicit GEMM, 99 % of the FLOPs).
-Every conv launch inside the timed region is bracketed by HIP events on the launch stream;
-achieved = sum of algorithmic conv FLOPs / sum of conv kernel time, peak = 157.3 TFLOP/s (fp32 MFMA dense).
+Every conv launch inside the timed region (forward and VJP plans) is bracketed by HIP events on the launch
+stream; achieved = sum of algorithmic conv FLOPs / sum of conv kernel time, peak = 157.3 TFLOP/s (fp32 MFMA).
+traffic = HBM bytes per conv launch from the committed PMC pass of this command (profiles/), corrected per
+MI355X_MICROARCH.md (FETCH_SIZE x2).
 cpu_baseline: the CPU oracle (torch-CPU restatement of the reference path, oracle/) timed on this host's cores
-for the same network at B=1 (rank 0, N=1 only): 1 warm-up + 2 timed forward evaluations.
+for the same network and branch at B=1 (rank 0, N=1 only), bounded sample.
 """
 import argparse
 import json
@@ -31,7 +36,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def cpu_baseline(net, args, n_timed=2):
+def cpu_baseline(net, args, guided: bool):
+    """The CPU oracle (oracle/: torch-CPU restatement of the reference path) timed on this host for the same
+    full-size network at B=1: one warm-up forward evaluation, then a bounded timed sample of the same branch the
+    GPU number is quoted on (guided: 1 evaluation = forward with autograd graph + input gradient; xi=0: 2 forward
+    evaluations)."""
     from oracle.nsgt_cqt import OracleCQT
     from oracle.unet import OracleUnet
     from oracle.edm import OracleEDM
@@ -42,16 +51,29 @@ def cpu_baseline(net, args, n_timed=2):
     orc = OracleUnet(n, bpo, OracleCQT(n, bpo, "oct", ("kaiser", 1), args.exp.sample_rate, L)).load_state_dict(net.state_dict())
     edm = OracleEDM()
     x = torch.from_numpy(seeded_normal(1, 0, L)).reshape(1, L) * 0.5
+    y = torch.from_numpy(seeded_normal(2, 0, L)).reshape(1, L) * 0.063
+    mask = torch.ones(1, L)
+    mask[:, L // 2 - 3307: L // 2 + 3308] = 0
     s = torch.full((1, 1), 0.5)
     with torch.no_grad():
-        edm.denoiser(x, orc, s)
-        t0 = time.time()
-        for _ in range(n_timed):
-            edm.denoiser(x, orc, s)
-        dt = (time.time() - t0) / n_timed
-    return {"value": round(1.0 / dt, 4), "unit": "denoiser-evals/s", "cores": cores, "kind": "port",
-            "sample": f"B=1 full-size 22.05 kHz network, forward-only (xi=0) evaluations: 1 warm-up + {n_timed} timed, "
-                      f"{dt:.2f} s each, torch {torch.__version__} CPU fp32"}
+        edm.denoiser(x, orc, s)                      # warm-up
+    t0 = time.time()
+    if guided:
+        n_timed = 1
+        xr = x.clone().requires_grad_()
+        xh = orc.CQTransform.apply_hpf_DC(edm.denoiser(xr, orc, s))
+        norm = torch.linalg.norm(y * mask - mask * xh, dim=1, ord=2)
+        torch.autograd.grad(norm.sum(), xr)
+    else:
+        n_timed = 2
+        with torch.no_grad():
+            for _ in range(n_timed):
+                edm.denoiser(x, orc, s)
+    dt = (time.time() - t0) / n_timed
+    what = "guided (xi=0.25: forward with graph + input-VJP by torch.autograd)" if guided else "forward-only (xi=0)"
+    return {"value": round(1.0 / dt, 4), "unit": "denoiser evaluations per second", "cores": cores, "kind": "port",
+            "sample": f"B=1 full-size 22.05 kHz network, {what}: 1 warm-up forward + {n_timed} timed evaluation(s), "
+                      f"{dt:.2f} s each, torch {torch.__version__} CPU fp32, {cores} threads"}
 
 
 def main():
@@ -60,7 +82,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="segments per GPU")
-    ap.add_argument("--xi", type=float, default=0.0, help="0 = replacement branch (forward only); 0.25 = guided (reference default)")
+    ap.add_argument("--xi", type=float, default=0.25, help="0.25 = reconstruction guidance (the reference tester's default, conf/tester/inpainting_tester.yaml:32); "
+                                                          "0 = replacement branch (forward only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-table", action="store_true", help="print per-shape conv kernel times (stderr)")
     a = ap.parse_args()
@@ -152,8 +175,14 @@ def main():
                          "algorithmic_gflop_per_launch": round(conv_flops / max(1, len(timing)) / 1e9, 2),
                          "conv_time_fraction_of_wall": round(conv_ms * 1e-3 / wall, 3)},
         }
+        tr = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")     # PMC pass of this same command (see profiles/README.md)
+        if os.path.exists(tr):
+            try:
+                out["roofline"]["traffic"] = json.load(open(tr)).get("hbm_bytes_per_conv_launch_corrected")
+            except Exception:
+                pass
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(net, args)
+            out["cpu_baseline"] = cpu_baseline(net, args, guided=a.xi > 0)
             out["cpu_baseline"]["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     D.barrier()

@@ -269,6 +269,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_mfma_kernel(const ConvDev
         load_frags(0, 0);
 #pragma unroll
         for (int slot = 0; slot < NSLOT; ++slot) {
+            // progress balancing: the hardware arbitrates the shared matrix pipe by priority, then AGE, so the
+            // oldest wave of a SIMD finishes its chunk thousands of cycles before the youngest and then idles
+            // at the barrier while the pipe runs under-occupied (measured with tools/conv_phase_probe.py).  A wave
+            // lowers its own priority as it advances through the chunk, which lets the laggards catch up.
+            if (slot == 0) __builtin_amdgcn_s_setprio(3);
+            else if (slot == 1) __builtin_amdgcn_s_setprio(2);
+            else if (slot == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int k = 0; k < KS_PER_SLOT; ++k) {
                 const int ks = slot * KS_PER_SLOT + k;          // k-step index: (tap, cp) with cp fastest
@@ -385,7 +393,7 @@ static int launch_m(const aid_conv2d_params* p, hipStream_t st) {
     switch (mb) {
         case 32: return launch_cfg<KH, KW, 1, 2, 1, 4, KC>(p, st);
         case 64:
-            if (KH == 5) return launch_cfg<KH, KW, 1, 2, 2, 8, KC>(p, st);     // 16 waves, 64x512
+            if (KH == 5 && p->T >= 64) return launch_cfg<KH, KW, 1, 2, 2, 8, KC>(p, st);     // 16 waves, 64x512
             return launch_cfg<KH, KW, 2, 2, 1, 4, KC>(p, st);
         case 96:
             if (KH == 5) return launch_cfg<KH, KW, 1, 2, 3, 4, KC>(p, st);     // 12 waves, 96x256
@@ -395,6 +403,8 @@ static int launch_m(const aid_conv2d_params* p, hipStream_t st) {
             return launch_cfg<KH, KW, 2, 2, 2, 4, KC>(p, st);
     }
 }
+
+int aid_conv53_dma_try(const aid_conv2d_params* p, hipStream_t st);   // aid_conv_dma.hip
 
 extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -408,7 +418,15 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     AID_REQUIRE(p->Cin_pad == cip && p->Cout_pad == cop, "aid_conv2d: packed weight dims mismatch (use aid_conv2d_pack_dims)");
     AID_REQUIRE(p->epi == 0 || (p->epi == 1 && p->aux.p && p->aux_scale), "aid_conv2d: epi=1 needs aux + aux_scale");
     AID_REQUIRE((int64_t)p->B * p->in_scale_ld < (1LL << 31), "aid_conv2d: in_scale too large");
-    if (p->KH == 5 && p->KW == 3) return launch_m<5, 3, 4>(p, st);
+    if (p->KH == 5 && p->KW == 3) {
+        static int use_dma = -1;
+        if (use_dma < 0) { const char* e = getenv("AID_CONV_DMA"); use_dma = e ? atoi(e) : 1; }
+        if (use_dma) {
+            const int r = aid_conv53_dma_try(p, st);     // direct-to-LDS kernel for the shapes that carry the FLOPs
+            if (r != 0) return r < 0 ? r : AID_OK;
+        }
+        return launch_m<5, 3, 4>(p, st);
+    }
     if (p->KH == 1 && p->KW == 1) {
         if (p->Cin <= 8) return launch_m<1, 1, 8>(p, st);
         return launch_m<1, 1, 32>(p, st);

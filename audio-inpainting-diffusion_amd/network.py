@@ -248,9 +248,18 @@ class _Builder:
             if res is not None and not fused_res:
                 gr = self.G(res)
                 self.add2_raw(gr, gy, gr, 1.0, alpha * res_scale)
+            gin, gsc = gy, out_scale
+            if kh > 1 and out_scale is not None:
+                # 5x3 dgrad: apply the gate in a copy pass so the conv input needs no in-kernel prologue
+                # (keeps it on the direct-to-LDS kernel)
+                gin = self._scratch(("g",) + tuple(gy.shape))
+                sp = _lib.ScaleActParams(_lib.view4(gy), _lib.view4(gin), out_scale.data_ptr(), out_scale.stride(0), gy.shape[0],
+                                         cout, gy.shape[2], gy.shape[3], 0)
+                self.plan.add("aid_scale_act", sp, gy, gin, out_scale)
+                gsc = None
             if norm_stats is not None:
                 gd = self._scratch(x.shape)
-                self._conv_raw(gy, gd, wpT, cout, cin, kh, kw, dil, out_scale, 0, in_scale, None, 1.0, alpha,
+                self._conv_raw(gin, gd, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, None, 1.0, alpha,
                                epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None)
                 dp = _lib.GroupDotParams(_lib.view4(gd), _lib.view4(x), B, cin, F, T, 8, self.stats_ws.data_ptr())
                 self.plan.add("aid_group_dot", dp, gd, x)
@@ -260,7 +269,7 @@ class _Builder:
                 self.plan.add("aid_norm_bwd", npar, gd, x, gy, norm_stats)
             else:
                 gx = self.G(x)
-                self._conv_raw(gy, gx, wpT, cout, cin, kh, kw, dil, out_scale, 0, in_scale, gx, 1.0 / alpha, alpha,
+                self._conv_raw(gin, gx, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, gx, 1.0 / alpha, alpha,
                                epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None)
         self.bwd.append(bw)
 

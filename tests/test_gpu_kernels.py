@@ -86,6 +86,13 @@ CONV_CASES = [
     (2, 96, 192, 1, 8, 1, 1, 1, False, False),       # qk GEMM, F = 1
     (1, 320, 640, 1, 128, 1, 1, 1, False, False),    # qk GEMM, larger K
     (3, 40, 40, 9, 12, 5, 3, 2, True, True),         # ragged: T not a power of two, odd row count
+    # no prologue -> direct-to-LDS (global_load_lds) kernel
+    (1, 64, 64, 24, 1024, 5, 3, 2, False, True),     # 64 x 512 tile, two t-tiles per row
+    (2, 96, 96, 20, 256, 5, 3, 8, False, True),      # 96 x 256 tile (weight rows padded to 128 in LDS)
+    (1, 128, 128, 40, 128, 5, 3, 16, False, True),   # 128 x 256 tile, ROWS = 2
+    (2, 256, 256, 24, 32, 5, 3, 64, False, True),    # two M tiles, ROWS = 8, dilation larger than F
+    (3, 64, 128, 9, 12, 5, 3, 1, False, False),      # ragged T (zero-page columns), odd rows, Cin != Cout
+    (1, 128, 64, 7, 8, 5, 3, 2, False, True),        # ROWS = 32 (halo area full)
 ]
 
 

@@ -28,7 +28,10 @@ def main():
     p = L.Conv2dParams()
     p.x, p.y, p.res, p.aux = L.view4(x), L.view4(y), L.view4(res), L.view4(None)
     p.wp = wp.data_ptr()
-    p.in_scale, p.in_scale_ld = isc.data_ptr(), isc.stride(0)
+    if act >= 0:
+        p.in_scale, p.in_scale_ld = isc.data_ptr(), isc.stride(0)
+    else:
+        p.in_scale, p.in_scale_ld, act = None, 0, 0       # act < 0: no prologue at all (direct-to-LDS kernel eligible)
     p.out_scale, p.out_scale_ld = osc.data_ptr(), osc.stride(0)
     p.B, p.Cin, p.Cout, p.F, p.T = B, Cin, Cout, F, T
     p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]

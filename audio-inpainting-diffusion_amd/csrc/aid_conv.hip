@@ -311,17 +311,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_mfma_kernel(const ConvDev
         const int64_t abase = p.aux.p ? ((int64_t)b * p.aux.sB + (int64_t)f * p.aux.sF + t) : 0;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+            // gather phase first (res / aux / gate), then compute + store: res may alias y (gradient accumulation),
+            // so the compiler would otherwise serialise load -> store element by element (16 dependent round trips)
+            float rv[16], uv[16], sv[16];
+            const int mbase = m0 + (wm * MT + i) * 32 + 4 * (lane >> 5);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                const bool ok = m < p.Cout;
+                rv[r] = (ok && p.res.p) ? p.res.p[rbase + (int64_t)m * p.res.sC] : 0.f;
+                sv[r] = (ok && p.out_scale) ? p.out_scale[(int64_t)b * p.out_scale_ld + m] : 1.f;
+                uv[r] = (ok && p.epi == 1) ? p.aux.p[abase + (int64_t)m * p.aux.sC] * p.aux_scale[(int64_t)b * p.aux_scale_ld + m] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
                 if (m >= p.Cout) continue;
-                float v = acc[i][j][r];
-                if (p.out_scale) v *= p.out_scale[(int64_t)b * p.out_scale_ld + m];
-                if (p.epi == 1) {
-                    const float u = p.aux.p[abase + (int64_t)m * p.aux.sC] * p.aux_scale[(int64_t)b * p.aux_scale_ld + m];
-                    v *= aid_dgelu(u);
-                }
-                if (p.res.p) v += p.res_scale * p.res.p[rbase + (int64_t)m * p.res.sC];
+                float v = acc[i][j][r] * sv[r];
+                if (p.epi == 1) v *= aid_dgelu(uv[r]);
+                v += p.res_scale * rv[r];
                 p.y.p[ybase + (int64_t)m * p.y.sC] = p.alpha * v;
             }
         }

@@ -122,3 +122,63 @@ def test_sampler_replacement_branch_vs_oracle():
     assert len(errs) == 7 and errs[0] < TOL and max(errs) < 5e-4
     assert rel_l2(out.cpu(), ref) < 5e-4
     assert float((out.cpu() - y)[:, :1700].abs().max()) < 1e-5   # observed samples are kept by the projection
+
+
+def test_unconditional_sampling_vs_oracle():
+    """predict_unconditional (edm_sampler_inpainting.py:155-162, :116-125): no observations, DC/Nyquist projector on x_hat."""
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.sampler import Sampler
+    from oracle.edm import OracleEDM
+    net, z, kw, args = _net_from_golden("a")
+    args.tester.T, args.tester.posterior_sampling.xi = 3, 0.0
+    Ls = kw["audio_len"]
+    smp = Sampler(model=net, diff_params=EDM(args), args=args)
+    smp.seeds, smp.trace = [3, 4], []
+    out = smp.predict_unconditional((2, Ls), torch.device(DEV))
+    # oracle: same loop, y = None
+    orc, edm = _oracle_for(net, kw), OracleEDM()
+    gens = [torch.Generator().manual_seed(s) for s in (3, 4)]
+    rn = lambda: torch.cat([torch.randn([1, Ls], generator=g) for g in gens])
+    t = edm.create_schedule(3)
+    gamma = edm.get_gamma(t)
+    x = rn() * t[0]
+    den = lambda xx, s: orc.CQTransform.apply_hpf_DC(edm.denoiser(xx, orc, s.reshape(1, 1).expand(2, 1)))
+    with torch.no_grad():
+        for i in range(3):
+            t_hat = t[i] + gamma[i] * t[i]
+            x = x + ((t_hat ** 2 - t[i] ** 2) ** 0.5) * rn()
+            d = -t_hat * ((den(x, t_hat) - x) / t_hat ** 2)
+            h = t[i + 1] - t_hat
+            if t[i + 1] != 0:
+                xp = x + h * d
+                dp = -t[i + 1] * ((den(xp, t[i + 1]) - xp) / t[i + 1] ** 2)
+                x = x + h * (0.5 * d + 0.5 * dp)
+            else:
+                x = x + h * d
+    e = rel_l2(out.cpu(), x)
+    print(f"unconditional sampler (3 steps): rel-L2 vs oracle = {e:.3e}")
+    assert e < 5e-4
+
+
+def test_cfgB_44k_8_octave_network_vs_oracle():
+    """BASELINE.json configs[4] shape class: the 44.1 kHz / 8-octave network (242 M parameters), L=184184, B=1,
+    against the CPU oracle (full size; ~20 s of CPU)."""
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    from oracle.nsgt_cqt import OracleCQT
+    from oracle.unet import OracleUnet
+    args = make_args("musicnet44k", audio_len=184184, T=128, gap_ms=1500.0)
+    net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(DEV)), 1, gate_scale=10.0, affine_scale=10.0)
+    Ls = args.exp.audio_len
+    x = torch.from_numpy(seeded_normal(11, 0, Ls)).reshape(1, Ls) * 0.5
+    cn = torch.tensor([[-0.6]])
+    with torch.no_grad():
+        y = net(x.to(DEV), cn.to(DEV)).cpu()
+    orc = OracleUnet(8, 64, OracleCQT(8, 64, "oct", ("kaiser", 1), 44100, Ls)).load_state_dict(net.state_dict())
+    with torch.no_grad():
+        ref = orc(x, cn)
+    e = rel_l2(y, ref)
+    print(f"cfg-B 44.1 kHz 8-octave network: rel-L2 vs oracle = {e:.3e}; GFLOP/eval = {net.flops_per_eval(1) / 1e9:.1f}")
+    assert e < TOL
+    assert abs(net.flops_per_eval(1) / 1.590e12 - 1) < 0.02      # SURVEY.md section 8d: 1.590 TFLOP

@@ -164,3 +164,34 @@ def test_guided_evaluation_and_sampler_vs_oracle():
     errs = [rel_l2(a.cpu(), b) for a, b in zip(smp.trace, osmp.trace)]
     print("guided per-evaluation x_hat rel-L2:", ["%.2e" % e for e in errs], " final:", "%.2e" % rel_l2(out.cpu(), ref))
     assert len(errs) == 5 and errs[0] < 1e-4 and max(errs) < 5e-4
+
+
+def test_full_size_guided_evaluation_vs_oracle_autograd():
+    """Full cfg-A network (186 M parameters, L=184184), B=1: x_hat and the reconstruction-guidance gradient of
+    network.denoise_guided against torch.autograd over the CPU oracle (~60 s of CPU, ~18 GB host RAM)."""
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
+    from audio_inpainting_diffusion_amd.masks import long_gap_mask
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    from oracle.edm import OracleEDM
+    from oracle.nsgt_cqt import OracleCQT
+    from oracle.unet import OracleUnet
+    args = make_args("maestro22k")
+    net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(DEV)), 0, gate_scale=10.0, affine_scale=10.0)
+    Ls = args.exp.audio_len
+    edm = OracleEDM()
+    x = torch.from_numpy(seeded_normal(21, 0, Ls)).reshape(1, Ls) * 0.3
+    y = torch.from_numpy(seeded_normal(22, 0, Ls)).reshape(1, Ls) * 0.063
+    mask = long_gap_mask(Ls, 22050, 300)
+    s = torch.full((1, 1), 0.4)
+    v = lambda t: t.reshape(-1).to(DEV).contiguous()
+    xh, g, nrm = net.denoise_guided(x.to(DEV), v(edm.cnoise(s)), v(edm.cin(s)), v(edm.cskip(s)), v(edm.cout(s)), True,
+                                    (y * mask).to(DEV), mask.to(DEV))
+    orc = OracleUnet(7, 64, OracleCQT(7, 64, "oct", ("kaiser", 1), 22050, Ls)).load_state_dict(net.state_dict())
+    xr = x.clone().requires_grad_()
+    xh_ref = orc.CQTransform.apply_hpf_DC(edm.denoiser(xr, orc, s))
+    norm = torch.linalg.norm(y * mask - mask * xh_ref, dim=1, ord=2)
+    g_ref = torch.autograd.grad(norm.sum(), xr)[0]
+    e1, e2 = rel_l2(xh.cpu(), xh_ref.detach()), rel_l2(g.cpu(), g_ref)
+    print(f"full-size guided evaluation: x_hat rel-L2 = {e1:.3e}, rec_grads rel-L2 = {e2:.3e}, |norm diff| = {abs(float(nrm.cpu()) - float(norm)):.2e}")
+    assert e1 < 1e-4 and e2 < 1e-4

@@ -172,3 +172,26 @@ def test_smooth_mask_matches_oracle_and_reference_geometry():
     a, b = prepare_smooth_mask(m, 50), smooth_mask_rows(m, 50)
     assert torch.equal(a, b)
     assert float(a[0, start - 1]) < 1e-3 and float(a[0, start - 50]) == 1.0 and float(a[0, start + gap]) == 0.0
+
+
+def test_masks_match_reference_prepare_mask_geometry():
+    """Closed forms quoted in SURVEY.md section 8c: 300 ms @22050 -> 6615 samples from 88785; 1.5 s @44100 -> 66150;
+    25/50/100 ms @16 kHz -> 400/800/1600 samples, 4 gaps."""
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.masks import long_gap_mask, mask_from_args, short_gaps_mask
+    from audio_inpainting_diffusion_amd.sampler import prepare_smooth_mask
+    L = 184184
+    m = long_gap_mask(L, 22050, 300)
+    z = (m[0] == 0).nonzero().flatten()
+    assert (len(z), int(z[0])) == (6615, 88785)
+    assert int((long_gap_mask(L, 44100, 1500)[0] == 0).sum()) == 66150
+    for ms, n in ((25, 400), (50, 800), (100, 1600)):
+        g = torch.Generator().manual_seed(ms)
+        m = short_gaps_mask(L, 16000, ms, 4, g)
+        assert (m == 0).sum() <= 4 * n and (m == 0).sum() >= n
+        sm = prepare_smooth_mask(m, 100)
+        assert float(sm.min()) == 0.0 and float(sm.max()) == 1.0 and torch.all(sm >= m * 0)   # cross-fades stay in [0,1]
+    a = make_args("librispeech16k", T=70, gap_ms=50.0)
+    assert a.tester.T == 70 and a.tester.data_consistency.hann_size == 100
+    assert mask_from_args(a, torch.Generator().manual_seed(0)).shape == (1, L)
+    assert torch.equal(mask_from_args(make_args("maestro22k", gap_ms=300.0)), long_gap_mask(L, 22050, 300))

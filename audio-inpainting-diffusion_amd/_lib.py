@@ -106,6 +106,11 @@ class ScaleActParams(C.Structure):
                 ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("act", C.c_int)]
 
 
+class FftPassParams(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("twiddle", C.c_void_p), ("B", C.c_int), ("N", C.c_int), ("R", C.c_int),
+                ("Ns", C.c_int), ("in_mode", C.c_int), ("out_mode", C.c_int), ("sign", C.c_float), ("out_scale", C.c_float)]
+
+
 class GroupDotParams(C.Structure):
     _fields_ = [("u", View), ("v", View), ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("groups", C.c_int),
                 ("ws", C.c_void_p)]
@@ -135,7 +140,7 @@ class RowNormParams(C.Structure):
 EXPORTS = ["aid_abi_version", "aid_last_error", "aid_group_stats", "aid_conv2d", "aid_conv2d_pack_dims", "aid_resample",
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
-           "aid_time_attention_bwd", "aid_guidance_seed", "aid_row_norm", "aid_scale_act"]
+           "aid_time_attention_bwd", "aid_guidance_seed", "aid_row_norm", "aid_scale_act", "aid_fft_pass"]
 
 _lib = None
 

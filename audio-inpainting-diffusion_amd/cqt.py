@@ -26,6 +26,22 @@ def _next_pow2(n: int) -> int:
     return 1 << (int(n) - 1).bit_length()
 
 
+def fft_radices(n: int):
+    """Radix schedule for aid_fft_pass: 16s, then 8/4/2, then the odd primes (<= 31) in increasing order."""
+    out = []
+    while n % 16 == 0:
+        out.append(16); n //= 16
+    for r in (8, 4, 2):
+        if n % r == 0:
+            out.append(r); n //= r
+    for r in (3, 5, 7, 11, 13, 17, 19, 23, 29, 31):
+        while n % r == 0:
+            out.append(r); n //= r
+    if n != 1:
+        raise NotImplementedError(f"signal length has a prime factor > 31 (remaining factor {n})")
+    return out
+
+
 class CQTPlan:
     def __init__(self, numocts: int, binsoct: int, fs: float, audio_len: int, window=("kaiser", 1.0)):
         L = int(audio_len)
@@ -106,6 +122,9 @@ class CQTPlan:
         wv[0] = wv[-1] = 1.0
         self.w_over_L = (wv / L).astype(np.float32)      # d irfft / dY_v  (real inner product)  = w_v/L * rfft(g)_v
         self.L_over_w = (L / wv).astype(np.float32)      # adjoint of rfft expressed through irfft
+        self.radices = fft_radices(L)
+        self.twiddle_L = np.stack([np.cos(2 * np.pi * np.arange(L) / L), -np.sin(2 * np.pi * np.arange(L) / L)], axis=-1
+                                  ).astype(np.float32).reshape(-1)          # exp(-2 pi i m / L)
         self.Tmax = int(max(T_oct))
         m = np.arange(self.Tmax // 2, dtype=np.float64)
         tw = np.exp(-2j * np.pi * m / self.Tmax)
@@ -131,9 +150,38 @@ class CQTransform:
             t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
             self._dev = dict(device=device, rc=t(P.rc), Lg=t(P.Lg), goff=t(P.goff), g=t(P.g), gdM=t(P.gdM), Tk=t(P.Tk),
                              woff=t(P.woff), kfirst=t(P.kfirst), kcount=t(P.kcount), twiddle=t(P.twiddle), hpf=t(P.hpf),
-                             g_over_T=t(P.g_over_T), w_over_L=t(P.w_over_L), L_over_w=t(P.L_over_w),
+                             g_over_T=t(P.g_over_T), w_over_L=t(P.w_over_L), L_over_w=t(P.L_over_w), twiddle_L=t(P.twiddle_L),
                              T_oct=t(np.array(P.T_oct, dtype=np.int32)))
         return self._dev
+
+    # ---- length-L real FFTs on our own mixed-radix kernel (csrc/aid_fft.hip) -----------------------------------
+    def _fft(self, src, B, in_mode, out_mode, sign, out_scale, out):
+        from . import _lib
+        P = self.plan
+        tab = self._tables(src.device)
+        L = P.L
+        bufs = [torch.empty(B, L, 2, device=src.device, dtype=torch.float32) for _ in range(2)]
+        cur, Ns = src, 1
+        for i, R in enumerate(P.radices):
+            last = i == len(P.radices) - 1
+            dst = out if last else bufs[i & 1]
+            p = _lib.FftPassParams(cur.data_ptr(), dst.data_ptr(), tab["twiddle_L"].data_ptr(), B, L, R, Ns,
+                                   in_mode if i == 0 else 0, out_mode if last else 0, sign, out_scale)
+            _lib.call("aid_fft_pass", p)
+            cur, Ns = dst, Ns * R
+        return out
+
+    def rfft(self, x: torch.Tensor) -> torch.Tensor:
+        """x[B,L] real -> [B,L/2+1] complex64  (= torch.fft.rfft)"""
+        B = x.shape[0]
+        out = torch.empty(B, self.plan.Lh, 2, device=x.device, dtype=torch.float32)
+        return torch.view_as_complex(self._fft(x.contiguous().float(), B, 1, 2, -1.0, 1.0, out))
+
+    def irfft(self, Y: torch.Tensor) -> torch.Tensor:
+        """Y[B,L/2+1] complex -> [B,L] real  (= torch.fft.irfft(Y, n=L))"""
+        B = Y.shape[0]
+        out = torch.empty(B, self.plan.L, device=Y.device, dtype=torch.float32)
+        return self._fft(torch.view_as_real(Y.contiguous()), B, 2, 1, +1.0, 1.0 / self.plan.L, out)
 
     # ---- planar API used by the network ----------------------------------------------------------------
     def alloc_octaves(self, B, device) -> List[torch.Tensor]:
@@ -145,7 +193,7 @@ class CQTransform:
         from . import _lib
         assert x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == self.Ls
         tab = self._tables(x.device)
-        spec = torch.fft.rfft(x, dim=-1)
+        spec = self.rfft(x)
         _lib.cqt_analysis(self, tab, torch.view_as_real(spec), outs, in_scale)
         return spec
 
@@ -202,7 +250,7 @@ class CQTransform:
         """list of complex [B,1,bins,T_o] -> [B,1,L]   (unet...py:841)"""
         octs = [torch.stack((ci.squeeze(1).real, ci.squeeze(1).imag), dim=1).contiguous().float() for ci in c]
         Y = self.synthesis_spectrum(octs)
-        return torch.fft.irfft(Y, n=self.Ls, dim=-1).unsqueeze(1)
+        return self.irfft(Y).unsqueeze(1)
 
     def apply_hpf_DC(self, x: torch.Tensor) -> torch.Tensor:
         """x[B,L] minus its DC- and Nyquist-band frame components (edm_sampler_inpainting.py:63,123).
@@ -213,8 +261,8 @@ class CQTransform:
 
     def _hpf(self, x):
         tab = self._tables(x.device)
-        X = torch.fft.rfft(x.detach().float().contiguous(), dim=-1)
-        return torch.fft.irfft(self.spectrum_scale(X, tab["hpf"]), n=self.Ls, dim=-1)
+        X = self.rfft(x.detach().float().contiguous())
+        return self.irfft(self.spectrum_scale(X, tab["hpf"]))
 
 
 class _HpfFn(torch.autograd.Function):

@@ -617,7 +617,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
         self.CQTransform.analysis(x, st["octs_in"])
         self._run_body(st, sigma)
         Y = self.CQTransform.synthesis_spectrum(st["octs_out"])
-        return torch.fft.irfft(Y, n=L, dim=-1)
+        return self.CQTransform.irfft(Y)
 
     @torch.no_grad()
     def denoise(self, x, cnoise, cin, cskip, cout, hpf: bool):
@@ -629,7 +629,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
         X = self.CQTransform.analysis(x.contiguous(), st["octs_in"], in_scale=cin)
         self._run_body(st, cnoise)
         Y = self.CQTransform.synthesis_spectrum(st["octs_out"], X=X, cskip=cskip, cout=cout, hpf=hpf)
-        return torch.fft.irfft(Y, n=L, dim=-1)
+        return self.CQTransform.irfft(Y)
 
     # ---------------------------------------------------------------------------------------------------
     # input-VJP (reconstruction guidance, testing/edm_sampler_inpainting.py:57-105)
@@ -661,10 +661,10 @@ class Unet_CQT_oct_with_attention(nn.Module):
         st = self._state(B)
         tr = self.CQTransform
         tab = tr._tables(g_pred.device)
-        G = torch.fft.rfft(g_pred.detach().float().contiguous(), dim=-1)
+        G = tr.rfft(g_pred.detach().float().contiguous())
         self._body_vjp(st, tr.spectrum_scale(G, tab["w_over_L"]))
         S = tr.analysis_adjoint(st["gin"])
-        return torch.fft.irfft(S, n=L, dim=-1)
+        return tr.irfft(S)
 
     @torch.no_grad()
     def denoise_guided(self, x, cnoise, cin, cskip, cout, hpf: bool, y, mask):
@@ -679,19 +679,19 @@ class Unet_CQT_oct_with_attention(nn.Module):
         X = tr.analysis(x.contiguous(), st["octs_in"], in_scale=cin)
         self._run_body(st, cnoise)
         Y = tr.synthesis_spectrum(st["octs_out"], X=X, cskip=cskip, cout=cout, hpf=hpf)
-        x_hat = torch.fft.irfft(Y, n=L, dim=-1)
+        x_hat = tr.irfft(Y)
         g = torch.empty_like(x_hat)
         norm = torch.empty(B, device=x.device, dtype=torch.float32)
         m = mask if mask.dim() == 2 else mask.reshape(1, -1)
         sp = _lib.GuidanceSeedParams(x_hat.data_ptr(), y.data_ptr(), m.data_ptr(), m.stride(0) if m.shape[0] > 1 else 0,
                                      g.data_ptr(), norm.data_ptr(), B, L)
         _lib.call("aid_guidance_seed", sp)
-        Gh = torch.fft.rfft(g, dim=-1)
+        Gh = tr.rfft(g)
         if hpf:
             Gh = tr.spectrum_scale(Gh, tab["hpf"])                       # the projector is self-adjoint
         self._body_vjp(st, tr.spectrum_scale(Gh, tab["w_over_L"], per_item=cout))
         S = tr.analysis_adjoint(st["gin"], in_scale=cin, X=Gh, cskip=cskip)
-        return x_hat, torch.fft.irfft(S, n=L, dim=-1), norm
+        return x_hat, tr.irfft(S), norm
 
     def flops_per_eval(self, B: int = 1) -> int:
         """Algorithmic conv/GEMM/attention FLOPs of one forward evaluation at batch B (2*MACs)."""

@@ -212,6 +212,27 @@ typedef struct {
 int aid_cqt_gather(const aid_cqt_gather_params* p, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * aid_fft_pass -- one radix-R pass of a mixed-radix Stockham FFT of length N = prod(R_i) (R <= 32), batched.
+ *   replaces: the two length-L real FFTs per evaluation that cqt_nsgt_pytorch delegates to torch.fft
+ *             (L = 184184 = 8*7*11*13*23 for the shipped configurations; any smooth N with prime factors <= 31).
+ *   A full transform = one launch per radix, ping-ponging between two buffers (host drives the passes):
+ *     pass with radix R, Ns = product of the radices already applied:
+ *        v[r] = in[j + r*N/R] * W_N^{ r*k*N/(Ns*R) },  k = j mod Ns          (j < N/R)
+ *        out[(j/Ns)*Ns*R + k + q*Ns] = sum_r v[r] * W_R^{q r}
+ *   in_mode : 0 complex [B,N]; 1 real [B,N] (imag = 0);  2 half spectrum [B,N/2+1] extended Hermitian-ly
+ *   out_mode: 0 complex [B,N]; 1 real part only [B,N] (times out_scale); 2 first N/2+1 bins [B,N/2+1]
+ *   sign = -1 forward, +1 inverse (unnormalised; fold 1/N into out_scale).
+ *   twiddle: [N] complex exp(-2 pi i m / N) (fp64-computed on the host).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* in; float* out; const float* twiddle;
+    int B, N, R, Ns;
+    int in_mode, out_mode;
+    float sign, out_scale;
+} aid_fft_pass_params;
+int aid_fft_pass(const aid_fft_pass_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Sampler element-wise kernels (replace the tensor expressions of Sampler.predict / get_score,
  * testing/edm_sampler_inpainting.py:141-147, 204-251, 343).  All arrays [B, L]; per-sample scalars [B].
  *

@@ -261,3 +261,28 @@ def test_sampler_elementwise(L):
     out = torch.empty_like(xd)
     L.call("aid_axpby", L.AxpbyParams(xd.data_ptr(), yd.data_ptr(), out.data_ptr(), None, td.data_ptr(), B, Ls))
     assert rel_l2(out.cpu(), x + t[:, None] * y) < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Ls", [2048, 4096, 16384, 65536, 184184, 368368, 2 * 3 * 5 * 7 * 11 * 13])
+def test_mixed_radix_fft_vs_rocfft(L, Ls):
+    """aid_fft_pass (own mixed-radix Stockham) against torch.fft (rocFFT) as an independent GPU implementation and
+    against numpy fp64 on the host: rfft, irfft, round trip."""
+    from audio_inpainting_diffusion_amd.cqt import CQTransform, CQTPlan
+    tr = CQTransform.__new__(CQTransform)
+    tr.plan = type("P", (), {})()
+    from audio_inpainting_diffusion_amd.cqt import fft_radices
+    tr.plan.L, tr.plan.Lh, tr.plan.radices = Ls, Ls // 2 + 1, fft_radices(Ls)
+    tw = np.stack([np.cos(2 * np.pi * np.arange(Ls) / Ls), -np.sin(2 * np.pi * np.arange(Ls) / Ls)], axis=-1).astype(np.float32).reshape(-1)
+    tr._dev = dict(device=torch.device(DEV, 0), twiddle_L=torch.from_numpy(tw).to(DEV))
+    tr._tables = lambda device: tr._dev
+    x = _rand(3, Ls, seed=5)
+    xd = x.to(DEV)
+    X = tr.rfft(xd)
+    ref = np.fft.rfft(x.double().numpy(), axis=-1)
+    assert rel_l2(torch.view_as_real(X.cpu()), torch.view_as_real(torch.from_numpy(ref))) < 2e-6
+    assert rel_l2(torch.view_as_real(X.cpu()), torch.view_as_real(torch.fft.rfft(xd).cpu())) < 2e-6
+    Y = torch.complex(_rand(3, Ls // 2 + 1, seed=6), _rand(3, Ls // 2 + 1, seed=7)).to(DEV)
+    y = tr.irfft(Y)
+    assert rel_l2(y.cpu(), torch.fft.irfft(Y, n=Ls).cpu()) < 2e-6
+    assert rel_l2(tr.irfft(X).cpu(), x) < 2e-6

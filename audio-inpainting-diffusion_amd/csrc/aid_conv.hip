@@ -337,7 +337,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_mfma_kernel(const ConvDev
 }
 
 // ------------------------------------------------------------------------------------------------------
-static int pick_mblk(int Cout) { return Cout <= 32 ? 32 : (Cout <= 64 ? 64 : (Cout <= 96 ? 96 : 128)); }
+static int pick_mblk(int Cout) {
+    if (Cout <= 32) return 32;
+    if (Cout <= 64) return 64;
+    if (Cout <= 96 || (Cout % 96 == 0 && Cout % 128 != 0)) return 96;   // 96, 192, 288: no padded rows
+    return 128;
+}
 
 extern "C" void aid_conv2d_pack_dims(int Cin, int Cout, int* Cin_pad, int* Cout_pad) {
     const int mb = pick_mblk(Cout);
@@ -437,6 +442,10 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     }
     if (p->KH == 1 && p->KW == 1) {
         if (p->Cin <= 8) return launch_m<1, 1, 8>(p, st);
+        static int kc1 = -1;
+        if (kc1 < 0) { const char* e = getenv("AID_CONV_KC1"); kc1 = e ? atoi(e) : 16; }
+        if (kc1 == 16) return launch_m<1, 1, 16>(p, st);
+        if (kc1 == 8) return launch_m<1, 1, 8>(p, st);
         return launch_m<1, 1, 32>(p, st);
     }
     aid_set_error("aid_conv2d: unsupported kernel size (5x3 and 1x1 only)");

@@ -97,6 +97,7 @@ def main():
 
     rank, local, world = D.init_distributed()
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    local = local % max(1, torch.cuda.device_count())      # (several ranks may share a GPU in functional tests)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     T = 36

@@ -38,7 +38,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert set(_lib.EXPORTS) == declared
     a, b = _lib.pack_dims(2, 96)
     assert (a, b) == (32, 96)
-    assert _lib.pack_dims(256, 256) == (256, 256) and _lib.pack_dims(40, 5120) == (64, 5120)
+    assert _lib.pack_dims(256, 256) == (256, 256) and _lib.pack_dims(40, 5120) == (64, 5120) and _lib.pack_dims(64, 192) == (64, 192)
 
 
 @pytest.mark.parametrize("cfg", [(7, 64, 22050, 184184), (8, 64, 44100, 368368), (7, 8, 22050, 16384), (3, 8, 22050, 2048)])

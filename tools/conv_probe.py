@@ -24,7 +24,7 @@ def main():
     wp = L.pack_conv_weight(w)
     isc = torch.rand(B, Cin, device=dev) + 0.5
     osc = torch.randn(B, Cout, device=dev)
-    res = x if Cin == Cout else None
+    res = x if Cin == Cout else (y if os.environ.get('PROBE_RMW') else None)
     p = L.Conv2dParams()
     p.x, p.y, p.res, p.aux = L.view4(x), L.view4(y), L.view4(res), L.view4(None)
     p.wp = wp.data_ptr()

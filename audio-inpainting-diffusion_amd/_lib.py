@@ -42,7 +42,7 @@ class Conv2dParams(C.Structure):
                 ("Cin_pad", C.c_int), ("Cout_pad", C.c_int),
                 ("KH", C.c_int), ("KW", C.c_int), ("dilF", C.c_int),
                 ("act", C.c_int), ("epi", C.c_int),
-                ("alpha", C.c_float), ("res_scale", C.c_float)]
+                ("alpha", C.c_float), ("res_scale", C.c_float), ("wp_wino", C.c_void_p)]
 
 
 class ResampleParams(C.Structure):
@@ -225,6 +225,21 @@ def pack_conv_weight(w: torch.Tensor, transpose: bool = False) -> torch.Tensor:
     cip, cop = pack_dims(ci, co)
     out = torch.zeros(kh * kw, cip, cop, device=w.device, dtype=torch.float32)
     out[:, :ci, :co] = w.permute(2, 3, 1, 0).reshape(kh * kw, ci, co)
+    return out
+
+
+def pack_conv_weight_wino(w: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+    """[Cout,Cin,5,3] -> Winograd F(2,3) pack [4*5, Cin_pad, Cout_pad]: U = G w along kw, "tap" index xi*5+kh."""
+    w = w.detach().float()
+    if transpose:
+        w = w.flip(2, 3).permute(1, 0, 2, 3)
+    co, ci, kh, kw = w.shape
+    assert (kh, kw) == (5, 3)
+    w0, w1, w2 = w[..., 0], w[..., 1], w[..., 2]
+    U = torch.stack((w0, 0.5 * (w0 + w1 + w2), 0.5 * (w0 - w1 + w2), w2), dim=0)      # [4, co, ci, kh]
+    cip, cop = pack_dims(ci, co)
+    out = torch.zeros(4 * kh, cip, cop, device=w.device, dtype=torch.float32)
+    out[:, :ci, :co] = U.permute(0, 3, 2, 1).reshape(4 * kh, ci, co)
     return out
 
 

@@ -418,6 +418,7 @@ static int launch_m(const aid_conv2d_params* p, hipStream_t st) {
 }
 
 int aid_conv53_dma_try(const aid_conv2d_params* p, hipStream_t st);   // aid_conv_dma.hip
+int aid_conv53_wino_try(const aid_conv2d_params* p, hipStream_t st);  // aid_conv_wino.hip
 
 extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -434,6 +435,12 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     if (p->KH == 5 && p->KW == 3) {
         static int use_dma = -1;
         if (use_dma < 0) { const char* e = getenv("AID_CONV_DMA"); use_dma = e ? atoi(e) : 1; }
+        static int use_wino = -1;
+        if (use_wino < 0) { const char* e = getenv("AID_CONV_WINO"); use_wino = e ? atoi(e) : 1; }
+        if (use_wino && p->wp_wino) {
+            const int r = aid_conv53_wino_try(p, st);    // Winograd F(2,3) along T: 4 MFMAs per 2 outputs instead of 6
+            if (r != 0) return r < 0 ? r : AID_OK;
+        }
         if (use_dma) {
             const int r = aid_conv53_dma_try(p, st);     // direct-to-LDS kernel for the shapes that carry the FLOPs
             if (r != 0) return r < 0 ? r : AID_OK;

@@ -31,9 +31,9 @@ __device__ float4 g_aid_zero_page[16];
 #define GLDS16(gptr, lptr) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-template <int MT, int NT, int WGM, int WGN, int RMAX>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv53_dma_kernel(const ConvDmaDev a) {
-    constexpr int KH = 5, KW = 3, KC = 4, TAPS = 15;
+template <int MT, int NT, int WGM, int WGN, int RMAX, int KC, int MINW>
+__global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_dma_kernel(const ConvDmaDev a) {
+    constexpr int KH = 5, KW = 3, TAPS = 15;
     constexpr int NW = WGM * WGN;
     constexpr int NTHREADS = 64 * NW;
     constexpr int M_BLK = 32 * MT * WGM;
@@ -42,7 +42,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv53_dma_kernel(const ConvDm
     constexpr int XB = N_BLK + HALO;                    // floats per (ci,kh) block
     constexpr int XSZ = KC * KH * XB;
     constexpr int WROW = (M_BLK % 64 == 0) ? M_BLK : ((M_BLK + 63) / 64) * 64;   // LDS weight row stride (96 -> 128)
-    constexpr int WSZ = TAPS * KC * WROW;
+    constexpr int WSZ_RAW = TAPS * KC * WROW;
+    constexpr int WSZ = ((WSZ_RAW + 255) / 256) * 256;   // whole 1-KiB pieces (tail lanes read the zero page)
     constexpr int BUFSZ = XSZ + WSZ;
     constexpr int NXP = KC * KH * (N_BLK / 256);        // 1-KiB DMA pieces of the x tile
     constexpr int NWP = WSZ / 256;                      // 1-KiB DMA pieces of the weight tile
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv53_dma_kernel(const ConvDm
             const int row = e / WROW, col = e % WROW;   // row = tap*KC + ci
             const int tap = row / KC, ci = row % KC;
             plds[i] = XSZ + wp_ * 256;
-            if (col < M_BLK) {                          // (columns 96..127 of the 96-row tile stay zero)
+            if (col < M_BLK && e < WSZ_RAW) {            // (columns 96..127 of the 96-row tile, and the tail, stay zero)
                 psrc[i] = p.wp + ((int64_t)tap * p.Cin_pad + ci) * p.Cout_pad + m0 + col;
                 pstride[i] = KC * p.Cout_pad;
             }
@@ -204,9 +205,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv53_dma_kernel(const ConvDm
 #pragma unroll
         for (int ks = 0; ks < TAPS * (KC / 2); ++ks) {
             if (ks == 0) __builtin_amdgcn_s_setprio(3);
-            else if (ks == 6) __builtin_amdgcn_s_setprio(2);
-            else if (ks == 12) __builtin_amdgcn_s_setprio(1);
-            else if (ks == 18) __builtin_amdgcn_s_setprio(0);
+            else if (ks == 3 * (KC / 2)) __builtin_amdgcn_s_setprio(2);
+            else if (ks == 6 * (KC / 2)) __builtin_amdgcn_s_setprio(1);
+            else if (ks == 9 * (KC / 2)) __builtin_amdgcn_s_setprio(0);
             if (ks + 1 < TAPS * (KC / 2)) load_frags(ks + 1, (ks + 1) & 1);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv53_dma_kernel(const ConvDm
     }
 }
 
-template <int MT, int NT, int WGM, int WGN, int RMAX>
+template <int MT, int NT, int WGM, int WGN, int RMAX, int KC = 4, int MINW = 1>
 static int launch_dma(const aid_conv2d_params* p, hipStream_t st) {
     constexpr int M_BLK = 32 * MT * WGM;
     constexpr int N_BLK = 32 * NT * WGN;
@@ -285,11 +286,11 @@ static int launch_dma(const aid_conv2d_params* p, hipStream_t st) {
     if (ROWS > RMAX) return 1000;                          // halo area holds RMAX rows: caller falls back
     a.tiles_t = aid_cdiv(p->T, TT);
     a.nrows = p->B * p->F;
-    a.nchunks = p->Cin / 4;
+    a.nchunks = p->Cin / KC;
     const int rgroups = aid_cdiv(a.nrows, ROWS);
     dim3 grid((unsigned)(rgroups * a.tiles_t), (unsigned)(p->Cout_pad / M_BLK));
-    const size_t lds = sizeof(float) * 2 * ((size_t)4 * 5 * (N_BLK + 2 * RMAX) + (size_t)15 * 4 * WROW) + sizeof(int) * 2 * ROWS;
-    auto kern = conv53_dma_kernel<MT, NT, WGM, WGN, RMAX>;
+    const size_t lds = sizeof(float) * 2 * ((size_t)KC * 5 * (N_BLK + 2 * RMAX) + (size_t)((15 * KC * WROW + 255) / 256) * 256) + sizeof(int) * 2 * ROWS;
+    auto kern = conv53_dma_kernel<MT, NT, WGM, WGN, RMAX, KC, MINW>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -311,7 +312,12 @@ int aid_conv53_dma_try(const aid_conv2d_params* p, hipStream_t st) {
     int rc;
     static int cfg = -1;
     if (cfg < 0) { const char* e = getenv("AID_DMA_CFG"); cfg = e ? atoi(e) : 0; }
-    if (cfg != 2 && p->Cout_pad % 64 == 0) rc = launch_dma<1, 2, 2, 4, 16>(p, st);   // 64 x 256, 8 waves, 2 workgroups per CU
+    if (cfg == 3 && p->Cout_pad % 64 == 0) rc = launch_dma<2, 2, 1, 4, 16, 2>(p, st);   // KC=2, 64x256, 4 waves: 3 workgroups per CU
+    else if (cfg == 5 && p->Cout_pad % 64 == 0) rc = launch_dma<1, 2, 2, 4, 16, 2>(p, st);   // KC=2, 64x256, 8 waves
+    else if (cfg == 6 && p->Cout_pad % 64 == 0) rc = launch_dma<1, 2, 2, 4, 16, 2, 6>(p, st);   // same, <= 80 VGPRs: 3 workgroups per CU
+    else if (cfg == 7 && p->Cout_pad % 64 == 0) rc = launch_dma<1, 2, 2, 4, 16, 2, 8>(p, st);   // same, <= 64 VGPRs: 4 workgroups per CU
+    else if (cfg == 4 && p->Cout_pad % 128 == 0) rc = launch_dma<1, 2, 4, 4, 16, 2>(p, st);   // KC=2, 128x256, 16 waves, 2 per CU
+    else if (cfg != 2 && p->Cout_pad % 64 == 0) rc = launch_dma<1, 2, 2, 4, 16>(p, st);   // 64 x 256, 8 waves, 2 workgroups per CU
     else if (cfg == 1 && p->Cout_pad % 32 == 0) rc = launch_dma<1, 2, 1, 4, 16>(p, st);   // 32 x 256, 4 waves, 2-3 workgroups per CU
     else if (p->Cout_pad % 128 == 0)      rc = launch_dma<1, 2, 4, 4, 32>(p, st);     // 128 x 256, 16 waves
     else if (p->Cout_pad % 96 == 0)  rc = launch_dma<1, 2, 3, 4, 32>(p, st);     //  96 x 256, 12 waves

@@ -209,7 +209,7 @@ class _Builder:
         self.plan.add("aid_group_stats", p, x, gamma, mod, scale, stats)
 
     def _conv_raw(self, x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha, epi=0,
-                  aux=None, aux_scale=None):
+                  aux=None, aux_scale=None, wpw=None):
         B, _, F, T = x.shape
         assert x.shape[1] == cin and y.shape[1] == cout and y.shape[0] == B and y.shape[2] == F and y.shape[3] == T
         p = _lib.Conv2dParams()
@@ -222,11 +222,12 @@ class _Builder:
         p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
         p.KH, p.KW, p.dilF, p.act, p.epi = kh, kw, dil, act, epi
         p.alpha, p.res_scale = alpha, res_scale
-        assert wp.shape[0] == kh * kw
-        self.plan.add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale, aux, aux_scale, flops=2 * B * F * T * cin * cout * kh * kw)
+        p.wp_wino = _lib.ptr(wpw)
+        assert wp.shape[0] == kh * kw and (wpw is None or wpw.shape == (4 * kh, wp.shape[1], wp.shape[2]))
+        self.plan.add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, flops=2 * B * F * T * cin * cout * kh * kw)
 
     def conv(self, x, y, wp, cin, cout, kh=1, kw=1, dil=1, in_scale=None, act=0, out_scale=None, res=None,
-             res_scale=1.0, alpha=1.0, wpT=None, norm_stats=None):
+             res_scale=1.0, alpha=1.0, wpT=None, norm_stats=None, wpw=None, wpwT=None):
         """Forward conv + registration of its input-VJP.  ``norm_stats``: the (mean, 1/(std+eps)) buffer when
         ``in_scale`` was produced by ``stats`` from this same ``x`` (the scale then depends on x)."""
         if act and kh > 1:
@@ -235,7 +236,7 @@ class _Builder:
             sp = _lib.ScaleActParams(_lib.view4(x), _lib.view4(hbuf), in_scale.data_ptr(), in_scale.stride(0), x.shape[0], cin,
                                      x.shape[2], x.shape[3], 1)
             self.plan.add("aid_scale_act", sp, x, hbuf, in_scale)
-            self._conv_raw(hbuf, y, wp, cin, cout, kh, kw, dil, None, 0, out_scale, res, res_scale, alpha)
+            self._conv_raw(hbuf, y, wp, cin, cout, kh, kw, dil, None, 0, out_scale, res, res_scale, alpha, wpw=wpw)
         else:
             self._conv_raw(x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha)
         if wpT is None:
@@ -260,7 +261,7 @@ class _Builder:
             if norm_stats is not None:
                 gd = self._scratch(x.shape)
                 self._conv_raw(gin, gd, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, None, 1.0, alpha,
-                               epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None)
+                               epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None, wpw=wpwT)
                 dp = _lib.GroupDotParams(_lib.view4(gd), _lib.view4(x), B, cin, F, T, 8, self.stats_ws.data_ptr())
                 self.plan.add("aid_group_dot", dp, gd, x)
                 npar = _lib.NormBwdParams(_lib.view4(gd), _lib.view4(x), _lib.view4(gy if fused_res else None), _lib.view4(self.G(x)),
@@ -410,6 +411,9 @@ class Unet_CQT_oct_with_attention(nn.Module):
             if leaf == "weight" and w.dim() >= 3:                       # conv weights (2-D ones are Linears)
                 put(name, _lib.pack_conv_weight(w))
                 put(name + "#T", _lib.pack_conv_weight(w, transpose=True))
+                if w.dim() == 4 and tuple(w.shape[2:]) == (5, 3) and w.shape[0] >= 64 and w.shape[1] >= 64:
+                    put(name + "#W", _lib.pack_conv_weight_wino(w))                     # Winograd F(2,3) packs
+                    put(name + "#WT", _lib.pack_conv_weight_wino(w, transpose=True))
             elif leaf == "gamma":
                 put(name, w.detach().reshape(-1).float())
         # stacked modulation matrix: [affine2, gate2]? then per step [affine.k, gate.k], block after block
@@ -473,7 +477,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
             xn = bd.buf(B, N, F, T)
             bd.conv(x, xn, W[pfx + f"H.{k}.weight"], N, N, kh, kw, dil=(2 ** k if kh > 1 else 1), in_scale=sc, act=1,
                     out_scale=self._mod(st, pfx + f"gate.{k}"), res=x, alpha=RSQRT2, wpT=W[pfx + f"H.{k}.weight#T"],
-                    norm_stats=stb)
+                    norm_stats=stb, wpw=W.get(pfx + f"H.{k}.weight#W"), wpwT=W.get(pfx + f"H.{k}.weight#WT"))
             x = xn
         if blk.proj_place == "after":
             assert hasattr(blk, "proj_out") and hasattr(blk, "res_conv")

@@ -96,8 +96,9 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("wino", [0, 1])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d(L, case):
+def test_conv2d(L, case, wino):
     B, Cin, Cout, Fd, T, KH, KW, dil, pro, epi = case
     x = _rand(B, Cin, Fd, T, seed=10)
     w = _rand(Cout, Cin, KH, KW, seed=11, scale=1.0 / math.sqrt(Cin * KH * KW))
@@ -125,6 +126,12 @@ def test_conv2d(L, case):
     p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
     p.KH, p.KW, p.dilF, p.act, p.epi = KH, KW, dil, act, 0
     p.alpha, p.res_scale = alpha, res_scale
+    wpw = None
+    if wino:
+        if (KH, KW) != (5, 3) or pro or Cin % 4 or Cout < 64:
+            pytest.skip("Winograd path needs a plain-copy 5x3 conv with Cin % 4 == 0 and Cout >= 64")
+        wpw = L.pack_conv_weight_wino(wd)
+        p.wp_wino = wpw.data_ptr()
     L.call("aid_conv2d", p)
     torch.cuda.synchronize()
     assert rel_l2(y.cpu(), ref) < 1e-5

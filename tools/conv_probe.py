@@ -37,6 +37,9 @@ def main():
     p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
     p.KH, p.KW, p.dilF, p.act, p.epi = KH, KW, dil, act, 0
     p.alpha, p.res_scale = 1 / math.sqrt(2), 1.0
+    if os.environ.get('PROBE_WINO', '0') != '0' and KH == 5:
+        wpw = L.pack_conv_weight_wino(w)
+        p.wp_wino = wpw.data_ptr()
     for _ in range(2):
         L.call("aid_conv2d", p)
     torch.cuda.synchronize()

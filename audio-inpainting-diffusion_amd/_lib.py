@@ -42,7 +42,7 @@ class Conv2dParams(C.Structure):
                 ("Cin_pad", C.c_int), ("Cout_pad", C.c_int),
                 ("KH", C.c_int), ("KW", C.c_int), ("dilF", C.c_int),
                 ("act", C.c_int), ("epi", C.c_int),
-                ("alpha", C.c_float), ("res_scale", C.c_float), ("wp_wino", C.c_void_p)]
+                ("alpha", C.c_float), ("res_scale", C.c_float), ("wp_wino", C.c_void_p), ("wino_taps", C.c_int)]
 
 
 class ResampleParams(C.Structure):
@@ -228,18 +228,24 @@ def pack_conv_weight(w: torch.Tensor, transpose: bool = False) -> torch.Tensor:
     return out
 
 
-def pack_conv_weight_wino(w: torch.Tensor, transpose: bool = False) -> torch.Tensor:
-    """[Cout,Cin,5,3] -> Winograd F(2,3) pack [4*5, Cin_pad, Cout_pad]: U = G w along kw, "tap" index xi*5+kh."""
-    w = w.detach().float()
+def pack_conv_weight_wino(w: torch.Tensor, transpose: bool = False, f4: bool = True) -> torch.Tensor:
+    """[Cout,Cin,5,3] -> Winograd pack [NXI*5, Cin_pad, Cout_pad]: U = G w along kw, "tap" index xi*5+kh.
+    f4=False: F(2,3), NXI=4;  f4=True: F(4,3), NXI=6 (computed in float64, stored fp32)."""
+    w = w.detach().double()
     if transpose:
         w = w.flip(2, 3).permute(1, 0, 2, 3)
     co, ci, kh, kw = w.shape
     assert (kh, kw) == (5, 3)
     w0, w1, w2 = w[..., 0], w[..., 1], w[..., 2]
-    U = torch.stack((w0, 0.5 * (w0 + w1 + w2), 0.5 * (w0 - w1 + w2), w2), dim=0)      # [4, co, ci, kh]
+    if f4:
+        U = torch.stack((w0 / 4, -(w0 + w1 + w2) / 6, -(w0 - w1 + w2) / 6, (w0 + 2 * w1 + 4 * w2) / 24,
+                         (w0 - 2 * w1 + 4 * w2) / 24, w2), dim=0)
+    else:
+        U = torch.stack((w0, 0.5 * (w0 + w1 + w2), 0.5 * (w0 - w1 + w2), w2), dim=0)      # [NXI, co, ci, kh]
+    nxi = U.shape[0]
     cip, cop = pack_dims(ci, co)
-    out = torch.zeros(4 * kh, cip, cop, device=w.device, dtype=torch.float32)
-    out[:, :ci, :co] = U.permute(0, 3, 2, 1).reshape(4 * kh, ci, co)
+    out = torch.zeros(nxi * kh, cip, cop, device=w.device, dtype=torch.float32)
+    out[:, :ci, :co] = U.permute(0, 3, 2, 1).reshape(nxi * kh, ci, co).float()
     return out
 
 

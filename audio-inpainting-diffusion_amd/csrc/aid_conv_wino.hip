@@ -284,6 +284,274 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino_kernel(const
     }
 }
 
+// ---- F(4,3): 6 products per 4 outputs (2x fewer MFMAs than direct).  tau now indexes GROUPS of 4 output samples:
+//   V = B^T d (d = 6 samples 4g-1 .. 4g+4):  V0 = 4d0-5d2+d4, V1 = (d3+d4)-4(d1+d2), V2 = (d4-d3)+4(d1-d2),
+//                                             V3 = (d4-d2)+2(d3-d1), V4 = (d4-d2)-2(d3-d1), V5 = 4d1-5d3+d5
+//   U = G w: w0/4, -(w0+w1+w2)/6, -(w0-w1+w2)/6, (w0+2w1+4w2)/24, (w0-2w1+4w2)/24, w2   (30 "taps" xi*5+kh)
+//   y0 = M0+M1+M2+M3+M4, y1 = (M1-M2)+2(M3-M4), y2 = (M1+M2)+4(M3+M4), y3 = (M1-M2)+8(M3-M4)+M5
+// fp32 error of F(4,3) measured at 2e-6 relative for K=1280 (direct fp32 accumulation: 1e-6).
+// MT m-tiles x NTT group-tiles (32 groups = 128 outputs) per wave; N_BLK = 128*NTT*WGN outputs
+template <int MT, int NTT, int WGM, int WGN, int RMAX, int KC, int MINW>
+__global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4_kernel(const ConvWinoDev a) {
+    constexpr int KH = 5, NXI = 6, TAPS = NXI * KH;     // 30 transformed taps
+    constexpr int NW = WGM * WGN;
+    constexpr int NTHREADS = 64 * NW;
+    constexpr int M_BLK = 32 * MT * WGM;
+    constexpr int N_BLK = 128 * NTT * WGN;              // output samples per tile
+    constexpr int HALO = 2 * RMAX;
+    constexpr int XB = N_BLK + HALO;
+    constexpr int XSZ = KC * KH * XB;
+    constexpr int WROW = (M_BLK % 64 == 0) ? M_BLK : ((M_BLK + 63) / 64) * 64;
+    constexpr int WSZ_RAW = TAPS * KC * WROW;
+    constexpr int WSZ = ((WSZ_RAW + 255) / 256) * 256;
+    constexpr int BUFSZ = XSZ + WSZ;
+    constexpr int NXP = KC * KH * (N_BLK / 256);
+    constexpr int NWP = WSZ / 256;
+    constexpr int NP = NXP + NWP;
+    constexpr int PPW = (NP + NW - 1) / NW;
+    constexpr int HQ = (2 * KC * KH * RMAX + NTHREADS - 1) / NTHREADS;
+    constexpr int NSTEP = KH * (KC / 2);                // (kh, ci-pair) steps per chunk, 4*MT*NTT MFMAs each
+    static_assert(N_BLK % 256 == 0, "x tile must be whole 1-KiB pieces");
+
+    const aid_conv2d_params& p = a.p;
+    const int TT = 1 << a.tt_log2;
+    const int ROWS = 1 << a.rows_log2;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* rowinfo = (int*)(smem + 2 * BUFSZ);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN;
+    const int wn = wave % WGN;
+
+    const int tile_t = blockIdx.x % a.tiles_t;
+    const int rg = blockIdx.x / a.tiles_t;
+    const int row0 = rg << a.rows_log2;
+    const int t0 = tile_t << a.tt_log2;
+    const int m0 = blockIdx.y * M_BLK;
+
+    for (int r = tid; r < ROWS; r += NTHREADS) {
+        const int rid = row0 + r;
+        int b = -1, f = 0;
+        if (rid < a.nrows) { b = rid / p.F; f = rid - b * p.F; }
+        rowinfo[2 * r] = b;
+        rowinfo[2 * r + 1] = f;
+    }
+    __syncthreads();
+
+    // ---- DMA piece descriptors (identical scheme to conv53_dma_kernel; weights use the 20-tap Winograd pack) ----
+    const float* psrc[PPW];
+    int pstride[PPW], plds[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int pc = wave + i * NW;
+        psrc[i] = a.zero; pstride[i] = 0; plds[i] = -1;
+        if (pc < NXP) {
+            const int blk = pc / (N_BLK / 256), sub = pc % (N_BLK / 256);
+            const int ci = blk / KH, kh = blk % KH;
+            const int n = sub * 256 + 4 * lane;
+            const int rr = n >> a.tt_log2, tt = n & (TT - 1);
+            const int b = rowinfo[2 * rr];
+            const int fi = rowinfo[2 * rr + 1] + (kh - KH / 2) * p.dilF;
+            plds[i] = blk * XB + sub * 256;
+            if (b >= 0 && fi >= 0 && fi < p.F && t0 + tt < p.T) {
+                psrc[i] = p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + t0 + tt;
+                pstride[i] = (int)(KC * p.x.sC);
+            }
+        } else if (pc < NP) {
+            const int wp_ = pc - NXP;
+            const int e = wp_ * 256 + 4 * lane;
+            const int row = e / WROW, col = e % WROW;
+            const int tap = row / KC, ci = row % KC;
+            plds[i] = XSZ + wp_ * 256;
+            if (col < M_BLK && e < WSZ_RAW) {
+                psrc[i] = p.wp_wino + ((int64_t)tap * p.Cin_pad + ci) * p.Cout_pad + m0 + col;
+                pstride[i] = KC * p.Cout_pad;
+            }
+        }
+    }
+    const int nhalo = 2 * KC * KH * ROWS;
+    const float* hsrc[HQ];
+    int hstride[HQ], hlds[HQ];
+#pragma unroll
+    for (int i = 0; i < HQ; ++i) {
+        const int h = tid + i * NTHREADS;
+        hsrc[i] = a.zero; hstride[i] = 0; hlds[i] = -1;
+        if (h < nhalo) {
+            const int side = h & 1;
+            const int rr = (h >> 1) & (ROWS - 1);
+            const int blk = (h >> 1) >> a.rows_log2;
+            const int ci = blk / KH, kh = blk % KH;
+            const int b = rowinfo[2 * rr];
+            const int fi = rowinfo[2 * rr + 1] + (kh - KH / 2) * p.dilF;
+            const int t = side ? (t0 + TT) : (t0 - 1);
+            hlds[i] = blk * XB + N_BLK + rr * 2 + side;
+            if (b >= 0 && fi >= 0 && fi < p.F && t >= 0 && t < p.T) {
+                hsrc[i] = p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + t;
+                hstride[i] = (int)(KC * p.x.sC);
+            }
+        }
+    }
+    // ---- operand addresses -----------------------------------------------------------------------------------------
+    const int half = lane >> 5;
+    const int ttau_log2 = a.tt_log2 - 2;                 // groups per row = TT/4
+    int vD0[NTT], vD12[NTT], vD3[NTT];                   // float offsets of d0 | (d1..d4) | d5 inside a (ci,kh) block
+#pragma unroll
+    for (int j = 0; j < NTT; ++j) {
+        const int nt = (wn * NTT + j) * 32 + (lane & 31);            // tau index inside the tile
+        const int rr = nt >> ttau_log2, tau = nt & ((TT >> 2) - 1);
+        const int n = rr * TT + 4 * tau;                             // core position of d1
+        vD12[j] = half * KH * XB + n;
+        vD0[j] = half * KH * XB + ((tau == 0) ? (N_BLK + rr * 2) : (n - 1));
+        vD3[j] = half * KH * XB + ((4 * tau + 4 >= TT) ? (N_BLK + rr * 2 + 1) : (n + 4));
+    }
+    int vA[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) vA[i] = XSZ + half * WROW + (wm * MT + i) * 32 + (lane & 31);
+
+    f32x16 acc[MT][NTT][NXI];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTT; ++j)
+#pragma unroll
+            for (int x = 0; x < NXI; ++x)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][x][r] = 0.f;
+
+    float hv[HQ];
+    auto issue_dma = [&](int ch, float* buf) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            if (plds[i] >= 0) {
+                const float* src = psrc[i] + (int64_t)ch * pstride[i];
+                GLDS16W(src, buf + plds[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < HQ; ++i) hv[i] = hsrc[i][(int64_t)ch * hstride[i]];
+    };
+    auto write_halo = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < HQ; ++i)
+            if (hlds[i] >= 0) buf[hlds[i]] = hv[i];
+    };
+
+    issue_dma(0, smem);
+    write_halo(smem);
+    __syncthreads();
+
+    auto chunk = [&](auto curc, int ch) {
+        constexpr int cur = decltype(curc)::value;
+        const float* Bf = smem + cur * BUFSZ;
+        float* Nx = smem + (cur ^ 1) * BUFSZ;
+        const bool more = (ch + 1) < a.nchunks;
+        if (more) issue_dma(ch + 1, Nx);
+        // raw samples of step s+1 are fetched while the MFMAs of step s run
+        float d0[2][NTT], d3[2][NTT];
+        float4 d12[2][NTT];
+        float av[2][MT][NXI];
+        auto load_step = [&](int s, int buf) {
+            const int kh = s / (KC / 2), cp = s % (KC / 2);
+            const int xo = (2 * cp * KH + kh) * XB;
+#pragma unroll
+            for (int j = 0; j < NTT; ++j) {
+                d0[buf][j] = Bf[vD0[j] + xo];
+                d12[buf][j] = *reinterpret_cast<const float4*>(Bf + vD12[j] + xo);
+                d3[buf][j] = Bf[vD3[j] + xo];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int x = 0; x < NXI; ++x)
+                    av[buf][i][x] = Bf[vA[i] + ((x * KH + kh) * KC + 2 * cp) * WROW];
+        };
+        load_step(0, 0);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            if (s == 0) __builtin_amdgcn_s_setprio(3);
+            else if (s == (NSTEP + 3) / 4) __builtin_amdgcn_s_setprio(2);
+            else if (s == (NSTEP + 1) / 2) __builtin_amdgcn_s_setprio(1);
+            else if (s == (3 * NSTEP + 3) / 4) __builtin_amdgcn_s_setprio(0);
+            if (s + 1 < NSTEP) load_step(s + 1, (s + 1) & 1);
+            const int bq = s & 1;
+#pragma unroll
+            for (int j = 0; j < NTT; ++j) {
+                const float e0 = d0[bq][j], e1 = d12[bq][j].x, e2 = d12[bq][j].y, e3 = d12[bq][j].z, e4 = d12[bq][j].w, e5 = d3[bq][j];
+                const float s12 = e1 + e2, m12 = e1 - e2, m42 = e4 - e2, m31 = e3 - e1;
+                const float V[NXI] = {4.f * e0 - 5.f * e2 + e4, (e3 + e4) - 4.f * s12, (e4 - e3) + 4.f * m12,
+                                      m42 + 2.f * m31, m42 - 2.f * m31, 4.f * e1 - 5.f * e3 + e5};
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int x = 0; x < NXI; ++x)
+                        acc[i][j][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[bq][i][x], V[x], acc[i][j][x], 0, 0, 0);
+            }
+        }
+        if (more) write_halo(Nx);
+        __syncthreads();
+    };
+    for (int ch = 0; ch < a.nchunks; ch += 2) {
+        chunk(std::integral_constant<int, 0>{}, ch);
+        if (ch + 1 < a.nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
+    }
+    __builtin_amdgcn_s_setprio(0);
+
+    // ---- epilogue: output transform, then gate / dGELU / residual, four samples per lane -------------------------------
+#pragma unroll
+    for (int j = 0; j < NTT; ++j) {
+        const int nt = (wn * NTT + j) * 32 + (lane & 31);
+        const int rr = nt >> ttau_log2, tau = nt & ((TT >> 2) - 1);
+        const int b = rowinfo[2 * rr];
+        const int f = rowinfo[2 * rr + 1];
+        const int t = t0 + 4 * tau;
+        if (b < 0 || t >= p.T) continue;                 // T % 4 == 0: the four samples are in range together
+        const int64_t ybase = (int64_t)b * p.y.sB + (int64_t)f * p.y.sF + t;
+        const int64_t rbase = p.res.p ? ((int64_t)b * p.res.sB + (int64_t)f * p.res.sF + t) : 0;
+        const int64_t abase = p.aux.p ? ((int64_t)b * p.aux.sB + (int64_t)f * p.aux.sF + t) : 0;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int mbase = m0 + (wm * MT + i) * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 4) {         // batches of 4 rows: gather, then compute + store
+                float4 rv[4], uv[4];
+                float sv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = r0 + q;
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    const bool ok = m < p.Cout;
+                    rv[q] = (ok && p.res.p) ? *reinterpret_cast<const float4*>(p.res.p + rbase + (int64_t)m * p.res.sC) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    sv[q] = (ok && p.out_scale) ? p.out_scale[(int64_t)b * p.out_scale_ld + m] : 1.f;
+                    if (ok && p.epi == 1) {
+                        const float as = p.aux_scale[(int64_t)b * p.aux_scale_ld + m];
+                        const float4 u = *reinterpret_cast<const float4*>(p.aux.p + abase + (int64_t)m * p.aux.sC);
+                        uv[q] = make_float4(u.x * as, u.y * as, u.z * as, u.w * as);
+                    } else uv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = r0 + q;
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    if (m >= p.Cout) continue;
+                    const float M0 = acc[i][j][0][r], M1 = acc[i][j][1][r], M2 = acc[i][j][2][r], M3 = acc[i][j][3][r],
+                                M4 = acc[i][j][4][r], M5 = acc[i][j][5][r];
+                    const float a12 = M1 + M2, s12 = M1 - M2, a34 = M3 + M4, s34 = M3 - M4;
+                    float y0 = (M0 + a12 + a34) * sv[q];
+                    float y1 = (s12 + 2.f * s34) * sv[q];
+                    float y2 = (a12 + 4.f * a34) * sv[q];
+                    float y3 = (s12 + 8.f * s34 + M5) * sv[q];
+                    if (p.epi == 1) { y0 *= aid_dgelu(uv[q].x); y1 *= aid_dgelu(uv[q].y); y2 *= aid_dgelu(uv[q].z); y3 *= aid_dgelu(uv[q].w); }
+                    y0 += p.res_scale * rv[q].x; y1 += p.res_scale * rv[q].y; y2 += p.res_scale * rv[q].z; y3 += p.res_scale * rv[q].w;
+                    *reinterpret_cast<float4*>(p.y.p + ybase + (int64_t)m * p.y.sC) = make_float4(p.alpha * y0, p.alpha * y1, p.alpha * y2, p.alpha * y3);
+                }
+            }
+        }
+    }
+}
+
 template <int MT, int NTT, int WGM, int WGN, int RMAX, int KC, int MINW = 1>
 static int launch_wino(const aid_conv2d_params* p, hipStream_t st) {
     constexpr int M_BLK = 32 * MT * WGM;
@@ -321,6 +589,43 @@ static int launch_wino(const aid_conv2d_params* p, hipStream_t st) {
     return AID_OK;
 }
 
+template <int MT, int NTT, int WGM, int WGN, int RMAX, int KC, int MINW = 1>
+static int launch_wino4(const aid_conv2d_params* p, hipStream_t st) {
+    constexpr int M_BLK = 32 * MT * WGM;
+    constexpr int N_BLK = 128 * NTT * WGN;
+    constexpr int WROW = (M_BLK % 64 == 0) ? M_BLK : ((M_BLK + 63) / 64) * 64;
+    static const float* zero = nullptr;
+    if (!zero) {
+        void* z = nullptr;
+        if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_aid_zero_page_w)) != hipSuccess) { aid_set_error("aid_conv2d: zero page lookup failed"); return AID_E_LAUNCH; }
+        zero = (const float*)z;
+    }
+    ConvWinoDev a;
+    a.p = *p;
+    a.zero = zero;
+    int TT = aid_pow2ceil(p->T);
+    if (TT > N_BLK) TT = N_BLK;
+    a.tt_log2 = aid_ilog2(TT);
+    const int ROWS = N_BLK / TT;
+    if (ROWS > RMAX) return 1000;
+    a.rows_log2 = aid_ilog2(ROWS);
+    a.tiles_t = aid_cdiv(p->T, TT);
+    a.nrows = p->B * p->F;
+    a.nchunks = p->Cin / KC;
+    const int rgroups = aid_cdiv(a.nrows, ROWS);
+    dim3 grid((unsigned)(rgroups * a.tiles_t), (unsigned)(p->Cout_pad / M_BLK));
+    const size_t lds = sizeof(float) * 2 * ((size_t)KC * 5 * (N_BLK + 2 * RMAX) + (size_t)((30 * KC * WROW + 255) / 256) * 256) + sizeof(int) * 2 * ROWS;
+    auto kern = conv53_wino4_kernel<MT, NTT, WGM, WGN, RMAX, KC, MINW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), lds, st, a);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}
+
 // returns 1 if the Winograd kernel took the launch, 0 if not eligible, <0 on error
 int aid_conv53_wino_try(const aid_conv2d_params* p, hipStream_t st) {
     if (!p->wp_wino || !(p->KH == 5 && p->KW == 3) || p->in_scale || p->act != 0) return 0;
@@ -334,6 +639,18 @@ int aid_conv53_wino_try(const aid_conv2d_params* p, hipStream_t st) {
     static int cfg = -1;
     if (cfg < 0) { const char* e = getenv("AID_WINO_CFG"); cfg = e ? atoi(e) : 0; }
     int rc;
+    if (p->wino_taps == 30) {                              // F(4,3) pack
+        if ((p->y.sB % 4) || (p->y.sC % 4) || (p->y.sF % 4) || (((uintptr_t)p->y.p) & 15)) return 0;
+        if (p->res.p && ((p->res.sB % 4) || (p->res.sC % 4) || (p->res.sF % 4) || (((uintptr_t)p->res.p) & 15))) return 0;
+        if (p->aux.p && ((p->aux.sB % 4) || (p->aux.sC % 4) || (p->aux.sF % 4) || (((uintptr_t)p->aux.p) & 15))) return 0;
+        if (cfg == 2 && p->Cout_pad % 64 == 0)      rc = launch_wino4<1, 1, 2, 2, 16, 2, 1>(p, st);   // 64 x 256, 4 waves
+        else if (p->Cout_pad % 64 == 0)             rc = launch_wino4<1, 1, 2, 4, 16, 2, 3>(p, st);   // 64 x 512, 8 waves (158 VGPRs: 1 workgroup / CU)
+        else if (cfg == 1 && p->Cout_pad % 96 == 0) rc = launch_wino4<1, 1, 3, 2, 16, 2, 1>(p, st);   // 96 x 256, 6 waves
+        else if (p->Cout_pad % 96 == 0)             rc = launch_wino4<1, 1, 3, 4, 16, 2, 3>(p, st);   // 96 x 512, 12 waves
+        else return 0;
+        if (rc == 1000) return 0;
+        return rc == AID_OK ? 1 : rc;
+    }
     if (cfg == 1 && p->Cout_pad % 64 == 0)      rc = launch_wino<1, 1, 2, 4, 16, 4>(p, st);   // 64 x 256, 8 waves, KC=4 (1 workgroup / CU)
     else if (cfg == 2 && p->Cout_pad % 64 == 0) rc = launch_wino<1, 2, 2, 2, 16, 2>(p, st);   // 64 x 256, 4 waves, 128 acc
     else if (cfg == 3 && p->Cout_pad % 64 == 0) rc = launch_wino<1, 1, 2, 4, 16, 2>(p, st);   // 64 x 256, 8 waves, KC=2, 132 VGPRs: 1 workgroup / CU

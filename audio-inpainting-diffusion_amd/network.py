@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -223,7 +224,8 @@ class _Builder:
         p.KH, p.KW, p.dilF, p.act, p.epi = kh, kw, dil, act, epi
         p.alpha, p.res_scale = alpha, res_scale
         p.wp_wino = _lib.ptr(wpw)
-        assert wp.shape[0] == kh * kw and (wpw is None or wpw.shape == (4 * kh, wp.shape[1], wp.shape[2]))
+        p.wino_taps = 0 if wpw is None else wpw.shape[0]
+        assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] in (20, 30) and wpw.shape[1:] == wp.shape[1:]))
         self.plan.add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, flops=2 * B * F * T * cin * cout * kh * kw)
 
     def conv(self, x, y, wp, cin, cout, kh=1, kw=1, dil=1, in_scale=None, act=0, out_scale=None, res=None,
@@ -365,6 +367,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
                 _ResBlock(dim_out, 2, 1, (1, 1), E, proj_place="after"),
                 _ResBlock(dim_in, dim_out, self.num_dils[i], (5, 3), E, attention=bool(self.attention_layers[i]), heads=H,
                           fdim=(i + 1) * bpo)]))
+        self.winograd_f4 = os.environ.get("AID_WINOGRAD", "4") != "2"     # F(4,3) by default; AID_WINOGRAD=2 selects F(2,3)
         self._packed: Dict[str, torch.Tensor] = {}
         self._packed_ver = None
         self._states: Dict[int, dict] = {}
@@ -412,8 +415,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
                 put(name, _lib.pack_conv_weight(w))
                 put(name + "#T", _lib.pack_conv_weight(w, transpose=True))
                 if w.dim() == 4 and tuple(w.shape[2:]) == (5, 3) and w.shape[0] >= 64 and w.shape[1] >= 64:
-                    put(name + "#W", _lib.pack_conv_weight_wino(w))                     # Winograd F(2,3) packs
-                    put(name + "#WT", _lib.pack_conv_weight_wino(w, transpose=True))
+                    put(name + "#W", _lib.pack_conv_weight_wino(w, f4=self.winograd_f4))     # Winograd packs (F(4,3) or F(2,3))
+                    put(name + "#WT", _lib.pack_conv_weight_wino(w, transpose=True, f4=self.winograd_f4))
             elif leaf == "gamma":
                 put(name, w.detach().reshape(-1).float())
         # stacked modulation matrix: [affine2, gate2]? then per step [affine.k, gate.k], block after block

@@ -82,7 +82,9 @@ int aid_group_stats(const aid_group_stats_params* p, void* stream);
  *   launcher uses F(2,3) along T -- U = G w (U0=w0, U1=(w0+w1+w2)/2, U2=(w0-w1+w2)/2, U3=w2, packed as 20 "taps"
  *   xi*KH+kh), V = B^T d formed from the LDS strip at fragment-load time, 4 MFMAs per 2 output samples instead of 6,
  *   y0 = m0+m1+m2, y1 = m1-m2-m3 in the epilogue.  Same fp32 MFMA, 1.5x fewer of them; results differ from the
- *   direct form only by fp32 rounding (tests: <= 2e-6 rel-L2).
+ *   direct form only by fp32 rounding (tests: <= 2e-6 rel-L2).  F(4,3) (wino_taps = 30): 6 MFMAs per 4 output
+ *   samples (2x fewer than direct); U = G w with G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],
+ *   [1/24,-1/12,1/6],[0,0,1]]; fp32 error ~2x that of direct accumulation.
  *   weights are PRE-PACKED by the host: wp[KH*KW][Cin_pad][Cout_pad], cout contiguous, zero padded
  *   (Cin_pad % 32 == 0, Cout_pad a multiple of the M tile the launcher picks for Cout) -- see aid_conv2d_pack_dims.
  * ------------------------------------------------------------------------------------------------- */
@@ -97,7 +99,8 @@ typedef struct {
     int KH, KW, dilF;
     int act, epi;
     float alpha, res_scale;
-    const float* wp_wino;     /* optional: Winograd F(2,3) pack [4*KH][Cin_pad][Cout_pad] of the same 5x3 weights (see below) */
+    const float* wp_wino;     /* optional: Winograd pack of the same 5x3 weights: F(2,3) = 20 taps, F(4,3) = 30 taps (see below) */
+    int wino_taps;            /* 20 or 30 (0 when wp_wino is NULL) */
 } aid_conv2d_params;
 int aid_conv2d(const aid_conv2d_params* p, void* stream);
 /* padded dims the packed weight buffer must have for a given (Cin, Cout) */

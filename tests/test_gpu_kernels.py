@@ -96,7 +96,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("wino", [0, 1])
+@pytest.mark.parametrize("wino", [0, 20, 30])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d(L, case, wino):
     B, Cin, Cout, Fd, T, KH, KW, dil, pro, epi = case
@@ -130,8 +130,8 @@ def test_conv2d(L, case, wino):
     if wino:
         if (KH, KW) != (5, 3) or pro or Cin % 4 or Cout < 64:
             pytest.skip("Winograd path needs a plain-copy 5x3 conv with Cin % 4 == 0 and Cout >= 64")
-        wpw = L.pack_conv_weight_wino(wd)
-        p.wp_wino = wpw.data_ptr()
+        wpw = L.pack_conv_weight_wino(wd, f4=(wino == 30))
+        p.wp_wino, p.wino_taps = wpw.data_ptr(), wino
     L.call("aid_conv2d", p)
     torch.cuda.synchronize()
     assert rel_l2(y.cpu(), ref) < 1e-5

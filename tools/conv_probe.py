@@ -38,8 +38,9 @@ def main():
     p.KH, p.KW, p.dilF, p.act, p.epi = KH, KW, dil, act, 0
     p.alpha, p.res_scale = 1 / math.sqrt(2), 1.0
     if os.environ.get('PROBE_WINO', '0') != '0' and KH == 5:
-        wpw = L.pack_conv_weight_wino(w)
-        p.wp_wino = wpw.data_ptr()
+        f4 = os.environ.get('PROBE_WINO') == '30'
+        wpw = L.pack_conv_weight_wino(w, f4=f4)
+        p.wp_wino, p.wino_taps = wpw.data_ptr(), wpw.shape[0]
     for _ in range(2):
         L.call("aid_conv2d", p)
     torch.cuda.synchronize()

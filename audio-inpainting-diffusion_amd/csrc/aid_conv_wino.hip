@@ -644,6 +644,7 @@ int aid_conv53_wino_try(const aid_conv2d_params* p, hipStream_t st) {
         if (p->res.p && ((p->res.sB % 4) || (p->res.sC % 4) || (p->res.sF % 4) || (((uintptr_t)p->res.p) & 15))) return 0;
         if (p->aux.p && ((p->aux.sB % 4) || (p->aux.sC % 4) || (p->aux.sF % 4) || (((uintptr_t)p->aux.p) & 15))) return 0;
         if (cfg == 2 && p->Cout_pad % 64 == 0)      rc = launch_wino4<1, 1, 2, 2, 16, 2, 1>(p, st);   // 64 x 256, 4 waves
+        else if (cfg == 3 && p->Cout_pad % 64 == 0) rc = launch_wino4<1, 1, 2, 4, 16, 4, 3>(p, st);   // 64 x 512, 8 waves, KC=4
         else if (p->Cout_pad % 64 == 0)             rc = launch_wino4<1, 1, 2, 4, 16, 2, 3>(p, st);   // 64 x 512, 8 waves (158 VGPRs: 1 workgroup / CU)
         else if (cfg == 1 && p->Cout_pad % 96 == 0) rc = launch_wino4<1, 1, 3, 2, 16, 2, 1>(p, st);   // 96 x 256, 6 waves
         else if (p->Cout_pad % 96 == 0)             rc = launch_wino4<1, 1, 3, 4, 16, 2, 3>(p, st);   // 96 x 512, 12 waves

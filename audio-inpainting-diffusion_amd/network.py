@@ -169,6 +169,8 @@ class _Builder:
         self.bwd = []          # closures emitting the VJP ops of each forward op (run in reverse by finish_backward)
         self.bplan = None
         self.gmap = {}         # storage data_ptr -> flat gradient storage of the same size
+        self.gstate = {}       # storage data_ptr -> 'full' (first contribution overwrites the whole tensor: no zero fill,
+                               #   no read-modify-write) | 'zero' (touched through partial views: zero-filled, accumulated)
         self.scratch = {}      # shape -> scratch tensor for dgrad outputs awaiting the normalisation backward
 
     # ---- gradient storage: one flat buffer per activation storage, views share strides/offsets ------------
@@ -179,6 +181,18 @@ class _Builder:
             g = self.gmap[st.data_ptr()] = torch.zeros(st.nbytes() // 4, device=self.device, dtype=torch.float32)
             self.nbytes += g.numel() * 4
         return g.as_strided(t.size(), t.stride(), t.storage_offset())
+
+    def _gacc(self, t) -> bool:
+        """Decide, at plan-build time, whether the next gradient contribution to activation ``t`` must accumulate
+        (True) or may simply overwrite (False: it is the first contribution and covers the whole storage)."""
+        st = t.untyped_storage()
+        key = st.data_ptr()
+        state = self.gstate.get(key)
+        if state is None:
+            whole = t.is_contiguous() and t.numel() * 4 == st.nbytes()
+            self.gstate[key] = "full" if whole else "zero"
+            return not whole
+        return True
 
     def _scratch(self, shape):
         key = tuple(shape)
@@ -250,7 +264,10 @@ class _Builder:
             fused_res = (norm_stats is not None) and (res is x)
             if res is not None and not fused_res:
                 gr = self.G(res)
-                self.add2_raw(gr, gy, gr, 1.0, alpha * res_scale)
+                if self._gacc(res):
+                    self.add2_raw(gr, gy, gr, 1.0, alpha * res_scale)
+                else:
+                    self.add2_raw(gy, None, gr, alpha * res_scale, 0.0)
             gin, gsc = gy, out_scale
             if kh > 1 and out_scale is not None:
                 # 5x3 dgrad: apply the gate in a copy pass so the conv input needs no in-kernel prologue
@@ -268,16 +285,17 @@ class _Builder:
                 self.plan.add("aid_group_dot", dp, gd, x)
                 npar = _lib.NormBwdParams(_lib.view4(gd), _lib.view4(x), _lib.view4(gy if fused_res else None), _lib.view4(self.G(x)),
                                           B, cin, F, T, 8, norm_stats.data_ptr(), self.stats_ws.data_ptr(), 1e-7,
-                                          alpha * res_scale, 1)
+                                          alpha * res_scale, 1 if self._gacc(x) else 0)
                 self.plan.add("aid_norm_bwd", npar, gd, x, gy, norm_stats)
             else:
                 gx = self.G(x)
-                self._conv_raw(gin, gx, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, gx, 1.0 / alpha, alpha,
+                self._conv_raw(gin, gx, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, gx if self._gacc(x) else None, 1.0 / alpha, alpha,
                                epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None)
         self.bwd.append(bw)
 
 
     def add2_raw(self, u, v, y, a, b):
+        """y = a*u + b*v   (v may be None: y = a*u)"""
         B, Cc, F, T = u.shape
         p = _lib.Add2Params(_lib.view4(u), _lib.view4(v), _lib.view4(y), B, Cc, F, T, a, b)
         self.plan.add("aid_add2", p, u, v, y)
@@ -287,8 +305,11 @@ class _Builder:
 
         def bw():
             gy, gu, gv = self.G(y), self.G(u), self.G(v)
-            self.add2_raw(gu, gy, gu, 1.0, a)
-            self.add2_raw(gv, gy, gv, 1.0, b)
+            for tt, gt, c in ((u, gu, a), (v, gv, b)):
+                if self._gacc(tt):
+                    self.add2_raw(gt, gy, gt, 1.0, c)
+                else:
+                    self.add2_raw(gy, None, gt, c, 0.0)
         self.bwd.append(bw)
 
     def _resample_raw(self, x, y, up, adjoint=0, accumulate=0):
@@ -298,7 +319,7 @@ class _Builder:
 
     def resample(self, x, y, up):
         self._resample_raw(x, y, up)
-        self.bwd.append(lambda: self._resample_raw(self.G(y), self.G(x), up, adjoint=1, accumulate=1))
+        self.bwd.append(lambda: self._resample_raw(self.G(y), self.G(x), up, adjoint=1, accumulate=1 if self._gacc(x) else 0))
 
     def attention(self, qk, v, out, heads, F, T):
         B = v.shape[0]
@@ -310,8 +331,9 @@ class _Builder:
         def bw():
             gq, gv, go = self.G(qk), self.G(v), self.G(out)
             assert gq.is_contiguous() and gv.is_contiguous() and go.is_contiguous()
+            self._gacc(qk)                                   # d(qk) is written, never accumulated
             bp = _lib.AttentionBwdParams(qk.data_ptr(), v.data_ptr(), probs.data_ptr(), go.data_ptr(), gq.data_ptr(), gv.data_ptr(),
-                                         B, heads, F, T, scale, 1)
+                                         B, heads, F, T, scale, 1 if self._gacc(v) else 0)
             self.plan.add("aid_time_attention_bwd", bp, qk, v, probs, go, gq, gv, flops=10 * B * heads * T * T * F)
         self.bwd.append(bw)
 
@@ -647,7 +669,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
             st["plan_bwd"] = bd.finish_backward()
             st["gin"] = [bd.G(t) for t in st["octs_in"]]
             st["gout"] = [bd.G(t) for t in st["octs_out"]]
-            st["gzero"] = list(bd.gmap.values())
+            st["gzero"] = [g for k, g in bd.gmap.items() if bd.gstate.get(k) != "full"]
             st["nbytes"] = bd.nbytes
         return st["plan_bwd"]
 

@@ -125,7 +125,7 @@ class NormBwdParams(C.Structure):
 class AttentionBwdParams(C.Structure):
     _fields_ = [("qk", C.c_void_p), ("v", C.c_void_p), ("probs", C.c_void_p), ("gout", C.c_void_p),
                 ("gqk", C.c_void_p), ("gv", C.c_void_p), ("B", C.c_int), ("H", C.c_int), ("F", C.c_int), ("T", C.c_int),
-                ("scale", C.c_float), ("accumulate_gv", C.c_int)]
+                ("scale", C.c_float), ("accumulate_gv", C.c_int), ("ws", C.c_void_p)]
 
 
 class GuidanceSeedParams(C.Structure):

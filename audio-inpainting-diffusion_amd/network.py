@@ -332,9 +332,10 @@ class _Builder:
             gq, gv, go = self.G(qk), self.G(v), self.G(out)
             assert gq.is_contiguous() and gv.is_contiguous() and go.is_contiguous()
             self._gacc(qk)                                   # d(qk) is written, never accumulated
+            dsws = self._scratch(("ds", B, heads, T, T))
             bp = _lib.AttentionBwdParams(qk.data_ptr(), v.data_ptr(), probs.data_ptr(), go.data_ptr(), gq.data_ptr(), gv.data_ptr(),
-                                         B, heads, F, T, scale, 1 if self._gacc(v) else 0)
-            self.plan.add("aid_time_attention_bwd", bp, qk, v, probs, go, gq, gv, flops=10 * B * heads * T * T * F)
+                                         B, heads, F, T, scale, 1 if self._gacc(v) else 0, dsws.data_ptr())
+            self.plan.add("aid_time_attention_bwd", bp, qk, v, probs, go, gq, gv, dsws, flops=10 * B * heads * T * T * F)
         self.bwd.append(bw)
 
 

@@ -304,6 +304,7 @@ typedef struct {
     int B, H, F, T;
     float scale;
     int accumulate_gv;
+    float* ws;                    /* scratch [B,H,T,T] (dS) */
 } aid_attention_bwd_params;
 int aid_time_attention_bwd(const aid_attention_bwd_params* p, void* stream);
 

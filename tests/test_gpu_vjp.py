@@ -82,8 +82,9 @@ def test_attention_bwd(L, shape):
     L.call("aid_time_attention", L.AttentionParams(qd.data_ptr(), vd.data_ptr(), o.data_ptr(), probs.data_ptr(), B, H, Fd, T, sc))
     gq = torch.empty_like(qd)
     gv = torch.full_like(vd, 0.5)
+    ws = torch.empty(B, H, T, T, device=DEV)
     L.call("aid_time_attention_bwd", L.AttentionBwdParams(qd.data_ptr(), vd.data_ptr(), probs.data_ptr(), god.data_ptr(), gq.data_ptr(),
-                                                          gv.data_ptr(), B, H, Fd, T, sc, 1))
+                                                          gv.data_ptr(), B, H, Fd, T, sc, 1, ws.data_ptr()))
     assert rel_l2(gq.cpu(), gq_ref) < 2e-5
     assert rel_l2(gv.cpu() - 0.5, gv_ref) < 2e-5
 

@@ -393,16 +393,24 @@ static int launch_m(const aid_conv2d_params* p, hipStream_t st) {
     // AID_CONV_CFG=n selects alternative tile / wave-count configurations (tuning experiments only)
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("AID_CONV_CFG"); dbg = e ? atoi(e) : 0; }
-    if (KH == 5 && mb == 128 && dbg == 1) return launch_cfg<KH, KW, 1, 2, 4, 4, KC>(p, st);   // 16 waves, 128x256
-    if (KH == 5 && mb == 128 && dbg == 2) return launch_cfg<KH, KW, 2, 4, 2, 4, KC>(p, st);   // 8 waves, 128x512
-    if (KH == 5 && mb == 128 && dbg == 3) return launch_cfg<KH, KW, 2, 4, 2, 2, KC>(p, st);   // 4 waves, 128x256
-    if (KH == 5 && mb == 128 && dbg == 4) return launch_cfg<KH, KW, 2, 1, 2, 4, KC>(p, st);   // 8 waves, 128x128
-    if (KH == 5 && mb == 64 && dbg == 1) return launch_cfg<KH, KW, 2, 1, 1, 8, KC>(p, st);    // 8 waves, 64x256
-    if (KH == 5 && mb == 64 && dbg == 2) return launch_cfg<KH, KW, 1, 1, 2, 8, KC>(p, st);    // 16 waves, 64x256
-    if (KH == 5 && mb == 64 && dbg == 3) return launch_cfg<KH, KW, 1, 2, 2, 8, KC>(p, st);    // 16 waves, 64x512
-    if (KH == 5 && mb == 96 && dbg == 1) return launch_cfg<KH, KW, 1, 2, 3, 4, KC>(p, st);    // 12 waves, 96x256
-    if (KH == 5 && mb == 96 && dbg == 2) return launch_cfg<KH, KW, 3, 2, 1, 4, KC>(p, st);    // 4 waves, 96x256
-    if (KH == 5 && mb == 96 && dbg == 3) return launch_cfg<KH, KW, 3, 2, 1, 8, KC>(p, st);    // 8 waves, 96x512
+    static int c1 = -1;
+    if (c1 < 0) { const char* e = getenv("AID_CONV_1X1"); c1 = e ? atoi(e) : 1; }
+    if (KH == 1 && c1 == 1) {           // more waves per CU for the short-K (memory-bound) channel projections
+        switch (mb) {
+            case 32: return launch_cfg<KH, KW, 1, 2, 1, 4, KC>(p, st);
+            case 64: return launch_cfg<KH, KW, 1, 2, 2, 4, KC>(p, st);     // 64x256, 8 waves, 2 workgroups / CU
+            case 96: return launch_cfg<KH, KW, 1, 2, 3, 4, KC>(p, st);     // 96x256, 12 waves
+            default: return launch_cfg<KH, KW, 1, 2, 4, 4, KC>(p, st);     // 128x256, 16 waves
+        }
+    }
+    if (KH == 1 && c1 == 2) {
+        switch (mb) {
+            case 32: return launch_cfg<KH, KW, 1, 2, 1, 4, KC>(p, st);
+            case 64: return launch_cfg<KH, KW, 1, 2, 2, 4, KC>(p, st);
+            case 96: return launch_cfg<KH, KW, 1, 2, 3, 4, KC>(p, st);
+            default: return launch_cfg<KH, KW, 2, 1, 2, 4, KC>(p, st);     // 128x128, 8 waves, 2 workgroups / CU
+        }
+    }
     switch (mb) {
         case 32: return launch_cfg<KH, KW, 1, 2, 1, 4, KC>(p, st);
         case 64:

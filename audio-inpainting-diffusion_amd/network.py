@@ -126,9 +126,11 @@ class _Plan:
         self.flops = 0
         self.timing = None     # set to a list to bracket every conv launch with HIP events (bench.py roofline)
 
-    def add(self, name, params, *tensors, flops=0):
+    def add(self, name, params, *tensors, flops=0, nbytes=0):
         fn = getattr(_lib.lib(), name)
         self.ops.append((fn, C.addressof(params), name, flops))
+        self.opbytes = getattr(self, "opbytes", {})
+        self.opbytes[C.addressof(params)] = nbytes
         self.descr = getattr(self, "descr", [])
         if name == "aid_conv2d":
             q = params
@@ -153,7 +155,7 @@ class _Plan:
                 e0.record()
                 rc = fn(addr, stream)
                 e1.record()
-                timing.append((e0, e1, flops, self.descr[len(timing) % 1] if False else self._cur_descr(fn, addr)))
+                timing.append((e0, e1, flops, self._cur_descr(fn, addr), self.opbytes.get(addr, 0)))
             else:
                 rc = fn(addr, stream)
             if rc != 0:
@@ -240,7 +242,10 @@ class _Builder:
         p.wp_wino = _lib.ptr(wpw)
         p.wino_taps = 0 if wpw is None else wpw.shape[0]
         assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] in (20, 30) and wpw.shape[1:] == wp.shape[1:]))
-        self.plan.add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, flops=2 * B * F * T * cin * cout * kh * kw)
+        # algorithmic HBM bytes: x once, residual / aux once, y once, weights once
+        nb = 4 * (B * F * T * (cin + cout * (1 + (res is not None) + (aux is not None))) + cin * cout * kh * kw)
+        self.plan.add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, flops=2 * B * F * T * cin * cout * kh * kw,
+                      nbytes=nb)
 
     def conv(self, x, y, wp, cin, cout, kh=1, kw=1, dil=1, in_scale=None, act=0, out_scale=None, res=None,
              res_scale=1.0, alpha=1.0, wpT=None, norm_stats=None, wpw=None, wpwT=None):

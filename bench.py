@@ -160,7 +160,7 @@ def main():
                      for t in timing)
     if a.conv_table and rank == 0:
         agg = {}
-        for e0, e1, f, d in timing:
+        for e0, e1, f, d, _nb in timing:
             r = agg.setdefault(d, [0, 0.0, 0])
             r[0] += 1; r[1] += e0.elapsed_time(e1); r[2] += f
         for d, (n, ms, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
@@ -181,6 +181,7 @@ def main():
                          "achieved": round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 4),
                          "traffic": None, "launches": len(timing), "avg_launch_us": round(1e3 * conv_ms / max(1, len(timing)), 1),
                          "algorithmic_gflop_per_launch": round(conv_flops / max(1, len(timing)) / 1e9, 2),
+                         "algorithmic_mb_per_launch": round(sum(t[4] for t in timing) / max(1, len(timing)) / 1e6, 1),
                          "executed_mfma_tflops": round(exec_flops / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else 0.0,
                          "conv_time_fraction_of_wall": round(conv_ms * 1e-3 / wall, 3)},
         }

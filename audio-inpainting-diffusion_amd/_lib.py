@@ -137,10 +137,20 @@ class RowNormParams(C.Structure):
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("B", C.c_int), ("L", C.c_int64)]
 
 
+class StftParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("frames", C.c_void_p), ("out", C.c_void_p),
+                ("window", C.c_void_p), ("twiddle", C.c_void_p), ("inv_env", C.c_void_p),
+                ("mask", C.c_void_p), ("mask_sB", C.c_int64), ("mask_ld", C.c_int64),
+                ("add1", C.c_void_p), ("add2", C.c_void_p), ("c0", C.c_float),
+                ("B", C.c_int), ("L", C.c_int64), ("Lp", C.c_int64),
+                ("n_fft", C.c_int), ("hop", C.c_int), ("n_frames", C.c_int), ("adjoint", C.c_int)]
+
+
 EXPORTS = ["aid_abi_version", "aid_last_error", "aid_group_stats", "aid_conv2d", "aid_conv2d_pack_dims", "aid_resample",
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
-           "aid_time_attention_bwd", "aid_guidance_seed", "aid_row_norm", "aid_scale_act", "aid_fft_pass"]
+           "aid_time_attention_bwd", "aid_guidance_seed", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
+           "aid_stft_frames", "aid_stft_ola"]
 
 _lib = None
 

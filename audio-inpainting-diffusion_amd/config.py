@@ -61,6 +61,8 @@ TESTER_LONG = dict(
     data_consistency=dict(use=True, type="always", smooth=True, hann_size=50),
     diff_params=dict(same_as_training=False, sigma_data=0.063, sigma_min=1e-4, sigma_max=1, P_mean=-1.2,
                      P_std=1.2, ro=13, ro_train=13, Schurn=10, Snoise=1.0, Stmin=0, Stmax=50),
+    spectrogram_inpainting=dict(stft=dict(window="hann", n_fft=1024, hop_length=256, win_length=1024),
+                                time_mask_length=2000, time_start_idx="None", min_masked_freq=300, max_masked_freq=2000),
     inpainting=dict(mask_mode="long", long=dict(gap_length=1500, start_gap_idx="None"),
                     short=dict(num_gaps=4, gap_length=25, start_gap_idx="None")))
 

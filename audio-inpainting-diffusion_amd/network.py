@@ -702,10 +702,11 @@ class Unet_CQT_oct_with_attention(nn.Module):
         return tr.irfft(S)
 
     @torch.no_grad()
-    def denoise_guided(self, x, cnoise, cin, cskip, cout, hpf: bool, y, mask):
+    def denoise_guided(self, x, cnoise, cin, cskip, cout, hpf: bool, y, mask, degradation=None):
         """Fused guided evaluation: x_hat = [hpf](cskip*x + cout*F(cin*x)) and
-        rec_grads = d/dx || y - mask*x_hat ||_2 (per item, edm_sampler_inpainting.py:60-81), computed with the
-        hand-written input-VJP instead of torch.autograd.  Returns (x_hat, rec_grads, norm[B])."""
+        rec_grads = d/dx || y - A(x_hat) ||_2 (per item, edm_sampler_inpainting.py:60-81), computed with the
+        hand-written input-VJP instead of torch.autograd.  A = time-domain mask (default) or any linear operator
+        object with ``apply`` / ``adjoint`` (stft.SpectralMask).  Returns (x_hat, rec_grads, norm[B])."""
         self._check_input(x)
         B, L = x.shape
         st = self._state(B)
@@ -717,16 +718,29 @@ class Unet_CQT_oct_with_attention(nn.Module):
         x_hat = tr.irfft(Y)
         g = torch.empty_like(x_hat)
         norm = torch.empty(B, device=x.device, dtype=torch.float32)
-        m = mask if mask.dim() == 2 else mask.reshape(1, -1)
-        sp = _lib.GuidanceSeedParams(x_hat.data_ptr(), y.data_ptr(), m.data_ptr(), m.stride(0) if m.shape[0] > 1 else 0,
-                                     g.data_ptr(), norm.data_ptr(), B, L)
-        _lib.call("aid_guidance_seed", sp)
+        if degradation is None:
+            m = mask if mask.dim() == 2 else mask.reshape(1, -1)
+            sp = _lib.GuidanceSeedParams(x_hat.data_ptr(), y.data_ptr(), m.data_ptr(), m.stride(0) if m.shape[0] > 1 else 0,
+                                         g.data_ptr(), norm.data_ptr(), B, L)
+            _lib.call("aid_guidance_seed", sp)
+        else:                                    # g = -A^T (y - A x_hat) / ||y - A x_hat||
+            den = degradation.apply(x_hat)
+            ones = self._ones_row(L, x.device)
+            sp = _lib.GuidanceSeedParams(den.data_ptr(), y.data_ptr(), ones.data_ptr(), 0, g.data_ptr(), norm.data_ptr(), B, L)
+            _lib.call("aid_guidance_seed", sp)
+            g = degradation.adjoint(g)
         Gh = tr.rfft(g)
         if hpf:
             Gh = tr.spectrum_scale(Gh, tab["hpf"])                       # the projector is self-adjoint
         self._body_vjp(st, tr.spectrum_scale(Gh, tab["w_over_L"], per_item=cout))
         S = tr.analysis_adjoint(st["gin"], in_scale=cin, X=Gh, cskip=cskip)
         return x_hat, tr.irfft(S), norm
+
+    def _ones_row(self, L, device):
+        o = getattr(self, "_ones_cache", None)
+        if o is None or o.shape[1] != L or o.device != device:
+            o = self._ones_cache = torch.ones(1, L, device=device, dtype=torch.float32)
+        return o
 
     def flops_per_eval(self, B: int = 1) -> int:
         """Algorithmic conv/GEMM/attention FLOPs of one forward evaluation at batch B (2*MACs)."""

@@ -2,7 +2,8 @@
 
 Call surface kept from the reference (testing/edm_sampler_inpainting.py): ``Sampler(model, diff_params, args,
 rid=False)`` (:10), public attributes ``xi / nb_steps / order`` (:19-32), ``predict_inpainting(y_masked, mask)``
-(:327), ``predict_unconditional(shape, device)`` (:155), ``update_diff_params`` (:43).  The loop (:178-262) stays
+(:327), ``predict_spectrogram_inpainting(y_masked, mask[F,T])`` (:348), ``predict_unconditional(shape, device)`` (:155),
+``update_diff_params`` (:43).  The loop (:178-262) stays
 in Python but is sync-free: the schedule, gamma and every per-step scalar live on the host (float32 torch
 arithmetic identical to the reference), noise is drawn from the CPU generator in the reference's order and
 copied asynchronously, and each step costs two fused element-wise launches besides the denoiser evaluations.
@@ -22,6 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .stft import SpectralMask
 
 
 def prepare_smooth_mask(mask: torch.Tensor, size: int) -> torch.Tensor:
@@ -60,6 +62,7 @@ class Sampler:
         self.rid = rid
         if rid:
             raise NotImplementedError("rid=True debug buffers are not built (SURVEY.md section 2, row 4)")
+        self.spectral = None
         self.seeds: Optional[List[int]] = None      # per-item RNG seeds; None -> global torch CPU generator
         self.trace = None                           # set to [] to record every projected x_hat (tests)
         self.n_evals = 0
@@ -118,7 +121,7 @@ class Sampler:
             s1 = t_i.reshape(1)
             x_hat, rec_grads, _ = self.model.denoise_guided(
                 x, self._vec(dp.cnoise(s1), B, x.device), self._vec(dp.cin(s1), B, x.device), self._vec(dp.cskip(s1), B, x.device),
-                self._vec(dp.cout(s1), B, x.device), hpf, self.y, self.mask)
+                self._vec(dp.cout(s1), B, x.device), hpf, self.y, self.mask, self.spectral)
             gn = torch.empty(B, device=x.device, dtype=torch.float32)
             _lib.call("aid_row_norm", _lib.RowNormParams(rec_grads.data_ptr(), gn.data_ptr(), B, L))
             normguide = gn / self.args.exp.audio_len ** 0.5                      # (:83) per item
@@ -132,7 +135,7 @@ class Sampler:
             x_hat = dp.denoiser(x, self.model, sig)
             if hpf:
                 x_hat = self.model.CQTransform.apply_hpf_DC(x_hat)
-            den_rec = self.mask * x_hat
+            den_rec = self.mask * x_hat if self.spectral is None else _SpectralFn.apply(x_hat, self.spectral)
             if nrm == "smoothl1":
                 norm = torch.nn.functional.smooth_l1_loss(self.y, den_rec, reduction="none",
                                                           beta=self.args.tester.posterior_sampling.smoothl1_beta).sum(dim=1)
@@ -149,6 +152,8 @@ class Sampler:
         xnext = torch.empty_like(x)
         dout = torch.empty_like(x) if mode == 0 else None
         proj = self.data_consistency and self.y is not None
+        if proj and self.spectral is not None:                     # y + x_hat - A(x_hat)   (:360)
+            x_hat, proj = self.spectral.project(x_hat, self.y), False
         xh_out = torch.empty_like(x) if self.trace is not None else None
         tv, hv = self._vec(t_i, B, x.device), self._vec(h, B, x.device)   # keep alive until after the launch
         p = _lib.ScoreStepParams(x.data_ptr(), x_hat.data_ptr(), _lib.ptr(self.y) if proj else None,
@@ -164,7 +169,7 @@ class Sampler:
     # ---------------------------------------------------------------------------------------------------
     def predict_unconditional(self, shape, device):
         self.y = None
-        self.mask = self.smask = None
+        self.mask = self.smask = self.spectral = None
         return self.predict(shape, device)
 
     def begin(self, shape, device):
@@ -213,12 +218,13 @@ class Sampler:
             self.step(state, i)
         x = state["x"]
         if self.data_consistency_end and self.y is not None:
-            x = self.smask * self.y + (1 - self.smask) * x
+            x = self.smask * self.y + (1 - self.smask) * x if self.spectral is None else self.spectral.project(x, self.y)
         return x.detach()
 
     def predict_inpainting(self, y_masked, mask):
         """y_masked[B,L], mask[1|B,L] -> inpainted [B,L] on y_masked.device   (:327-346)"""
         self.mask = mask.to(y_masked.device)
+        self.spectral = None
         self.y = y_masked.contiguous().float()
         if self.data_consistency or self.data_consistency_end:
             sm = prepare_smooth_mask(mask, self.args.tester.data_consistency.hann_size) if self.smooth else mask.float()
@@ -226,4 +232,23 @@ class Sampler:
         return self.predict(self.y.shape, self.y.device)
 
     def predict_spectrogram_inpainting(self, y_masked, mask):
-        raise NotImplementedError("spectrogram inpainting (STFT-domain mask) is SURVEY.md section 8f item 1 -- next")
+        """y_masked[B,L], mask[F,T] (or [B,F,T]) over the STFT of tester.spectrogram_inpainting.stft -> [B,L]
+        (:348-364): degradation = STFT-domain masking, projection y + x - A(x)."""
+        st = self.args.tester.spectrogram_inpainting.stft
+        self.y = y_masked.contiguous().float()
+        self.mask = self.smask = None
+        self.spectral = SpectralMask(mask, self.y.shape[-1], st.n_fft, st.hop_length, st.win_length, st.window, self.y.device)
+        return self.predict(self.y.shape, self.y.device)
+
+
+class _SpectralFn(torch.autograd.Function):
+    """A(x) with A^T as its backward -- only used when a foreign (non-MI355X) model is driven through torch.autograd."""
+
+    @staticmethod
+    def forward(ctx, x, op):
+        ctx.op = op
+        return op.apply(x.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.op.adjoint(g.contiguous()), None

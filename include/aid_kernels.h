@@ -319,6 +319,31 @@ typedef struct { const float* x; float* out; int B; int64_t L; } aid_row_norm_pa
 int aid_row_norm(const aid_row_norm_params* p, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * aid_stft_frames / aid_stft_ola -- the STFT-domain masking operator of spectrogram inpainting and its adjoint.
+ *   replaces: Sampler.apply_spectral_mask (testing/edm_sampler_inpainting.py:271-290):
+ *       x -> pad to a multiple of n_fft -> torch.stft(n_fft, hop, win, hann, center=True, reflect) -> * mask[F,T]
+ *         -> torch.istft -> crop to L,
+ *     used as the degradation inside the guidance norm (:65-75, through torch.autograd) and in the projection
+ *     y + x - A(x) (:360).  adjoint = 1 gives A^T (what autograd would compute), reusing both kernels.
+ *   aid_stft_frames: x [B,L] -> frames [B, n_frames, n_fft]   (window, FFT, mask, inverse FFT, window / n_fft)
+ *   aid_stft_ola   : frames -> out [B,L] = c0 * (overlap-add [* 1/envelope when adjoint = 0]) + add1 + add2
+ *   Lp = L + (n_fft - L % n_fft) (the reference always pads, :283), n_frames = 1 + Lp/hop,
+ *   window [n_fft] (win_length centre-padded to n_fft by the host), twiddle [n_fft/2] complex exp(-2 pi i m/n_fft),
+ *   mask [F = n_fft/2+1 rows, leading dimension mask_ld >= n_frames], per-sample stride mask_sB (0 = shared),
+ *   inv_env [Lp] = 1 / sum_n window^2 (the istft normalisation, trimmed by n_fft/2).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* x; float* frames; float* out;
+    const float* window; const float* twiddle; const float* inv_env;
+    const float* mask; int64_t mask_sB; int64_t mask_ld;
+    const float* add1; const float* add2; float c0;
+    int B; int64_t L; int64_t Lp;
+    int n_fft, hop, n_frames, adjoint;
+} aid_stft_params;
+int aid_stft_frames(const aid_stft_params* p, void* stream);
+int aid_stft_ola(const aid_stft_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * aid_scale_act -- h = act(x * scale[b,c]) on [B,C,F,T] views (act: 0 none, 1 erf-GELU).
  *   The normalise -> modulate -> GELU prologue of a dilated step (unet...py:475-482) evaluated ONCE per element
  *   into a scratch tensor; the 5x3 conv then stages plain copies (inside the conv's LDS staging the same GELU

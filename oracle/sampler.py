@@ -5,7 +5,8 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Pinned by tests/golden/sampl
 the reference's own ``Sampler`` driving a toy denoiser).
 
 Follows reference testing/edm_sampler_inpainting.py: get_score_rec_guidance :57-113, get_score :115-153,
-predict :178-262, apply_mask :264-269, prepare_smooth_mask :302-325, predict_inpainting :327-346.
+predict :178-262, apply_mask :264-269, apply_spectral_mask :271-290, prepare_smooth_mask :302-325,
+predict_inpainting :327-346, predict_spectrogram_inpainting :348-364.
 
 Batch semantics.  The reference is only ever run at B=1 (its guided branch raises for B>1 with norm=2,
 :75-:78).  Here every quantity the reference reduces over the whole batch (the guidance norm :75, the
@@ -40,6 +41,18 @@ def smooth_mask_rows(mask: torch.Tensor, size: int) -> torch.Tensor:
     return out
 
 
+def spectral_mask_apply(x: torch.Tensor, mask: torch.Tensor, n_fft=1024, hop=256, win_length=1024) -> torch.Tensor:
+    """apply_spectral_mask (:271-290): zero-pad to a multiple of n_fft, stft (Hann), times mask[F,T] (or [B,F,T]),
+    istft, crop.  Differentiable (the reference takes the guidance gradient through it with autograd)."""
+    window = torch.hann_window(win_length, dtype=x.dtype)
+    L = x.shape[-1]
+    xp = torch.nn.functional.pad(x, (0, n_fft - L % n_fft), mode="constant", value=0)
+    X = torch.stft(xp, n_fft, hop, win_length, window, return_complex=True)
+    X = X * (mask.unsqueeze(0) if mask.dim() == 2 else mask)
+    y = torch.istft(X, n_fft, hop, win_length, window, return_complex=False)
+    return y[..., 0:L]
+
+
 class OracleSampler:
     def __init__(self, model, edm, T=35, order=2, xi=0.25, norm=2, data_consistency=True, smooth=True,
                  hann_size=50, filter_out_cqt_DC_Nyq=True, audio_len=None):
@@ -49,6 +62,8 @@ class OracleSampler:
         self.filter_hpf = filter_out_cqt_DC_Nyq
         self.audio_len = audio_len
         self.trace = None
+        self.degradation = lambda x: self.mask * x                                          # apply_mask (:264-269)
+        self.project = lambda x: self.smask * self.y + (1 - self.smask) * x                 # (:343)
 
     # -- one denoiser evaluation (:115-153) ------------------------------------------------------
     def get_score(self, x, t_i):
@@ -59,7 +74,7 @@ class OracleSampler:
             x_hat = self.edm.denoiser(x, self.model, sig)
             if self.filter_hpf:
                 x_hat = self.model.CQTransform.apply_hpf_DC(x_hat)
-            norm = torch.linalg.norm(self.y - self.mask * x_hat, dim=1, ord=self.norm)      # [B]  (:75)
+            norm = torch.linalg.norm(self.y - self.degradation(x_hat), dim=1, ord=self.norm)   # [B]  (:65,:75)
             g = torch.autograd.grad(norm.sum(), x)[0]                                       # per-item grads
             L = self.audio_len if self.audio_len is not None else x.shape[-1]
             normguide = torch.linalg.norm(g, dim=1, keepdim=True) / L ** 0.5                # (:83) per item
@@ -70,7 +85,7 @@ class OracleSampler:
             with torch.no_grad():
                 x_hat = self.edm.denoiser(x, self.model, sig)
         if self.data_consistency:
-            x_hat = self.smask * self.y + (1 - self.smask) * x_hat                          # (:343)
+            x_hat = self.project(x_hat)                                                     # (:100, :343 / :360)
         if self.trace is not None:
             self.trace.append(x_hat.detach().clone())
         return (x_hat - x) / t_i ** 2                                                       # (:105)
@@ -83,8 +98,23 @@ class OracleSampler:
     # -- the loop (:178-262) -----------------------------------------------------------------------
     def predict_inpainting(self, y_masked, mask, seeds: Optional[List[int]] = None, record: bool = False):
         self.y, self.mask = y_masked, mask
+        self.degradation = lambda x: self.mask * x
+        self.project = lambda x: self.smask * self.y + (1 - self.smask) * x
         if self.data_consistency:
             self.smask = smooth_mask_rows(mask, self.hann_size) if self.smooth else mask
+        return self._predict(seeds, record)
+
+    def predict_spectrogram_inpainting(self, y_masked, mask, stft=(1024, 256, 1024), seeds: Optional[List[int]] = None,
+                                       record: bool = False):
+        """(:348-364) degradation = STFT-domain mask, projection = y + x - A(x)."""
+        self.y, self.mask = y_masked, mask
+        n_fft, hop, win = stft
+        self.degradation = lambda x: spectral_mask_apply(x, self.mask, n_fft, hop, win)
+        self.project = lambda x: self.y + x - self.degradation(x)
+        return self._predict(seeds, record)
+
+    def _predict(self, seeds, record):
+        y_masked = self.y
         self.trace = [] if record else None
         shape = y_masked.shape
         gens = None if seeds is None else [torch.Generator().manual_seed(int(s)) for s in seeds]

@@ -19,6 +19,7 @@ Fixtures written (inputs + reference outputs only -- data, not code):
                      (weights are regenerated from the seeded initialiser, seed stored)
   edm_schedule.npz   create_schedule / get_gamma for T in {35,36,70,128} with the tester parameters
   sampler_toy.npz    full sampler trajectories (reference Sampler + EDM driving a toy denoiser)
+  sampler_spectral.npz   spectrogram inpainting: apply_spectral_mask + full trajectories (guided / replacement)
   unet_full_cfgA.npz (--full) full-size 22.05 kHz network output for the seeded weights/input (B=1)
 """
 import argparse
@@ -198,6 +199,36 @@ def gen_sampler(out):
     np.savez_compressed(os.path.join(out, "sampler_toy.npz"), **d)
 
 
+def gen_spectral(out):
+    """Spectrogram inpainting: the reference's apply_spectral_mask operator and full sampler trajectories."""
+    import diff_params.edm as E
+    import testing.edm_sampler_inpainting as S
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.init import seeded_normal
+    L, T = 2000, 5
+    n_fft, hop = 128, 32
+    d = {"L": np.array(L), "T": np.array(T), "stft": np.array([n_fft, hop, n_fft])}
+    net = _ToyNet(L)
+    Lp = L + (n_fft - L % n_fft)
+    mask = torch.ones(n_fft // 2 + 1, 1 + Lp // hop)
+    mask[6:30, 20:41] = 0
+    d["mask"] = mask.numpy()
+    for tag, xi, seed in (("sg_s0", 0.25, 0), ("sg_s1", 0.25, 1), ("sr_s0", 0.0, 0)):
+        args = make_args(audio_len=L, T=T, xi=xi)
+        st = args.tester.spectrogram_inpainting.stft
+        st.n_fft, st.hop_length, st.win_length = n_fft, hop, n_fft
+        smp = S.Sampler(model=net, diff_params=E.EDM(args), args=args, rid=False)
+        y = torch.from_numpy(seeded_normal(6, seed, L)).reshape(1, L) * 0.063
+        smp.mask = mask
+        ym = smp.apply_spectral_mask(y)
+        torch.manual_seed(seed)
+        x = smp.predict_spectrogram_inpainting(ym, mask)
+        d[f"{tag}.y0"], d[f"{tag}.y"], d[f"{tag}.out"] = y.numpy(), ym.numpy(), x.numpy()
+        d[f"{tag}.meta"] = np.array([xi, seed], dtype=np.float64)
+        print("spectral", tag, "masked rms", float(ym.pow(2).mean().sqrt()), "out rms", float(x.pow(2).mean().sqrt()))
+    np.savez_compressed(os.path.join(out, "sampler_spectral.npz"), **d)
+
+
 def gen_full(out):
     import networks.unet_cqt_oct_with_projattention_adaLN_2 as R
     from audio_inpainting_diffusion_amd.config import make_args
@@ -224,9 +255,10 @@ if __name__ == "__main__":
     a = ap.parse_args()
     _setup_imports()
     torch.set_grad_enabled(True)
-    todo = a.only.split(",") if a.only else ["ops", "unet", "edm", "sampler"] + (["full"] if a.full else [])
+    todo = a.only.split(",") if a.only else ["ops", "unet", "edm", "sampler", "spectral"] + (["full"] if a.full else [])
     if "ops" in todo: gen_ops(HERE)
     if "unet" in todo: gen_unet_small(HERE)
     if "edm" in todo: gen_edm(HERE)
     if "sampler" in todo: gen_sampler(HERE)
+    if "spectral" in todo: gen_spectral(HERE)
     if "full" in todo: gen_full(HERE)

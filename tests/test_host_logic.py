@@ -195,3 +195,77 @@ def test_masks_match_reference_prepare_mask_geometry():
     assert a.tester.T == 70 and a.tester.data_consistency.hann_size == 100
     assert mask_from_args(a, torch.Generator().manual_seed(0)).shape == (1, L)
     assert torch.equal(mask_from_args(make_args("maestro22k", gap_ms=300.0)), long_gap_mask(L, 22050, 300))
+
+
+def _emulate_stft_kernels(x, mask, L, n_fft, hop, win, adjoint):
+    """numpy transcription of csrc/aid_stft.hip (frames kernel + overlap-add gather) in float64."""
+    from audio_inpainting_diffusion_amd.stft import stft_tables
+    w, env, _ = stft_tables(L, n_fft, hop, win)
+    Lp, N, half = len(env), n_fft, n_fft // 2
+    nfr = 1 + Lp // hop
+    B = x.shape[0]
+    fr = np.zeros((B, nfr, N))
+    f = np.arange(N)
+    fm = np.where(f <= half, f, N - f)
+    for n in range(nfr):
+        q = n * hop - half + np.arange(N)
+        if adjoint:
+            inside, qq = (q >= 0) & (q < Lp), np.clip(q, 0, Lp - 1)
+        else:
+            qq = np.where(q < 0, -q, q)
+            qq = np.where(qq >= Lp, 2 * (Lp - 1) - qq, qq)
+            inside = np.ones(N, bool)
+        ok = inside & (qq < L)
+        v = np.where(ok, x[:, np.minimum(qq, L - 1)], 0.0)
+        if adjoint:
+            v = v * np.where(ok, 1.0 / env[qq], 0.0)
+        fr[:, n] = np.fft.ifft(np.fft.fft(v * w, axis=-1) * mask[fm, n], axis=-1).real * w
+
+    def cover(pos):
+        q = pos + half
+        n1 = min(q // hop, nfr - 1)
+        n0 = 0 if q - (N - 1) < 0 else -(-(q - (N - 1)) // hop)
+        return sum((fr[:, n, q - n * hop] for n in range(n0, n1 + 1)), np.zeros(B))
+
+    out = np.zeros((B, L))
+    for t in range(L):
+        v = cover(t)
+        if adjoint:
+            if 1 <= t <= half:
+                v = v + cover(-t)
+            r = 2 * (Lp - 1) - t
+            if Lp <= r < Lp + half:
+                v = v + cover(r)
+        else:
+            v = v / env[t]
+        out[:, t] = v
+    return out
+
+
+@pytest.mark.parametrize("case", [(1000, 64, 16, 64), (1024, 64, 16, 64), (777, 128, 32, 128), (1500, 64, 16, 32)])
+def test_stft_mask_device_algorithm_and_adjoint_match_oracle(case):
+    """The frame/overlap-add decomposition the HIP kernels use (and its transposed border handling) equals
+    torch.stft -> mask -> torch.istft and the gradient autograd takes through it."""
+    from oracle.sampler import spectral_mask_apply
+    L, n_fft, hop, win = case
+    Lp = L + (n_fft - L % n_fft)
+    rng = np.random.default_rng(0)
+    mask = (rng.random((n_fft // 2 + 1, 1 + Lp // hop)) > 0.3).astype(np.float64)
+    x, g = rng.standard_normal((2, L)), rng.standard_normal((2, L))
+    xt = torch.from_numpy(x).requires_grad_()
+    ref = spectral_mask_apply(xt, torch.from_numpy(mask), n_fft, hop, win)
+    (ref * torch.from_numpy(g)).sum().backward()
+    assert rel_l2(_emulate_stft_kernels(x, mask, L, n_fft, hop, win, 0), ref.detach()) < 1e-7
+    assert rel_l2(_emulate_stft_kernels(g, mask, L, n_fft, hop, win, 1), xt.grad) < 1e-7
+
+
+def test_spectral_mask_matches_reference_prepare_spectral_mask_geometry():
+    """tester_inpainting.py:256-294 with conf/tester/inpainting_tester.yaml:78-87 at 22.05 kHz, L=184184."""
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.masks import spectral_mask_from_args
+    A = spectral_mask_from_args(make_args("maestro22k"))
+    assert tuple(A.shape) == (513, 721)
+    zr, zc = np.nonzero((A == 0).any(1).numpy())[0], np.nonzero((A == 0).any(0).numpy())[0]
+    assert (zr[0], zr[-1] + 1) == (14, 93)              # 300 Hz .. 2 kHz in 21.53 Hz bins
+    assert (zc[0], zc[-1] + 1) == (273, 445)            # (92092 - 22050)//256, + 44100//256
+    assert int((A == 0).sum()) == (93 - 14) * (445 - 273)

@@ -130,3 +130,20 @@ def test_sampler_batch_items_are_independent():
     for b in range(2):
         one = s.predict_inpainting((y * mask)[b:b + 1], mask[b:b + 1], seeds=[11 + b])
         assert rel_l2(both[b:b + 1], one) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["sg_s0", "sg_s1", "sr_s0"])
+def test_spectrogram_inpainting_operator_and_trajectories(tag):
+    """apply_spectral_mask (edm_sampler_inpainting.py:271-290) and predict_spectrogram_inpainting (:348-364)."""
+    from oracle.sampler import spectral_mask_apply
+    z = np.load(os.path.join(GOLDEN, "sampler_spectral.npz"))
+    L, T = int(z["L"]), int(z["T"])
+    stft = tuple(int(v) for v in z["stft"])
+    xi, seed = z[tag + ".meta"]
+    mask = torch.from_numpy(z["mask"])
+    ym = spectral_mask_apply(torch.from_numpy(z[tag + ".y0"]), mask, *stft)
+    assert rel_l2(ym, z[tag + ".y"]) < 1e-6
+    s = OracleSampler(_Toy(L), OracleEDM(), T=T, xi=float(xi), audio_len=L)
+    torch.manual_seed(int(seed))
+    out = s.predict_spectrogram_inpainting(torch.from_numpy(z[tag + ".y"]), mask, stft=stft)
+    assert rel_l2(out, z[tag + ".out"]) < 1e-5

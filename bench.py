@@ -39,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def cpu_baseline(net, args, guided: bool):
+def cpu_baseline(net, args, guided: bool, spectral: bool = False):
     """The CPU oracle (oracle/: torch-CPU restatement of the reference path) timed on this host for the same
     full-size network at B=1: one warm-up forward evaluation, then a bounded timed sample of the same branch the
     GPU number is quoted on (guided: 1 evaluation = forward with autograd graph + input gradient; xi=0: 2 forward
@@ -65,7 +65,13 @@ def cpu_baseline(net, args, guided: bool):
         n_timed = 1
         xr = x.clone().requires_grad_()
         xh = orc.CQTransform.apply_hpf_DC(edm.denoiser(xr, orc, s))
-        norm = torch.linalg.norm(y * mask - mask * xh, dim=1, ord=2)
+        if spectral:
+            from oracle.sampler import spectral_mask_apply
+            from audio_inpainting_diffusion_amd.masks import spectral_mask_from_args
+            sm = spectral_mask_from_args(args)
+            norm = torch.linalg.norm(spectral_mask_apply(y, sm) - spectral_mask_apply(xh, sm), dim=1, ord=2)
+        else:
+            norm = torch.linalg.norm(y * mask - mask * xh, dim=1, ord=2)
         torch.autograd.grad(norm.sum(), xr)
     else:
         n_timed = 2
@@ -75,7 +81,7 @@ def cpu_baseline(net, args, guided: bool):
     dt = (time.time() - t0) / n_timed
     what = "guided (xi=0.25: forward with graph + input-VJP by torch.autograd)" if guided else "forward-only (xi=0)"
     return {"value": round(1.0 / dt, 4), "unit": "denoiser evaluations per second", "cores": cores, "kind": "port",
-            "sample": f"B=1 full-size 22.05 kHz network, {what}: 1 warm-up forward + {n_timed} timed evaluation(s), "
+            "sample": f"B=1 full-size {args.exp.exp_name} network, {what}: 1 warm-up forward + {n_timed} timed evaluation(s), "
                       f"{dt:.2f} s each, torch {torch.__version__} CPU fp32, {cores} threads"}
 
 
@@ -84,9 +90,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="segments per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="segments per GPU (default: 8 / 16 / 4 by workload)")
     ap.add_argument("--xi", type=float, default=0.25, help="0.25 = reconstruction guidance (the reference tester's default, conf/tester/inpainting_tester.yaml:32); "
                                                           "0 = replacement branch (forward only)")
+    ap.add_argument("--task", choices=["inpainting", "spectrogram"], default="inpainting",
+                    help="inpainting = time-domain gap (the headline metric); spectrogram = STFT-domain mask "
+                         "(predict_spectrogram_inpainting, conf/tester/inpainting_tester.yaml:78-87)")
+    ap.add_argument("--workload", choices=["maestro22k", "librispeech16k", "musicnet44k"], default="maestro22k",
+                    help="maestro22k = BASELINE.json configs[1] (the metric's configuration); librispeech16k = configs[3] "
+                         "(16 kHz, 4 short gaps of 50 ms, T=70, batch 16); musicnet44k = configs[4] (44.1 kHz 8-octave "
+                         "network, 1.5 s gap, T=128, batch 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-table", action="store_true", help="print per-shape conv kernel times (stderr)")
     a = ap.parse_args()
@@ -103,10 +116,10 @@ def main():
     local = local % max(1, torch.cuda.device_count())      # (several ranks may share a GPU in functional tests)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    T = 36
+    T, gap_ms, B_def = {"maestro22k": (36, 300.0, 8), "librispeech16k": (70, 50.0, 16), "musicnet44k": (128, 1500.0, 4)}[a.workload]
     assert a.warmup + a.steps <= T - 1, "timed steps must be Heun steps (the last step of the schedule is Euler)"
-    args = make_args("maestro22k", audio_len=184184, T=T, gap_ms=300.0, xi=a.xi)
-    L, B = args.exp.audio_len, a.batch
+    args = make_args(a.workload, audio_len=184184, T=T, gap_ms=gap_ms, xi=a.xi)
+    L, B = args.exp.audio_len, (a.batch or B_def)
 
     net = Unet_CQT_oct_with_attention(args, dev)
     if rank == 0:
@@ -119,16 +132,21 @@ def main():
 
     lo, hi = D.shard_range(world * B, rank, world)
     y = torch.stack([torch.from_numpy(seeded_normal(7, g, L)) for g in range(lo, hi)]) * 0.063
-    gap = int(300.0 * args.exp.sample_rate / 1000)
-    start = L // 2 - gap // 2                       # tester_inpainting.py:231-254
-    mask = torch.ones(1, L)
-    mask[:, start:start + gap] = 0
+    from audio_inpainting_diffusion_amd.masks import mask_from_args, spectral_mask_from_args
+    from audio_inpainting_diffusion_amd.sampler import prepare_smooth_mask
     smp = Sampler(model=net, diff_params=EDM(args), args=args)
     smp.seeds = D.item_seeds(1234, lo, hi)
-    smp.mask = mask.to(dev)
-    smp.y = (y * mask).to(dev).contiguous()
-    from audio_inpainting_diffusion_amd.sampler import prepare_smooth_mask
-    smp.smask = prepare_smooth_mask(mask, args.tester.data_consistency.hann_size).to(dev).contiguous()
+    if a.task == "spectrogram":
+        from audio_inpainting_diffusion_amd.stft import SpectralMask
+        stc = args.tester.spectrogram_inpainting.stft
+        smp.spectral = SpectralMask(spectral_mask_from_args(args), L, stc.n_fft, stc.hop_length, stc.win_length, stc.window, dev)
+        smp.mask = smp.smask = None
+        smp.y = smp.spectral.apply(y.to(dev).contiguous())
+    else:
+        mask = mask_from_args(args, generator=torch.Generator().manual_seed(99))     # tester_inpainting.py:231-254
+        smp.mask = mask.to(dev)
+        smp.y = (y * mask).to(dev).contiguous()
+        smp.smask = prepare_smooth_mask(mask, args.tester.data_consistency.hann_size).to(dev).contiguous()
 
     state = smp.begin((B, L), dev)
     for i in range(a.warmup):
@@ -172,10 +190,14 @@ def main():
             "metric": "denoiser-steps/sec", "value": round(evals / wall, 3), "unit": "denoiser evaluations (one segment each) per second, whole job",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * wall / a.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: batch 8 x 22.05 kHz MAESTRO-shape segments (L=184184) per GPU, 300 ms gap, "
-                                   "T=36 EDM schedule, Heun steps %d..%d" % (a.warmup, a.warmup + a.steps - 1),
+            "config": {"workload": {"maestro22k": "BASELINE.json configs[1]: batch %d x 22.05 kHz MAESTRO-shape segments (L=184184) per GPU, 300 ms gap, ",
+                                    "librispeech16k": "BASELINE.json configs[3]: batch %d x 16 kHz LibriSpeech-shape segments (L=184184) per GPU, 4 gaps of 50 ms, ",
+                                    "musicnet44k": "BASELINE.json configs[4]: batch %d x 44.1 kHz segments (L=184184) per GPU, 8-octave network, 1.5 s gap, "}[a.workload] % B
+                                   + "T=%d EDM schedule, Heun steps %d..%d" % (T, a.warmup, a.warmup + a.steps - 1)
+                                   + ("; STFT-domain mask (spectrogram inpainting)" if a.task == "spectrogram" else ""),
                        "branch": "xi=%g (%s)" % (a.xi, "reconstruction guidance: forward + input-VJP" if a.xi > 0 else "replacement / data-consistency: forward only"),
-                       "segments_per_gpu": B, "evals_per_step": 2, "network": "unet_cqt_oct_with_attention 22 kHz, 186.3 M params, random-init (seeded)",
+                       "segments_per_gpu": B, "evals_per_step": 2,
+                       "network": "unet_cqt_oct_with_attention %s, %.1f M params, random-init (seeded)" % ("44.1 kHz 8-octave" if a.workload == "musicnet44k" else "7-octave", sum(p.numel() for p in net.parameters()) / 1e6),
                        "parallelism": "segments sharded %d-way, one process per GPU, weights broadcast once (%.0f MB in %.3f s), no collective in the loop" % (world, nbytes / 1e6, t_bcast)},
             "roofline": {"bound": "mfma", "kernel": "aid_conv2d: conv53_wino4_kernel (Winograd F(4,3), 5x3 layers) + conv_mfma_kernel (1x1), fp32 v_mfma_f32_32x32x2_f32",
                          "achieved": round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 4),
@@ -192,7 +214,7 @@ def main():
             except Exception:
                 pass
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(net, args, guided=a.xi > 0)
+            out["cpu_baseline"] = cpu_baseline(net, args, guided=a.xi > 0, spectral=a.task == "spectrogram")
             out["cpu_baseline"]["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     D.barrier()

@@ -13,7 +13,7 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaid_hip.so")
+LIB_PATH = os.environ.get("AID_LIB_PATH") or os.path.join(_HERE, "libaid_hip.so")      # override: kernel experiments only
 AID_CQT_MAX_OCT = 12
 AID_STATS_SPLIT = 32
 

@@ -12,6 +12,9 @@
 // VALU ops feed four MFMAs -- so x traffic and LDS footprint do not grow; only the weight tile does (20 vs 15 taps).
 // Epilogue: output transform in registers, both samples of a pair stored as one float2.
 #include "aid_common.h"
+#ifndef WINO_EXP
+#define WINO_EXP 0     // experiment gates (tools/wino_exp.sh): 1 no DMA, 2 no barrier, 4 no transform, 8 no LDS reads, 16 no setprio
+#endif
 #include <type_traits>
 #include <stdlib.h>
 
@@ -317,8 +320,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4_kernel(cons
     const int TT = 1 << a.tt_log2;
     const int ROWS = 1 << a.rows_log2;
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    int* rowinfo = (int*)(smem + 2 * BUFSZ);
+    // Two STATIC buffers (not one dynamic array): distinct LDS objects carry alias scopes after LDS lowering, so the
+    // waitcnt pass knows the ds_reads of chunk c cannot touch the buffer the direct-to-LDS loads of chunk c+1 write,
+    // and leaves those loads in flight for the whole chunk (with a single dynamic array it emitted s_waitcnt vmcnt(0)
+    // right after issuing them: the "asynchronous" staging was synchronous).
+    __shared__ __attribute__((aligned(16))) float sbuf0[BUFSZ];
+    __shared__ __attribute__((aligned(16))) float sbuf1[BUFSZ];
+    __shared__ int rowinfo[2 * RMAX];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -439,16 +447,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4_kernel(cons
             if (hlds[i] >= 0) buf[hlds[i]] = hv[i];
     };
 
-    issue_dma(0, smem);
-    write_halo(smem);
+    issue_dma(0, sbuf0);
+    write_halo(sbuf0);
     __syncthreads();
 
     auto chunk = [&](auto curc, int ch) {
         constexpr int cur = decltype(curc)::value;
-        const float* Bf = smem + cur * BUFSZ;
-        float* Nx = smem + (cur ^ 1) * BUFSZ;
+        const float* Bf = cur ? sbuf1 : sbuf0;
+        float* Nx = cur ? sbuf0 : sbuf1;
         const bool more = (ch + 1) < a.nchunks;
+#if !(WINO_EXP & 1)
         if (more) issue_dma(ch + 1, Nx);
+#endif
         // raw samples of step s+1 are fetched while the MFMAs of step s run
         float d0[2][NTT], d3[2][NTT];
         float4 d12[2][NTT];
@@ -471,18 +481,28 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4_kernel(cons
         load_step(0, 0);
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
+#if !(WINO_EXP & 16)
             if (s == 0) __builtin_amdgcn_s_setprio(3);
             else if (s == (NSTEP + 3) / 4) __builtin_amdgcn_s_setprio(2);
             else if (s == (NSTEP + 1) / 2) __builtin_amdgcn_s_setprio(1);
             else if (s == (3 * NSTEP + 3) / 4) __builtin_amdgcn_s_setprio(0);
+#endif
+#if !(WINO_EXP & 8)
             if (s + 1 < NSTEP) load_step(s + 1, (s + 1) & 1);
             const int bq = s & 1;
+#else
+            const int bq = 0;
+#endif
 #pragma unroll
             for (int j = 0; j < NTT; ++j) {
                 const float e0 = d0[bq][j], e1 = d12[bq][j].x, e2 = d12[bq][j].y, e3 = d12[bq][j].z, e4 = d12[bq][j].w, e5 = d3[bq][j];
                 const float s12 = e1 + e2, m12 = e1 - e2, m42 = e4 - e2, m31 = e3 - e1;
+#if !(WINO_EXP & 4)
                 const float V[NXI] = {4.f * e0 - 5.f * e2 + e4, (e3 + e4) - 4.f * s12, (e4 - e3) + 4.f * m12,
                                       m42 + 2.f * m31, m42 - 2.f * m31, 4.f * e1 - 5.f * e3 + e5};
+#else
+                const float V[NXI] = {e0, e1, e2, e3, e4, e5 + s12 * 0.f + m12 * 0.f + m42 * 0.f + m31 * 0.f};
+#endif
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -490,8 +510,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4_kernel(cons
                         acc[i][j][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[bq][i][x], V[x], acc[i][j][x], 0, 0, 0);
             }
         }
+#if !(WINO_EXP & 1)
         if (more) write_halo(Nx);
+#endif
+#if !(WINO_EXP & 2)
         __syncthreads();
+#endif
     };
     for (int ch = 0; ch < a.nchunks; ch += 2) {
         chunk(std::integral_constant<int, 0>{}, ch);
@@ -614,14 +638,8 @@ static int launch_wino4(const aid_conv2d_params* p, hipStream_t st) {
     a.nchunks = p->Cin / KC;
     const int rgroups = aid_cdiv(a.nrows, ROWS);
     dim3 grid((unsigned)(rgroups * a.tiles_t), (unsigned)(p->Cout_pad / M_BLK));
-    const size_t lds = sizeof(float) * 2 * ((size_t)KC * 5 * (N_BLK + 2 * RMAX) + (size_t)((30 * KC * WROW + 255) / 256) * 256) + sizeof(int) * 2 * ROWS;
-    auto kern = conv53_wino4_kernel<MT, NTT, WGM, WGN, RMAX, KC, MINW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), lds, st, a);
+    auto kern = conv53_wino4_kernel<MT, NTT, WGM, WGN, RMAX, KC, MINW>;      // LDS is static (see the kernel)
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), 0, st, a);
     AID_CHECK_LAUNCH();
     return AID_OK;
 }

@@ -24,6 +24,7 @@ struct ConvWinoDev {
     aid_conv2d_params p;
     const float* zero;
     int tt_log2, rows_log2, tiles_t, nrows, nchunks;
+    int nx, ny, per_xcd;      // F(4,3) kernel: 1-D grid of 8*per_xcd workgroups, swizzled per XCD (see the kernel); per_xcd = 0: plain 2-D grid
 };
 
 __device__ float4 g_aid_zero_page_w[16];   // (device symbols are per translation unit without -fgpu-rdc)
@@ -334,11 +335,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4_kernel(cons
     const int wm = wave / WGN;
     const int wn = wave % WGN;
 
-    const int tile_t = blockIdx.x % a.tiles_t;
-    const int rg = blockIdx.x / a.tiles_t;
+    // XCD-aware tile order.  Hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2).
+    // Logical tile L = xcd * per_xcd + (id / 8): every XCD walks ONE contiguous range of (row-group, m-tile) pairs, m-tile
+    // fastest, so the Cout tiles of the same activations and the row groups that share dilated rows meet in the same L2.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (a.per_xcd > 0) {
+        const int Lt = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+        if (Lt >= a.nx * a.ny) return;
+        bx = Lt / a.ny;
+        by = Lt - bx * a.ny;
+    }
+    const int tile_t = bx % a.tiles_t;
+    const int rg = bx / a.tiles_t;
     const int row0 = rg << a.rows_log2;
     const int t0 = tile_t << a.tt_log2;
-    const int m0 = blockIdx.y * M_BLK;
+    const int m0 = by * M_BLK;
 
     for (int r = tid; r < ROWS; r += NTHREADS) {
         const int rid = row0 + r;
@@ -639,6 +650,13 @@ static int launch_wino4(const aid_conv2d_params* p, hipStream_t st) {
     const int rgroups = aid_cdiv(a.nrows, ROWS);
     dim3 grid((unsigned)(rgroups * a.tiles_t), (unsigned)(p->Cout_pad / M_BLK));
     auto kern = conv53_wino4_kernel<MT, NTT, WGM, WGN, RMAX, KC, MINW>;      // LDS is static (see the kernel)
+    static int xcd = -1;
+    if (xcd < 0) { const char* e = getenv("AID_CONV_XCD"); xcd = e ? atoi(e) : 1; }
+    a.nx = (int)grid.x; a.ny = (int)grid.y; a.per_xcd = 0;
+    if (xcd) {
+        a.per_xcd = (a.nx * a.ny + 7) / 8;
+        grid = dim3((unsigned)(8 * a.per_xcd), 1);
+    }
     hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), 0, st, a);
     AID_CHECK_LAUNCH();
     return AID_OK;

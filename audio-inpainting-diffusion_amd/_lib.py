@@ -42,7 +42,8 @@ class Conv2dParams(C.Structure):
                 ("Cin_pad", C.c_int), ("Cout_pad", C.c_int),
                 ("KH", C.c_int), ("KW", C.c_int), ("dilF", C.c_int),
                 ("act", C.c_int), ("epi", C.c_int),
-                ("alpha", C.c_float), ("res_scale", C.c_float), ("wp_wino", C.c_void_p), ("wino_taps", C.c_int)]
+                ("alpha", C.c_float), ("res_scale", C.c_float), ("wp_wino", C.c_void_p), ("wino_taps", C.c_int),
+                ("x_wino", C.c_int)]
 
 
 class ResampleParams(C.Structure):
@@ -103,7 +104,7 @@ class Add2Params(C.Structure):
 
 class ScaleActParams(C.Structure):
     _fields_ = [("x", View), ("y", View), ("scale", C.c_void_p), ("scale_ld", C.c_int64),
-                ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("act", C.c_int)]
+                ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("act", C.c_int), ("wino", C.c_int)]
 
 
 class FftPassParams(C.Structure):
@@ -150,7 +151,7 @@ EXPORTS = ["aid_abi_version", "aid_last_error", "aid_group_stats", "aid_conv2d",
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
-           "aid_stft_frames", "aid_stft_ola"]
+           "aid_stft_frames", "aid_stft_ola", "aid_conv2d_wino_input_supported"]
 
 _lib = None
 
@@ -170,11 +171,13 @@ def lib():
                 raise AidError(f"libaid_hip.so does not export {name}")
         L.aid_conv2d_pack_dims.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.aid_conv2d_pack_dims.restype = None
+        L.aid_conv2d_wino_input_supported.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.aid_conv2d_wino_input_supported.restype = C.c_int
         for name in EXPORTS[2:]:
-            if name != "aid_conv2d_pack_dims":
+            if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported"):
                 getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, name).restype = C.c_int
-        if L.aid_abi_version() != 1:
+        if L.aid_abi_version() != 2:
             raise AidError("ABI version mismatch")
         _lib = L
     return _lib

@@ -427,6 +427,7 @@ static int launch_m(const aid_conv2d_params* p, hipStream_t st) {
 
 int aid_conv53_dma_try(const aid_conv2d_params* p, hipStream_t st);   // aid_conv_dma.hip
 int aid_conv53_wino_try(const aid_conv2d_params* p, hipStream_t st);  // aid_conv_wino.hip
+int aid_conv1x1_stream_try(const aid_conv2d_params* p, hipStream_t st);  // aid_conv1x1.hip
 
 extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -440,6 +441,11 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     AID_REQUIRE(p->Cin_pad == cip && p->Cout_pad == cop, "aid_conv2d: packed weight dims mismatch (use aid_conv2d_pack_dims)");
     AID_REQUIRE(p->epi == 0 || (p->epi == 1 && p->aux.p && p->aux_scale), "aid_conv2d: epi=1 needs aux + aux_scale");
     AID_REQUIRE((int64_t)p->B * p->in_scale_ld < (1LL << 31), "aid_conv2d: in_scale too large");
+    AID_REQUIRE(!p->x_wino || (p->KH == 5 && p->KW == 3 && p->wp_wino), "aid_conv2d: x_wino is a 5x3 Winograd-path input layout");
+    if (p->x_wino) {
+        const int r = aid_conv53_wino_try(p, st);
+        return r == 1 ? AID_OK : (r < 0 ? r : AID_E_BADARG);
+    }
     if (p->KH == 5 && p->KW == 3) {
         static int use_dma = -1;
         if (use_dma < 0) { const char* e = getenv("AID_CONV_DMA"); use_dma = e ? atoi(e) : 1; }
@@ -456,6 +462,10 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
         return launch_m<5, 3, 4>(p, st);
     }
     if (p->KH == 1 && p->KW == 1) {
+        {
+            const int r = aid_conv1x1_stream_try(p, st);     // memory-bound channel projections: streaming kernel
+            if (r != 0) return r < 0 ? r : AID_OK;
+        }
         if (p->Cin <= 8) return launch_m<1, 1, 8>(p, st);
         static int kc1 = -1;
         if (kc1 < 0) { const char* e = getenv("AID_CONV_KC1"); kc1 = e ? atoi(e) : 16; }

@@ -587,6 +587,244 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4_kernel(cons
     }
 }
 
+// ---- F(4,3) with the input transform done by the producer (aid_scale_act(wino=1), x_wino = 1) -----------------------------
+// x is V = B^T d, [B, Cin, F, 6, T/4].  The kernel only stages and multiplies: no halo samples, no transform VALU at
+// fragment-load time, and every B fragment is a conflict-free ds_read_b32 of 32 consecutive groups of one plane
+// (the in-kernel transform read d0 / d5 with stride 4: 4-way bank conflicts on a third of the LDS reads).
+// LDS block per (ci,kh): six planes [xi][N_BLK/4 groups]; a 1-KiB direct-to-LDS piece = two half-planes.
+template <int MT, int NTT, int WGM, int WGN, int RMAX, int KC, int MINW>
+__global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(const ConvWinoDev a) {
+    constexpr int KH = 5, NXI = 6, TAPS = NXI * KH;     // 30 transformed taps
+    constexpr int NW = WGM * WGN;
+    constexpr int NTHREADS = 64 * NW;
+    constexpr int M_BLK = 32 * MT * WGM;
+    constexpr int N_BLK = 128 * NTT * WGN;              // output samples per tile
+    constexpr int NG = N_BLK / 4;                       // groups of 4 outputs per tile = length of one V plane in LDS
+    constexpr int XB = NXI * NG;                        // a (ci,kh) block: six planes [xi][group]
+    constexpr int XSZ = KC * KH * XB;
+    constexpr int WROW = (M_BLK % 64 == 0) ? M_BLK : ((M_BLK + 63) / 64) * 64;
+    constexpr int WSZ_RAW = TAPS * KC * WROW;
+    constexpr int WSZ = ((WSZ_RAW + 255) / 256) * 256;
+    constexpr int BUFSZ = XSZ + WSZ;
+    constexpr int NXP = KC * KH * (XB / 256);
+    constexpr int NWP = WSZ / 256;
+    constexpr int NP = NXP + NWP;
+    constexpr int PPW = (NP + NW - 1) / NW;
+    constexpr int NSTEP = KH * (KC / 2);                // (kh, ci-pair) steps per chunk, 4*MT*NTT MFMAs each
+    static_assert(XB % 256 == 0 && NG % 128 == 0, "a 1-KiB piece is two half-planes of 32 lanes x 4 groups");
+
+    const aid_conv2d_params& p = a.p;
+    const int TT = 1 << a.tt_log2;
+    const int ROWS = 1 << a.rows_log2;
+
+    // Two STATIC buffers (not one dynamic array): distinct LDS objects carry alias scopes after LDS lowering, so the
+    // waitcnt pass knows the ds_reads of chunk c cannot touch the buffer the direct-to-LDS loads of chunk c+1 write,
+    // and leaves those loads in flight for the whole chunk (with a single dynamic array it emitted s_waitcnt vmcnt(0)
+    // right after issuing them: the "asynchronous" staging was synchronous).
+    __shared__ __attribute__((aligned(16))) float sbuf0[BUFSZ];
+    __shared__ __attribute__((aligned(16))) float sbuf1[BUFSZ];
+    __shared__ int rowinfo[2 * RMAX];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN;
+    const int wn = wave % WGN;
+
+    // XCD-aware tile order.  Hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own L2).
+    // Logical tile L = xcd * per_xcd + (id / 8): every XCD walks ONE contiguous range of (row-group, m-tile) pairs, m-tile
+    // fastest, so the Cout tiles of the same activations and the row groups that share dilated rows meet in the same L2.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (a.per_xcd > 0) {
+        const int Lt = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+        if (Lt >= a.nx * a.ny) return;
+        bx = Lt / a.ny;
+        by = Lt - bx * a.ny;
+    }
+    const int tile_t = bx % a.tiles_t;
+    const int rg = bx / a.tiles_t;
+    const int row0 = rg << a.rows_log2;
+    const int t0 = tile_t << a.tt_log2;
+    const int m0 = by * M_BLK;
+
+    for (int r = tid; r < ROWS; r += NTHREADS) {
+        const int rid = row0 + r;
+        int b = -1, f = 0;
+        if (rid < a.nrows) { b = rid / p.F; f = rid - b * p.F; }
+        rowinfo[2 * r] = b;
+        rowinfo[2 * r + 1] = f;
+    }
+    __syncthreads();
+
+    // ---- DMA piece descriptors (identical scheme to conv53_dma_kernel; weights use the 20-tap Winograd pack) ----
+    const float* psrc[PPW];
+    int pstride[PPW], plds[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int pc = wave + i * NW;
+        psrc[i] = a.zero; pstride[i] = 0; plds[i] = -1;
+        if (pc < NXP) {
+            const int blk = pc / (XB / 256), q = pc % (XB / 256);
+            const int ci = blk / KH, kh = blk % KH;
+            const int e = q * 256 + 4 * lane;            // float offset inside the block = xi * NG + group
+            const int xi = e / NG, gq = e % NG;
+            const int rr = gq >> (a.tt_log2 - 2), gl = gq & ((TT >> 2) - 1);
+            const int b = rowinfo[2 * rr];
+            const int fi = rowinfo[2 * rr + 1] + (kh - KH / 2) * p.dilF;
+            plds[i] = blk * XB + q * 256;
+            if (b >= 0 && fi >= 0 && fi < p.F && t0 + 4 * gl < p.T) {
+                psrc[i] = p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + (int64_t)xi * (p.T >> 2) + (t0 >> 2) + gl;
+                pstride[i] = (int)(KC * p.x.sC);
+            }
+        } else if (pc < NP) {
+            const int wp_ = pc - NXP;
+            const int e = wp_ * 256 + 4 * lane;
+            const int row = e / WROW, col = e % WROW;
+            const int tap = row / KC, ci = row % KC;
+            plds[i] = XSZ + wp_ * 256;
+            if (col < M_BLK && e < WSZ_RAW) {
+                psrc[i] = p.wp_wino + ((int64_t)tap * p.Cin_pad + ci) * p.Cout_pad + m0 + col;
+                pstride[i] = KC * p.Cout_pad;
+            }
+        }
+    }
+    // ---- operand addresses -----------------------------------------------------------------------------------------
+    const int half = lane >> 5;
+    const int ttau_log2 = a.tt_log2 - 2;                 // groups per row = TT/4
+    int vB[NTT];                                         // float offset of V[0][group] inside a (ci,kh) block
+#pragma unroll
+    for (int j = 0; j < NTT; ++j) vB[j] = half * KH * XB + (wn * NTT + j) * 32 + (lane & 31);
+    int vA[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) vA[i] = XSZ + half * WROW + (wm * MT + i) * 32 + (lane & 31);
+
+    f32x16 acc[MT][NTT][NXI];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTT; ++j)
+#pragma unroll
+            for (int x = 0; x < NXI; ++x)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][x][r] = 0.f;
+
+    auto issue_dma = [&](int ch, float* buf) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            if (plds[i] >= 0) {
+                const float* src = psrc[i] + (int64_t)ch * pstride[i];
+                GLDS16W(src, buf + plds[i]);
+            }
+        }
+    };
+
+    issue_dma(0, sbuf0);
+    __syncthreads();
+
+    auto chunk = [&](auto curc, int ch) {
+        constexpr int cur = decltype(curc)::value;
+        const float* Bf = cur ? sbuf1 : sbuf0;
+        float* Nx = cur ? sbuf0 : sbuf1;
+        const bool more = (ch + 1) < a.nchunks;
+#if !(WINO_EXP & 1)
+        if (more) issue_dma(ch + 1, Nx);
+#endif
+        // fragments of step s+1 are fetched while the MFMAs of step s run
+        float bv[2][NTT][NXI];
+        float av[2][MT][NXI];
+        auto load_step = [&](int s, int buf) {
+            const int kh = s / (KC / 2), cp = s % (KC / 2);
+            const int xo = (2 * cp * KH + kh) * XB;
+#pragma unroll
+            for (int j = 0; j < NTT; ++j)
+#pragma unroll
+                for (int x = 0; x < NXI; ++x) bv[buf][j][x] = Bf[vB[j] + xo + x * NG];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int x = 0; x < NXI; ++x)
+                    av[buf][i][x] = Bf[vA[i] + ((x * KH + kh) * KC + 2 * cp) * WROW];
+        };
+        load_step(0, 0);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            if (s == 0) __builtin_amdgcn_s_setprio(3);
+            else if (s == (NSTEP + 3) / 4) __builtin_amdgcn_s_setprio(2);
+            else if (s == (NSTEP + 1) / 2) __builtin_amdgcn_s_setprio(1);
+            else if (s == (3 * NSTEP + 3) / 4) __builtin_amdgcn_s_setprio(0);
+            if (s + 1 < NSTEP) load_step(s + 1, (s + 1) & 1);
+            const int bq = s & 1;
+#pragma unroll
+            for (int j = 0; j < NTT; ++j)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int x = 0; x < NXI; ++x)
+                        acc[i][j][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[bq][i][x], bv[bq][j][x], acc[i][j][x], 0, 0, 0);
+        }
+#if !(WINO_EXP & 2)
+        __syncthreads();
+#endif
+    };
+    for (int ch = 0; ch < a.nchunks; ch += 2) {
+        chunk(std::integral_constant<int, 0>{}, ch);
+        if (ch + 1 < a.nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
+    }
+    __builtin_amdgcn_s_setprio(0);
+
+    // ---- epilogue: output transform, then gate / dGELU / residual, four samples per lane -------------------------------
+#pragma unroll
+    for (int j = 0; j < NTT; ++j) {
+        const int nt = (wn * NTT + j) * 32 + (lane & 31);
+        const int rr = nt >> ttau_log2, tau = nt & ((TT >> 2) - 1);
+        const int b = rowinfo[2 * rr];
+        const int f = rowinfo[2 * rr + 1];
+        const int t = t0 + 4 * tau;
+        if (b < 0 || t >= p.T) continue;                 // T % 4 == 0: the four samples are in range together
+        const int64_t ybase = (int64_t)b * p.y.sB + (int64_t)f * p.y.sF + t;
+        const int64_t rbase = p.res.p ? ((int64_t)b * p.res.sB + (int64_t)f * p.res.sF + t) : 0;
+        const int64_t abase = p.aux.p ? ((int64_t)b * p.aux.sB + (int64_t)f * p.aux.sF + t) : 0;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int mbase = m0 + (wm * MT + i) * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 4) {         // batches of 4 rows: gather, then compute + store
+                float4 rv[4], uv[4];
+                float sv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = r0 + q;
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    const bool ok = m < p.Cout;
+                    rv[q] = (ok && p.res.p) ? *reinterpret_cast<const float4*>(p.res.p + rbase + (int64_t)m * p.res.sC) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    sv[q] = (ok && p.out_scale) ? p.out_scale[(int64_t)b * p.out_scale_ld + m] : 1.f;
+                    if (ok && p.epi == 1) {
+                        const float as = p.aux_scale[(int64_t)b * p.aux_scale_ld + m];
+                        const float4 u = *reinterpret_cast<const float4*>(p.aux.p + abase + (int64_t)m * p.aux.sC);
+                        uv[q] = make_float4(u.x * as, u.y * as, u.z * as, u.w * as);
+                    } else uv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = r0 + q;
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    if (m >= p.Cout) continue;
+                    const float M0 = acc[i][j][0][r], M1 = acc[i][j][1][r], M2 = acc[i][j][2][r], M3 = acc[i][j][3][r],
+                                M4 = acc[i][j][4][r], M5 = acc[i][j][5][r];
+                    const float a12 = M1 + M2, s12 = M1 - M2, a34 = M3 + M4, s34 = M3 - M4;
+                    float y0 = (M0 + a12 + a34) * sv[q];
+                    float y1 = (s12 + 2.f * s34) * sv[q];
+                    float y2 = (a12 + 4.f * a34) * sv[q];
+                    float y3 = (s12 + 8.f * s34 + M5) * sv[q];
+                    if (p.epi == 1) { y0 *= aid_dgelu(uv[q].x); y1 *= aid_dgelu(uv[q].y); y2 *= aid_dgelu(uv[q].z); y3 *= aid_dgelu(uv[q].w); }
+                    y0 += p.res_scale * rv[q].x; y1 += p.res_scale * rv[q].y; y2 += p.res_scale * rv[q].z; y3 += p.res_scale * rv[q].w;
+                    *reinterpret_cast<float4*>(p.y.p + ybase + (int64_t)m * p.y.sC) = make_float4(p.alpha * y0, p.alpha * y1, p.alpha * y2, p.alpha * y3);
+                }
+            }
+        }
+    }
+}
+
 template <int MT, int NTT, int WGM, int WGN, int RMAX, int KC, int MINW = 1>
 static int launch_wino(const aid_conv2d_params* p, hipStream_t st) {
     constexpr int M_BLK = 32 * MT * WGM;
@@ -662,8 +900,73 @@ static int launch_wino4(const aid_conv2d_params* p, hipStream_t st) {
     return AID_OK;
 }
 
+template <int MT, int NTT, int WGM, int WGN, int RMAX, int KC, int MINW = 1>
+static int launch_wino4v(const aid_conv2d_params* p, hipStream_t st) {
+    constexpr int M_BLK = 32 * MT * WGM;
+    constexpr int N_BLK = 128 * NTT * WGN;
+    constexpr int WROW = (M_BLK % 64 == 0) ? M_BLK : ((M_BLK + 63) / 64) * 64;
+    static const float* zero = nullptr;
+    if (!zero) {
+        void* z = nullptr;
+        if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_aid_zero_page_w)) != hipSuccess) { aid_set_error("aid_conv2d: zero page lookup failed"); return AID_E_LAUNCH; }
+        zero = (const float*)z;
+    }
+    ConvWinoDev a;
+    a.p = *p;
+    a.zero = zero;
+    int TT = aid_pow2ceil(p->T);
+    if (TT > N_BLK) TT = N_BLK;
+    a.tt_log2 = aid_ilog2(TT);
+    const int ROWS = N_BLK / TT;
+    if (ROWS > RMAX) return 1000;
+    a.rows_log2 = aid_ilog2(ROWS);
+    a.tiles_t = aid_cdiv(p->T, TT);
+    a.nrows = p->B * p->F;
+    a.nchunks = p->Cin / KC;
+    const int rgroups = aid_cdiv(a.nrows, ROWS);
+    dim3 grid((unsigned)(rgroups * a.tiles_t), (unsigned)(p->Cout_pad / M_BLK));
+    auto kern = conv53_wino4v_kernel<MT, NTT, WGM, WGN, RMAX, KC, MINW>;      // LDS is static (see the kernel)
+    static int xcd = -1;
+    if (xcd < 0) { const char* e = getenv("AID_CONV_XCD"); xcd = e ? atoi(e) : 1; }
+    a.nx = (int)grid.x; a.ny = (int)grid.y; a.per_xcd = 0;
+    if (xcd) {
+        a.per_xcd = (a.nx * a.ny + 7) / 8;
+        grid = dim3((unsigned)(8 * a.per_xcd), 1);
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), 0, st, a);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}
+
+static bool wino_v_shape_ok(int Cin, int Cout, int T) {
+    int cip, cop;
+    aid_conv2d_pack_dims(Cin, Cout, &cip, &cop);
+    return (Cin % 4) == 0 && Cout >= 64 && ((cop % 64) == 0 || (cop % 96) == 0) && (T % 16) == 0 && T >= 32;
+}
+
+extern "C" int aid_conv2d_wino_input_supported(int Cin, int Cout, int T) { return wino_v_shape_ok(Cin, Cout, T) ? 1 : 0; }
+
+// x_wino = 1: the caller already wrote the Winograd-domain input; there is no other kernel that can read it
+static int conv53_wino_v(const aid_conv2d_params* p, hipStream_t st) {
+    AID_REQUIRE(p->wp_wino && p->wino_taps == 30 && p->KH == 5 && p->KW == 3 && !p->in_scale && p->act == 0,
+                "aid_conv2d: x_wino needs the 30-tap Winograd pack of a 5x3 layer and no in-kernel prologue");
+    AID_REQUIRE(wino_v_shape_ok(p->Cin, p->Cout, p->T), "aid_conv2d: shape not supported with x_wino (see aid_conv2d_wino_input_supported)");
+    AID_REQUIRE(p->x.sF >= 6 * (p->T / 4) && (int64_t)4 * p->x.sC < (1LL << 31), "aid_conv2d: x_wino rows are [6][T/4]");
+    auto al4 = [](const aid_view& v) { return (v.sB % 4) == 0 && (v.sC % 4) == 0 && (v.sF % 4) == 0 && (((uintptr_t)v.p) & 15) == 0; };
+    AID_REQUIRE(al4(p->x) && al4(p->y) && (!p->res.p || al4(p->res)) && (!p->aux.p || al4(p->aux)), "aid_conv2d: x_wino views must be 16-byte aligned");
+    int rc;
+    static int vcfg = -1;
+    if (vcfg < 0) { const char* e = getenv("AID_WINO_VCFG"); vcfg = e ? atoi(e) : 0; }
+    if (vcfg == 1 && p->Cout_pad % 128 == 0) rc = launch_wino4v<2, 1, 2, 4, 16, 2, 2>(p, st);     // 128 x 512, 8 waves, 192 accumulators
+    else if (p->Cout_pad % 64 == 0) rc = launch_wino4v<1, 1, 2, 4, 16, 2, 2>(p, st);     // 64 x 512, 8 waves
+    else                       rc = launch_wino4v<1, 1, 3, 4, 16, 2, 3>(p, st);     // 96 x 512, 12 waves
+    AID_REQUIRE(rc != 1000, "aid_conv2d: x_wino tile does not fit this T");
+    return rc;
+}
+
 // returns 1 if the Winograd kernel took the launch, 0 if not eligible, <0 on error
 int aid_conv53_wino_try(const aid_conv2d_params* p, hipStream_t st) {
+    if (p->x_wino) { const int rc = conv53_wino_v(p, st); return rc == AID_OK ? 1 : rc; }
     if (!p->wp_wino || !(p->KH == 5 && p->KW == 3) || p->in_scale || p->act != 0) return 0;
     if ((p->Cin % 4) != 0 || p->Cout < 64 || (p->T % 4) != 0) return 0;
     if (aid_pow2ceil(p->T) < 8) return 0;

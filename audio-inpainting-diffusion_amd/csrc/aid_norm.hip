@@ -240,11 +240,77 @@ __global__ __launch_bounds__(256) void scale_act_kernel(const SaDev a) {
     *reinterpret_cast<float4*>(p.y.p + (int64_t)b * p.y.sB + (int64_t)c * p.y.sC + (int64_t)f * p.y.sF + o4) = v;
 }
 
+// Same pass, Winograd-domain output (see aid_kernels.h): one thread produces 4 consecutive groups (16 samples) of one
+// row: 4 float4 loads + the two neighbours, 6 float4 stores (one per plane xi; a row of y is [6][T/4]).
+__global__ __launch_bounds__(256) void scale_act_wino_kernel(const SaDev a) {
+    const aid_scale_act_params& p = a.p;
+    const int tid = threadIdx.x;
+    const int lpr = 1 << a.lpr_log2;                     // threads per row segment (16 samples each)
+    const int sub = tid >> a.lpr_log2, lq = tid & (lpr - 1);
+    const int rpb = 256 >> a.lpr_log2;
+    const int tile = blockIdx.x % a.tiles;
+    const int row = (blockIdx.x / a.tiles) * rpb + sub;
+    if (row >= a.nrows) return;
+    const int o16 = (tile * lpr + lq) * 16;
+    if (o16 >= p.T) return;
+    const int f = row % p.F;
+    const int bc = row / p.F;
+    const int c = bc % p.C;
+    const int b = bc / p.C;
+    const float sc = p.scale ? p.scale[(int64_t)b * p.scale_ld + c] : 1.f;
+    const float* xr = p.x.p + (int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)f * p.x.sF;
+    float h[18];                                         // h[0] = sample o16-1 ... h[17] = sample o16+16
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + o16 + 4 * q);
+        h[1 + 4 * q] = v.x; h[2 + 4 * q] = v.y; h[3 + 4 * q] = v.z; h[4 + 4 * q] = v.w;
+    }
+    h[0] = (o16 > 0) ? xr[o16 - 1] : 0.f;
+    h[17] = (o16 + 16 < p.T) ? xr[o16 + 16] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+        float v = h[i] * sc;
+        if (p.act == 1) v = aid_gelu(v);
+        h[i] = v;                                        // (gelu(0) = 0: the zero padding stays zero)
+    }
+    float V[6][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float e0 = h[4 * g], e1 = h[4 * g + 1], e2 = h[4 * g + 2], e3 = h[4 * g + 3], e4 = h[4 * g + 4], e5 = h[4 * g + 5];
+        const float s12 = e1 + e2, m12 = e1 - e2, m42 = e4 - e2, m31 = e3 - e1;
+        V[0][g] = 4.f * e0 - 5.f * e2 + e4;
+        V[1][g] = (e3 + e4) - 4.f * s12;
+        V[2][g] = (e4 - e3) + 4.f * m12;
+        V[3][g] = m42 + 2.f * m31;
+        V[4][g] = m42 - 2.f * m31;
+        V[5][g] = 4.f * e1 - 5.f * e3 + e5;
+    }
+    const int G = p.T >> 2;
+    float* yr = p.y.p + (int64_t)b * p.y.sB + (int64_t)c * p.y.sC + (int64_t)f * p.y.sF + (o16 >> 2);
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi)
+        *reinterpret_cast<float4*>(yr + (int64_t)xi * G) = make_float4(V[xi][0], V[xi][1], V[xi][2], V[xi][3]);
+}
+
 extern "C" int aid_scale_act(const aid_scale_act_params* p, void* stream) {
     AID_REQUIRE(p && p->x.p && p->y.p, "aid_scale_act: null pointer");
     AID_REQUIRE((p->T % 4) == 0, "aid_scale_act: T must be a multiple of 4");
     SaDev a;
     a.p = *p;
+    if (p->wino) {
+        AID_REQUIRE((p->T % 16) == 0, "aid_scale_act: the Winograd-domain output needs T % 16 == 0");
+        AID_REQUIRE((p->y.sB % 4) == 0 && (p->y.sC % 4) == 0 && (p->y.sF % 4) == 0 && (((uintptr_t)p->y.p) & 15) == 0 && p->y.sF >= 6 * (p->T / 4),
+                    "aid_scale_act: Winograd-domain output rows are [6][T/4], 16-byte aligned");
+        int lpr = aid_pow2ceil(p->T / 16);
+        if (lpr > 256) lpr = 256;
+        a.lpr_log2 = aid_ilog2(lpr);
+        a.nrows = p->B * p->C * p->F;
+        a.tiles = aid_cdiv(p->T / 16, lpr);
+        const int rpb = 256 / lpr;
+        hipLaunchKernelGGL(scale_act_wino_kernel, dim3((unsigned)(aid_cdiv(a.nrows, rpb) * a.tiles)), dim3(256), 0, (hipStream_t)stream, a);
+        AID_CHECK_LAUNCH();
+        return AID_OK;
+    }
     int lpr = aid_pow2ceil(p->T / 4);
     if (lpr > 256) lpr = 256;
     a.lpr_log2 = aid_ilog2(lpr);

@@ -174,6 +174,7 @@ class _Builder:
         self.gstate = {}       # storage data_ptr -> 'full' (first contribution overwrites the whole tensor: no zero fill,
                                #   no read-modify-write) | 'zero' (touched through partial views: zero-filled, accumulated)
         self.scratch = {}      # shape -> scratch tensor for dgrad outputs awaiting the normalisation backward
+        self.wino_v = os.environ.get("AID_WINO_V", "1") != "0"      # Winograd-domain conv inputs (see _wino_input); 0 = in-kernel transform
 
     # ---- gradient storage: one flat buffer per activation storage, views share strides/offsets ------------
     def G(self, t):
@@ -226,9 +227,10 @@ class _Builder:
         self.plan.add("aid_group_stats", p, x, gamma, mod, scale, stats)
 
     def _conv_raw(self, x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha, epi=0,
-                  aux=None, aux_scale=None, wpw=None):
-        B, _, F, T = x.shape
-        assert x.shape[1] == cin and y.shape[1] == cout and y.shape[0] == B and y.shape[2] == F and y.shape[3] == T
+                  aux=None, aux_scale=None, wpw=None, x_wino=False):
+        B, _, F, T = y.shape
+        assert x.shape[1] == cin and y.shape[1] == cout and x.shape[0] == B and x.shape[2] == F
+        assert x.shape[3] == (6 * (T // 4) if x_wino else T)
         p = _lib.Conv2dParams()
         p.x, p.y, p.res, p.aux = _lib.view4(x), _lib.view4(y), _lib.view4(res), _lib.view4(aux)
         p.wp = wp.data_ptr()
@@ -241,11 +243,18 @@ class _Builder:
         p.alpha, p.res_scale = alpha, res_scale
         p.wp_wino = _lib.ptr(wpw)
         p.wino_taps = 0 if wpw is None else wpw.shape[0]
+        p.x_wino = int(x_wino)
         assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] in (20, 30) and wpw.shape[1:] == wp.shape[1:]))
         # algorithmic HBM bytes: x once, residual / aux once, y once, weights once
         nb = 4 * (B * F * T * (cin + cout * (1 + (res is not None) + (aux is not None))) + cin * cout * kh * kw)
         self.plan.add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, flops=2 * B * F * T * cin * cout * kh * kw,
                       nbytes=nb)
+
+    def _wino_input(self, cin, cout, T, wp, wpw):
+        """True when the pre-pass should write the F(4,3) input transform (aid_scale_act wino=1 -> aid_conv2d x_wino=1):
+        measured +5-8 % on the 64-wide M tiles, -5 % on the 96-wide one (12 waves, 123 KB of LDS), which stays in-kernel."""
+        return (self.wino_v and wpw is not None and wpw.shape[0] == 30 and wp.shape[2] % 64 == 0
+                and bool(_lib.lib().aid_conv2d_wino_input_supported(cin, cout, T)))
 
     def conv(self, x, y, wp, cin, cout, kh=1, kw=1, dil=1, in_scale=None, act=0, out_scale=None, res=None,
              res_scale=1.0, alpha=1.0, wpT=None, norm_stats=None, wpw=None, wpwT=None):
@@ -253,11 +262,13 @@ class _Builder:
         ``in_scale`` was produced by ``stats`` from this same ``x`` (the scale then depends on x)."""
         if act and kh > 1:
             # evaluate norm*mod -> GELU once per element into a scratch tensor; the conv stages plain copies
-            hbuf = self._scratch(("h",) + tuple(x.shape))
+            xw = self._wino_input(cin, cout, x.shape[3], wp, wpw)
+            hshape = (x.shape[0], cin, x.shape[2], 6 * (x.shape[3] // 4)) if xw else tuple(x.shape)
+            hbuf = self._scratch(("h",) + hshape)
             sp = _lib.ScaleActParams(_lib.view4(x), _lib.view4(hbuf), in_scale.data_ptr(), in_scale.stride(0), x.shape[0], cin,
-                                     x.shape[2], x.shape[3], 1)
+                                     x.shape[2], x.shape[3], 1, int(xw))
             self.plan.add("aid_scale_act", sp, x, hbuf, in_scale)
-            self._conv_raw(hbuf, y, wp, cin, cout, kh, kw, dil, None, 0, out_scale, res, res_scale, alpha, wpw=wpw)
+            self._conv_raw(hbuf, y, wp, cin, cout, kh, kw, dil, None, 0, out_scale, res, res_scale, alpha, wpw=wpw, x_wino=xw)
         else:
             self._conv_raw(x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha)
         if wpT is None:
@@ -273,19 +284,21 @@ class _Builder:
                     self.add2_raw(gr, gy, gr, 1.0, alpha * res_scale)
                 else:
                     self.add2_raw(gy, None, gr, alpha * res_scale, 0.0)
-            gin, gsc = gy, out_scale
+            gin, gsc, gw = gy, out_scale, False
             if kh > 1 and out_scale is not None:
                 # 5x3 dgrad: apply the gate in a copy pass so the conv input needs no in-kernel prologue
                 # (keeps it on the direct-to-LDS kernel)
-                gin = self._scratch(("g",) + tuple(gy.shape))
+                gw = norm_stats is not None and self._wino_input(cout, cin, gy.shape[3], wpT, wpwT)
+                gshape = (gy.shape[0], cout, gy.shape[2], 6 * (gy.shape[3] // 4)) if gw else tuple(gy.shape)
+                gin = self._scratch(("g",) + gshape)
                 sp = _lib.ScaleActParams(_lib.view4(gy), _lib.view4(gin), out_scale.data_ptr(), out_scale.stride(0), gy.shape[0],
-                                         cout, gy.shape[2], gy.shape[3], 0)
+                                         cout, gy.shape[2], gy.shape[3], 0, int(gw))
                 self.plan.add("aid_scale_act", sp, gy, gin, out_scale)
                 gsc = None
             if norm_stats is not None:
                 gd = self._scratch(x.shape)
                 self._conv_raw(gin, gd, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, None, 1.0, alpha,
-                               epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None, wpw=wpwT)
+                               epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None, wpw=wpwT, x_wino=gw)
                 dp = _lib.GroupDotParams(_lib.view4(gd), _lib.view4(x), B, cin, F, T, 8, self.stats_ws.data_ptr())
                 self.plan.add("aid_group_dot", dp, gd, x)
                 npar = _lib.NormBwdParams(_lib.view4(gd), _lib.view4(x), _lib.view4(gy if fused_res else None), _lib.view4(self.G(x)),

@@ -28,7 +28,7 @@ extern "C" {
 #define AID_E_BADARG (-1)   /* unsupported shape / null pointer / misaligned stride */
 #define AID_E_LAUNCH (-2)   /* hipLaunchKernel reported an error                    */
 
-#define AID_ABI_VERSION 1
+#define AID_ABI_VERSION 2
 int aid_abi_version(void);
 /* last HIP error string seen by a launcher in this process (never NULL) */
 const char* aid_last_error(void);
@@ -101,8 +101,13 @@ typedef struct {
     float alpha, res_scale;
     const float* wp_wino;     /* optional: Winograd pack of the same 5x3 weights: F(2,3) = 20 taps, F(4,3) = 30 taps (see below) */
     int wino_taps;            /* 20 or 30 (0 when wp_wino is NULL) */
+    int x_wino;               /* 1: `x` is the F(4,3) INPUT TRANSFORM of the activations, written by aid_scale_act(wino=1):
+                                 [B, Cin, F, 6, T/4] (sF = 6*T/4 ...), V = B^T d per group of 4 samples; needs wp_wino with 30 taps
+                                 and aid_conv2d_wino_input_supported(...) != 0.  The kernel then stages and multiplies only. */
 } aid_conv2d_params;
 int aid_conv2d(const aid_conv2d_params* p, void* stream);
+/* non-zero when a 5x3 layer of this shape can take Winograd-domain input (x_wino = 1) */
+int aid_conv2d_wino_input_supported(int Cin, int Cout, int T);
 /* padded dims the packed weight buffer must have for a given (Cin, Cout) */
 void aid_conv2d_pack_dims(int Cin, int Cout, int* Cin_pad, int* Cout_pad);
 
@@ -348,11 +353,16 @@ int aid_stft_ola(const aid_stft_params* p, void* stream);
  *   The normalise -> modulate -> GELU prologue of a dilated step (unet...py:475-482) evaluated ONCE per element
  *   into a scratch tensor; the 5x3 conv then stages plain copies (inside the conv's LDS staging the same GELU
  *   would be re-evaluated for each of the 5 dilated rows and each Cout tile).
+ *   wino = 1 additionally applies the Winograd F(4,3) input transform in the same pass (the conv kernel then neither
+ *   transforms at fragment-load time nor needs halo samples):
+ *     V0 = 4d0-5d2+d4, V1 = (d3+d4)-4(d1+d2), V2 = (d4-d3)+4(d1-d2), V3 = (d4-d2)+2(d3-d1), V4 = (d4-d2)-2(d3-d1), V5 = 4d1-5d3+d5
  * ------------------------------------------------------------------------------------------------- */
 typedef struct {
     aid_view x, y;
     const float* scale; int64_t scale_ld;
     int B, C, F, T, act;
+    int wino;                 /* 1: write the F(4,3) input transform of h along T instead of h itself: y is [B,C,F,6,T/4],
+                                 y[..,xi,g] = (B^T d)[xi], d = h[4g-1 .. 4g+4] (zero outside the row); T % 16 == 0 */
 } aid_scale_act_params;
 int aid_scale_act(const aid_scale_act_params* p, void* stream);
 

@@ -86,6 +86,14 @@ CONV_CASES = [
     (2, 96, 192, 1, 8, 1, 1, 1, False, False),       # qk GEMM, F = 1
     (1, 320, 640, 1, 128, 1, 1, 1, False, False),    # qk GEMM, larger K
     (3, 40, 40, 9, 12, 5, 3, 2, True, True),         # ragged: T not a power of two, odd row count
+    # 1x1 with enough positions -> streaming kernel (aid_conv1x1.hip)
+    (2, 64, 192, 16, 64, 1, 1, 1, True, True),       # two 96-wide Cout slices, per-(b,ci) prologue scale
+    (2, 96, 64, 8, 32, 1, 1, 1, False, True),        # 64-wide slice, a wave spans two rows
+    (1, 128, 128, 4, 512, 1, 1, 1, False, False),    # 128-wide slice
+    (2, 192, 96, 12, 16, 1, 1, 1, True, True),       # a wave spans four rows
+    (3, 64, 40, 16, 64, 1, 1, 1, False, True),       # Cout padded to 64: masked rows
+    (2, 512, 256, 8, 32, 1, 1, 1, False, True),      # K = 512, two 128-wide slices
+    (4, 64, 64, 18, 32, 1, 1, 1, True, True),        # F*T = 9 * 64: the 64-positions-per-wave variant
     # no prologue -> direct-to-LDS (global_load_lds) kernel
     (1, 64, 64, 24, 1024, 5, 3, 2, False, True),     # 64 x 512 tile, two t-tiles per row
     (2, 96, 96, 20, 256, 5, 3, 8, False, True),      # 96 x 256 tile (weight rows padded to 128 in LDS)
@@ -136,6 +144,60 @@ def test_conv2d(L, case, wino):
     torch.cuda.synchronize()
     assert rel_l2(y.cpu(), ref) < 1e-5
     assert float(ybig[:, :2].min()) == 7.0 and float(ybig[:, 2 + Cout:].min()) == 7.0, "wrote outside its channel slice"
+
+
+WINO_V_CASES = [
+    # B, Cin, Cout, F, T, dil, act, epilogue
+    (1, 64, 64, 24, 1024, 2, 1, True),       # two t-tiles per row, GELU prologue
+    (2, 96, 64, 20, 256, 8, 0, True),        # Cin != Cout, two rows per tile
+    (1, 128, 128, 40, 128, 16, 1, True),     # two M tiles, ROWS = 4
+    (2, 256, 256, 24, 32, 64, 1, True),      # ROWS = 16, dilation larger than F
+    (3, 64, 128, 9, 48, 1, 0, False),        # T not a power of two (zero-page groups), odd rows
+    (1, 64, 96, 12, 64, 4, 1, True),         # 96-wide M tile (12 waves)
+]
+
+
+@pytest.mark.parametrize("case", WINO_V_CASES)
+def test_conv2d_winograd_domain_input(L, case):
+    """aid_scale_act(wino=1) -> aid_conv2d(x_wino=1): the input transform of F(4,3) done by the producer pass."""
+    B, Cin, Cout, Fd, T, dil, act, epi = case
+    assert L.lib().aid_conv2d_wino_input_supported(Cin, Cout, T)
+    x = _rand(B, Cin, Fd, T, seed=30)
+    w = _rand(Cout, Cin, 5, 3, seed=31, scale=1.0 / math.sqrt(Cin * 15))
+    in_scale = 1.0 + 0.5 * _rand(B, Cin, seed=32)
+    out_scale = _rand(B, Cout, seed=33) if epi else None
+    res = _rand(B, Cout, Fd, T, seed=34) if epi else None
+    alpha, res_scale = (1 / math.sqrt(2), 1.5) if epi else (1.0, 1.0)
+    ref = _conv_ref(x, w, dil, in_scale, act, out_scale, res, res_scale, alpha)
+    xd, wd, isd = x.to(DEV), w.to(DEV), in_scale.to(DEV)
+    G = T // 4
+    # (1) the transform itself against its definition
+    xv = torch.full((B, Cin, Fd, 6 * G + 4), 7.0, device=DEV)[..., :6 * G]          # padded rows: strided view
+    L.call("aid_scale_act", L.ScaleActParams(L.view4(xd), L.view4(xv), isd.data_ptr(), isd.stride(0), B, Cin, Fd, T, act, 1))
+    h = x * in_scale[:, :, None, None]
+    if act:
+        h = F.gelu(h)
+    d = F.pad(h, (1, 4)).unfold(-1, 6, 4)[..., :G, :]                               # d[..., g, :] = h[4g-1 .. 4g+4]
+    BT = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0],
+                       [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=torch.float32)
+    Vref = torch.einsum("xk,bcfgk->bcfxg", BT, d).reshape(B, Cin, Fd, 6 * G)
+    assert rel_l2(xv.cpu(), Vref) < 1e-6
+    # (2) the convolution on it
+    wp, wpw = L.pack_conv_weight(wd), L.pack_conv_weight_wino(wd, f4=True)
+    y = torch.empty(B, Cout, Fd, T, device=DEV)
+    p = L.Conv2dParams()
+    resd = None if res is None else res.to(DEV)
+    osd = None if out_scale is None else out_scale.to(DEV)
+    p.x, p.y, p.res, p.aux = L.view4(xv), L.view4(y), L.view4(resd), L.view4(None)
+    p.wp, p.wp_wino, p.wino_taps, p.x_wino = wp.data_ptr(), wpw.data_ptr(), 30, 1
+    p.out_scale, p.out_scale_ld = L.ptr(osd), (0 if osd is None else osd.stride(0))
+    p.B, p.Cin, p.Cout, p.F, p.T = B, Cin, Cout, Fd, T
+    p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
+    p.KH, p.KW, p.dilF, p.act, p.epi = 5, 3, dil, 0, 0
+    p.alpha, p.res_scale = alpha, res_scale
+    L.call("aid_conv2d", p)
+    torch.cuda.synchronize()
+    assert rel_l2(y.cpu(), ref) < 1e-5
 
 
 # ---------------------------------------------------------------------------------------------------------

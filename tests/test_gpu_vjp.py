@@ -26,7 +26,8 @@ def _rand(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
 
 
-@pytest.mark.parametrize("case", [(2, 16, 24, 16, 5, 3, 2), (1, 64, 20, 256, 5, 3, 8), (2, 32, 12, 8, 1, 1, 1), (2, 128, 16, 32, 5, 3, 4)])
+@pytest.mark.parametrize("case", [(2, 16, 24, 16, 5, 3, 2), (1, 64, 20, 256, 5, 3, 8), (2, 32, 12, 8, 1, 1, 1), (2, 128, 16, 32, 5, 3, 4),
+                                  (2, 64, 16, 64, 1, 1, 1)])
 def test_fused_step_vjp(L, case):
     """One ResnetBlock step  y = (x + conv(gelu(norm(x)*(1+g))) * s)/sqrt2  (unet...py:472-482): dgrad conv with
     dGELU epilogue + group-dot + normalisation backward vs torch.autograd."""

@@ -41,6 +41,12 @@ def main():
         f4 = os.environ.get('PROBE_WINO') == '30'
         wpw = L.pack_conv_weight_wino(w, f4=f4)
         p.wp_wino, p.wino_taps = wpw.data_ptr(), wpw.shape[0]
+    if os.environ.get('PROBE_V', '0') != '0':         # Winograd-domain input written by aid_scale_act(wino=1)
+        assert L.lib().aid_conv2d_wino_input_supported(Cin, Cout, T)
+        xv = torch.empty(B, Cin, F, 6 * (T // 4), device=dev)
+        sp = L.ScaleActParams(L.view4(x), L.view4(xv), None, 0, B, Cin, F, T, 0, 1)
+        L.call("aid_scale_act", sp)
+        p.x, p.x_wino = L.view4(xv), 1
     for _ in range(2):
         L.call("aid_conv2d", p)
     torch.cuda.synchronize()

@@ -43,7 +43,7 @@ class Conv2dParams(C.Structure):
                 ("KH", C.c_int), ("KW", C.c_int), ("dilF", C.c_int),
                 ("act", C.c_int), ("epi", C.c_int),
                 ("alpha", C.c_float), ("res_scale", C.c_float), ("wp_wino", C.c_void_p), ("wino_taps", C.c_int),
-                ("x_wino", C.c_int)]
+                ("x_wino", C.c_int), ("ws", C.c_void_p), ("ws_bytes", C.c_int64)]
 
 
 class ResampleParams(C.Structure):

@@ -31,6 +31,8 @@ struct ConvDev {
     int tiles_t;      // ceil(T / TT)
     int nrows;        // B*F
     int nchunks;      // ceil(Cin / KC)
+    int splits, cps;  // split-K: blockIdx.z owns chunks [z*cps, min(nchunks, (z+1)*cps)); splits = 1: whole K, normal epilogue
+    float* ws;        // [splits][B][Cout][F][T] partial sums when splits > 1
 };
 
 __device__ __forceinline__ float4 xform4(float4 v, float sc, int act) {
@@ -238,19 +240,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_mfma_kernel(const ConvDev
         }
     };
 
-    // ---- prologue: chunk 0 -> buffer 0 -----------------------------------------------------------------------
-    issue_loads(0);
+    // ---- prologue: first chunk of this workgroup's K range -> buffer 0 ------------------------------------------------
+    const int cb = (int)blockIdx.z * a.cps;
+    const int nloc = (a.nchunks - cb < a.cps) ? (a.nchunks - cb) : a.cps;
+    issue_loads(cb * KC);
     write_slot(smem, smem + XSZ, -1);
-    if (KW > 1 && !halo_fast) halo_slow(smem, 0);
+    if (KW > 1 && !halo_fast) halo_slow(smem, cb * KC);
     __syncthreads();
 
-    for (int ch = 0; ch < a.nchunks; ++ch) {
+    for (int ch = 0; ch < nloc; ++ch) {
         const int cur = ch & 1;
         const float* Xs = smem + cur * BUFSZ;
         const float* Ws = Xs + XSZ;
         float* Xn = smem + (cur ^ 1) * BUFSZ;
         float* Wn = Xn + XSZ;
-        const bool more = (ch + 1) < a.nchunks;
+        const bool more = (ch + 1) < nloc;
         // operand fragments are fetched one k-step AHEAD of the MFMAs that consume them (explicit register
         // double buffer), so every ds_read has a full k-step of matrix work to land behind
         float av[2][MT], bv[2][NT];
@@ -288,11 +292,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_mfma_kernel(const ConvDev
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][i], bv[ks & 1][j], acc[i][j], 0, 0, 0);
                 // the next chunk's global loads are issued BEHIND the first MFMAs of this chunk, so the matrix
                 // pipe is already busy while the wave spends its issue slots on address arithmetic / VMEM
-                if (slot == 0 && k == 0 && more) issue_loads((ch + 1) * KC);
+                if (slot == 0 && k == 0 && more) issue_loads((cb + ch + 1) * KC);
             }
             if (more && slot > 0) write_slot(Xn, Wn, slot - 1);
         }
-        if (more && KW > 1 && !halo_fast) halo_slow(Xn, (ch + 1) * KC);
+        if (more && KW > 1 && !halo_fast) halo_slow(Xn, (cb + ch + 1) * KC);
         __syncthreads();
     }
 
@@ -306,6 +310,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_mfma_kernel(const ConvDev
         const int f = rowinfo[2 * rr + 1];
         const int t = t0 + tt;
         if (b < 0 || t >= p.T) continue;
+        if (a.splits > 1) {                              // split-K: raw partial sums, reduced by conv_splitk_reduce_kernel
+            const int64_t ft = (int64_t)p.F * p.T;
+            float* wsb = a.ws + (((int64_t)blockIdx.z * p.B + b) * p.Cout) * ft + (int64_t)f * p.T + t;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int mbase = m0 + (wm * MT + i) * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    if (m < p.Cout) wsb[(int64_t)m * ft] = acc[i][j][r];
+                }
+            }
+            continue;
+        }
         const int64_t ybase = (int64_t)b * p.y.sB + (int64_t)f * p.y.sF + t;
         const int64_t rbase = p.res.p ? ((int64_t)b * p.res.sB + (int64_t)f * p.res.sF + t) : 0;
         const int64_t abase = p.aux.p ? ((int64_t)b * p.aux.sB + (int64_t)f * p.aux.sF + t) : 0;
@@ -336,6 +354,31 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_mfma_kernel(const ConvDev
     }
 }
 
+// y = alpha * (res_scale*res + out_scale * sum_z ws[z])  -- fixed summation order: deterministic
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const aid_conv2d_params p, const float* __restrict__ ws, int splits) {
+    const int64_t ft = (int64_t)p.F * p.T;
+    const int64_t q4 = ft >> 2;                           // float4s per (b, m) plane (T % 4 == 0)
+    const int64_t total = (int64_t)p.B * p.Cout * q4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int64_t bm = i / q4, e = (i - bm * q4) * 4;
+    const int b = (int)(bm / p.Cout), m = (int)(bm - (int64_t)b * p.Cout);
+    const int f = (int)(e / p.T), t = (int)(e - (int64_t)f * p.T);
+    const int64_t plane = (int64_t)p.B * p.Cout * ft;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < splits; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(ws + z * plane + bm * ft + e);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float sc = p.out_scale ? p.out_scale[(int64_t)b * p.out_scale_ld + m] : 1.f;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.res.p) r = *reinterpret_cast<const float4*>(p.res.p + (int64_t)b * p.res.sB + (int64_t)m * p.res.sC + (int64_t)f * p.res.sF + t);
+    float4 o;
+    o.x = p.alpha * (p.res_scale * r.x + s.x * sc); o.y = p.alpha * (p.res_scale * r.y + s.y * sc);
+    o.z = p.alpha * (p.res_scale * r.z + s.z * sc); o.w = p.alpha * (p.res_scale * r.w + s.w * sc);
+    *reinterpret_cast<float4*>(p.y.p + (int64_t)b * p.y.sB + (int64_t)m * p.y.sC + (int64_t)f * p.y.sF + t) = o;
+}
+
 // ------------------------------------------------------------------------------------------------------
 static int pick_mblk(int Cout) {
     if (Cout <= 32) return 32;
@@ -351,7 +394,7 @@ extern "C" void aid_conv2d_pack_dims(int Cin, int Cout, int* Cin_pad, int* Cout_
 }
 
 template <int KH, int KW, int MT, int NT, int WGM, int WGN, int KC>
-static int launch_cfg(const aid_conv2d_params* p, hipStream_t st) {
+static int launch_cfg(const aid_conv2d_params* p, hipStream_t st, int splits = 1) {
     constexpr int M_BLK = 32 * MT * WGM;
     constexpr int N_BLK = 32 * NT * WGN;
     ConvDev a;
@@ -365,8 +408,11 @@ static int launch_cfg(const aid_conv2d_params* p, hipStream_t st) {
     a.tiles_t = aid_cdiv(p->T, TT);
     a.nrows = p->B * p->F;
     a.nchunks = aid_cdiv(p->Cin, KC);
+    a.cps = aid_cdiv(a.nchunks, splits);
+    a.splits = aid_cdiv(a.nchunks, a.cps);               // (no empty K ranges)
+    a.ws = p->ws;
     const int rgroups = aid_cdiv(a.nrows, ROWS);
-    dim3 grid((unsigned)(rgroups * a.tiles_t), (unsigned)(p->Cout_pad / M_BLK));
+    dim3 grid((unsigned)(rgroups * a.tiles_t), (unsigned)(p->Cout_pad / M_BLK), (unsigned)a.splits);
     const size_t lds = sizeof(float) * 2 * ((size_t)KC * ROWS * KH * (TT + (KW > 1 ? 8 : 0)) + (size_t)KH * KW * KC * M_BLK) +
                        sizeof(int) * 2 * ROWS;
     AID_REQUIRE(lds <= 160 * 1024, "aid_conv2d: LDS tile too large");
@@ -378,6 +424,11 @@ static int launch_cfg(const aid_conv2d_params* p, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), lds, st, a);
     AID_CHECK_LAUNCH();
+    if (a.splits > 1) {
+        const int64_t total = (int64_t)p->B * p->Cout * ((int64_t)p->F * p->T / 4);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *p, (const float*)p->ws, a.splits);
+        AID_CHECK_LAUNCH();
+    }
     return AID_OK;
 }
 
@@ -385,9 +436,22 @@ template <int KH, int KW, int KC>
 static int launch_m(const aid_conv2d_params* p, hipStream_t st) {
     int mb = pick_mblk(p->Cout);
     if (mb == 128) {
-        // grid-starved GEMMs (qk projections: N = B*T columns only): trade tile height for more workgroups
+        // grid-starved GEMMs (qk projections: N = B*T columns only)
         const int64_t npos = (int64_t)p->B * p->F * p->T;
         const int64_t ntiles = (npos + 255) / 256;
+        static int sk = -1;
+        if (sk < 0) { const char* e = getenv("AID_CONV_SPLITK"); sk = e ? atoi(e) : 1; }
+        const int64_t wg64 = ntiles * (p->Cout_pad / 64);
+        if (KH == 1 && sk && p->ws && p->epi == 0 && wg64 < 384 && p->Cin >= 16 * KC && p->Cout_pad % 64 == 0 && (p->T % 4) == 0) {
+            // split K over several workgroups per 64 x 256 tile (deterministic two-pass reduction through ws)
+            int S = (int)((768 + wg64 - 1) / wg64);
+            if (S > 8) S = 8;
+            const int64_t need = (int64_t)S * p->B * p->Cout * p->F * p->T * 4;
+            auto al4 = [](const aid_view& v) { return (v.sB % 4) == 0 && (v.sC % 4) == 0 && (v.sF % 4) == 0 && (((uintptr_t)v.p) & 15) == 0; };
+            if (S > 1 && need <= p->ws_bytes && al4(p->y) && (!p->res.p || al4(p->res)))
+                return launch_cfg<KH, KW, 1, 2, 2, 4, KC>(p, st, S);
+        }
+        // single pass: trade tile height for more workgroups
         if (ntiles * (p->Cout_pad / 128) < 192) mb = (ntiles * (p->Cout_pad / 64) < 192) ? 32 : 64;
     }
     // AID_CONV_CFG=n selects alternative tile / wave-count configurations (tuning experiments only)

@@ -244,10 +244,14 @@ class _Builder:
         p.wp_wino = _lib.ptr(wpw)
         p.wino_taps = 0 if wpw is None else wpw.shape[0]
         p.x_wino = int(x_wino)
+        ws = None
+        if F == 1 and kh == 1 and epi == 0:              # qk projections: few columns, long K -> split-K scratch (aid_kernels.h)
+            ws = self._scratch(("ws", 8 * B * cout * T))
+            p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
         assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] in (20, 30) and wpw.shape[1:] == wp.shape[1:]))
         # algorithmic HBM bytes: x once, residual / aux once, y once, weights once
         nb = 4 * (B * F * T * (cin + cout * (1 + (res is not None) + (aux is not None))) + cin * cout * kh * kw)
-        self.plan.add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, flops=2 * B * F * T * cin * cout * kh * kw,
+        self.plan.add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, ws, flops=2 * B * F * T * cin * cout * kh * kw,
                       nbytes=nb)
 
     def _wino_input(self, cin, cout, T, wp, wpw):

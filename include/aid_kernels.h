@@ -104,6 +104,10 @@ typedef struct {
     int x_wino;               /* 1: `x` is the F(4,3) INPUT TRANSFORM of the activations, written by aid_scale_act(wino=1):
                                  [B, Cin, F, 6, T/4] (sF = 6*T/4 ...), V = B^T d per group of 4 samples; needs wp_wino with 30 taps
                                  and aid_conv2d_wino_input_supported(...) != 0.  The kernel then stages and multiplies only. */
+    float* ws; int64_t ws_bytes; /* optional scratch (the library never allocates): lets grid-starved 1x1 GEMMs (the qk projections:
+                                 B*T columns only, K of several thousand) split K over up to 8 workgroups per tile; partial sums
+                                 go to ws[S][B][Cout][F][T] and a second kernel reduces them in a FIXED order (deterministic) and
+                                 applies the epilogue.  NULL / too small: single-pass kernel. */
 } aid_conv2d_params;
 int aid_conv2d(const aid_conv2d_params* p, void* stream);
 /* non-zero when a 5x3 layer of this shape can take Winograd-domain input (x_wino = 1) */

@@ -84,7 +84,8 @@ CONV_CASES = [
     (2, 24, 8, 12, 8, 1, 1, 1, True, False),         # attention proj_in (scale prologue, no GELU)
     (2, 8, 24, 12, 8, 1, 1, 1, False, True),         # attention proj_out
     (2, 96, 192, 1, 8, 1, 1, 1, False, False),       # qk GEMM, F = 1
-    (1, 320, 640, 1, 128, 1, 1, 1, False, False),    # qk GEMM, larger K
+    (1, 320, 640, 1, 128, 1, 1, 1, False, False),    # qk GEMM, larger K (split-K through the scratch buffer)
+    (2, 1024, 512, 1, 64, 1, 1, 1, False, True),     # qk-sized GEMM with gate + residual epilogue after the split-K reduction
     (3, 40, 40, 9, 12, 5, 3, 2, True, True),         # ragged: T not a power of two, odd row count
     # 1x1 with enough positions -> streaming kernel (aid_conv1x1.hip)
     (2, 64, 192, 16, 64, 1, 1, 1, True, True),       # two 96-wide Cout slices, per-(b,ci) prologue scale
@@ -134,6 +135,9 @@ def test_conv2d(L, case, wino):
     p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
     p.KH, p.KW, p.dilF, p.act, p.epi = KH, KW, dil, act, 0
     p.alpha, p.res_scale = alpha, res_scale
+    if Fd == 1:                                          # scratch for the split-K path (NULL -> single pass, also valid)
+        ws = torch.empty(8 * B * Cout * T, device=DEV)
+        p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
     wpw = None
     if wino:
         if (KH, KW) != (5, 3) or pro or Cin % 4 or Cout < 64:

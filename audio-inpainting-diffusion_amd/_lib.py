@@ -43,7 +43,8 @@ class Conv2dParams(C.Structure):
                 ("KH", C.c_int), ("KW", C.c_int), ("dilF", C.c_int),
                 ("act", C.c_int), ("epi", C.c_int),
                 ("alpha", C.c_float), ("res_scale", C.c_float), ("wp_wino", C.c_void_p), ("wino_taps", C.c_int),
-                ("x_wino", C.c_int), ("ws", C.c_void_p), ("ws_bytes", C.c_int64)]
+                ("x_wino", C.c_int), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+                ("dot_ws", C.c_void_p), ("dot_n", C.c_int)]
 
 
 class ResampleParams(C.Structure):
@@ -120,7 +121,8 @@ class GroupDotParams(C.Structure):
 class NormBwdParams(C.Structure):
     _fields_ = [("gd", View), ("x", View), ("gy", View), ("out", View),
                 ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("groups", C.c_int),
-                ("stats", C.c_void_p), ("ws", C.c_void_p), ("eps", C.c_float), ("a", C.c_float), ("accumulate", C.c_int)]
+                ("stats", C.c_void_p), ("ws", C.c_void_p), ("eps", C.c_float), ("a", C.c_float), ("accumulate", C.c_int),
+                ("ws_n", C.c_int)]
 
 
 class AttentionBwdParams(C.Structure):
@@ -151,7 +153,7 @@ EXPORTS = ["aid_abi_version", "aid_last_error", "aid_group_stats", "aid_conv2d",
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
-           "aid_stft_frames", "aid_stft_ola", "aid_conv2d_wino_input_supported"]
+           "aid_stft_frames", "aid_stft_ola", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials"]
 
 _lib = None
 
@@ -173,8 +175,10 @@ def lib():
         L.aid_conv2d_pack_dims.restype = None
         L.aid_conv2d_wino_input_supported.argtypes = [C.c_int, C.c_int, C.c_int]
         L.aid_conv2d_wino_input_supported.restype = C.c_int
+        L.aid_conv2d_dot_partials.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+        L.aid_conv2d_dot_partials.restype = C.c_int
         for name in EXPORTS[2:]:
-            if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported"):
+            if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials"):
                 getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, name).restype = C.c_int
         if L.aid_abi_version() != 2:

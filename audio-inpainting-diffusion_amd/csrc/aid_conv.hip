@@ -506,6 +506,14 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     AID_REQUIRE(p->epi == 0 || (p->epi == 1 && p->aux.p && p->aux_scale), "aid_conv2d: epi=1 needs aux + aux_scale");
     AID_REQUIRE((int64_t)p->B * p->in_scale_ld < (1LL << 31), "aid_conv2d: in_scale too large");
     AID_REQUIRE(!p->x_wino || (p->KH == 5 && p->KW == 3 && p->wp_wino), "aid_conv2d: x_wino is a 5x3 Winograd-path input layout");
+    if (p->dot_ws) {
+        AID_REQUIRE(p->KH == 5 && p->KW == 3 && p->wp_wino && p->wino_taps == 30 && p->epi == 1 && !p->res.p,
+                    "aid_conv2d: dot_ws is an option of the F(4,3) dGELU epilogue");
+        AID_REQUIRE(p->dot_n > 0 && p->dot_n == aid_conv2d_dot_partials(p->Cin, p->Cout, p->F, p->T), "aid_conv2d: dot_n != aid_conv2d_dot_partials()");
+        const int r = aid_conv53_wino_try(p, st);
+        if (r == 0) aid_set_error("aid_conv2d: dot_ws given but the layer is not eligible for the F(4,3) kernels");
+        return r == 1 ? AID_OK : (r < 0 ? r : AID_E_BADARG);
+    }
     if (p->x_wino) {
         const int r = aid_conv53_wino_try(p, st);
         return r == 1 ? AID_OK : (r < 0 ? r : AID_E_BADARG);

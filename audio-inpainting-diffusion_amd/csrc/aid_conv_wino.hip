@@ -535,6 +535,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4_kernel(cons
     __builtin_amdgcn_s_setprio(0);
 
     // ---- epilogue: output transform, then gate / dGELU / residual, four samples per lane -------------------------------
+    float dsum[MT][4];                                   // <y, aux> per block of 4 rows (dot_ws)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dsum[i][q] = 0.f;
 #pragma unroll
     for (int j = 0; j < NTT; ++j) {
         const int nt = (wn * NTT + j) * 32 + (lane & 31);
@@ -551,8 +556,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4_kernel(cons
             const int mbase = m0 + (wm * MT + i) * 32 + 4 * (lane >> 5);
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += 4) {         // batches of 4 rows: gather, then compute + store
-                float4 rv[4], uv[4];
-                float sv[4];
+                float4 rv[4], ur[4];                      // residual, raw aux (scaled by `as` when the dGELU is evaluated)
+                float sv[4], as[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int r = r0 + q;
@@ -561,10 +566,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4_kernel(cons
                     rv[q] = (ok && p.res.p) ? *reinterpret_cast<const float4*>(p.res.p + rbase + (int64_t)m * p.res.sC) : make_float4(0.f, 0.f, 0.f, 0.f);
                     sv[q] = (ok && p.out_scale) ? p.out_scale[(int64_t)b * p.out_scale_ld + m] : 1.f;
                     if (ok && p.epi == 1) {
-                        const float as = p.aux_scale[(int64_t)b * p.aux_scale_ld + m];
-                        const float4 u = *reinterpret_cast<const float4*>(p.aux.p + abase + (int64_t)m * p.aux.sC);
-                        uv[q] = make_float4(u.x * as, u.y * as, u.z * as, u.w * as);
-                    } else uv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        as[q] = p.aux_scale[(int64_t)b * p.aux_scale_ld + m];
+                        ur[q] = *reinterpret_cast<const float4*>(p.aux.p + abase + (int64_t)m * p.aux.sC);
+                    } else { as[q] = 0.f; ur[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -578,11 +582,48 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4_kernel(cons
                     float y1 = (s12 + 2.f * s34) * sv[q];
                     float y2 = (a12 + 4.f * a34) * sv[q];
                     float y3 = (s12 + 8.f * s34 + M5) * sv[q];
-                    if (p.epi == 1) { y0 *= aid_dgelu(uv[q].x); y1 *= aid_dgelu(uv[q].y); y2 *= aid_dgelu(uv[q].z); y3 *= aid_dgelu(uv[q].w); }
+                    if (p.epi == 1) { y0 *= aid_dgelu(ur[q].x * as[q]); y1 *= aid_dgelu(ur[q].y * as[q]); y2 *= aid_dgelu(ur[q].z * as[q]); y3 *= aid_dgelu(ur[q].w * as[q]); }
                     y0 += p.res_scale * rv[q].x; y1 += p.res_scale * rv[q].y; y2 += p.res_scale * rv[q].z; y3 += p.res_scale * rv[q].w;
-                    *reinterpret_cast<float4*>(p.y.p + ybase + (int64_t)m * p.y.sC) = make_float4(p.alpha * y0, p.alpha * y1, p.alpha * y2, p.alpha * y3);
+                    y0 *= p.alpha; y1 *= p.alpha; y2 *= p.alpha; y3 *= p.alpha;
+                    *reinterpret_cast<float4*>(p.y.p + ybase + (int64_t)m * p.y.sC) = make_float4(y0, y1, y2, y3);
+                    if (p.dot_ws) dsum[i][r0 >> 2] += (y0 * ur[q].x + y1 * ur[q].y) + (y2 * ur[q].z + y3 * ur[q].w);
                 }
             }
+        }
+    }
+    // ---- optional: <y, aux> per (sample, channel group), one partial per tile (replaces the aid_group_dot pass) -----------
+    if (p.dot_ws) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = dsum[i][q];
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 32);     // the 32 lanes of a half-wave share their rows
+                dsum[i][q] = v;
+            }
+        float* red = sbuf0;                              // (every wave is past the last chunk's barrier)
+        if ((lane & 31) == 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[((wave * 2 + half) * MT + i) * 4 + q] = dsum[i][q];
+        }
+        __syncthreads();
+        const int cpg = p.Cout >> 3;                     // channels per group (8 groups); M_BLK % cpg == 0 (host-checked)
+        const int g = m0 / cpg + tid;
+        if (tid < M_BLK / cpg && g < 8) {
+            float sacc = 0.f;
+            for (int w = 0; w < NW; ++w)                 // fixed order: deterministic
+                for (int h = 0; h < 2; ++h)
+                    for (int i = 0; i < MT; ++i)
+                        for (int q = 0; q < 4; ++q) {
+                            const int mrow = m0 + ((w / WGN) * MT + i) * 32 + 4 * h + 8 * q;
+                            if (mrow / cpg == g) sacc += red[((w * 2 + h) * MT + i) * 4 + q];
+                        }
+            const int b = rowinfo[0];
+            const int ptile = ((row0 - b * p.F) >> a.rows_log2) * a.tiles_t + tile_t;
+            p.dot_ws[((int64_t)b * 8 + g) * p.dot_n + ptile] = (double)sacc;
         }
     }
 }
@@ -773,6 +814,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
     __builtin_amdgcn_s_setprio(0);
 
     // ---- epilogue: output transform, then gate / dGELU / residual, four samples per lane -------------------------------
+    float dsum[MT][4];                                   // <y, aux> per block of 4 rows (dot_ws)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dsum[i][q] = 0.f;
 #pragma unroll
     for (int j = 0; j < NTT; ++j) {
         const int nt = (wn * NTT + j) * 32 + (lane & 31);
@@ -789,8 +835,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
             const int mbase = m0 + (wm * MT + i) * 32 + 4 * (lane >> 5);
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += 4) {         // batches of 4 rows: gather, then compute + store
-                float4 rv[4], uv[4];
-                float sv[4];
+                float4 rv[4], ur[4];                      // residual, raw aux (scaled by `as` when the dGELU is evaluated)
+                float sv[4], as[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int r = r0 + q;
@@ -799,10 +845,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
                     rv[q] = (ok && p.res.p) ? *reinterpret_cast<const float4*>(p.res.p + rbase + (int64_t)m * p.res.sC) : make_float4(0.f, 0.f, 0.f, 0.f);
                     sv[q] = (ok && p.out_scale) ? p.out_scale[(int64_t)b * p.out_scale_ld + m] : 1.f;
                     if (ok && p.epi == 1) {
-                        const float as = p.aux_scale[(int64_t)b * p.aux_scale_ld + m];
-                        const float4 u = *reinterpret_cast<const float4*>(p.aux.p + abase + (int64_t)m * p.aux.sC);
-                        uv[q] = make_float4(u.x * as, u.y * as, u.z * as, u.w * as);
-                    } else uv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        as[q] = p.aux_scale[(int64_t)b * p.aux_scale_ld + m];
+                        ur[q] = *reinterpret_cast<const float4*>(p.aux.p + abase + (int64_t)m * p.aux.sC);
+                    } else { as[q] = 0.f; ur[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -816,11 +861,48 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
                     float y1 = (s12 + 2.f * s34) * sv[q];
                     float y2 = (a12 + 4.f * a34) * sv[q];
                     float y3 = (s12 + 8.f * s34 + M5) * sv[q];
-                    if (p.epi == 1) { y0 *= aid_dgelu(uv[q].x); y1 *= aid_dgelu(uv[q].y); y2 *= aid_dgelu(uv[q].z); y3 *= aid_dgelu(uv[q].w); }
+                    if (p.epi == 1) { y0 *= aid_dgelu(ur[q].x * as[q]); y1 *= aid_dgelu(ur[q].y * as[q]); y2 *= aid_dgelu(ur[q].z * as[q]); y3 *= aid_dgelu(ur[q].w * as[q]); }
                     y0 += p.res_scale * rv[q].x; y1 += p.res_scale * rv[q].y; y2 += p.res_scale * rv[q].z; y3 += p.res_scale * rv[q].w;
-                    *reinterpret_cast<float4*>(p.y.p + ybase + (int64_t)m * p.y.sC) = make_float4(p.alpha * y0, p.alpha * y1, p.alpha * y2, p.alpha * y3);
+                    y0 *= p.alpha; y1 *= p.alpha; y2 *= p.alpha; y3 *= p.alpha;
+                    *reinterpret_cast<float4*>(p.y.p + ybase + (int64_t)m * p.y.sC) = make_float4(y0, y1, y2, y3);
+                    if (p.dot_ws) dsum[i][r0 >> 2] += (y0 * ur[q].x + y1 * ur[q].y) + (y2 * ur[q].z + y3 * ur[q].w);
                 }
             }
+        }
+    }
+    // ---- optional: <y, aux> per (sample, channel group), one partial per tile (replaces the aid_group_dot pass) -----------
+    if (p.dot_ws) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = dsum[i][q];
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 32);     // the 32 lanes of a half-wave share their rows
+                dsum[i][q] = v;
+            }
+        float* red = sbuf0;                              // (every wave is past the last chunk's barrier)
+        if ((lane & 31) == 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[((wave * 2 + half) * MT + i) * 4 + q] = dsum[i][q];
+        }
+        __syncthreads();
+        const int cpg = p.Cout >> 3;                     // channels per group (8 groups); M_BLK % cpg == 0 (host-checked)
+        const int g = m0 / cpg + tid;
+        if (tid < M_BLK / cpg && g < 8) {
+            float sacc = 0.f;
+            for (int w = 0; w < NW; ++w)                 // fixed order: deterministic
+                for (int h = 0; h < 2; ++h)
+                    for (int i = 0; i < MT; ++i)
+                        for (int q = 0; q < 4; ++q) {
+                            const int mrow = m0 + ((w / WGN) * MT + i) * 32 + 4 * h + 8 * q;
+                            if (mrow / cpg == g) sacc += red[((w * 2 + h) * MT + i) * 4 + q];
+                        }
+            const int b = rowinfo[0];
+            const int ptile = ((row0 - b * p.F) >> a.rows_log2) * a.tiles_t + tile_t;
+            p.dot_ws[((int64_t)b * 8 + g) * p.dot_n + ptile] = (double)sacc;
         }
     }
 }
@@ -946,6 +1028,21 @@ static bool wino_v_shape_ok(int Cin, int Cout, int T) {
 
 extern "C" int aid_conv2d_wino_input_supported(int Cin, int Cout, int T) { return wino_v_shape_ok(Cin, Cout, T) ? 1 : 0; }
 
+// tiles per sample of the F(4,3) kernels (64|96 x 512 tiles) when the per-tile <y, aux> partials are well defined
+extern "C" int aid_conv2d_dot_partials(int Cin, int Cout, int F, int T) {
+    int cip, cop;
+    aid_conv2d_pack_dims(Cin, Cout, &cip, &cop);
+    if ((Cin % 4) || Cout < 64 || (Cout % 8) || (T % 4) || aid_pow2ceil(T) < 8) return 0;
+    const int mblk = (cop % 64 == 0) ? 64 : ((cop % 96 == 0) ? 96 : 0);
+    const int cpg = Cout / 8;
+    if (!mblk || (cpg % 4) || (mblk % cpg)) return 0;
+    int TT = aid_pow2ceil(T);
+    if (TT > 512) TT = 512;
+    const int ROWS = 512 / TT;
+    if (ROWS > 16 || (F % ROWS)) return 0;
+    return (F / ROWS) * aid_cdiv(T, TT);
+}
+
 // x_wino = 1: the caller already wrote the Winograd-domain input; there is no other kernel that can read it
 static int conv53_wino_v(const aid_conv2d_params* p, hipStream_t st) {
     AID_REQUIRE(p->wp_wino && p->wino_taps == 30 && p->KH == 5 && p->KW == 3 && !p->in_scale && p->act == 0,
@@ -984,7 +1081,7 @@ int aid_conv53_wino_try(const aid_conv2d_params* p, hipStream_t st) {
         if (p->aux.p && ((p->aux.sB % 4) || (p->aux.sC % 4) || (p->aux.sF % 4) || (((uintptr_t)p->aux.p) & 15))) return 0;
         if (cfg == 2 && p->Cout_pad % 64 == 0)      rc = launch_wino4<1, 1, 2, 2, 16, 2, 1>(p, st);   // 64 x 256, 4 waves
         else if (cfg == 3 && p->Cout_pad % 64 == 0) rc = launch_wino4<1, 1, 2, 4, 16, 4, 3>(p, st);   // 64 x 512, 8 waves, KC=4
-        else if (p->Cout_pad % 64 == 0)             rc = launch_wino4<1, 1, 2, 4, 16, 2, 3>(p, st);   // 64 x 512, 8 waves (158 VGPRs: 1 workgroup / CU)
+        else if (p->Cout_pad % 64 == 0)             rc = launch_wino4<1, 1, 2, 4, 16, 2, 2>(p, st);   // 64 x 512, 8 waves (158 VGPRs: 1 workgroup / CU)
         else if (cfg == 1 && p->Cout_pad % 96 == 0) rc = launch_wino4<1, 1, 3, 2, 16, 2, 1>(p, st);   // 96 x 256, 6 waves
         else if (p->Cout_pad % 96 == 0)             rc = launch_wino4<1, 1, 3, 4, 16, 2, 3>(p, st);   // 96 x 512, 12 waves
         else return 0;

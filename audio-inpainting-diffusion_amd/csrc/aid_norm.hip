@@ -151,8 +151,9 @@ __global__ void norm_bwd_coef(const NbDev a) {
     const aid_norm_bwd_params& p = a.p;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.B * p.groups) return;
+    const int nk = p.ws_n > 0 ? p.ws_n : AID_STATS_SPLIT;
     double d = 0.0;
-    for (int k = 0; k < AID_STATS_SPLIT; ++k) d += p.ws[(int64_t)i * AID_STATS_SPLIT + k];
+    for (int k = 0; k < nk; ++k) d += p.ws[(int64_t)i * nk + k];
     const double inv = (double)p.stats[2 * i + 1];
     const double sd = 1.0 / inv - (double)p.eps;
     const double n = (double)a.cg * p.F * p.T;
@@ -199,7 +200,7 @@ extern "C" int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream) {
     a.p = *p;
     a.cg = p->C / p->groups;
     // coefficients live right behind the dot partials in the caller's scratch (ws holds B*groups*SPLIT*2 doubles)
-    a.coef = reinterpret_cast<float*>(const_cast<double*>(p->ws) + (int64_t)p->B * p->groups * AID_STATS_SPLIT);
+    a.coef = reinterpret_cast<float*>(const_cast<double*>(p->ws) + (int64_t)p->B * p->groups * (p->ws_n > 0 ? p->ws_n : AID_STATS_SPLIT));
     int lpr = aid_pow2ceil(p->T / 4);
     if (lpr > 256) lpr = 256;
     a.lpr_log2 = aid_ilog2(lpr);

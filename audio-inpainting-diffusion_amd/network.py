@@ -174,6 +174,7 @@ class _Builder:
         self.gstate = {}       # storage data_ptr -> 'full' (first contribution overwrites the whole tensor: no zero fill,
                                #   no read-modify-write) | 'zero' (touched through partial views: zero-filled, accumulated)
         self.scratch = {}      # shape -> scratch tensor for dgrad outputs awaiting the normalisation backward
+        self.fuse_dot = os.environ.get("AID_FUSE_DOT", "1") != "0"  # <gd, x> partials from the dgrad conv epilogue instead of aid_group_dot
         self.wino_v = os.environ.get("AID_WINO_V", "1") != "0"      # Winograd-domain conv inputs (see _wino_input); 0 = in-kernel transform
 
     # ---- gradient storage: one flat buffer per activation storage, views share strides/offsets ------------
@@ -227,7 +228,7 @@ class _Builder:
         self.plan.add("aid_group_stats", p, x, gamma, mod, scale, stats)
 
     def _conv_raw(self, x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha, epi=0,
-                  aux=None, aux_scale=None, wpw=None, x_wino=False):
+                  aux=None, aux_scale=None, wpw=None, x_wino=False, dot=None):
         B, _, F, T = y.shape
         assert x.shape[1] == cin and y.shape[1] == cout and x.shape[0] == B and x.shape[2] == F
         assert x.shape[3] == (6 * (T // 4) if x_wino else T)
@@ -244,6 +245,8 @@ class _Builder:
         p.wp_wino = _lib.ptr(wpw)
         p.wino_taps = 0 if wpw is None else wpw.shape[0]
         p.x_wino = int(x_wino)
+        if dot is not None:                              # (buffer, partials per (b, group)): <y, aux> folded into the epilogue
+            p.dot_ws, p.dot_n = dot[0].data_ptr(), dot[1]
         ws = None
         if F == 1 and kh == 1 and epi == 0:              # qk projections: few columns, long K -> split-K scratch (aid_kernels.h)
             ws = self._scratch(("ws", 8 * B * cout * T))
@@ -253,6 +256,14 @@ class _Builder:
         nb = 4 * (B * F * T * (cin + cout * (1 + (res is not None) + (aux is not None))) + cin * cout * kh * kw)
         self.plan.add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, ws, flops=2 * B * F * T * cin * cout * kh * kw,
                       nbytes=nb)
+
+    def _dot_ws(self, n):
+        """scratch for the per-tile <gd, x> partials written by the conv epilogue: [B*8, n] doubles + B*8 floats (coef)"""
+        t = self.scratch.get(("dot", n))
+        if t is None:
+            t = self.scratch[("dot", n)] = torch.zeros(self.B * 8 * (n + 1), device=self.device, dtype=torch.float64)
+            self.nbytes += t.numel() * 8
+        return t
 
     def _wino_input(self, cin, cout, T, wp, wpw):
         """True when the pre-pass should write the F(4,3) input transform (aid_scale_act wino=1 -> aid_conv2d x_wino=1):
@@ -301,13 +312,20 @@ class _Builder:
                 gsc = None
             if norm_stats is not None:
                 gd = self._scratch(x.shape)
+                # <gd, x> per (sample, group): folded into the dgrad conv's epilogue when it runs on the F(4,3) kernels
+                nd = 0
+                if self.fuse_dot and act and kh == 5 and gsc is None and wpwT is not None and wpwT.shape[0] == 30:
+                    nd = int(_lib.lib().aid_conv2d_dot_partials(cout, cin, F, T))
+                dws = self._dot_ws(nd) if nd else self.stats_ws
                 self._conv_raw(gin, gd, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, None, 1.0, alpha,
-                               epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None, wpw=wpwT, x_wino=gw)
-                dp = _lib.GroupDotParams(_lib.view4(gd), _lib.view4(x), B, cin, F, T, 8, self.stats_ws.data_ptr())
-                self.plan.add("aid_group_dot", dp, gd, x)
+                               epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None, wpw=wpwT, x_wino=gw,
+                               dot=(dws, nd) if nd else None)
+                if not nd:
+                    dp = _lib.GroupDotParams(_lib.view4(gd), _lib.view4(x), B, cin, F, T, 8, self.stats_ws.data_ptr())
+                    self.plan.add("aid_group_dot", dp, gd, x)
                 npar = _lib.NormBwdParams(_lib.view4(gd), _lib.view4(x), _lib.view4(gy if fused_res else None), _lib.view4(self.G(x)),
-                                          B, cin, F, T, 8, norm_stats.data_ptr(), self.stats_ws.data_ptr(), 1e-7,
-                                          alpha * res_scale, 1 if self._gacc(x) else 0)
+                                          B, cin, F, T, 8, norm_stats.data_ptr(), dws.data_ptr(), 1e-7,
+                                          alpha * res_scale, 1 if self._gacc(x) else 0, nd)
                 self.plan.add("aid_norm_bwd", npar, gd, x, gy, norm_stats)
             else:
                 gx = self.G(x)

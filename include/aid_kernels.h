@@ -108,10 +108,16 @@ typedef struct {
                                  B*T columns only, K of several thousand) split K over up to 8 workgroups per tile; partial sums
                                  go to ws[S][B][Cout][F][T] and a second kernel reduces them in a FIXED order (deterministic) and
                                  applies the epilogue.  NULL / too small: single-pass kernel. */
+    double* dot_ws; int dot_n;   /* optional (input-VJP, epi = 1 on the F(4,3) path only): the epilogue also reduces <y, aux> per
+                                 (sample, channel group of Cout/8) over its tile and writes one partial per tile,
+                                 dot_ws[(b*8 + g) * dot_n + tile_in_sample] -- the aid_group_dot pass over the dgrad output
+                                 folded into the conv that produces it.  dot_n must equal aid_conv2d_dot_partials(...). */
 } aid_conv2d_params;
 int aid_conv2d(const aid_conv2d_params* p, void* stream);
 /* non-zero when a 5x3 layer of this shape can take Winograd-domain input (x_wino = 1) */
 int aid_conv2d_wino_input_supported(int Cin, int Cout, int T);
+/* number of per-tile partial dots per (sample, group) the F(4,3) epilogue writes for this shape; 0 = not supported */
+int aid_conv2d_dot_partials(int Cin, int Cout, int F, int T);
 /* padded dims the packed weight buffer must have for a given (Cin, Cout) */
 void aid_conv2d_pack_dims(int Cin, int Cout, int* Cin_pad, int* Cout_pad);
 
@@ -301,9 +307,11 @@ typedef struct {
     aid_view gd, x, gy, out;      /* gy.p may be NULL */
     int B, C, F, T, groups;
     const float* stats;           /* [B, groups, 2] (mean, 1/(std+eps)) from the forward aid_group_stats */
-    const double* ws;             /* partial dots from aid_group_dot */
+    const double* ws;             /* partial dots from aid_group_dot (ws_n = 0) or from the conv epilogue (ws_n partials per (b,g));
+                                     B*groups floats of scratch follow the partials */
     float eps, a;
     int accumulate;
+    int ws_n;
 } aid_norm_bwd_params;
 int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream);
 

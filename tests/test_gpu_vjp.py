@@ -197,3 +197,45 @@ def test_full_size_guided_evaluation_vs_oracle_autograd():
     e1, e2 = rel_l2(xh.cpu(), xh_ref.detach()), rel_l2(g.cpu(), g_ref)
     print(f"full-size guided evaluation: x_hat rel-L2 = {e1:.3e}, rec_grads rel-L2 = {e2:.3e}, |norm diff| = {abs(float(nrm.cpu()) - float(norm)):.2e}")
     assert e1 < 1e-4 and e2 < 1e-4
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 16, 64, 2, 1), (1, 96, 96, 16, 128, 4, 0), (1, 128, 256, 16, 32, 8, 1), (2, 256, 128, 32, 256, 1, 1)])
+def test_conv_epilogue_dot_partials(L, case):
+    """dgrad conv with the dGELU epilogue + dot_ws: the per-tile partials of <y, aux> per (sample, channel group) that
+    replace the aid_group_dot pass, on the in-kernel-transform and the Winograd-domain-input F(4,3) kernels."""
+    B, Cin, Cout, Fd, T, dil, xw = case
+    P = L.lib().aid_conv2d_dot_partials(Cin, Cout, Fd, T)
+    assert P > 0
+    g = _rand(B, Cin, Fd, T, seed=40)
+    w = _rand(Cout, Cin, 5, 3, seed=41, scale=1.0 / math.sqrt(Cin * 15))
+    aux = _rand(B, Cout, Fd, T, seed=42)
+    asc = 1.0 + 0.3 * _rand(B, Cout, seed=43)
+    gd, wd, auxd, ascd = g.to(DEV), w.to(DEV), aux.to(DEV), asc.to(DEV)
+    wp, wpw = L.pack_conv_weight(wd), L.pack_conv_weight_wino(wd, f4=True)
+    y = torch.empty(B, Cout, Fd, T, device=DEV)
+    ws = torch.full((B * 8 * (P + 1),), float("nan"), device=DEV, dtype=torch.float64)
+    p = L.Conv2dParams()
+    xin = gd
+    if xw:
+        xin = torch.empty(B, Cin, Fd, 6 * (T // 4), device=DEV)
+        L.call("aid_scale_act", L.ScaleActParams(L.view4(gd), L.view4(xin), None, 0, B, Cin, Fd, T, 0, 1))
+    p.x, p.y, p.res, p.aux = L.view4(xin), L.view4(y), L.view4(None), L.view4(auxd)
+    p.wp, p.wp_wino, p.wino_taps, p.x_wino = wp.data_ptr(), wpw.data_ptr(), 30, int(xw)
+    p.out_scale, p.out_scale_ld = ascd.data_ptr(), ascd.stride(0)
+    p.aux_scale, p.aux_scale_ld = ascd.data_ptr(), ascd.stride(0)
+    p.B, p.Cin, p.Cout, p.F, p.T = B, Cin, Cout, Fd, T
+    p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
+    p.KH, p.KW, p.dilF, p.act, p.epi = 5, 3, dil, 0, 1
+    p.alpha, p.res_scale = 0.7, 1.0
+    p.dot_ws, p.dot_n = ws.data_ptr(), P
+    L.call("aid_conv2d", p)
+    torch.cuda.synchronize()
+    yc = y.cpu().double()
+    u = aux.double() * asc.double()[:, :, None, None]
+    dg = 0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
+    ref = 0.7 * F.conv2d(g.double(), w.double(), padding="same", dilation=(dil, 1)) * asc.double()[:, :, None, None] * dg
+    assert rel_l2(yc, ref) < 1e-5
+    got = ws[:B * 8 * P].cpu().reshape(B, 8, P).sum(-1)
+    want = (yc * aux.double()).reshape(B, 8, Cout // 8, Fd, T).sum((2, 3, 4))
+    assert torch.isfinite(got).all()
+    assert float((got - want).abs().max()) < 1e-5 * float((yc.abs() * aux.double().abs()).reshape(B, 8, -1).sum(-1).max())

@@ -79,8 +79,14 @@ def make_args(name: str = "maestro22k", audio_len: int = 184184, T: int = 36, ga
     maestro22k   : exp=maestro22k_8s (fs 22050, L 184184, conf/exp/maestro22k_8s.yaml:51-52) + 7-octave net
     librispeech16k: exp=librispeech16k_8s (fs 16000, same L) + 7-octave net + short-gap tester (T 70, hann 100)
     musicnet44k  : exp=musicnet44k_4s/8s (fs 44100) + 8-octave net
+    maestro22k_noattention : same as maestro22k with conf/network/paper_1912_unet_cqt_oct_noattention_adaln.yaml
+                   (attention_layers all 0, use_rel_pos: True -- unused without attention blocks)
     """
-    if name == "maestro22k":
+    if name == "maestro22k_noattention":
+        fs, net = 22050, copy.deepcopy(NETWORK_22K)
+        net["attention_layers"] = [0] * 8
+        net["attention_dict"]["use_rel_pos"] = True
+    elif name == "maestro22k":
         fs, net = 22050, NETWORK_22K
     elif name == "librispeech16k":
         fs, net = 16000, NETWORK_22K

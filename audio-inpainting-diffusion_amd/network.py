@@ -390,7 +390,10 @@ class Unet_CQT_oct_with_attention(nn.Module):
         self.depth = self.num_octs = int(net.cqt.num_octs)
         self.bins_per_oct = int(net.cqt.bins_per_oct)
         self.emb_dim = int(net.emb_dim)
-        if not net.use_norm or net.use_fencoding or net.attention_dict.use_rel_pos or net.attention_dict.bias_qkv:
+        has_attn = any(int(v) for v in net.attention_layers)
+        # use_rel_pos / bias_qkv only exist inside TimeAttentionBlock: the shipped no-attention configuration
+        # (conf/network/paper_1912_unet_cqt_oct_noattention_adaln.yaml, attention_layers all 0) sets use_rel_pos: True
+        if not net.use_norm or net.use_fencoding or (has_attn and (net.attention_dict.use_rel_pos or net.attention_dict.bias_qkv)):
             raise NotImplementedError("only use_norm=True, use_fencoding=False, use_rel_pos=False, bias_qkv=False "
                                       "(the shipped configurations) are built")
         if net.bottleneck_type != "res_dil_convs":

@@ -33,7 +33,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in aid_kernels.h but not exported"
     lib.aid_abi_version.restype = ctypes.c_int
-    assert lib.aid_abi_version() == 1
+    assert lib.aid_abi_version() == int(re.search(r"#define AID_ABI_VERSION (\d+)", hdr).group(1)) == 2
     from audio_inpainting_diffusion_amd import _lib
     assert set(_lib.EXPORTS) == declared
     a, b = _lib.pack_dims(2, 96)
@@ -269,3 +269,37 @@ def test_spectral_mask_matches_reference_prepare_spectral_mask_geometry():
     assert (zr[0], zr[-1] + 1) == (14, 93)              # 300 Hz .. 2 kHz in 21.53 Hz bins
     assert (zc[0], zc[-1] + 1) == (273, 445)            # (92092 - 22050)//256, + 44100//256
     assert int((A == 0).sum()) == (93 - 14) * (445 - 273)
+
+
+def test_checkpoint_loading_strategies_and_long_file_window():
+    """harness.load_checkpoint follows utils/training_utils.py:214-289 (strict -> non-strict -> shape-matched);
+    centre_gap_window reproduces tester_inpainting.py:399-411."""
+    from audio_inpainting_diffusion_amd.config import small_args
+    from audio_inpainting_diffusion_amd.harness import centre_gap_window, load_checkpoint
+    from audio_inpainting_diffusion_amd.init import seeded_init_
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    src = seeded_init_(Unet_CQT_oct_with_attention(small_args(), torch.device("cpu")), 1)
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    dst = Unet_CQT_oct_with_attention(small_args(), torch.device("cpu"))
+    assert load_checkpoint(dst, {"it": 750000, "ema": sd}) == (750000, "strict")
+    assert all(torch.equal(a, b) for a, b in zip(dst.state_dict().values(), sd.values()))
+    k0 = next(k for k in sd if k.endswith("H.0.weight"))
+    extra = dict(sd, **{"not.a.parameter": torch.zeros(3)})
+    del extra[k0]
+    dst = Unet_CQT_oct_with_attention(small_args(), torch.device("cpu"))
+    assert load_checkpoint(dst, {"ema": extra}) == (0, "non-strict")
+    bad = dict(sd)
+    bad[k0] = torch.zeros(1, 2, 3)                                   # wrong shape: only the third strategy survives
+    dst = Unet_CQT_oct_with_attention(small_args(), torch.device("cpu"))
+    before = dst.state_dict()[k0].clone()
+    assert load_checkpoint(dst, {"ema": bad})[1] == "shape-matched"
+    assert torch.equal(dst.state_dict()[k0], before)
+    k1 = next(k for k in sd if k.endswith("H.1.weight"))
+    assert torch.equal(dst.state_dict()[k1], sd[k1])
+    assert load_checkpoint(dst, {"ema": {"nothing": torch.zeros(1)}})[1] == "non-strict"      # (as the reference: attempt 2 accepts it)
+    with pytest.raises(ValueError):
+        load_checkpoint(dst, {"ema": {k0: torch.zeros(1, 2, 3)}})                            # nothing matches by name AND shape
+    # 6 s file at 22.05 kHz, 1.5 s gap, 184184-sample model window
+    assert centre_gap_window(132300 * 2, 184184, 33075) == (132300 - 16537, 132300 - 92092)
+    with pytest.raises(ValueError):
+        centre_gap_window(1000, 184184, 10)

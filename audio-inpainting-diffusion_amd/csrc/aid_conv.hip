@@ -492,6 +492,7 @@ static int launch_m(const aid_conv2d_params* p, hipStream_t st) {
 int aid_conv53_dma_try(const aid_conv2d_params* p, hipStream_t st);   // aid_conv_dma.hip
 int aid_conv53_wino_try(const aid_conv2d_params* p, hipStream_t st);  // aid_conv_wino.hip
 int aid_conv1x1_stream_try(const aid_conv2d_params* p, hipStream_t st);  // aid_conv1x1.hip
+int aid_conv1x1_dma_try(const aid_conv2d_params* p, hipStream_t st);     // aid_conv1x1_dma.hip
 
 extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -535,7 +536,9 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     }
     if (p->KH == 1 && p->KW == 1) {
         {
-            const int r = aid_conv1x1_stream_try(p, st);     // memory-bound channel projections: streaming kernel
+            int r = aid_conv1x1_dma_try(p, st);              // direct-to-LDS kernel, 2-3 workgroups per CU (K % 16 == 0, Cout tile 64/96/128)
+            if (r != 0) return r < 0 ? r : AID_OK;
+            r = aid_conv1x1_stream_try(p, st);               // remaining short-K / narrow projections: streaming kernel
             if (r != 0) return r < 0 ? r : AID_OK;
         }
         if (p->Cin <= 8) return launch_m<1, 1, 8>(p, st);

@@ -168,8 +168,10 @@ int aid_conv1x1_stream_try(const aid_conv2d_params* p, hipStream_t st) {
     static int cfg = -1;
     if (cfg < 0) { const char* e = getenv("AID_C1_CFG"); cfg = e ? atoi(e) : 0; }
     if (cfg == 9) return 0;
-    // measured (profiles/r01_conv1x1_probe.txt): ahead of the LDS-tiled kernel for the short-K / write-dominated
-    // projections (Cin <= 96: 8-35 %), behind it (10-18 %) once K >= 256 makes the layer MFMA-bound
+    // measured (profiles/r01_conv1x1_probe.txt): ahead of the register-staged tiled kernel for the short-K / write-dominated
+    // projections (Cin <= 96: 8-35 %), behind it (10-18 %) once K >= 256 makes the layer MFMA-bound; the direct-to-LDS kernel
+    // (aid_conv1x1_dma.hip, tried first) is 17-20 % ahead of this one wherever it is eligible, so this kernel now serves the
+    // shapes that one refuses (K % 16 != 0, Cout tiles of 32)
     if (cfg == 0 && !(p->Cin <= 96 || p->Cout_pad <= 32)) return 0;
     int nt = (cfg == 0 || cfg == 1 || cfg == 4 || cfg == 5) ? 4 : 2;
     if (nt == 4 && ((ft % 128) || (p->T % 4))) nt = 2;

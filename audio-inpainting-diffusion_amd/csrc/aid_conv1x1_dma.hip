@@ -1,0 +1,281 @@
+// conv11_dma_kernel: 1x1 channel projections (res_conv / skip projections, unet...py:412-415,:488-491) as an
+// fp32-MFMA GEMM with DIRECT-TO-LDS staging and small workgroup footprints.
+//
+// Why a third 1x1 kernel: these layers sit at the ridge (40-130 FLOP/B).  The register-staged tiled kernel
+// (conv_mfma_kernel) runs a tile's load, MFMA and store phases back to back with one workgroup per CU; the streaming kernel
+// (aid_conv1x1.hip) never overlaps a wave's loads, MFMAs and stores either.  Measured 12-20 % ahead of both.  Here
+//   * both operands go HBM/L2 -> LDS with global_load_lds_dwordx4 into two STATIC buffers (see aid_conv_wino.hip: distinct
+//     LDS objects keep the loads of chunk c+1 in flight while chunk c is multiplied);
+//   * a buffer is 24 KB (16 channels x 256 positions + 16 x 128 weights) and a wave holds 64 accumulators, so two to three
+//     workgroups share a CU: one tile's store-heavy epilogue overlaps another tile's K loop;
+//   * a lane's NT = 2 position tiles are INTERLEAVED (tile j = positions 2n + j), so the B fragments of both tiles are ONE
+//     conflict-free ds_read_b64 and the epilogue stores float2.
+// Per-(b,ci) prologue scale (in_scale) is applied to the A fragment (a tile never straddles two samples: host-checked).
+#include "aid_common.h"
+#include <type_traits>
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct C11Dev {
+    aid_conv2d_params p;
+    const float* zero;
+    int tt_log2, rows_log2, tiles_t, nrows, nchunks;
+    int nx, ny, per_xcd;
+};
+
+__device__ float4 g_aid_zero_page_c11[16];
+
+#define GLDS16C(gptr, lptr) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+// MT m-tiles (32 cout) x 2 interleaved position tiles per wave; WGM x WGN waves; N_BLK = 64 * WGN positions
+template <int MT, int WGM, int WGN, int RMAX, int KC, int MINW>
+__global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv11_dma_kernel(const C11Dev a) {
+    constexpr int NT = 2;
+    constexpr int NW = WGM * WGN;
+    constexpr int NTHREADS = 64 * NW;
+    constexpr int M_BLK = 32 * MT * WGM;
+    constexpr int N_BLK = 32 * NT * WGN;
+    constexpr int XSZ = KC * N_BLK;
+    constexpr int WROW = (M_BLK % 64 == 0) ? M_BLK : ((M_BLK + 63) / 64) * 64;
+    constexpr int WSZ = KC * WROW;
+    constexpr int BUFSZ = XSZ + WSZ;
+    constexpr int NXP = XSZ / 256;
+    constexpr int NWP = WSZ / 256;
+    constexpr int NP = NXP + NWP;
+    constexpr int PPW = (NP + NW - 1) / NW;
+    constexpr int NSTEP = KC / 2;
+    static_assert(N_BLK % 256 == 0 && WSZ % 256 == 0, "whole 1-KiB pieces");
+
+    const aid_conv2d_params& p = a.p;
+    const int TT = 1 << a.tt_log2;
+    const int ROWS = 1 << a.rows_log2;
+
+    __shared__ __attribute__((aligned(16))) float sbuf0[BUFSZ];
+    __shared__ __attribute__((aligned(16))) float sbuf1[BUFSZ];
+    __shared__ int rowinfo[2 * RMAX];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN;
+    const int wn = wave % WGN;
+
+    // XCD-aware tile order (see conv53_wino4_kernel): one contiguous (row-group, Cout-tile) range per XCD, Cout tile fastest
+    const int Lt = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+    if (Lt >= a.nx * a.ny) return;
+    const int bx = Lt / a.ny;
+    const int by = Lt - bx * a.ny;
+    const int tile_t = bx % a.tiles_t;
+    const int rg = bx / a.tiles_t;
+    const int row0 = rg << a.rows_log2;
+    const int t0 = tile_t << a.tt_log2;
+    const int m0 = by * M_BLK;
+
+    for (int r = tid; r < ROWS; r += NTHREADS) {
+        const int rid = row0 + r;
+        int b = -1, f = 0;
+        if (rid < a.nrows) { b = rid / p.F; f = rid - b * p.F; }
+        rowinfo[2 * r] = b;
+        rowinfo[2 * r + 1] = f;
+    }
+    __syncthreads();
+
+    // ---- DMA piece descriptors ---------------------------------------------------------------------------------------
+    const float* psrc[PPW];
+    int pstride[PPW], plds[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int pc = wave + i * NW;
+        psrc[i] = a.zero; pstride[i] = 0; plds[i] = -1;
+        if (pc < NXP) {
+            const int ci = pc / (N_BLK / 256), sub = pc % (N_BLK / 256);
+            const int n = sub * 256 + 4 * lane;
+            const int rr = n >> a.tt_log2, tt = n & (TT - 1);
+            const int b = rowinfo[2 * rr];
+            const int f = rowinfo[2 * rr + 1];
+            plds[i] = ci * N_BLK + sub * 256;
+            if (b >= 0 && t0 + tt < p.T) {
+                psrc[i] = p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)f * p.x.sF + t0 + tt;
+                pstride[i] = (int)(KC * p.x.sC);
+            }
+        } else if (pc < NP) {
+            const int wp_ = pc - NXP;
+            const int e = wp_ * 256 + 4 * lane;
+            const int ci = e / WROW, col = e % WROW;
+            plds[i] = XSZ + wp_ * 256;
+            if (col < M_BLK) {
+                psrc[i] = p.wp + (int64_t)ci * p.Cout_pad + m0 + col;
+                pstride[i] = KC * p.Cout_pad;
+            }
+        }
+    }
+    // ---- operand addresses ---------------------------------------------------------------------------------------------
+    const int half = lane >> 5;
+    const int vB = half * N_BLK + wn * 64 + 2 * (lane & 31);        // float2: positions (2n, 2n+1) of this wave's 64
+    int vA[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) vA[i] = XSZ + half * WROW + (wm * MT + i) * 32 + (lane & 31);
+    const int b_tile = rowinfo[0];
+    const float* sp = (p.in_scale && b_tile >= 0) ? p.in_scale + (int64_t)b_tile * p.in_scale_ld + half : nullptr;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto issue_dma = [&](int ch, float* buf) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            if (plds[i] >= 0) {
+                const float* src = psrc[i] + (int64_t)ch * pstride[i];
+                GLDS16C(src, buf + plds[i]);
+            }
+        }
+    };
+    float sc[2][NSTEP];                                              // prologue scales of the current / next chunk
+    auto load_scales = [&](int ch, int q) {
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const int ci = ch * KC + 2 * s + half;
+            sc[q][s] = (sp && ci < p.Cin) ? sp[ch * KC + 2 * s] : 1.f;
+        }
+    };
+
+    issue_dma(0, sbuf0);
+    load_scales(0, 0);
+    __syncthreads();
+
+    auto chunk = [&](auto curc, int ch) {
+        constexpr int cur = decltype(curc)::value;
+        const float* Bf = cur ? sbuf1 : sbuf0;
+        float* Nx = cur ? sbuf0 : sbuf1;
+        const bool more = (ch + 1) < a.nchunks;
+        if (more) { issue_dma(ch + 1, Nx); load_scales(ch + 1, cur ^ 1); }
+        float2 bv[2];
+        float av[2][MT];
+        auto load_step = [&](int s, int buf) {
+            bv[buf] = *reinterpret_cast<const float2*>(Bf + vB + 2 * s * N_BLK);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[buf][i] = Bf[vA[i] + 2 * s * WROW];
+        };
+        load_step(0, 0);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            if (s + 1 < NSTEP) load_step(s + 1, (s + 1) & 1);
+            const int bq = s & 1;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const float aw = av[bq][i] * sc[cur][s];
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, bv[bq].x, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw, bv[bq].y, acc[i][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    };
+    for (int ch = 0; ch < a.nchunks; ch += 2) {
+        chunk(std::integral_constant<int, 0>{}, ch);
+        if (ch + 1 < a.nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
+    }
+
+    // ---- epilogue: two consecutive positions per lane and output channel ---------------------------------------------
+    const int n = wn * 64 + 2 * (lane & 31);
+    const int rr = n >> a.tt_log2, tt = n & (TT - 1);
+    const int b = rowinfo[2 * rr];
+    const int f = rowinfo[2 * rr + 1];
+    const int t = t0 + tt;
+    if (b < 0 || t >= p.T) return;                                   // T % 2 == 0: both samples in range together
+    const int64_t ybase = (int64_t)b * p.y.sB + (int64_t)f * p.y.sF + t;
+    const int64_t rbase = p.res.p ? ((int64_t)b * p.res.sB + (int64_t)f * p.res.sF + t) : 0;
+    const int64_t abase = p.aux.p ? ((int64_t)b * p.aux.sB + (int64_t)f * p.aux.sF + t) : 0;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int mbase = m0 + (wm * MT + i) * 32 + 4 * half;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 4) {             // gather 4 rows, then compute + store (res may alias y)
+            float2 rv[4], uv[4];
+            float sv[4], as[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + q;
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                const bool ok = m < p.Cout;
+                rv[q] = (ok && p.res.p) ? *reinterpret_cast<const float2*>(p.res.p + rbase + (int64_t)m * p.res.sC) : make_float2(0.f, 0.f);
+                sv[q] = (ok && p.out_scale) ? p.out_scale[(int64_t)b * p.out_scale_ld + m] : 1.f;
+                if (ok && p.epi == 1) {
+                    as[q] = p.aux_scale[(int64_t)b * p.aux_scale_ld + m];
+                    uv[q] = *reinterpret_cast<const float2*>(p.aux.p + abase + (int64_t)m * p.aux.sC);
+                } else { as[q] = 0.f; uv[q] = make_float2(0.f, 0.f); }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + q;
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                if (m >= p.Cout) continue;
+                float y0 = acc[i][0][r] * sv[q], y1 = acc[i][1][r] * sv[q];
+                if (p.epi == 1) { y0 *= aid_dgelu(uv[q].x * as[q]); y1 *= aid_dgelu(uv[q].y * as[q]); }
+                y0 += p.res_scale * rv[q].x;
+                y1 += p.res_scale * rv[q].y;
+                *reinterpret_cast<float2*>(p.y.p + ybase + (int64_t)m * p.y.sC) = make_float2(p.alpha * y0, p.alpha * y1);
+            }
+        }
+    }
+}
+
+template <int MT, int WGM, int WGN, int RMAX, int KC, int MINW>
+static int launch_c11(const aid_conv2d_params* p, hipStream_t st) {
+    constexpr int M_BLK = 32 * MT * WGM;
+    constexpr int N_BLK = 64 * WGN;
+    static const float* zero = nullptr;
+    if (!zero) {
+        void* z = nullptr;
+        if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_aid_zero_page_c11)) != hipSuccess) { aid_set_error("aid_conv2d: zero page lookup failed"); return AID_E_LAUNCH; }
+        zero = (const float*)z;
+    }
+    C11Dev a;
+    a.p = *p;
+    a.zero = zero;
+    int TT = aid_pow2ceil(p->T);
+    if (TT > N_BLK) TT = N_BLK;
+    a.tt_log2 = aid_ilog2(TT);
+    const int ROWS = N_BLK / TT;
+    if (ROWS > RMAX) return 1000;
+    a.rows_log2 = aid_ilog2(ROWS);
+    a.tiles_t = aid_cdiv(p->T, TT);
+    a.nrows = p->B * p->F;
+    a.nchunks = aid_cdiv(p->Cin, KC);
+    a.nx = aid_cdiv(a.nrows, ROWS) * a.tiles_t;
+    a.ny = p->Cout_pad / M_BLK;
+    a.per_xcd = (a.nx * a.ny + 7) / 8;
+    hipLaunchKernelGGL((conv11_dma_kernel<MT, WGM, WGN, RMAX, KC, MINW>), dim3((unsigned)(8 * a.per_xcd)), dim3(64 * WGM * WGN), 0, st, a);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}
+
+// returns 1 if this kernel took the launch, 0 if not eligible, <0 on error
+int aid_conv1x1_dma_try(const aid_conv2d_params* p, hipStream_t st) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("AID_C1_DMA"); on = e ? atoi(e) : 1; }
+    if (!on || !(p->KH == 1 && p->KW == 1) || p->act != 0) return 0;
+    if (p->F == 1 || p->Cin < 32 || (p->Cin % 16) || p->Cout < 32) return 0;      // (K is walked in whole 16-channel chunks: no ragged tail)
+    if ((p->T % 4) || aid_pow2ceil(p->T) < 8) return 0;
+    auto al = [](const aid_view& v, int q) { return (v.sB % q) == 0 && (v.sC % q) == 0 && (v.sF % q) == 0 && (((uintptr_t)v.p) & (4 * q - 1)) == 0; };
+    if (!al(p->x, 4) || !al(p->y, 2) || (p->res.p && !al(p->res, 2)) || (p->aux.p && !al(p->aux, 2))) return 0;
+    if ((int64_t)4 * 16 * p->x.sC >= (1LL << 31)) return 0;
+    // a tile (256 positions) must stay inside one sample when a per-(b,ci) scale is applied to the weights
+    int TT = aid_pow2ceil(p->T); if (TT > 256) TT = 256;
+    const int ROWS = 256 / TT;
+    if (ROWS > 16) return 0;
+    if (p->in_scale && (p->F % ROWS)) return 0;
+    int rc;
+    if (p->Cout_pad % 128 == 0)      rc = launch_c11<2, 2, 4, 16, 16, 4>(p, st);      // 128 x 256, 8 waves, 2 workgroups / CU
+    else if (p->Cout_pad % 64 == 0)  rc = launch_c11<1, 2, 4, 16, 16, 4>(p, st);      //  64 x 256
+    else if (p->Cout_pad % 96 == 0)  rc = launch_c11<3, 1, 4, 16, 16, 2>(p, st);      //  96 x 256, 4 waves
+    else return 0;
+    if (rc == 1000) return 0;
+    return rc == AID_OK ? 1 : rc;
+}

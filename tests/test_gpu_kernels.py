@@ -95,6 +95,10 @@ CONV_CASES = [
     (3, 64, 40, 16, 64, 1, 1, 1, False, True),       # Cout padded to 64: masked rows
     (2, 512, 256, 8, 32, 1, 1, 1, False, True),      # K = 512, two 128-wide slices
     (4, 64, 64, 18, 32, 1, 1, 1, True, True),        # F*T = 9 * 64: the 64-positions-per-wave variant
+    # 1x1 with K >= 128 -> direct-to-LDS kernel (aid_conv1x1_dma.hip)
+    (2, 128, 96, 16, 64, 1, 1, 1, True, True),       # 96-wide tile (4 waves), prologue scale on the weight fragment
+    (1, 256, 192, 8, 128, 1, 1, 1, True, True),      # three 64-wide Cout tiles, two rows per tile
+    (2, 144, 128, 8, 256, 1, 1, 1, False, True),     # K = 9 chunks (odd chunk count), 128-wide tile
     # no prologue -> direct-to-LDS (global_load_lds) kernel
     (1, 64, 64, 24, 1024, 5, 3, 2, False, True),     # 64 x 512 tile, two t-tiles per row
     (2, 96, 96, 20, 256, 5, 3, 8, False, True),      # 96 x 256 tile (weight rows padded to 128 in LDS)

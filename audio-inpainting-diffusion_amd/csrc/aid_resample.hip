@@ -1,5 +1,7 @@
 // aid_resample: 2:1 cubic FIR resampling along T (reflect padding) and the exact adjoints of both maps.
-// HBM-bound; each thread produces 4 consecutive outputs (one float4 store), inputs come through L1/L2.
+// HBM-bound; each thread produces 4 consecutive outputs (one float4 store).  Interior threads fetch their input window with
+// 3-4 vector loads and evaluate the taps from registers (same terms, same order as the scalar formulas below, which remain
+// the path for the threads whose window touches a row border: reflect padding / folded adjoint terms).
 #include "aid_common.h"
 
 __constant__ float c_h[8] = {-0.01171875f, -0.03515625f, 0.11328125f, 0.43359375f,
@@ -8,6 +10,7 @@ __constant__ float c_h[8] = {-0.01171875f, -0.03515625f, 0.11328125f, 0.43359375
 struct ResDev {
     aid_resample_params p;
     int Tout, lpr_log2, nrows, tiles;   // tiles = thread-tiles per row
+    int xvec;                           // input view is float4-addressable: interior fast path allowed
 };
 
 __device__ __forceinline__ int refl(int i, int T) {
@@ -88,13 +91,62 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResDev a) {
     const float* x = p.x.p + (int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)f * p.x.sF;
     float* y = p.y.p + (int64_t)b * p.y.sB + (int64_t)c * p.y.sC + (int64_t)f * p.y.sF;
     float v[4];
+    if (a.xvec && o4 >= 8 && o4 + 12 <= a.Tout) {
+        // ---- interior: input window in registers -------------------------------------------------------------------
+        if (MODE == 0 || MODE == 3) {
+            // MODE 0: x[2*o4-4 .. 2*o4+11], output e = sum_k h[k] x[2(o4+e)+k-3]               -> w[2e+k+1]
+            // MODE 3: g[2*o4-4 .. 2*o4+11], output e = sum_q h[7-2q] g[2(o4+e+2-q)] + h[6-2q] g[2(o4+e+1-q)+1]
+            //                                                                                    -> w[2e+8-2q], w[2e+7-2q]
+            float w[16];
+            const float4* src = reinterpret_cast<const float4*>(x + 2 * o4 - 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int o = o4 + e;
-        if (MODE == 0) v[e] = down_at(x, p.T, o);
-        else if (MODE == 1) v[e] = up_at(x, p.T, o);
-        else if (MODE == 2) v[e] = down_adj_at(x, a.Tout, o);   // x holds g (T/2 entries), Tout = T of the down input
-        else v[e] = up_adj_at(x, a.Tout, o);                     // x holds g (2T entries), Tout = T of the up input
+            for (int q = 0; q < 4; ++q) { const float4 t = src[q]; w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s = 0.f;
+                if (MODE == 0) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s += c_h[k] * w[2 * e + k + 1];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        s += c_h[7 - 2 * q] * w[2 * e + 8 - 2 * q];
+                        s += c_h[6 - 2 * q] * w[2 * e + 7 - 2 * q];
+                    }
+                }
+                v[e] = s;
+            }
+        } else {
+            // MODE 1: x[o4/2-2 .. o4/2+3];  MODE 2: g[o4/2-2 .. o4/2+3]
+            float w[6];
+            const float2* src = reinterpret_cast<const float2*>(x + (o4 >> 1) - 2);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { const float2 t = src[q]; w[2 * q] = t.x; w[2 * q + 1] = t.y; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s;
+                if (MODE == 1) {
+                    const int m = e >> 1;                    // w index of x[m0 + m - 2]
+                    if ((e & 1) == 0) s = c_h[7] * w[m] + c_h[5] * w[m + 1] + c_h[3] * w[m + 2] + c_h[1] * w[m + 3];
+                    else              s = c_h[6] * w[m + 1] + c_h[4] * w[m + 2] + c_h[2] * w[m + 3] + c_h[0] * w[m + 4];
+                } else {
+                    s = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (((e + 3 - k) & 1) == 0) s += c_h[k] * w[((e + 3 - k) >> 1) + 2];     // g[(o4+e+3-k)/2]
+                }
+                v[e] = s;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int o = o4 + e;
+            if (MODE == 0) v[e] = down_at(x, p.T, o);
+            else if (MODE == 1) v[e] = up_at(x, p.T, o);
+            else if (MODE == 2) v[e] = down_adj_at(x, a.Tout, o);   // x holds g (T/2 entries), Tout = T of the down input
+            else v[e] = up_adj_at(x, a.Tout, o);                     // x holds g (2T entries), Tout = T of the up input
+        }
     }
     float4 r = make_float4(v[0], v[1], v[2], v[3]);
     if (p.accumulate) {
@@ -115,6 +167,7 @@ extern "C" int aid_resample(const aid_resample_params* p, void* stream) {
     AID_REQUIRE(a.Tout >= 4 && (a.Tout % 4) == 0, "aid_resample: output length must be a multiple of 4");
     AID_REQUIRE((p->y.sB % 4) == 0 && (p->y.sC % 4) == 0 && (p->y.sF % 4) == 0 && (((uintptr_t)p->y.p) & 15) == 0,
                 "aid_resample: output view must be float4-addressable");
+    a.xvec = ((p->x.sB % 4) == 0 && (p->x.sC % 4) == 0 && (p->x.sF % 4) == 0 && (((uintptr_t)p->x.p) & 15) == 0) ? 1 : 0;
     const int min_in = (mode == 0) ? 4 : (mode == 1 ? 3 : 0);
     AID_REQUIRE(p->T >= min_in, "aid_resample: input too short for reflect padding");
     int lpr = aid_pow2ceil(a.Tout / 4);

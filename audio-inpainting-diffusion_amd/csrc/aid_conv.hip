@@ -493,6 +493,7 @@ int aid_conv53_dma_try(const aid_conv2d_params* p, hipStream_t st);   // aid_con
 int aid_conv53_wino_try(const aid_conv2d_params* p, hipStream_t st);  // aid_conv_wino.hip
 int aid_conv1x1_stream_try(const aid_conv2d_params* p, hipStream_t st);  // aid_conv1x1.hip
 int aid_conv1x1_dma_try(const aid_conv2d_params* p, hipStream_t st);     // aid_conv1x1_dma.hip
+int aid_conv_small_try(const aid_conv2d_params* p, hipStream_t st);      // aid_conv_small.hip
 
 extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -518,6 +519,10 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     if (p->x_wino) {
         const int r = aid_conv53_wino_try(p, st);
         return r == 1 ? AID_OK : (r < 0 ? r : AID_E_BADARG);
+    }
+    if (p->Cin <= 8 || p->Cout <= 8) {
+        const int r = aid_conv_small_try(p, st);             // 2- / 8-channel projections: VALU streaming kernels
+        if (r != 0) return r < 0 ? r : AID_OK;
     }
     if (p->KH == 5 && p->KW == 3) {
         static int use_dma = -1;

@@ -147,13 +147,16 @@ extern "C" int aid_group_dot(const aid_group_dot_params* p, void* stream) {
 struct NbDev { aid_norm_bwd_params p; int cg, lpr_log2, nrows, tiles; float* coef; };
 
 // coef[b,g] = <gd,x>_g * inv / ((n-1) * std)   (written into the tail of the ws buffer as floats)
-__global__ void norm_bwd_coef(const NbDev a) {
+// one wave per (b, g): lane l adds partials l, l+64, ... then a fixed xor tree (deterministic)
+__global__ __launch_bounds__(64) void norm_bwd_coef(const NbDev a) {
     const aid_norm_bwd_params& p = a.p;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.B * p.groups) return;
+    const int i = blockIdx.x;
     const int nk = p.ws_n > 0 ? p.ws_n : AID_STATS_SPLIT;
     double d = 0.0;
-    for (int k = 0; k < nk; ++k) d += p.ws[(int64_t)i * nk + k];
+    for (int k = threadIdx.x; k < nk; k += 64) d += p.ws[(int64_t)i * nk + k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
+    if (threadIdx.x != 0) return;
     const double inv = (double)p.stats[2 * i + 1];
     const double sd = 1.0 / inv - (double)p.eps;
     const double n = (double)a.cg * p.F * p.T;
@@ -207,7 +210,7 @@ extern "C" int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream) {
     a.nrows = p->B * p->C * p->F;
     a.tiles = aid_cdiv(p->T / 4, lpr);
     const int rpb = 256 / lpr;
-    hipLaunchKernelGGL(norm_bwd_coef, dim3(aid_cdiv(p->B * p->groups, 64)), dim3(64), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(norm_bwd_coef, dim3(p->B * p->groups), dim3(64), 0, (hipStream_t)stream, a);
     AID_CHECK_LAUNCH();
     hipLaunchKernelGGL(norm_bwd_kernel, dim3((unsigned)(aid_cdiv(a.nrows, rpb) * a.tiles)), dim3(256), 0, (hipStream_t)stream, a);
     AID_CHECK_LAUNCH();

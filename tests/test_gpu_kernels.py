@@ -87,6 +87,13 @@ CONV_CASES = [
     (1, 320, 640, 1, 128, 1, 1, 1, False, False),    # qk GEMM, larger K (split-K through the scratch buffer)
     (2, 1024, 512, 1, 64, 1, 1, 1, False, True),     # qk-sized GEMM with gate + residual epilogue after the split-K reduction
     (3, 40, 40, 9, 12, 5, 3, 2, True, True),         # ragged: T not a power of two, odd row count
+    # few-channel layers -> VALU streaming kernels (aid_conv_small.hip)
+    (2, 96, 2, 12, 64, 5, 3, 4, False, True),        # pyramid-projection input gradient C -> 2
+    (2, 2, 96, 12, 64, 5, 3, 8, False, True),        # pyramid projection 2 -> C, dilation > F/2
+    (2, 64, 2, 10, 32, 1, 1, 1, True, True),         # out-block projection with prologue scale
+    (2, 96, 8, 6, 16, 1, 1, 1, True, False),         # attention proj_in
+    (2, 8, 64, 6, 16, 1, 1, 1, False, True),         # attention proj_out
+    (3, 2, 40, 5, 12, 1, 1, 1, False, False),        # ragged rows, Cout not a multiple of anything
     # 1x1 with enough positions -> streaming kernel (aid_conv1x1.hip)
     (2, 64, 192, 16, 64, 1, 1, 1, True, True),       # two 96-wide Cout slices, per-(b,ci) prologue scale
     (2, 96, 64, 8, 32, 1, 1, 1, False, True),        # 64-wide slice, a wave spans two rows

@@ -370,3 +370,105 @@ def test_mixed_radix_fft_vs_rocfft(L, Ls):
     y = tr.irfft(Y)
     assert rel_l2(y.cpu(), torch.fft.irfft(Y, n=Ls).cpu()) < 2e-6
     assert rel_l2(tr.irfft(X).cpu(), x) < 2e-6
+
+
+def test_conv2d_dispatch_fuzz(L):
+    """Seeded random sweep over the aid_conv2d dispatch space (F(4,3) with and without Winograd-domain input, direct
+    5x3, tiled / streaming / direct-to-LDS 1x1, few-channel VALU kernels, split-K) with strided views, residuals that
+    alias the output, dGELU epilogues and the dot partials: every launch against the fp64 reference."""
+    rng = np.random.default_rng(20260928)
+    n_checked, paths = 0, set()
+    for it in range(70):
+        k53 = bool(rng.integers(0, 2))
+        KH, KW = (5, 3) if k53 else (1, 1)
+        Cin = int(rng.choice([2, 8, 16, 40, 64, 96, 128, 144, 256]))
+        Cout = int(rng.choice([2, 8, 24, 64, 96, 128, 192, 256]))
+        T = int(rng.choice([8, 12, 16, 32, 48, 64, 128, 256]))
+        Fd = int(rng.choice([1, 3, 8, 12, 16])) if not k53 else int(rng.choice([5, 8, 12, 16, 24]))
+        B = int(rng.integers(1, 4))
+        if B * Cin * Fd * T * (15 if k53 else 1) * Cout > 4e9:
+            continue
+        dil = int(rng.choice([1, 2, 4, 16])) if k53 else 1
+        use_in = bool(rng.integers(0, 2))
+        act = int(use_in and rng.integers(0, 2))
+        use_out = bool(rng.integers(0, 2))
+        use_res = bool(rng.integers(0, 2))
+        epi = int(rng.integers(0, 3) == 0)
+        alias = use_res and bool(rng.integers(0, 2))            # residual = the output buffer (gradient accumulation)
+        wino = k53 and not use_in and Cin % 4 == 0 and Cout >= 64 and bool(rng.integers(0, 2))
+        xw = wino and bool(L.lib().aid_conv2d_wino_input_supported(Cin, Cout, T)) and bool(rng.integers(0, 2))
+        g = torch.Generator().manual_seed(1000 + it)
+        x = torch.randn(B, Cin, Fd, T, generator=g)
+        w = torch.randn(Cout, Cin, KH, KW, generator=g) / math.sqrt(Cin * KH * KW)
+        in_scale = (1.0 + 0.5 * torch.randn(B, Cin, generator=g)) if use_in else None
+        out_scale = torch.randn(B, Cout, generator=g) if use_out else None
+        res = torch.randn(B, Cout, Fd, T, generator=g) if use_res else None
+        aux = torch.randn(B, Cout, Fd, T, generator=g) if epi else None
+        asc = (1.0 + 0.3 * torch.randn(B, Cout, generator=g)) if epi else None
+        alpha, res_scale = float(rng.choice([1.0, 0.7071])), float(rng.choice([1.0, 1.5]))
+        h = x.double() * (in_scale.double()[:, :, None, None] if use_in else 1.0)
+        if act:
+            h = F.gelu(h)
+        ref = F.conv2d(h, w.double(), padding="same", dilation=(dil, 1) if k53 else 1)
+        if use_out:
+            ref = ref * out_scale.double()[:, :, None, None]
+        if epi:
+            u = aux.double() * asc.double()[:, :, None, None]
+            ref = ref * (0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi))
+        if use_res:
+            ref = ref + res_scale * res.double()
+        ref = alpha * ref
+        dev = lambda t: None if t is None else t.to(DEV)
+        xd, wd = x.to(DEV), w.to(DEV)
+        wp = L.pack_conv_weight(wd)
+        ybig = torch.full((B, Cout + 8, Fd, T), 7.0, device=DEV)
+        y = ybig[:, 4:4 + Cout]                                  # strided view (16-byte aligned channel offset)
+        resd = dev(res)
+        if alias:
+            y.copy_(resd)
+            resd = y
+        p = L.Conv2dParams()
+        keep = [dev(in_scale), dev(out_scale), dev(aux), dev(asc)]
+        xin = xd
+        if xw:
+            xin = torch.empty(B, Cin, Fd, 6 * (T // 4), device=DEV)
+            L.call("aid_scale_act", L.ScaleActParams(L.view4(xd), L.view4(xin), None, 0, B, Cin, Fd, T, 0, 1))
+        p.x, p.y, p.res, p.aux = L.view4(xin), L.view4(y), L.view4(resd), L.view4(keep[2])
+        p.wp = wp.data_ptr()
+        p.in_scale, p.in_scale_ld = L.ptr(keep[0]), (0 if keep[0] is None else keep[0].stride(0))
+        p.out_scale, p.out_scale_ld = L.ptr(keep[1]), (0 if keep[1] is None else keep[1].stride(0))
+        p.aux_scale, p.aux_scale_ld = L.ptr(keep[3]), (0 if keep[3] is None else keep[3].stride(0))
+        p.B, p.Cin, p.Cout, p.F, p.T = B, Cin, Cout, Fd, T
+        p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
+        p.KH, p.KW, p.dilF, p.act, p.epi = KH, KW, dil, act, epi
+        p.alpha, p.res_scale = alpha, res_scale
+        p.x_wino = int(xw)
+        if wino:
+            wpw = L.pack_conv_weight_wino(wd, f4=True)
+            p.wp_wino, p.wino_taps = wpw.data_ptr(), 30
+        ws = None
+        if Fd == 1 and not k53:
+            ws = torch.empty(8 * B * Cout * T, device=DEV)
+            p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        P = 0
+        dws = None
+        if wino and epi and not use_res:
+            P = int(L.lib().aid_conv2d_dot_partials(Cin, Cout, Fd, T))
+            if P:
+                dws = torch.full((B * 8 * (P + 1),), float("nan"), device=DEV, dtype=torch.float64)
+                p.dot_ws, p.dot_n = dws.data_ptr(), P
+        L.call("aid_conv2d", p)
+        torch.cuda.synchronize()
+        e = rel_l2(y.cpu().double(), ref)
+        tag = f"it{it} {KH}x{KW} B{B} Cin{Cin} Cout{Cout} F{Fd} T{T} d{dil} in{int(use_in)} act{act} out{int(use_out)} res{int(use_res)} alias{int(alias)} epi{epi} wino{int(wino)} xw{int(xw)} P{P}"
+        assert e < 2e-5, tag + f": rel-L2 {e:.2e}"
+        assert float(ybig[:, :4].min()) == 7.0 and float(ybig[:, 4 + Cout:].min()) == 7.0, tag + ": wrote outside its channel slice"
+        if P:
+            got = dws[:B * 8 * P].cpu().reshape(B, 8, P).sum(-1)
+            want = (y.cpu().double() * aux.double()).reshape(B, 8, Cout // 8, Fd, T).sum((2, 3, 4))
+            scale = float((y.cpu().double().abs() * aux.double().abs()).reshape(B, 8, -1).sum(-1).max())
+            assert float((got - want).abs().max()) < 1e-5 * scale, tag + ": dot partials"
+        n_checked += 1
+        paths.add((KH, wino, xw, Cin <= 8 or Cout <= 8, Fd == 1, bool(P)))
+    print(f"conv dispatch fuzz: {n_checked} launches, {len(paths)} distinct path classes")
+    assert n_checked >= 50 and len(paths) >= 8

@@ -199,7 +199,7 @@ def main():
                        "segments_per_gpu": B, "evals_per_step": 2,
                        "network": "unet_cqt_oct_with_attention %s, %.1f M params, random-init (seeded)" % ("44.1 kHz 8-octave" if a.workload == "musicnet44k" else "7-octave", sum(p.numel() for p in net.parameters()) / 1e6),
                        "parallelism": "segments sharded %d-way, one process per GPU, weights broadcast once (%.0f MB in %.3f s), no collective in the loop" % (world, nbytes / 1e6, t_bcast)},
-            "roofline": {"bound": "mfma", "kernel": "aid_conv2d: conv53_wino4v_kernel / conv53_wino4_kernel (Winograd F(4,3), 5x3 layers) + conv_mfma_kernel / conv1x1_stream_kernel (1x1), fp32 v_mfma_f32_32x32x2_f32",
+            "roofline": {"bound": "mfma", "kernel": "aid_conv2d: conv53_wino4v_kernel / conv53_wino4_kernel (Winograd F(4,3), 5x3 layers) + conv11_dma_kernel / conv_mfma_kernel (1x1, qk GEMMs), fp32 v_mfma_f32_32x32x2_f32",
                          "note": "achieved = ALGORITHMIC direct-form FLOPs / measured time; Winograd F(4,3) issues half of them as MFMAs (executed_mfma_tflops), so achieved can exceed the fp32 MFMA peak",
                          "achieved": round(achieved, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(achieved / 157.3, 4),
                          "traffic": None, "launches": len(timing), "avg_launch_us": round(1e3 * conv_ms / max(1, len(timing)), 1),

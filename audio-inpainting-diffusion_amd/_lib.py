@@ -140,6 +140,12 @@ class RowNormParams(C.Structure):
     _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("B", C.c_int), ("L", C.c_int64)]
 
 
+class ResamplePolyParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("kernel", C.c_void_p), ("x_ld", C.c_int64), ("y_ld", C.c_int64),
+                ("L", C.c_int64), ("Lout", C.c_int64), ("B", C.c_int), ("orig_freq", C.c_int), ("new_freq", C.c_int),
+                ("width", C.c_int), ("K", C.c_int)]
+
+
 class StftParams(C.Structure):
     _fields_ = [("x", C.c_void_p), ("frames", C.c_void_p), ("out", C.c_void_p),
                 ("window", C.c_void_p), ("twiddle", C.c_void_p), ("inv_env", C.c_void_p),
@@ -153,7 +159,7 @@ EXPORTS = ["aid_abi_version", "aid_last_error", "aid_group_stats", "aid_conv2d",
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
-           "aid_stft_frames", "aid_stft_ola", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials"]
+           "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials"]
 
 _lib = None
 

@@ -186,3 +186,37 @@ extern "C" int aid_resample(const aid_resample_params* p, void* stream) {
     AID_CHECK_LAUNCH();
     return AID_OK;
 }
+
+// =====================================================================================================
+// aid_resample_poly: rational-ratio polyphase sinc resampling of whole waveforms (the tester's pre-processing,
+// utils/training_utils.py:140-212 -> torchaudio.functional.resample(orig, new) with its default Hann-windowed sinc kernel).
+//   y[b, i*new + j] = sum_k kernel[j][k] * xpad[b, i*orig + k],  xpad = x zero-padded by (width, width + orig)
+// kernel [new][K = 2*width + orig] is built on the host (stft.py-style float64 table).  One thread per output sample;
+// the K-tap windows of neighbouring outputs overlap almost completely, so the loads are L1 hits.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void resample_poly_kernel(const aid_resample_poly_params p) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= p.Lout) return;
+    const int64_t i = n / p.new_freq;
+    const int j = (int)(n - i * p.new_freq);
+    const float* k = p.kernel + (int64_t)j * p.K;
+    const float* x = p.x + (int64_t)b * p.x_ld;
+    const int64_t base = i * p.orig_freq - p.width;
+    float acc = 0.f;
+    for (int t = 0; t < p.K; ++t) {
+        const int64_t q = base + t;
+        if (q >= 0 && q < p.L) acc += k[t] * x[q];
+    }
+    p.y[(int64_t)b * p.y_ld + n] = acc;
+}
+
+extern "C" int aid_resample_poly(const aid_resample_poly_params* p, void* stream) {
+    AID_REQUIRE(p && p->x && p->y && p->kernel, "aid_resample_poly: null pointer");
+    AID_REQUIRE(p->orig_freq > 0 && p->new_freq > 0 && p->K == 2 * p->width + p->orig_freq && p->L > 0 && p->Lout > 0 && p->B > 0,
+                "aid_resample_poly: bad geometry (K must be 2*width + orig_freq)");
+    AID_REQUIRE(p->Lout <= (p->L * p->new_freq + p->orig_freq - 1) / p->orig_freq, "aid_resample_poly: Lout exceeds ceil(new*L/orig)");
+    hipLaunchKernelGGL(resample_poly_kernel, dim3((unsigned)((p->Lout + 255) / 256), p->B), dim3(256), 0, (hipStream_t)stream, *p);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}

@@ -73,3 +73,96 @@ def inpaint_long(sampler, files: Sequence[torch.Tensor], gap_ms: float, sample_r
         x = x.reshape(-1).float()
         out.append(torch.cat((x[:s0], p, x[s0 + audio_len:])))       # (:415)
     return out
+
+
+# ---- waveform pre-/post-processing of the tester --------------------------------------------------------------------------------
+def _sinc_kernel(orig: int, new: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """Hann-windowed sinc per output phase, [new, 2*width + orig] float64 -- torchaudio's default resampling kernel."""
+    import math
+    import numpy as np
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = np.arange(-width, width + orig, dtype=np.float64)[None, :] / orig
+    t = np.arange(0, -new, -1, dtype=np.float64)[:, None] / new + idx
+    t = np.clip(t * base, -lowpass_filter_width, lowpass_filter_width)
+    window = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    k = np.where(t == 0, 1.0, np.sin(t) / np.where(t == 0, 1.0, t)) * window * (base / orig)
+    return k, width
+
+
+_KERNELS = {}
+
+
+def resample(x: torch.Tensor, orig_freq: int, new_freq: int) -> torch.Tensor:
+    """x [B, L] on the GPU -> [B, ceil(new*L/orig)]   (aid_resample_poly; replaces torchaudio.functional.resample)"""
+    import math
+    import numpy as np
+    from . import _lib
+    g = math.gcd(int(orig_freq), int(new_freq))
+    o, n = int(orig_freq) // g, int(new_freq) // g
+    if o == n:
+        return x
+    if not x.is_cuda:
+        raise _lib.AidError("harness.resample runs on the GPU only (no CPU fallback)")
+    key = (o, n, x.device)
+    if key not in _KERNELS:
+        k, width = _sinc_kernel(o, n)
+        _KERNELS[key] = (torch.from_numpy(np.ascontiguousarray(k, dtype=np.float32)).to(x.device), width)
+    k, width = _KERNELS[key]
+    x = x.contiguous().float()
+    B, L = x.shape
+    Lout = (n * L + o - 1) // o
+    y = torch.empty(B, Lout, device=x.device, dtype=torch.float32)
+    p = _lib.ResamplePolyParams(x.data_ptr(), y.data_ptr(), k.data_ptr(), x.stride(0), y.stride(0), L, Lout, B, o, n, width, k.shape[1])
+    _lib.call("aid_resample_poly", p)
+    return y
+
+
+def resample_batch(audio: torch.Tensor, fs, fs_target: int, length_target: int) -> torch.Tensor:
+    """resample_batch (utils/training_utils.py:140-212) for a batch recorded at one sampling rate ``fs`` (scalar or [B] tensor of
+    equal values; the reference's mixed-rate branches return after their first item and are not reproduced)."""
+    f = fs.reshape(-1) if torch.is_tensor(fs) else torch.tensor([fs])
+    if not bool((f == f[0]).all()):
+        raise NotImplementedError("mixed sampling rates in one batch")
+    f = int(f[0])
+    if fs_target == 22050 and f == 44100:
+        return resample(audio, 2, 1)[:, :length_target]
+    if fs_target == 22050 and f == 48000:
+        return resample(audio, 160 * 2, 147)[:, :length_target]            # the reference's approximation of 48k -> 22.05k (:152)
+    if fs_target == 44100 and f == 44100:
+        return audio[:, :length_target]
+    if fs_target == 44100 and f == 48000:
+        return resample(audio, 160, 147)[:, :length_target]
+    return resample(audio, f, fs_target)[:, :length_target]
+
+
+def write_audio_file(x: torch.Tensor, sr: int, string: str, path: str = "tmp") -> str:
+    """utils/logging.py:295-319 (mono branch): flatten, rescale when max(x) >= 1, 16-bit PCM wav (soundfile's default subtype for
+    .wav; written with the standard library, soundfile is not a dependency here)."""
+    import os
+    import wave
+    import numpy as np
+    os.makedirs(path, exist_ok=True)
+    fn = os.path.join(path, string + ".wav")
+    a = x.detach().flatten().cpu().numpy().astype(np.float64)
+    if np.abs(np.max(a)) >= 1:
+        a = a / np.abs(np.max(a))                                       # (sic: max, not max-abs -- as the reference)
+    pcm = np.clip(np.rint(a * 32767.0), -32768, 32767).astype("<i2")
+    with wave.open(fn, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(int(sr))
+        w.writeframes(pcm.tobytes())
+    return fn
+
+
+def read_wav(fn: str):
+    """(waveform float32 [1, L] in [-1, 1), sampling rate) of a 16-bit PCM mono wav"""
+    import wave
+    import numpy as np
+    with wave.open(fn, "rb") as w:
+        assert w.getsampwidth() == 2 and w.getnchannels() == 1
+        sr, n = w.getframerate(), w.getnframes()
+        a = np.frombuffer(w.readframes(n), dtype="<i2").astype(np.float32) / 32768.0
+    return torch.from_numpy(a).reshape(1, -1), sr

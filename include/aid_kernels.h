@@ -336,6 +336,23 @@ typedef struct { const float* x; float* out; int B; int64_t L; } aid_row_norm_pa
 int aid_row_norm(const aid_row_norm_params* p, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * aid_resample_poly -- rational-ratio (orig -> new) polyphase sinc resampling of whole waveforms.
+ *   replaces: torchaudio.functional.resample as called by resample_batch (utils/training_utils.py:140-212; used by
+ *             Tester.resample_audio, testing/tester_inpainting.py:558-560): 44.1k -> 22.05k (2:1), 48k -> 22.05k (320:147),
+ *             48k -> 44.1k (160:147), anything -> fs_target.
+ *   y[b, i*new + j] = sum_{k < K} kernel[j*K + k] * xpad[b, i*orig + k],  xpad = x zero-padded by `width` on the left,
+ *   K = 2*width + orig; orig/new already divided by their gcd; Lout <= ceil(new*L/orig) outputs are written.
+ *   The kernel table (Hann-windowed sinc, lowpass_filter_width 6, rolloff 0.99) is the host's (harness.py).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* x; float* y; const float* kernel;
+    int64_t x_ld, y_ld;           /* row strides of x [B, L] and y [B, Lout] */
+    int64_t L, Lout;
+    int B, orig_freq, new_freq, width, K;
+} aid_resample_poly_params;
+int aid_resample_poly(const aid_resample_poly_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * aid_stft_frames / aid_stft_ola -- the STFT-domain masking operator of spectrogram inpainting and its adjoint.
  *   replaces: Sampler.apply_spectral_mask (testing/edm_sampler_inpainting.py:271-290):
  *       x -> pad to a multiple of n_fft -> torch.stft(n_fft, hop, win, hann, center=True, reflect) -> * mask[F,T]

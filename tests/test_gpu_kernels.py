@@ -472,3 +472,23 @@ def test_conv2d_dispatch_fuzz(L):
         paths.add((KH, wino, xw, Cin <= 8 or Cout <= 8, Fd == 1, bool(P)))
     print(f"conv dispatch fuzz: {n_checked} launches, {len(paths)} distinct path classes")
     assert n_checked >= 50 and len(paths) >= 8
+
+
+@pytest.mark.parametrize("ratio", [(2, 1), (320, 147), (160, 147), (44100, 16000), (22050, 44100)])
+def test_polyphase_resampler_vs_oracle(L, ratio):
+    """aid_resample_poly through harness.resample against the oracle's restatement of torchaudio's default resampler, and the
+    resample_batch case logic (utils/training_utils.py:140-212)."""
+    from audio_inpainting_diffusion_amd.harness import resample, resample_batch
+    from oracle import resample as O
+    o, n = ratio
+    x = _rand(3, 50001, seed=60)
+    ref = O.resample(x.double(), o, n)
+    got = resample(x.to(DEV), o, n).cpu()
+    assert got.shape == ref.shape
+    assert rel_l2(got, ref) < 2e-6
+    if ratio == (2, 1):
+        a = _rand(2, 200000, seed=61)
+        out = resample_batch(a.to(DEV), torch.tensor([44100, 44100]), 22050, 65536).cpu()
+        assert out.shape == (2, 65536) and rel_l2(out, O.resample_batch(a.double(), 44100, 22050, 65536)) < 2e-6
+        out = resample_batch(a.to(DEV), torch.tensor([48000, 48000]), 22050, 65536).cpu()
+        assert rel_l2(out, O.resample_batch(a.double(), 48000, 22050, 65536)) < 2e-6

@@ -303,3 +303,28 @@ def test_checkpoint_loading_strategies_and_long_file_window():
     assert centre_gap_window(132300 * 2, 184184, 33075) == (132300 - 16537, 132300 - 92092)
     with pytest.raises(ValueError):
         centre_gap_window(1000, 184184, 10)
+
+
+def test_resampling_kernel_tables_wav_io_and_case_logic(tmp_path):
+    """harness._sinc_kernel == the oracle's restatement of torchaudio's default kernel; write_audio_file (utils/logging.py:295-319)
+    round-trips through read_wav; oracle resample: tone in -> same tone out, lengths ceil(new*L/orig)."""
+    from audio_inpainting_diffusion_amd.harness import _sinc_kernel, read_wav, write_audio_file
+    from oracle.resample import resample, resample_batch, sinc_resample_kernel
+    for o, n in ((2, 1), (320, 147), (160, 147), (441, 160), (147, 320)):
+        k, w = sinc_resample_kernel(o, n)
+        k2, w2 = _sinc_kernel(o, n)
+        assert w == w2 and k.shape[-1] == 2 * w + o and float(np.abs(k[:, 0].numpy() - k2).max()) < 1e-15
+    t = torch.arange(48000, dtype=torch.float64) / 48000
+    x = torch.sin(2 * np.pi * 1000 * t)[None]
+    y = resample(x, 320, 147)
+    assert y.shape[-1] == int(np.ceil(147 * 48000 / 320))
+    tt = torch.arange(y.shape[-1], dtype=torch.float64) * 320 / 147 / 48000
+    assert float((y[0, 200:-200] - torch.sin(2 * np.pi * 1000 * tt)[200:-200]).abs().max()) < 2e-3
+    assert resample_batch(torch.zeros(2, 100000), torch.tensor([44100, 44100]), 22050, 40000).shape == (2, 40000)
+    assert resample_batch(torch.zeros(1, 100000), 48000, 44100, 50000).shape == (1, 50000)
+    sig = 0.5 * torch.sin(2 * np.pi * 440 * torch.arange(2205) / 22050)
+    fn = write_audio_file(sig.reshape(1, -1), 22050, "tone", path=str(tmp_path))
+    back, sr = read_wav(fn)
+    assert sr == 22050 and back.shape == (1, 2205) and float((back[0] - sig).abs().max()) < 1.0 / 32767
+    loud = write_audio_file(4.0 * sig.reshape(1, -1), 22050, "loud", path=str(tmp_path))      # max >= 1 -> rescaled to peak 1
+    assert abs(float(read_wav(loud)[0].max()) - 32767 / 32768) < 1e-4

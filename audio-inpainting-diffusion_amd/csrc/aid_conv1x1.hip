@@ -165,45 +165,25 @@ int aid_conv1x1_stream_try(const aid_conv2d_params* p, hipStream_t st) {
     if (p->Cin < 16 || (p->Cin & 1) || p->Cout < 32) return 0;
     const int64_t ft = (int64_t)p->F * p->T;
     if (p->F == 1 || (int64_t)p->B * ft < 2048) return 0;            // few positions (qk GEMMs, F = 1): the tiled kernel's job
-    static int cfg = -1;
-    if (cfg < 0) { const char* e = getenv("AID_C1_CFG"); cfg = e ? atoi(e) : 0; }
-    if (cfg == 9) return 0;
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("AID_C1_STREAM"); on = e ? atoi(e) : 1; }
+    if (!on) return 0;
     // measured (profiles/r01_conv1x1_probe.txt): ahead of the register-staged tiled kernel for the short-K / write-dominated
     // projections (Cin <= 96: 8-35 %), behind it (10-18 %) once K >= 256 makes the layer MFMA-bound; the direct-to-LDS kernel
-    // (aid_conv1x1_dma.hip, tried first) is 17-20 % ahead of this one wherever it is eligible, so this kernel now serves the
-    // shapes that one refuses (K % 16 != 0, Cout tiles of 32)
-    if (cfg == 0 && !(p->Cin <= 96 || p->Cout_pad <= 32)) return 0;
-    int nt = (cfg == 0 || cfg == 1 || cfg == 4 || cfg == 5) ? 4 : 2;
-    if (nt == 4 && ((ft % 128) || (p->T % 4))) nt = 2;
+    // (aid_conv1x1_dma.hip, tried first) is 17-20 % ahead of this one wherever it is eligible, so this kernel serves the shapes
+    // that one refuses (K % 16 != 0, Cout tiles of 32).  128 positions per wave (float4 traffic) when the geometry allows, else 64.
+    if (!(p->Cin <= 96 || p->Cout_pad <= 32)) return 0;
+    int nt = 4;
+    if ((ft % 128) || (p->T % 4)) nt = 2;
     if ((ft % (32 * nt)) || (p->T % nt)) return 0;                  // a wave's positions stay inside one sample b, vectors inside one row
     if (!view_ok(p->x, nt) || !view_ok(p->y, nt)) return 0;
     if (p->res.p && !view_ok(p->res, nt)) return 0;
     if (p->aux.p && !view_ok(p->aux, nt)) return 0;
     const int mt32 = p->Cout_pad / 32;
     int rc;
-    if (cfg == 4) {
-        if (mt32 % 2 == 0) rc = launch_c1<2, 4, 8, 2>(p, st);
-        else               rc = launch_c1<1, 4, 8, 2>(p, st);
-    } else if (cfg == 5) {
-        rc = launch_c1<1, 4, 8, 2>(p, st);
-    } else if (cfg == 6) {
-        if (mt32 % 3 == 0)      rc = launch_c1<3, 2, 8, 2>(p, st);
-        else if (mt32 % 2 == 0) rc = launch_c1<2, 2, 8, 2>(p, st);
-        else                    rc = launch_c1<1, 2, 8, 2>(p, st);
-    } else if (cfg == 7) {
-        rc = launch_c1<1, 2, 8, 2>(p, st);
-    } else if (nt == 4) {                                           // default: 128 positions per wave, float4 traffic
+    if (nt == 4) {
         if (mt32 % 2 == 0) rc = launch_c1<2, 4, 4, 2>(p, st);
         else               rc = launch_c1<1, 4, 4, 2>(p, st);
-    } else if (cfg == 2) {                                           // widest slices: activations read once, 1-2 waves / SIMD
-        if (mt32 % 6 == 0)      rc = launch_c1<6, 2, 4, 1>(p, st);
-        else if (mt32 % 4 == 0) rc = launch_c1<4, 2, 4, 2>(p, st);
-        else if (mt32 % 3 == 0) rc = launch_c1<3, 2, 4, 2>(p, st);
-        else if (mt32 % 2 == 0) rc = launch_c1<2, 2, 4, 2>(p, st);
-        else                    rc = launch_c1<1, 2, 4, 2>(p, st);
-    } else if (cfg == 3) {                                           // narrow slices: 4-5 waves / SIMD, slices re-read x through L2
-        if (mt32 % 2 == 0) rc = launch_c1<2, 2, 4, 2>(p, st);
-        else               rc = launch_c1<1, 2, 4, 2>(p, st);
     } else {
         if (mt32 % 4 == 0)      rc = launch_c1<4, 2, 4, 2>(p, st);   // 128-wide slices, 2 waves / SIMD
         else if (mt32 % 3 == 0) rc = launch_c1<3, 2, 4, 2>(p, st);   // 96-wide (Cout 96, 192), 3 waves / SIMD

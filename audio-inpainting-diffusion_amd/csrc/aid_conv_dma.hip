@@ -310,18 +310,9 @@ int aid_conv53_dma_try(const aid_conv2d_params* p, hipStream_t st) {
     if ((p->x.sB % 4) || (p->x.sC % 4) || (p->x.sF % 4) || (((uintptr_t)p->x.p) & 15)) return 0;
     if ((int64_t)4 * p->x.sC >= (1LL << 31)) return 0;
     int rc;
-    static int cfg = -1;
-    if (cfg < 0) { const char* e = getenv("AID_DMA_CFG"); cfg = e ? atoi(e) : 0; }
-    if (cfg == 3 && p->Cout_pad % 64 == 0) rc = launch_dma<2, 2, 1, 4, 16, 2>(p, st);   // KC=2, 64x256, 4 waves: 3 workgroups per CU
-    else if (cfg == 5 && p->Cout_pad % 64 == 0) rc = launch_dma<1, 2, 2, 4, 16, 2>(p, st);   // KC=2, 64x256, 8 waves
-    else if (cfg == 6 && p->Cout_pad % 64 == 0) rc = launch_dma<1, 2, 2, 4, 16, 2, 6>(p, st);   // same, <= 80 VGPRs: 3 workgroups per CU
-    else if (cfg == 7 && p->Cout_pad % 64 == 0) rc = launch_dma<1, 2, 2, 4, 16, 2, 8>(p, st);   // same, <= 64 VGPRs: 4 workgroups per CU
-    else if (cfg == 4 && p->Cout_pad % 128 == 0) rc = launch_dma<1, 2, 4, 4, 16, 2>(p, st);   // KC=2, 128x256, 16 waves, 2 per CU
-    else if (cfg != 2 && p->Cout_pad % 64 == 0) rc = launch_dma<1, 2, 2, 4, 16>(p, st);   // 64 x 256, 8 waves, 2 workgroups per CU
-    else if (cfg == 1 && p->Cout_pad % 32 == 0) rc = launch_dma<1, 2, 1, 4, 16>(p, st);   // 32 x 256, 4 waves, 2-3 workgroups per CU
-    else if (p->Cout_pad % 128 == 0)      rc = launch_dma<1, 2, 4, 4, 32>(p, st);     // 128 x 256, 16 waves
+    // (round-1 experiments with 4/16-wave tiles, KC = 2 and 3-4 workgroups per CU are recorded in DESIGN.md section 3.1)
+    if (p->Cout_pad % 64 == 0)       rc = launch_dma<1, 2, 2, 4, 16>(p, st);     //  64 x 256, 8 waves, 2 workgroups per CU
     else if (p->Cout_pad % 96 == 0)  rc = launch_dma<1, 2, 3, 4, 32>(p, st);     //  96 x 256, 12 waves
-    else if (p->Cout_pad % 64 == 0)  rc = launch_dma<1, 2, 2, 8, 32>(p, st);     //  64 x 512, 16 waves
     else return 0;
     if (rc == 1000) return 0;
     return rc == AID_OK ? 1 : rc;

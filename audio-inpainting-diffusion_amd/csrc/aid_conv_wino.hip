@@ -1052,10 +1052,7 @@ static int conv53_wino_v(const aid_conv2d_params* p, hipStream_t st) {
     auto al4 = [](const aid_view& v) { return (v.sB % 4) == 0 && (v.sC % 4) == 0 && (v.sF % 4) == 0 && (((uintptr_t)v.p) & 15) == 0; };
     AID_REQUIRE(al4(p->x) && al4(p->y) && (!p->res.p || al4(p->res)) && (!p->aux.p || al4(p->aux)), "aid_conv2d: x_wino views must be 16-byte aligned");
     int rc;
-    static int vcfg = -1;
-    if (vcfg < 0) { const char* e = getenv("AID_WINO_VCFG"); vcfg = e ? atoi(e) : 0; }
-    if (vcfg == 1 && p->Cout_pad % 128 == 0) rc = launch_wino4v<2, 1, 2, 4, 16, 2, 2>(p, st);     // 128 x 512, 8 waves, 192 accumulators
-    else if (p->Cout_pad % 64 == 0) rc = launch_wino4v<1, 1, 2, 4, 16, 2, 2>(p, st);     // 64 x 512, 8 waves
+    if (p->Cout_pad % 64 == 0) rc = launch_wino4v<1, 1, 2, 4, 16, 2, 2>(p, st);     // 64 x 512, 8 waves
     else                       rc = launch_wino4v<1, 1, 3, 4, 16, 2, 3>(p, st);     // 96 x 512, 12 waves
     AID_REQUIRE(rc != 1000, "aid_conv2d: x_wino tile does not fit this T");
     return rc;
@@ -1072,26 +1069,18 @@ int aid_conv53_wino_try(const aid_conv2d_params* p, hipStream_t st) {
     if (p->res.p && ((p->res.sB % 2) || (p->res.sC % 2) || (p->res.sF % 2) || (((uintptr_t)p->res.p) & 7))) return 0;
     if (p->aux.p && ((p->aux.sB % 2) || (p->aux.sC % 2) || (p->aux.sF % 2) || (((uintptr_t)p->aux.p) & 7))) return 0;
     if ((int64_t)4 * p->x.sC >= (1LL << 31)) return 0;
-    static int cfg = -1;
-    if (cfg < 0) { const char* e = getenv("AID_WINO_CFG"); cfg = e ? atoi(e) : 0; }
     int rc;
     if (p->wino_taps == 30) {                              // F(4,3) pack
         if ((p->y.sB % 4) || (p->y.sC % 4) || (p->y.sF % 4) || (((uintptr_t)p->y.p) & 15)) return 0;
         if (p->res.p && ((p->res.sB % 4) || (p->res.sC % 4) || (p->res.sF % 4) || (((uintptr_t)p->res.p) & 15))) return 0;
         if (p->aux.p && ((p->aux.sB % 4) || (p->aux.sC % 4) || (p->aux.sF % 4) || (((uintptr_t)p->aux.p) & 15))) return 0;
-        if (cfg == 2 && p->Cout_pad % 64 == 0)      rc = launch_wino4<1, 1, 2, 2, 16, 2, 1>(p, st);   // 64 x 256, 4 waves
-        else if (cfg == 3 && p->Cout_pad % 64 == 0) rc = launch_wino4<1, 1, 2, 4, 16, 4, 3>(p, st);   // 64 x 512, 8 waves, KC=4
-        else if (p->Cout_pad % 64 == 0)             rc = launch_wino4<1, 1, 2, 4, 16, 2, 2>(p, st);   // 64 x 512, 8 waves (158 VGPRs: 1 workgroup / CU)
-        else if (cfg == 1 && p->Cout_pad % 96 == 0) rc = launch_wino4<1, 1, 3, 2, 16, 2, 1>(p, st);   // 96 x 256, 6 waves
-        else if (p->Cout_pad % 96 == 0)             rc = launch_wino4<1, 1, 3, 4, 16, 2, 3>(p, st);   // 96 x 512, 12 waves
+        if (p->Cout_pad % 64 == 0)      rc = launch_wino4<1, 1, 2, 4, 16, 2, 2>(p, st);   // 64 x 512, 8 waves, 1 workgroup / CU
+        else if (p->Cout_pad % 96 == 0) rc = launch_wino4<1, 1, 3, 4, 16, 2, 3>(p, st);   // 96 x 512, 12 waves
         else return 0;
         if (rc == 1000) return 0;
         return rc == AID_OK ? 1 : rc;
     }
-    if (cfg == 1 && p->Cout_pad % 64 == 0)      rc = launch_wino<1, 1, 2, 4, 16, 4>(p, st);   // 64 x 256, 8 waves, KC=4 (1 workgroup / CU)
-    else if (cfg == 2 && p->Cout_pad % 64 == 0) rc = launch_wino<1, 2, 2, 2, 16, 2>(p, st);   // 64 x 256, 4 waves, 128 acc
-    else if (cfg == 3 && p->Cout_pad % 64 == 0) rc = launch_wino<1, 1, 2, 4, 16, 2>(p, st);   // 64 x 256, 8 waves, KC=2, 132 VGPRs: 1 workgroup / CU
-    else if (p->Cout_pad % 64 == 0)             rc = launch_wino<1, 1, 2, 4, 16, 2, 4>(p, st);   // 64 x 256, 8 waves, KC=2, <=128 VGPRs: 2 workgroups / CU
+    if (p->Cout_pad % 64 == 0)                  rc = launch_wino<1, 1, 2, 4, 16, 2, 4>(p, st);   // 64 x 256, 8 waves, KC=2, <=128 VGPRs: 2 workgroups / CU
     else if (p->Cout_pad % 96 == 0)             rc = launch_wino<1, 1, 3, 4, 16, 2>(p, st);   // 96 x 256, 12 waves, KC=2
     else return 0;
     if (rc == 1000) return 0;

@@ -948,7 +948,6 @@ template <int MT, int NTT, int WGM, int WGN, int RMAX, int KC, int MINW = 1>
 static int launch_wino4(const aid_conv2d_params* p, hipStream_t st) {
     constexpr int M_BLK = 32 * MT * WGM;
     constexpr int N_BLK = 128 * NTT * WGN;
-    constexpr int WROW = (M_BLK % 64 == 0) ? M_BLK : ((M_BLK + 63) / 64) * 64;
     static const float* zero = nullptr;
     if (!zero) {
         void* z = nullptr;
@@ -986,7 +985,6 @@ template <int MT, int NTT, int WGM, int WGN, int RMAX, int KC, int MINW = 1>
 static int launch_wino4v(const aid_conv2d_params* p, hipStream_t st) {
     constexpr int M_BLK = 32 * MT * WGM;
     constexpr int N_BLK = 128 * NTT * WGN;
-    constexpr int WROW = (M_BLK % 64 == 0) ? M_BLK : ((M_BLK + 63) / 64) * 64;
     static const float* zero = nullptr;
     if (!zero) {
         void* z = nullptr;

@@ -59,9 +59,7 @@ class Sampler:
         if self.data_consistency or self.data_consistency_end:
             self.smooth = bool(dc.smooth)
         self.nb_steps = self.args.tester.T
-        self.rid = rid
-        if rid:
-            raise NotImplementedError("rid=True debug buffers are not built (SURVEY.md section 2, row 4)")
+        self.rid = rid                              # True: predict_* return the reference's 8-tuple of per-step buffers (:185-191, :260)
         self.spectral = None
         self.seeds: Optional[List[int]] = None      # per-item RNG seeds; None -> global torch CPU generator
         self.trace = None                           # set to [] to record every projected x_hat (tests)
@@ -128,6 +126,8 @@ class Sampler:
             s = -(float(t_i) * self.xi) / (normguide + 1e-6)                     # (:87), sign folded for the axpy
             out = torch.empty_like(x_hat)
             _lib.call("aid_axpby", _lib.AxpbyParams(x_hat.data_ptr(), rec_grads.data_ptr(), out.data_ptr(), None, s.data_ptr(), B, L))
+            if self.rid:                                                         # (:92-99: denoised estimate, s*rec_grads, updated estimate)
+                self._rid_last = (x_hat, -s[:, None] * rec_grads, out)
             return out                                                           # x_hat - s*rec_grads (:97)
         x = x.detach().requires_grad_()
         sig = t_i.reshape(1, 1).to(x.device).expand(B, 1)
@@ -144,7 +144,10 @@ class Sampler:
             rec_grads = torch.autograd.grad(outputs=norm.sum(), inputs=x)[0]
         normguide = torch.linalg.norm(rec_grads, dim=1, keepdim=True) / self.args.exp.audio_len ** 0.5
         s = float(t_i) * self.xi / (normguide + 1e-6)
-        return (x_hat.detach() - s * rec_grads).detach()
+        out = (x_hat.detach() - s * rec_grads).detach()
+        if self.rid:
+            self._rid_last = (x_hat.detach(), s * rec_grads, out)
+        return out
 
     def _score_step(self, x, x_hat, t_i, h, mode, x0=None, d0=None):
         """fused: projection (:343) + d = -t*score (:105,:230) + Euler proposal (:240) or Heun combine (:247)."""
@@ -154,7 +157,7 @@ class Sampler:
         proj = self.data_consistency and self.y is not None
         if proj and self.spectral is not None:                     # y + x_hat - A(x_hat)   (:360)
             x_hat, proj = self.spectral.project(x_hat, self.y), False
-        xh_out = torch.empty_like(x) if self.trace is not None else None
+        xh_out = torch.empty_like(x) if (self.trace is not None or self.rid) else None
         tv, hv = self._vec(t_i, B, x.device), self._vec(h, B, x.device)   # keep alive until after the launch
         p = _lib.ScoreStepParams(x.data_ptr(), x_hat.data_ptr(), _lib.ptr(self.y) if proj else None,
                                  _lib.ptr(self.smask) if proj else None, (self.smask.stride(0) if self.smask.shape[0] > 1 else 0) if proj else 0,
@@ -164,6 +167,7 @@ class Sampler:
         del tv, hv
         if self.trace is not None:
             self.trace.append(xh_out)
+        self._rid_pocs = xh_out
         return xnext, dout
 
     # ---------------------------------------------------------------------------------------------------
@@ -201,24 +205,39 @@ class Sampler:
             _lib.call("aid_axpby", p)                      # x + sqrt(t_hat^2 - t_i^2) * eps   (:214)
             del cv
             x = xn
+        rid = state.get("rid")
+        if rid is not None:
+            rid["xt"][i] = x.cpu()
         x_hat = self._denoise(x, t_hat)
         h = t[i + 1] - t_hat
         x_prime, d = self._score_step(x, x_hat, t_hat, h, mode=0)
+        if rid is not None:
+            rid["denoised"][i], rid["grads"][i], rid["grad_update"][i] = (v.cpu() for v in self._rid_last)
+            rid["pocs"][i] = self._rid_pocs.cpu()
         if t[i + 1] != 0 and self.order == 2:
             x_hat2 = self._denoise(x_prime, t[i + 1])
             x, _ = self._score_step(x_prime, x_hat2, t[i + 1], h, mode=1, x0=x, d0=d)
         else:
             x = x_prime
+        if rid is not None:
+            rid["xt2"][i] = x.cpu()
         state["x"] = x
         return state
 
     def predict(self, shape, device):
         state = self.begin(shape, device)
+        if self.rid:
+            if not (self.y is not None and self.xi > 0):
+                raise _lib.AidError("rid=True needs the reconstruction-guidance branch (the reference unpacks its 5-tuple only there, :217)")
+            state["rid"] = {k: torch.zeros((self.nb_steps,) + tuple(shape)) for k in ("denoised", "grads", "grad_update", "pocs", "xt", "xt2")}
         for i in range(self.nb_steps):
             self.step(state, i)
         x = state["x"]
         if self.data_consistency_end and self.y is not None:
             x = self.smask * self.y + (1 - self.smask) * x if self.spectral is None else self.spectral.project(x, self.y)
+        if self.rid:                                                             # (:260)
+            r = state["rid"]
+            return x.detach(), r["denoised"], r["grads"], r["grad_update"], r["pocs"], r["xt"], r["xt2"], state["t"]
         return x.detach()
 
     def predict_inpainting(self, y_masked, mask):

@@ -62,6 +62,7 @@ class OracleSampler:
         self.filter_hpf = filter_out_cqt_DC_Nyq
         self.audio_len = audio_len
         self.trace = None
+        self.rid = None                                 # set by predict_*(rid=True): per-step debug buffers (:185-191, :217-226, :255)
         self.degradation = lambda x: self.mask * x                                          # apply_mask (:264-269)
         self.project = lambda x: self.smask * self.y + (1 - self.smask) * x                 # (:343)
 
@@ -79,13 +80,16 @@ class OracleSampler:
             L = self.audio_len if self.audio_len is not None else x.shape[-1]
             normguide = torch.linalg.norm(g, dim=1, keepdim=True) / L ** 0.5                # (:83) per item
             s = t_i * self.xi / (normguide + 1e-6)                                          # (:87)
+            x_hat_old = x_hat.detach().clone()
             x_hat = (x_hat - s * g).detach()                                                # (:97)
             x = x.detach()
+            self._rid_last = (x_hat_old, (s * g).detach(), x_hat.clone())
         else:
             with torch.no_grad():
                 x_hat = self.edm.denoiser(x, self.model, sig)
         if self.data_consistency:
             x_hat = self.project(x_hat)                                                     # (:100, :343 / :360)
+        self._rid_pocs = x_hat.detach().clone()
         if self.trace is not None:
             self.trace.append(x_hat.detach().clone())
         return (x_hat - x) / t_i ** 2                                                       # (:105)
@@ -96,7 +100,8 @@ class OracleSampler:
         return torch.cat([torch.randn([1, shape[1]], generator=g) for g in gens], dim=0)
 
     # -- the loop (:178-262) -----------------------------------------------------------------------
-    def predict_inpainting(self, y_masked, mask, seeds: Optional[List[int]] = None, record: bool = False):
+    def predict_inpainting(self, y_masked, mask, seeds: Optional[List[int]] = None, record: bool = False, rid: bool = False):
+        self._want_rid = rid
         self.y, self.mask = y_masked, mask
         self.degradation = lambda x: self.mask * x
         self.project = lambda x: self.smask * self.y + (1 - self.smask) * x
@@ -117,6 +122,11 @@ class OracleSampler:
         y_masked = self.y
         self.trace = [] if record else None
         shape = y_masked.shape
+        rid = getattr(self, "_want_rid", False)
+        self._want_rid = False
+        if rid:
+            assert self.xi > 0, "the reference's rid buffers only exist on the guided branch (:217)"
+            R = {k: torch.zeros((self.nb_steps,) + tuple(shape)) for k in ("denoised", "grads", "grad_update", "pocs", "xt", "xt2")}
         gens = None if seeds is None else [torch.Generator().manual_seed(int(s)) for s in seeds]
         t = self.edm.create_schedule(self.nb_steps)
         x = self._randn(shape, gens) * t[0]
@@ -128,7 +138,12 @@ class OracleSampler:
                 t_hat = t[i] + gamma[i] * t[i]
                 eps = self._randn(shape, gens) * self.edm.Snoise
                 x = x + ((t_hat ** 2 - t[i] ** 2) ** (1 / 2)) * eps
+            if rid:
+                R["xt"][i] = x
             score = self.get_score(x, t_hat)
+            if rid:
+                R["denoised"][i], R["grads"][i], R["grad_update"][i] = self._rid_last
+                R["pocs"][i] = self._rid_pocs
             d = -t_hat * score
             h = t[i + 1] - t_hat
             if t[i + 1] != 0 and self.order == 2:
@@ -138,4 +153,8 @@ class OracleSampler:
                 x = x + h * ((1 / 2) * d + (1 / 2) * d_prime)
             else:
                 x = x + h * d
+            if rid:
+                R["xt2"][i] = x
+        if rid:                                                                             # (:260)
+            return x.detach(), R["denoised"], R["grads"], R["grad_update"], R["pocs"], R["xt"], R["xt2"], t
         return x.detach()

@@ -19,6 +19,7 @@ Fixtures written (inputs + reference outputs only -- data, not code):
                      (weights are regenerated from the seeded initialiser, seed stored)
   edm_schedule.npz   create_schedule / get_gamma for T in {35,36,70,128} with the tester parameters
   sampler_toy.npz    full sampler trajectories (reference Sampler + EDM driving a toy denoiser)
+  sampler_rid.npz        rid=True: the sampler's per-step debug buffers (denoised, grads, grad_update, pocs, xt, xt2, t)
   sampler_spectral.npz   spectrogram inpainting: apply_spectral_mask + full trajectories (guided / replacement)
   unet_full_cfgA.npz (--full) full-size 22.05 kHz network output for the seeded weights/input (B=1)
 """
@@ -199,6 +200,29 @@ def gen_sampler(out):
     np.savez_compressed(os.path.join(out, "sampler_toy.npz"), **d)
 
 
+def gen_rid(out):
+    """rid=True: the reference sampler's per-step debug buffers (edm_sampler_inpainting.py:185-191, :217-226, :255-260)."""
+    import diff_params.edm as E
+    import testing.edm_sampler_inpainting as S
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.init import seeded_normal
+    L, T = 2048, 4
+    net = _ToyNet(L)
+    args = make_args(audio_len=L, T=T, xi=0.25)
+    args.tester.data_consistency.hann_size = 20
+    smp = S.Sampler(model=net, diff_params=E.EDM(args), args=args, rid=True)
+    y = torch.from_numpy(seeded_normal(8, 0, L)).reshape(1, L) * 0.063
+    mask = torch.ones(1, L)
+    mask[:, 700:1000] = 0
+    torch.manual_seed(3)
+    res = smp.predict_inpainting(y * mask, mask)
+    names = ("out", "denoised", "grads", "grad_update", "pocs", "xt", "xt2", "t")
+    d = {n: r.numpy() for n, r in zip(names, res)}
+    d.update(y=(y * mask).numpy(), mask=mask.numpy(), L=np.array(L), T=np.array(T))
+    np.savez_compressed(os.path.join(out, "sampler_rid.npz"), **d)
+    print("rid", {n: tuple(r.shape) for n, r in zip(names, res)})
+
+
 def gen_spectral(out):
     """Spectrogram inpainting: the reference's apply_spectral_mask operator and full sampler trajectories."""
     import diff_params.edm as E
@@ -255,10 +279,11 @@ if __name__ == "__main__":
     a = ap.parse_args()
     _setup_imports()
     torch.set_grad_enabled(True)
-    todo = a.only.split(",") if a.only else ["ops", "unet", "edm", "sampler", "spectral"] + (["full"] if a.full else [])
+    todo = a.only.split(",") if a.only else ["ops", "unet", "edm", "sampler", "spectral", "rid"] + (["full"] if a.full else [])
     if "ops" in todo: gen_ops(HERE)
     if "unet" in todo: gen_unet_small(HERE)
     if "edm" in todo: gen_edm(HERE)
     if "sampler" in todo: gen_sampler(HERE)
     if "spectral" in todo: gen_spectral(HERE)
+    if "rid" in todo: gen_rid(HERE)
     if "full" in todo: gen_full(HERE)

@@ -239,3 +239,45 @@ def test_conv_epilogue_dot_partials(L, case):
     want = (yc * aux.double()).reshape(B, 8, Cout // 8, Fd, T).sum((2, 3, 4))
     assert torch.isfinite(got).all()
     assert float((got - want).abs().max()) < 1e-5 * float((yc.abs() * aux.double().abs()).reshape(B, 8, -1).sum(-1).max())
+
+
+def test_sampler_rid_debug_buffers_vs_oracle():
+    """Sampler(rid=True).predict_inpainting returns the reference's 8-tuple (edm_sampler_inpainting.py:185-191, :260)."""
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.sampler import Sampler
+    from oracle.edm import OracleEDM
+    from oracle.sampler import OracleSampler
+    net, orc, z, kw, args = _setup("a")
+    Ls = kw["audio_len"]
+    args.tester.T, args.tester.posterior_sampling.xi = 3, 0.25
+    args.tester.data_consistency.hann_size = 20
+    y = torch.from_numpy(z["x"]) * 0.126
+    mask = torch.ones(1, Ls)
+    mask[:, 1500:2100] = 0
+    smp = Sampler(model=net, diff_params=EDM(args), args=args, rid=True)
+    smp.seeds = [7, 8]
+    res = smp.predict_inpainting((y * mask).to(DEV), mask.to(DEV))
+    ref = OracleSampler(orc, OracleEDM(), T=3, xi=0.25, hann_size=20, audio_len=Ls).predict_inpainting(y * mask, mask, seeds=[7, 8], rid=True)
+    assert len(res) == 8
+    names = ("out", "denoised", "grads", "grad_update", "pocs", "xt", "xt2", "t")
+    for n, a, b in zip(names, res, ref):
+        assert tuple(a.shape) == tuple(b.shape), n
+        if n in ("denoised", "grads", "grad_update", "pocs", "xt"):
+            # first step is teacher-forced identical input; later steps inherit the (chaotic) drift of the trajectory
+            assert rel_l2(a[0].cpu(), b[0]) < 1e-4, n
+        assert rel_l2(a.cpu(), b) < 2e-3, n
+    smp0 = Sampler(model=net, diff_params=EDM(small_xi0(args)), args=small_xi0(args), rid=True)
+    with pytest.raises(L_AidError()):
+        smp0.predict_inpainting((y * mask).to(DEV), mask.to(DEV))
+
+
+def small_xi0(args):
+    import copy
+    a = copy.deepcopy(args)
+    a.tester.posterior_sampling.xi = 0.0
+    return a
+
+
+def L_AidError():
+    from audio_inpainting_diffusion_amd._lib import AidError
+    return AidError

@@ -147,3 +147,16 @@ def test_spectrogram_inpainting_operator_and_trajectories(tag):
     torch.manual_seed(int(seed))
     out = s.predict_spectrogram_inpainting(torch.from_numpy(z[tag + ".y"]), mask, stft=stft)
     assert rel_l2(out, z[tag + ".out"]) < 1e-5
+
+
+def test_sampler_rid_debug_buffers():
+    """rid=True (edm_sampler_inpainting.py:185-191, :217-226, :255-260): the 8-tuple of per-step buffers."""
+    z = np.load(os.path.join(GOLDEN, "sampler_rid.npz"))
+    L, T = int(z["L"]), int(z["T"])
+    s = OracleSampler(_Toy(L), OracleEDM(), T=T, xi=0.25, hann_size=20, audio_len=L)
+    torch.manual_seed(3)
+    res = s.predict_inpainting(torch.from_numpy(z["y"]), torch.from_numpy(z["mask"]), rid=True)
+    assert len(res) == 8
+    for name, r in zip(("out", "denoised", "grads", "grad_update", "pocs", "xt", "xt2", "t"), res):
+        assert tuple(r.shape) == z[name].shape, name
+        assert rel_l2(r, z[name]) < 1e-5, name

@@ -647,12 +647,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
     constexpr int WSZ_RAW = TAPS * KC * WROW;
     constexpr int WSZ = ((WSZ_RAW + 255) / 256) * 256;
     constexpr int BUFSZ = XSZ + WSZ;
-    constexpr int NXP = KC * KH * (XB / 256);
+    constexpr int NXP = XSZ / 256;                       // 1-KiB pieces over the whole x region (a piece may straddle two (ci,kh) blocks)
     constexpr int NWP = WSZ / 256;
     constexpr int NP = NXP + NWP;
     constexpr int PPW = (NP + NW - 1) / NW;
     constexpr int NSTEP = KH * (KC / 2);                // (kh, ci-pair) steps per chunk, 4*MT*NTT MFMAs each
-    static_assert(XB % 256 == 0 && NG % 128 == 0, "a 1-KiB piece is two half-planes of 32 lanes x 4 groups");
+    static_assert(XSZ % 256 == 0 && NG % 4 == 0, "whole 1-KiB pieces; a lane's 4 groups stay inside one plane");
 
     const aid_conv2d_params& p = a.p;
     const int TT = 1 << a.tt_log2;
@@ -705,14 +705,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
         const int pc = wave + i * NW;
         psrc[i] = a.zero; pstride[i] = 0; plds[i] = -1;
         if (pc < NXP) {
-            const int blk = pc / (XB / 256), q = pc % (XB / 256);
+            const int eg = pc * 256 + 4 * lane;          // float offset inside the x region = blk * XB + xi * NG + group
+            const int blk = eg / XB, e = eg % XB;
             const int ci = blk / KH, kh = blk % KH;
-            const int e = q * 256 + 4 * lane;            // float offset inside the block = xi * NG + group
             const int xi = e / NG, gq = e % NG;
             const int rr = gq >> (a.tt_log2 - 2), gl = gq & ((TT >> 2) - 1);
             const int b = rowinfo[2 * rr];
             const int fi = rowinfo[2 * rr + 1] + (kh - KH / 2) * p.dilF;
-            plds[i] = blk * XB + q * 256;
+            plds[i] = pc * 256;
             if (b >= 0 && fi >= 0 && fi < p.F && t0 + 4 * gl < p.T) {
                 psrc[i] = p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + (int64_t)xi * (p.T >> 2) + (t0 >> 2) + gl;
                 pstride[i] = (int)(KC * p.x.sC);
@@ -1018,6 +1018,17 @@ static int launch_wino4v(const aid_conv2d_params* p, hipStream_t st) {
     return AID_OK;
 }
 
+// Output positions per tile of the 64-wide F(4,3) kernels: 512, or 256 when a launch would otherwise put fewer than ~0.75
+// workgroups on each CU (small batches: the deep levels have few positions) -- twice the workgroups, 4 waves each.
+static int wino_tile_n(int B, int Cout_pad, int F, int T) {
+    if (Cout_pad % 64) return 512;
+    int TT = aid_pow2ceil(T); if (TT > 512) TT = 512;
+    const int64_t tiles = (int64_t)aid_cdiv((int64_t)B * F, 512 / TT) * aid_cdiv(T, TT) * (Cout_pad / 64);
+    static int thr = -1;
+    if (thr < 0) { const char* e = getenv("AID_WINO_SMALL_GRID"); thr = e ? atoi(e) : 160; }     // measured: B=1 +12 %, B=2 neutral, B>=4 never triggers on the shipped networks
+    return (tiles <= thr && aid_pow2ceil(T) >= 16) ? 256 : 512;
+}
+
 static bool wino_v_shape_ok(int Cin, int Cout, int T) {
     int cip, cop;
     aid_conv2d_pack_dims(Cin, Cout, &cip, &cop);
@@ -1027,16 +1038,17 @@ static bool wino_v_shape_ok(int Cin, int Cout, int T) {
 extern "C" int aid_conv2d_wino_input_supported(int Cin, int Cout, int T) { return wino_v_shape_ok(Cin, Cout, T) ? 1 : 0; }
 
 // tiles per sample of the F(4,3) kernels (64|96 x 512 tiles) when the per-tile <y, aux> partials are well defined
-extern "C" int aid_conv2d_dot_partials(int Cin, int Cout, int F, int T) {
+extern "C" int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T) {
     int cip, cop;
     aid_conv2d_pack_dims(Cin, Cout, &cip, &cop);
     if ((Cin % 4) || Cout < 64 || (Cout % 8) || (T % 4) || aid_pow2ceil(T) < 8) return 0;
     const int mblk = (cop % 64 == 0) ? 64 : ((cop % 96 == 0) ? 96 : 0);
     const int cpg = Cout / 8;
     if (!mblk || (cpg % 4) || (mblk % cpg)) return 0;
+    const int nblk = wino_tile_n(B, cop, F, T);
     int TT = aid_pow2ceil(T);
-    if (TT > 512) TT = 512;
-    const int ROWS = 512 / TT;
+    if (TT > nblk) TT = nblk;
+    const int ROWS = nblk / TT;
     if (ROWS > 16 || (F % ROWS)) return 0;
     return (F / ROWS) * aid_cdiv(T, TT);
 }
@@ -1050,7 +1062,9 @@ static int conv53_wino_v(const aid_conv2d_params* p, hipStream_t st) {
     auto al4 = [](const aid_view& v) { return (v.sB % 4) == 0 && (v.sC % 4) == 0 && (v.sF % 4) == 0 && (((uintptr_t)v.p) & 15) == 0; };
     AID_REQUIRE(al4(p->x) && al4(p->y) && (!p->res.p || al4(p->res)) && (!p->aux.p || al4(p->aux)), "aid_conv2d: x_wino views must be 16-byte aligned");
     int rc;
-    if (p->Cout_pad % 64 == 0) rc = launch_wino4v<1, 1, 2, 4, 16, 2, 2>(p, st);     // 64 x 512, 8 waves
+    if (p->Cout_pad % 64 == 0 && wino_tile_n(p->B, p->Cout_pad, p->F, p->T) == 256)
+                               rc = launch_wino4v<1, 1, 2, 2, 16, 2, 2>(p, st);     // 64 x 256, 4 waves: small grids
+    else if (p->Cout_pad % 64 == 0) rc = launch_wino4v<1, 1, 2, 4, 16, 2, 2>(p, st);     // 64 x 512, 8 waves
     else                       rc = launch_wino4v<1, 1, 3, 4, 16, 2, 3>(p, st);     // 96 x 512, 12 waves
     AID_REQUIRE(rc != 1000, "aid_conv2d: x_wino tile does not fit this T");
     return rc;
@@ -1072,7 +1086,9 @@ int aid_conv53_wino_try(const aid_conv2d_params* p, hipStream_t st) {
         if ((p->y.sB % 4) || (p->y.sC % 4) || (p->y.sF % 4) || (((uintptr_t)p->y.p) & 15)) return 0;
         if (p->res.p && ((p->res.sB % 4) || (p->res.sC % 4) || (p->res.sF % 4) || (((uintptr_t)p->res.p) & 15))) return 0;
         if (p->aux.p && ((p->aux.sB % 4) || (p->aux.sC % 4) || (p->aux.sF % 4) || (((uintptr_t)p->aux.p) & 15))) return 0;
-        if (p->Cout_pad % 64 == 0)      rc = launch_wino4<1, 1, 2, 4, 16, 2, 2>(p, st);   // 64 x 512, 8 waves, 1 workgroup / CU
+        if (p->Cout_pad % 64 == 0 && wino_tile_n(p->B, p->Cout_pad, p->F, p->T) == 256)
+                                        rc = launch_wino4<1, 1, 2, 2, 16, 2, 2>(p, st);   // 64 x 256, 4 waves: small grids
+        else if (p->Cout_pad % 64 == 0) rc = launch_wino4<1, 1, 2, 4, 16, 2, 2>(p, st);   // 64 x 512, 8 waves, 1 workgroup / CU
         else if (p->Cout_pad % 96 == 0) rc = launch_wino4<1, 1, 3, 4, 16, 2, 3>(p, st);   // 96 x 512, 12 waves
         else return 0;
         if (rc == 1000) return 0;

@@ -113,6 +113,7 @@ CONV_CASES = [
     (2, 256, 256, 24, 32, 5, 3, 64, False, True),    # two M tiles, ROWS = 8, dilation larger than F
     (3, 64, 128, 9, 12, 5, 3, 1, False, False),      # ragged T (zero-page columns), odd rows, Cin != Cout
     (1, 128, 64, 7, 8, 5, 3, 2, False, True),        # ROWS = 32 (halo area full)
+    (2, 64, 64, 128, 512, 5, 3, 2, False, True),     # 256 tiles of 512 positions: the full-grid 64 x 512 configuration (smaller launches take 64 x 256)
 ]
 
 
@@ -168,6 +169,7 @@ WINO_V_CASES = [
     (1, 128, 128, 40, 128, 16, 1, True),     # two M tiles, ROWS = 4
     (2, 256, 256, 24, 32, 64, 1, True),      # ROWS = 16, dilation larger than F
     (3, 64, 128, 9, 48, 1, 0, False),        # T not a power of two (zero-page groups), odd rows
+    (2, 64, 64, 128, 512, 4, 1, True),       # 256 tiles of 512 positions: the full-grid 64 x 512 configuration (smaller launches take 64 x 256)
     (1, 64, 96, 12, 64, 4, 1, True),         # 96-wide M tile (12 waves)
 ]
 
@@ -453,7 +455,7 @@ def test_conv2d_dispatch_fuzz(L):
         P = 0
         dws = None
         if wino and epi and not use_res:
-            P = int(L.lib().aid_conv2d_dot_partials(Cin, Cout, Fd, T))
+            P = int(L.lib().aid_conv2d_dot_partials(B, Cin, Cout, Fd, T))
             if P:
                 dws = torch.full((B * 8 * (P + 1),), float("nan"), device=DEV, dtype=torch.float64)
                 p.dot_ws, p.dot_n = dws.data_ptr(), P

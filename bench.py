@@ -206,6 +206,7 @@ def main():
                          "algorithmic_gflop_per_launch": round(conv_flops / max(1, len(timing)) / 1e9, 2),
                          "algorithmic_mb_per_launch": round(sum(t[4] for t in timing) / max(1, len(timing)) / 1e6, 1),
                          "executed_mfma_tflops": round(exec_flops / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else 0.0,
+                         "frac_executed_mfma": round(exec_flops / (conv_ms * 1e-3) / 1e12 / 157.3, 4) if conv_ms > 0 else 0.0,
                          "conv_time_fraction_of_wall": round(conv_ms * 1e-3 / wall, 3)},
         }
         tr = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")     # PMC pass of this same command (see profiles/README.md)

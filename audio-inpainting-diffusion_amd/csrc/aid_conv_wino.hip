@@ -32,6 +32,23 @@ __device__ float4 g_aid_zero_page_w[16];   // (device symbols are per translatio
 #define GLDS16W(gptr, lptr) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
+// Direct-to-LDS loads issued through inline asm (used by the triple-buffered Winograd-domain-input kernel): the compiler's
+// waitcnt insertion cannot tell which LDS buffer a global_load_lds writes and would drain vmcnt before the next ds_read of
+// ANY buffer; issued this way it does not see them and the kernel places its own s_waitcnt vmcnt(n).  vmcnt completes in
+// order, so every wait the compiler emits for its own loads stays correct (it can only over-wait).  M0 is a reserved
+// register: nothing else in these kernels keeps a value in it.
+#define AID_LDS_ADDR(lptr) ((unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)(lptr))
+#define AID_DMA16_RAW(gptr, lds_addr) \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gptr), "s"(lds_addr) : "memory")
+// s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
+#define AID_VMCNT(n) ((((n) & 15) | (7 << 4) | (15 << 8) | ((((n) >> 4) & 3) << 14)))
+#define AID_LGKMCNT0 (15 | (7 << 4) | (0 << 8) | (3 << 14))
+
+template <typename F, int... I>
+__device__ __forceinline__ void aid_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void aid_static_for(F&& f) { aid_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // MT m-tiles (32 cout) x NTT tau-tiles (32 tau = 64 outputs) per wave; WGM x WGN waves; N_BLK = 64*NTT*WGN outputs
 template <int MT, int NTT, int WGM, int WGN, int RMAX, int KC, int MINW>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino_kernel(const ConvWinoDev a) {
@@ -658,12 +675,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
     const int TT = 1 << a.tt_log2;
     const int ROWS = 1 << a.rows_log2;
 
-    // Two STATIC buffers (not one dynamic array): distinct LDS objects carry alias scopes after LDS lowering, so the
-    // waitcnt pass knows the ds_reads of chunk c cannot touch the buffer the direct-to-LDS loads of chunk c+1 write,
-    // and leaves those loads in flight for the whole chunk (with a single dynamic array it emitted s_waitcnt vmcnt(0)
-    // right after issuing them: the "asynchronous" staging was synchronous).
+    // THREE static buffers and a SPREAD issue: the direct-to-LDS loads of chunk c+2 are issued one or two per k-step
+    // while chunk c is multiplied.  Issuing a chunk's ~45 KiB of loads back to back at the top of a chunk (8 waves x 6
+    // instructions, 16 texture-address cycles each) back-pressured the vector-memory issue and held every wave's MFMA stream
+    // behind it: removing the loads gave +15-22 % (PMC: matrix pipe 76 -> 88 % busy at the same clock), a deeper prefetch
+    // alone nothing.  Spreading needs the extra chunk of distance: the last pieces are issued near the end of a chunk.
     __shared__ __attribute__((aligned(16))) float sbuf0[BUFSZ];
     __shared__ __attribute__((aligned(16))) float sbuf1[BUFSZ];
+    __shared__ __attribute__((aligned(16))) float sbuf2[BUFSZ];
     __shared__ int rowinfo[2 * RMAX];
 
     const int tid = threadIdx.x;
@@ -749,27 +768,34 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][x][r] = 0.f;
 
-    auto issue_dma = [&](int ch, float* buf) {
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            if (plds[i] >= 0) {
-                const float* src = psrc[i] + (int64_t)ch * pstride[i];
-                GLDS16W(src, buf + plds[i]);
-            }
+    static_assert(NP > (PPW - 1) * NW, "every wave owns PPW or PPW-1 pieces");
+    const int mine = (wave + (PPW - 1) * NW < NP) ? PPW : PPW - 1;      // loads this wave issues per chunk (exact)
+    auto issue_piece = [&](auto ic, int ch, float* buf) {
+        constexpr int i = decltype(ic)::value;
+        if (wave + i * NW < NP) {
+            const float* src = psrc[i] + (int64_t)ch * pstride[i];
+            const unsigned la = AID_LDS_ADDR(buf + plds[i]);
+            AID_DMA16_RAW(src, la);
         }
     };
+    auto issue_all = [&](int ch, float* buf) { aid_static_for<PPW>([&](auto ic) { issue_piece(ic, ch, buf); }); };
+    // pieces i with i % NSTEP == s are issued at k-step s
+    auto issue_step = [&](auto sc, int ch, float* buf) {
+        aid_static_for<PPW>([&](auto ic) {
+            if constexpr (decltype(ic)::value % NSTEP == decltype(sc)::value) issue_piece(ic, ch, buf);
+        });
+    };
 
-    issue_dma(0, sbuf0);
+    issue_all(0, sbuf0);
+    if (a.nchunks > 1) issue_all(1, sbuf1);
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 
     auto chunk = [&](auto curc, int ch) {
         constexpr int cur = decltype(curc)::value;
-        const float* Bf = cur ? sbuf1 : sbuf0;
-        float* Nx = cur ? sbuf0 : sbuf1;
-        const bool more = (ch + 1) < a.nchunks;
-#if !(WINO_EXP & 1)
-        if (more) issue_dma(ch + 1, Nx);
-#endif
+        const float* Bf = cur == 0 ? sbuf0 : (cur == 1 ? sbuf1 : sbuf2);
+        float* Nx = cur == 0 ? sbuf2 : (cur == 1 ? sbuf0 : sbuf1);       // buffer (cur + 2) % 3: read during the previous chunk
+        const bool more = (ch + 2) < a.nchunks;
         // fragments of step s+1 are fetched while the MFMAs of step s run
         float bv[2][NTT][NXI];
         float av[2][MT][NXI];
@@ -787,14 +813,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
                     av[buf][i][x] = Bf[vA[i] + ((x * KH + kh) * KC + 2 * cp) * WROW];
         };
         load_step(0, 0);
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
+        aid_static_for<NSTEP>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
             if (s == 0) __builtin_amdgcn_s_setprio(3);
             else if (s == (NSTEP + 3) / 4) __builtin_amdgcn_s_setprio(2);
             else if (s == (NSTEP + 1) / 2) __builtin_amdgcn_s_setprio(1);
             else if (s == (3 * NSTEP + 3) / 4) __builtin_amdgcn_s_setprio(0);
+#if !(WINO_EXP & 1)
+            if (more) issue_step(sc, ch + 2, Nx);        // this step's share of the loads of chunk ch+2
+#endif
             if (s + 1 < NSTEP) load_step(s + 1, (s + 1) & 1);
-            const int bq = s & 1;
+            constexpr int bq = s & 1;
 #pragma unroll
             for (int j = 0; j < NTT; ++j)
 #pragma unroll
@@ -802,14 +831,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
 #pragma unroll
                     for (int x = 0; x < NXI; ++x)
                         acc[i][j][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[bq][i][x], bv[bq][j][x], acc[i][j][x], 0, 0, 0);
+        });
+        // End of chunk: the loads of chunk ch+1 (issued during the previous chunk) must have landed; those of chunk ch+2
+        // (`mine` instructions of this wave, issued during this chunk) stay in flight.  __syncthreads() would drain them
+        // (its release fence waits for every outstanding VMEM store, LDS-DMA included), so the barrier is spelled out.
+        asm volatile("" ::: "memory");
+        if (more) {
+            if (mine == PPW) __builtin_amdgcn_s_waitcnt(AID_VMCNT(PPW)); else __builtin_amdgcn_s_waitcnt(AID_VMCNT(PPW - 1));
+        } else {
+            __builtin_amdgcn_s_waitcnt(AID_VMCNT(0));
         }
-#if !(WINO_EXP & 2)
-        __syncthreads();
-#endif
+        __builtin_amdgcn_s_waitcnt(AID_LGKMCNT0);        // this wave's reads of the buffer that is overwritten next
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     };
-    for (int ch = 0; ch < a.nchunks; ch += 2) {
+    for (int ch = 0; ch < a.nchunks; ch += 3) {
         chunk(std::integral_constant<int, 0>{}, ch);
         if (ch + 1 < a.nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
+        if (ch + 2 < a.nchunks) chunk(std::integral_constant<int, 2>{}, ch + 2);
     }
     __builtin_amdgcn_s_setprio(0);
 
@@ -1032,7 +1071,7 @@ static int wino_tile_n(int B, int Cout_pad, int F, int T) {
 static bool wino_v_shape_ok(int Cin, int Cout, int T) {
     int cip, cop;
     aid_conv2d_pack_dims(Cin, Cout, &cip, &cop);
-    return (Cin % 4) == 0 && Cout >= 64 && ((cop % 64) == 0 || (cop % 96) == 0) && (T % 16) == 0 && T >= 32;
+    return (Cin % 4) == 0 && Cout >= 64 && (cop % 64) == 0 && (T % 16) == 0 && T >= 32;
 }
 
 extern "C" int aid_conv2d_wino_input_supported(int Cin, int Cout, int T) { return wino_v_shape_ok(Cin, Cout, T) ? 1 : 0; }
@@ -1065,7 +1104,7 @@ static int conv53_wino_v(const aid_conv2d_params* p, hipStream_t st) {
     if (p->Cout_pad % 64 == 0 && wino_tile_n(p->B, p->Cout_pad, p->F, p->T) == 256)
                                rc = launch_wino4v<1, 1, 2, 2, 16, 2, 2>(p, st);     // 64 x 256, 4 waves: small grids
     else if (p->Cout_pad % 64 == 0) rc = launch_wino4v<1, 1, 2, 4, 16, 2, 2>(p, st);     // 64 x 512, 8 waves
-    else                       rc = launch_wino4v<1, 1, 3, 4, 16, 2, 3>(p, st);     // 96 x 512, 12 waves
+    else { aid_set_error("aid_conv2d: x_wino needs a 64-wide Cout tile (the 96-wide tile keeps the in-kernel transform: measured 5 % faster there)"); return AID_E_BADARG; }
     AID_REQUIRE(rc != 1000, "aid_conv2d: x_wino tile does not fit this T");
     return rc;
 }

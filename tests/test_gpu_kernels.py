@@ -170,7 +170,6 @@ WINO_V_CASES = [
     (2, 256, 256, 24, 32, 64, 1, True),      # ROWS = 16, dilation larger than F
     (3, 64, 128, 9, 48, 1, 0, False),        # T not a power of two (zero-page groups), odd rows
     (2, 64, 64, 128, 512, 4, 1, True),       # 256 tiles of 512 positions: the full-grid 64 x 512 configuration (smaller launches take 64 x 256)
-    (1, 64, 96, 12, 64, 4, 1, True),         # 96-wide M tile (12 waves)
 ]
 
 

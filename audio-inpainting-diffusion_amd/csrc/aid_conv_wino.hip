@@ -44,6 +44,18 @@ __device__ float4 g_aid_zero_page_w[16];   // (device symbols are per translatio
 #define AID_VMCNT(n) ((((n) & 15) | (7 << 4) | (15 << 8) | ((((n) >> 4) & 3) << 14)))
 #define AID_LGKMCNT0 (15 | (7 << 4) | (0 << 8) | (3 << 14))
 
+#ifndef AID_SPREAD
+#define AID_SPREAD 0
+#endif
+#if AID_SPREAD == 0
+#define AID_SPREAD_RULE(i, s, n) ((i) % (n) == (s))
+#elif AID_SPREAD == 1
+#define AID_SPREAD_RULE(i, s, n) ((i) / 2 == (s))
+#elif AID_SPREAD == 2
+#define AID_SPREAD_RULE(i, s, n) (((i) % ((n) - 1)) + 1 == (s))
+#else
+#define AID_SPREAD_RULE(i, s, n) ((s) == 0)
+#endif
 template <typename F, int... I>
 __device__ __forceinline__ void aid_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, typename F>
@@ -782,7 +794,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
     // pieces i with i % NSTEP == s are issued at k-step s
     auto issue_step = [&](auto sc, int ch, float* buf) {
         aid_static_for<PPW>([&](auto ic) {
-            if constexpr (decltype(ic)::value % NSTEP == decltype(sc)::value) issue_piece(ic, ch, buf);
+            if constexpr (AID_SPREAD_RULE(decltype(ic)::value, decltype(sc)::value, NSTEP)) issue_piece(ic, ch, buf);
         });
     };
 
@@ -836,13 +848,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
         // (`mine` instructions of this wave, issued during this chunk) stay in flight.  __syncthreads() would drain them
         // (its release fence waits for every outstanding VMEM store, LDS-DMA included), so the barrier is spelled out.
         asm volatile("" ::: "memory");
+#if !(WINO_EXP & 64)
         if (more) {
             if (mine == PPW) __builtin_amdgcn_s_waitcnt(AID_VMCNT(PPW)); else __builtin_amdgcn_s_waitcnt(AID_VMCNT(PPW - 1));
         } else {
             __builtin_amdgcn_s_waitcnt(AID_VMCNT(0));
         }
+#endif
         __builtin_amdgcn_s_waitcnt(AID_LGKMCNT0);        // this wave's reads of the buffer that is overwritten next
+#if !(WINO_EXP & 2)
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
     };
     for (int ch = 0; ch < a.nchunks; ch += 3) {

@@ -1,17 +1,17 @@
-"""MI355X-native EDM inpainting sampling hot path (CQT-octave U-Net denoiser under the Heun/EDM loop).
+"""Hyphenated alias of the package ``audio_inpainting_diffusion_amd`` (the real, importable directory).
 
-Drop-in plugin surface for the reference's dotted ``callable`` strings:
-
-    network.callable=audio-inpainting-diffusion_amd.network.Unet_CQT_oct_with_attention
-    tester.sampler_callable=audio-inpainting-diffusion_amd.sampler.Sampler
-    diff_params.callable=audio-inpainting-diffusion_amd.edm.EDM        (optional; the reference's own EDM also works)
-
-The directory name carries a hyphen, which ``importlib.import_module`` (what the reference's
-``dnnlib.call_func_by_name`` uses, utils/dnnlib/util.py:235-297) accepts; for ``import`` statements use the
-alias package ``audio_inpainting_diffusion_amd`` at the repo root, whose ``__path__`` is this directory.
-
-Everything numeric runs in hand-written HIP kernels (csrc/*.hip) behind the C-ABI declared in
-include/aid_kernels.h; there is no CPU or eager-PyTorch fallback: without the built ``libaid_hip.so``
-every operator raises.
+The reference resolves plugin classes with ``importlib.import_module`` (utils/dnnlib/util.py:235-297), which
+also accepts the repository's own hyphenated name, e.g.
+``network.callable=audio-inpainting-diffusion_amd.network.Unet_CQT_oct_with_attention``.  This alias registers
+the SAME module objects under both names (one class identity, one loaded ``libaid_hip.so``): nothing is executed twice.
 """
-__version__ = "0.1.0"
+import importlib as _importlib
+import pkgutil as _pkgutil
+import sys as _sys
+
+_real = _importlib.import_module("audio_inpainting_diffusion_amd")
+for _m in _pkgutil.iter_modules(_real.__path__):
+    if _m.name.startswith("lib"):          # libaid_hip.so is a C-ABI library (ctypes), not a Python extension module
+        continue
+    _sys.modules[__name__ + "." + _m.name] = _importlib.import_module(_real.__name__ + "." + _m.name)
+_sys.modules[__name__] = _real

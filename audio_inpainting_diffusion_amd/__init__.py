@@ -1,11 +1,16 @@
-"""Import alias for the hyphenated package directory ``audio-inpainting-diffusion_amd/``.
+"""MI355X-native EDM inpainting sampling hot path (CQT-octave U-Net denoiser under the Heun/EDM loop).
 
-``import audio_inpainting_diffusion_amd.network`` loads ``audio-inpainting-diffusion_amd/network.py``.
+Drop-in plugin surface for the reference's dotted ``callable`` strings:
+
+    network.callable=audio_inpainting_diffusion_amd.network.Unet_CQT_oct_with_attention
+    tester.sampler_callable=audio_inpainting_diffusion_amd.sampler.Sampler
+    diff_params.callable=audio_inpainting_diffusion_amd.edm.EDM        (optional; the reference's own EDM also works)
+
+``audio-inpainting-diffusion_amd`` (the repository's hyphenated name) is an alias directory that registers these
+same module objects under that name, so both spellings resolve to ONE set of classes and one loaded library.
+
+Everything numeric runs in hand-written HIP kernels (csrc/*.hip) behind the C-ABI declared in
+include/aid_kernels.h; there is no CPU or eager-PyTorch fallback: without the built ``libaid_hip.so``
+every operator raises.
 """
-import os as _os
-
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "audio-inpainting-diffusion_amd")
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
-del _os, _f
+__version__ = "0.2.0"

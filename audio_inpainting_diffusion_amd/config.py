@@ -38,7 +38,7 @@ _ATTN = dict(num_heads=8, attn_dropout=0.0, bias_qkv=False, N=0, rel_pos_num_buc
 # conf/network/paper_1912_unet_cqt_oct_attention_adaLN_2.yaml:6-64
 NETWORK_22K = dict(
     name="unet_cqt_oct_with_attention",
-    callable="audio-inpainting-diffusion_amd.network.Unet_CQT_oct_with_attention",
+    callable="audio_inpainting_diffusion_amd.network.Unet_CQT_oct_with_attention",
     use_fencoding=False, use_norm=True, filter_out_cqt_DC_Nyq=True, depth=7, emb_dim=256,
     Ns=[64, 96, 96, 128, 128, 256, 256], attention_layers=[0, 0, 0, 0, 1, 1, 1, 1], Ss=[2] * 7,
     num_dils=[2, 3, 4, 5, 6, 7, 7], cqt=dict(window="kaiser", beta=1, num_octs=7, bins_per_oct=64),
@@ -47,7 +47,7 @@ NETWORK_22K = dict(
 # conf/network/paper_1912_unet_cqt_oct_attention_44k_2.yaml
 NETWORK_44K = dict(
     name="unet_cqt_oct_with_attention",
-    callable="audio-inpainting-diffusion_amd.network.Unet_CQT_oct_with_attention",
+    callable="audio_inpainting_diffusion_amd.network.Unet_CQT_oct_with_attention",
     use_fencoding=False, use_norm=True, filter_out_cqt_DC_Nyq=True, depth=8, emb_dim=256,
     Ns=[64, 64, 96, 96, 128, 128, 256, 256], attention_layers=[0, 0, 0, 0, 0, 1, 1, 1, 1], Ss=[2] * 7,
     num_dils=[2, 3, 4, 5, 6, 7, 8, 8], cqt=dict(window="kaiser", beta=1, num_octs=8, bins_per_oct=64),
@@ -55,7 +55,7 @@ NETWORK_44K = dict(
 
 # conf/tester/inpainting_tester.yaml:20-57 (T is overridden per BASELINE.json config)
 TESTER_LONG = dict(
-    name="inpainting_tester", sampler_callable="audio-inpainting-diffusion_amd.sampler.Sampler",
+    name="inpainting_tester", sampler_callable="audio_inpainting_diffusion_amd.sampler.Sampler",
     T=35, order=2, filter_out_cqt_DC_Nyq=True,
     posterior_sampling=dict(xi=0.25, norm=2, smoothl1_beta=1),
     data_consistency=dict(use=True, type="always", smooth=True, hann_size=50),
@@ -67,7 +67,7 @@ TESTER_LONG = dict(
                     short=dict(num_gaps=4, gap_length=25, start_gap_idx="None")))
 
 # conf/diff_params/edm.yaml
-DIFF_PARAMS = dict(callable="audio-inpainting-diffusion_amd.edm.EDM", sigma_data=0.063, sigma_min=1e-5,
+DIFF_PARAMS = dict(callable="audio_inpainting_diffusion_amd.edm.EDM", sigma_data=0.063, sigma_min=1e-5,
                    sigma_max=10, P_mean=-1.2, P_std=1.2, ro=13, ro_train=10, Schurn=5, Snoise=1, Stmin=0,
                    Stmax=50, aweighting=dict(use_aweighting=False, ntaps=101))
 

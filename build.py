@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-PKG = os.path.join(ROOT, "audio-inpainting-diffusion_amd")
+PKG = os.path.join(ROOT, "audio_inpainting_diffusion_amd")
 SRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "libaid_hip.so")
 

@@ -2,7 +2,7 @@
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
 import anything from this package.  The product package
-(``audio-inpainting-diffusion_amd``) never imports it and fails loudly when its HIP
+(``audio_inpainting_diffusion_amd``) never imports it and fails loudly when its HIP
 extension is missing.
 
 Pinning status

@@ -13,7 +13,7 @@ is not under /root/reference and not installed.  What the call sites fix, and wh
   ``bwd(fwd(x)) == apply_hpf_DC(x)``.
 
 Algorithm (published NSGT, painless case; written band-by-band on purpose, the product builds
-vectorised tables independently in ``audio-inpainting-diffusion_amd/cqt.py``):
+vectorised tables independently in ``audio_inpainting_diffusion_amd/cqt.py``):
 
   centre frequencies  f_k = fmin * 2**(k/bpo), fmin = (fs/2)/2**numocts, k = 0..K-1   (K = numocts*bpo)
   in DFT bins         b_k = f_k * L / fs ;  band list = [DC, b_0..b_{K-1}, Nyquist]

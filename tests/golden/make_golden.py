@@ -9,7 +9,7 @@ temp dir so the import succeeds in this image:
   * ``cqt_nsgt_pytorch`` -- the un-vendored CQT package; the stub exposes ``CQT_nsgt`` = our oracle
                             NSGT-CQT (oracle/nsgt_cqt.py), so whole-network goldens = reference U-Net
                             body + our CQT definition (CQT parity itself is unpinned, see oracle/__init__.py).
-Weights come from the seeded counter-based initialiser (audio-inpainting-diffusion_amd/init.py) with O(1)
+Weights come from the seeded counter-based initialiser (audio_inpainting_diffusion_amd/init.py) with O(1)
 gates, loaded into the reference modules through ``load_state_dict``.
 
 Fixtures written (inputs + reference outputs only -- data, not code):

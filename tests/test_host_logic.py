@@ -25,7 +25,7 @@ def test_c_abi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "aid_kernels.h")).read()
     declared = set(re.findall(r"^\s*(?:int|void|const char\*)\s+(aid_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 15
-    so = os.path.join(ROOT, "audio-inpainting-diffusion_amd", "libaid_hip.so")
+    so = os.path.join(ROOT, "audio_inpainting_diffusion_amd", "libaid_hip.so")
     if not os.path.exists(so):
         import build
         build.build()
@@ -135,11 +135,19 @@ def test_state_dict_surface_matches_reference():
 
 
 def test_plugin_strings_resolve_like_the_reference_does():
-    """utils/dnnlib/util.py:235-273 resolves `callable` strings with importlib.import_module on dotted prefixes."""
-    for dotted in ("audio-inpainting-diffusion_amd.network.Unet_CQT_oct_with_attention",
-                   "audio-inpainting-diffusion_amd.sampler.Sampler", "audio-inpainting-diffusion_amd.edm.EDM"):
-        mod, _, attr = dotted.rpartition(".")
-        assert callable(getattr(importlib.import_module(mod), attr))
+    """utils/dnnlib/util.py:235-273 resolves `callable` strings with importlib.import_module on dotted prefixes.
+    Both spellings of the package (the importable one and the repository's hyphenated alias) must resolve to the
+    SAME class objects -- one identity for isinstance / pickling, one loaded libaid_hip.so."""
+    for tail in ("network.Unet_CQT_oct_with_attention", "sampler.Sampler", "edm.EDM"):
+        objs = []
+        for pkg in ("audio_inpainting_diffusion_amd", "audio-inpainting-diffusion_amd"):
+            mod, _, attr = (pkg + "." + tail).rpartition(".")
+            objs.append(getattr(importlib.import_module(mod), attr))
+        assert callable(objs[0]) and objs[0] is objs[1]
+        assert objs[0].__module__.startswith("audio_inpainting_diffusion_amd.")
+    import audio_inpainting_diffusion_amd._lib as a
+    b = importlib.import_module("audio-inpainting-diffusion_amd._lib")
+    assert a is b
 
 
 def test_edm_host_schedule_matches_golden():

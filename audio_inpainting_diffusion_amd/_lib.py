@@ -155,7 +155,7 @@ class StftParams(C.Structure):
                 ("n_fft", C.c_int), ("hop", C.c_int), ("n_frames", C.c_int), ("adjoint", C.c_int)]
 
 
-EXPORTS = ["aid_abi_version", "aid_last_error", "aid_group_stats", "aid_conv2d", "aid_conv2d_pack_dims", "aid_resample",
+EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_stats", "aid_conv2d", "aid_conv2d_pack_dims", "aid_resample",
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
@@ -174,6 +174,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.aid_last_error.restype = C.c_char_p
         L.aid_abi_version.restype = C.c_int
+        L.aid_last_kernel.restype = C.c_char_p
         for name in EXPORTS:
             if not hasattr(L, name):
                 raise AidError(f"libaid_hip.so does not export {name}")
@@ -183,7 +184,7 @@ def lib():
         L.aid_conv2d_wino_input_supported.restype = C.c_int
         L.aid_conv2d_dot_partials.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.aid_conv2d_dot_partials.restype = C.c_int
-        for name in EXPORTS[2:]:
+        for name in EXPORTS[3:]:
             if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials"):
                 getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, name).restype = C.c_int
@@ -251,20 +252,17 @@ def pack_conv_weight(w: torch.Tensor, transpose: bool = False) -> torch.Tensor:
     return out
 
 
-def pack_conv_weight_wino(w: torch.Tensor, transpose: bool = False, f4: bool = True) -> torch.Tensor:
-    """[Cout,Cin,5,3] -> Winograd pack [NXI*5, Cin_pad, Cout_pad]: U = G w along kw, "tap" index xi*5+kh.
-    f4=False: F(2,3), NXI=4;  f4=True: F(4,3), NXI=6 (computed in float64, stored fp32)."""
+def pack_conv_weight_wino(w: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+    """[Cout,Cin,5,3] -> Winograd F(4,3) pack [6*5, Cin_pad, Cout_pad]: U = G w along kw, "tap" index xi*5+kh
+    (computed in float64, stored fp32)."""
     w = w.detach().double()
     if transpose:
         w = w.flip(2, 3).permute(1, 0, 2, 3)
     co, ci, kh, kw = w.shape
     assert (kh, kw) == (5, 3)
     w0, w1, w2 = w[..., 0], w[..., 1], w[..., 2]
-    if f4:
-        U = torch.stack((w0 / 4, -(w0 + w1 + w2) / 6, -(w0 - w1 + w2) / 6, (w0 + 2 * w1 + 4 * w2) / 24,
-                         (w0 - 2 * w1 + 4 * w2) / 24, w2), dim=0)
-    else:
-        U = torch.stack((w0, 0.5 * (w0 + w1 + w2), 0.5 * (w0 - w1 + w2), w2), dim=0)      # [NXI, co, ci, kh]
+    U = torch.stack((w0 / 4, -(w0 + w1 + w2) / 6, -(w0 - w1 + w2) / 6, (w0 + 2 * w1 + 4 * w2) / 24,
+                     (w0 - 2 * w1 + 4 * w2) / 24, w2), dim=0)                              # [NXI, co, ci, kh]
     nxi = U.shape[0]
     cip, cop = pack_dims(ci, co)
     out = torch.zeros(nxi * kh, cip, cop, device=w.device, dtype=torch.float32)

@@ -7,6 +7,7 @@
 #define AID_WAVE 64
 
 void aid_set_error(const char* msg);
+void aid_note_kernel(const char* name);   // aid_capi.hip: records which device kernel an entry point dispatched to
 
 // Checks the launch that just happened; returns AID_E_LAUNCH from the enclosing function on failure.
 #define AID_CHECK_LAUNCH()                                   \

@@ -424,6 +424,7 @@ static int launch_cfg(const aid_conv2d_params* p, hipStream_t st, int splits = 1
     }
     hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), lds, st, a);
     AID_CHECK_LAUNCH();
+    aid_note_kernel(a.splits > 1 ? "conv_mfma_kernel+splitk" : (KH == 5 ? "conv_mfma_kernel(5x3)" : "conv_mfma_kernel(1x1)"));
     if (a.splits > 1) {
         const int64_t total = (int64_t)p->B * p->Cout * ((int64_t)p->F * p->T / 4);
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *p, (const float*)p->ws, a.splits);
@@ -439,10 +440,8 @@ static int launch_m(const aid_conv2d_params* p, hipStream_t st) {
         // grid-starved GEMMs (qk projections: N = B*T columns only)
         const int64_t npos = (int64_t)p->B * p->F * p->T;
         const int64_t ntiles = (npos + 255) / 256;
-        static int sk = -1;
-        if (sk < 0) { const char* e = getenv("AID_CONV_SPLITK"); sk = e ? atoi(e) : 1; }
         const int64_t wg64 = ntiles * (p->Cout_pad / 64);
-        if (KH == 1 && sk && p->ws && p->epi == 0 && wg64 < 384 && p->Cin >= 16 * KC && p->Cout_pad % 64 == 0 && (p->T % 4) == 0) {
+        if (KH == 1 && p->ws && p->epi == 0 && wg64 < 384 && p->Cin >= 16 * KC && p->Cout_pad % 64 == 0 && (p->T % 4) == 0) {
             // split K over several workgroups per 64 x 256 tile (deterministic two-pass reduction through ws)
             int S = (int)((768 + wg64 - 1) / wg64);
             if (S > 8) S = 8;
@@ -454,12 +453,7 @@ static int launch_m(const aid_conv2d_params* p, hipStream_t st) {
         // single pass: trade tile height for more workgroups
         if (ntiles * (p->Cout_pad / 128) < 192) mb = (ntiles * (p->Cout_pad / 64) < 192) ? 32 : 64;
     }
-    // AID_CONV_CFG=n selects alternative tile / wave-count configurations (tuning experiments only)
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("AID_CONV_CFG"); dbg = e ? atoi(e) : 0; }
-    static int c1 = -1;
-    if (c1 < 0) { const char* e = getenv("AID_CONV_1X1"); c1 = e ? atoi(e) : 1; }
-    if (KH == 1 && c1 == 1) {           // more waves per CU for the short-K (memory-bound) channel projections
+    if (KH == 1) {                      // more waves per CU for the short-K (memory-bound) channel projections
         switch (mb) {
             case 32: return launch_cfg<KH, KW, 1, 2, 1, 4, KC>(p, st);
             case 64: return launch_cfg<KH, KW, 1, 2, 2, 4, KC>(p, st);     // 64x256, 8 waves, 2 workgroups / CU
@@ -467,25 +461,13 @@ static int launch_m(const aid_conv2d_params* p, hipStream_t st) {
             default: return launch_cfg<KH, KW, 1, 2, 4, 4, KC>(p, st);     // 128x256, 16 waves
         }
     }
-    if (KH == 1 && c1 == 2) {
-        switch (mb) {
-            case 32: return launch_cfg<KH, KW, 1, 2, 1, 4, KC>(p, st);
-            case 64: return launch_cfg<KH, KW, 1, 2, 2, 4, KC>(p, st);
-            case 96: return launch_cfg<KH, KW, 1, 2, 3, 4, KC>(p, st);
-            default: return launch_cfg<KH, KW, 2, 1, 2, 4, KC>(p, st);     // 128x128, 8 waves, 2 workgroups / CU
-        }
-    }
     switch (mb) {
         case 32: return launch_cfg<KH, KW, 1, 2, 1, 4, KC>(p, st);
         case 64:
-            if (KH == 5 && p->T >= 64) return launch_cfg<KH, KW, 1, 2, 2, 8, KC>(p, st);     // 16 waves, 64x512
+            if (p->T >= 64) return launch_cfg<KH, KW, 1, 2, 2, 8, KC>(p, st);     // 16 waves, 64x512
             return launch_cfg<KH, KW, 2, 2, 1, 4, KC>(p, st);
-        case 96:
-            if (KH == 5) return launch_cfg<KH, KW, 1, 2, 3, 4, KC>(p, st);     // 12 waves, 96x256
-            return launch_cfg<KH, KW, 3, 1, 1, 8, KC>(p, st);
-        default:
-            if (KH == 5) return launch_cfg<KH, KW, 1, 2, 4, 4, KC>(p, st);     // 16 waves (4 per SIMD), 128x256
-            return launch_cfg<KH, KW, 2, 2, 2, 4, KC>(p, st);
+        case 96: return launch_cfg<KH, KW, 1, 2, 3, 4, KC>(p, st);     // 12 waves, 96x256
+        default: return launch_cfg<KH, KW, 1, 2, 4, 4, KC>(p, st);     // 16 waves (4 per SIMD), 128x256
     }
 }
 
@@ -525,19 +507,15 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
         if (r != 0) return r < 0 ? r : AID_OK;
     }
     if (p->KH == 5 && p->KW == 3) {
-        static int use_dma = -1;
-        if (use_dma < 0) { const char* e = getenv("AID_CONV_DMA"); use_dma = e ? atoi(e) : 1; }
-        static int use_wino = -1;
-        if (use_wino < 0) { const char* e = getenv("AID_CONV_WINO"); use_wino = e ? atoi(e) : 1; }
-        if (use_wino && p->wp_wino) {
-            const int r = aid_conv53_wino_try(p, st);    // Winograd F(2,3) along T: 4 MFMAs per 2 outputs instead of 6
+        if (p->wp_wino) {
+            const int r = aid_conv53_wino_try(p, st);    // Winograd F(4,3) along T: 6 MFMAs per 4 outputs instead of 12
             if (r != 0) return r < 0 ? r : AID_OK;
         }
-        if (use_dma) {
-            const int r = aid_conv53_dma_try(p, st);     // direct-to-LDS kernel for the shapes that carry the FLOPs
+        {
+            const int r = aid_conv53_dma_try(p, st);     // direct form, direct-to-LDS staging (layers without a Winograd pack)
             if (r != 0) return r < 0 ? r : AID_OK;
         }
-        return launch_m<5, 3, 4>(p, st);
+        return launch_m<5, 3, 4>(p, st);                 // register-staged kernel: in-kernel prologue, Cin = 2, odd shapes
     }
     if (p->KH == 1 && p->KW == 1) {
         {
@@ -547,11 +525,7 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
             if (r != 0) return r < 0 ? r : AID_OK;
         }
         if (p->Cin <= 8) return launch_m<1, 1, 8>(p, st);
-        static int kc1 = -1;
-        if (kc1 < 0) { const char* e = getenv("AID_CONV_KC1"); kc1 = e ? atoi(e) : 16; }
-        if (kc1 == 16) return launch_m<1, 1, 16>(p, st);
-        if (kc1 == 8) return launch_m<1, 1, 8>(p, st);
-        return launch_m<1, 1, 32>(p, st);
+        return launch_m<1, 1, 16>(p, st);
     }
     aid_set_error("aid_conv2d: unsupported kernel size (5x3 and 1x1 only)");
     return AID_E_BADARG;

@@ -165,9 +165,6 @@ int aid_conv1x1_stream_try(const aid_conv2d_params* p, hipStream_t st) {
     if (p->Cin < 16 || (p->Cin & 1) || p->Cout < 32) return 0;
     const int64_t ft = (int64_t)p->F * p->T;
     if (p->F == 1 || (int64_t)p->B * ft < 2048) return 0;            // few positions (qk GEMMs, F = 1): the tiled kernel's job
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("AID_C1_STREAM"); on = e ? atoi(e) : 1; }
-    if (!on) return 0;
     // measured (profiles/r01_conv1x1_probe.txt): ahead of the register-staged tiled kernel for the short-K / write-dominated
     // projections (Cin <= 96: 8-35 %), behind it (10-18 %) once K >= 256 makes the layer MFMA-bound; the direct-to-LDS kernel
     // (aid_conv1x1_dma.hip, tried first) is 17-20 % ahead of this one wherever it is eligible, so this kernel serves the shapes

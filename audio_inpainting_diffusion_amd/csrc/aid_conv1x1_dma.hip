@@ -258,9 +258,7 @@ static int launch_c11(const aid_conv2d_params* p, hipStream_t st) {
 
 // returns 1 if this kernel took the launch, 0 if not eligible, <0 on error
 int aid_conv1x1_dma_try(const aid_conv2d_params* p, hipStream_t st) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("AID_C1_DMA"); on = e ? atoi(e) : 1; }
-    if (!on || !(p->KH == 1 && p->KW == 1) || p->act != 0) return 0;
+    if (!(p->KH == 1 && p->KW == 1) || p->act != 0) return 0;
     if (p->F == 1 || p->Cin < 32 || (p->Cin % 16) || p->Cout < 32) return 0;      // (K is walked in whole 16-channel chunks: no ragged tail)
     if ((p->T % 4) || aid_pow2ceil(p->T) < 8) return 0;
     auto al = [](const aid_view& v, int q) { return (v.sB % q) == 0 && (v.sC % q) == 0 && (v.sF % q) == 0 && (((uintptr_t)v.p) & (4 * q - 1)) == 0; };

@@ -154,12 +154,10 @@ static int launch_cs(K kern, const aid_conv2d_params* p, hipStream_t st) {
 
 // returns 1 if a few-channel kernel took the launch, 0 if not eligible, <0 on error
 int aid_conv_small_try(const aid_conv2d_params* p, hipStream_t st) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("AID_CONV_SMALL"); on = e ? atoi(e) : 1; }
-    if (!on || p->act != 0 || p->epi != 0 || (p->T % 4)) return 0;
+    if (p->act != 0 || p->epi != 0 || (p->T % 4)) return 0;
     // one thread walks the whole "other" channel dimension: ahead of the MFMA kernels on the wide, shallow levels (C <= 96, many
     // positions: 1.3-1.8x), behind them where C >= 128 and a level has too few positions to hide the serial walk
-    if (on == 1 && (p->Cin > 96 || p->Cout > 96)) return 0;
+    if (p->Cin > 96 || p->Cout > 96) return 0;
     const bool k11 = p->KH == 1 && p->KW == 1, k53 = p->KH == 5 && p->KW == 3;
     if (!k11 && !k53) return 0;
     auto al4 = [](const aid_view& v) { return (v.sB % 4) == 0 && (v.sC % 4) == 0 && (v.sF % 4) == 0 && (((uintptr_t)v.p) & 15) == 0; };

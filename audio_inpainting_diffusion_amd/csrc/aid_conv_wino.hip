@@ -1,20 +1,12 @@
-// conv53_wino_kernel: the 5x3 dilated dense convolution with Winograd F(2,3) along T on fp32 MFMA.
+// The 5x3 dilated dense convolution with Winograd F(4,3) along T on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
 //
-// Once the direct kernel (aid_conv_dma.hip) keeps the fp32 matrix pipe ~80-88 % busy at the sustained clock, the
-// only way to go faster in exact-fp32 arithmetic is to issue FEWER MFMAs.  F(2,3) computes two neighbouring
-// outputs of the 3-tap (kw) correlation from 4 products instead of 6:
-//     V = B^T d :  V0 = d0-d2, V1 = d1+d2, V2 = d2-d1, V3 = d1-d3        (d = 4 consecutive input samples)
-//     U = G  w :  U0 = w0, U1 = (w0+w1+w2)/2, U2 = (w0-w1+w2)/2, U3 = w2   (pre-packed on the host, 20 "taps" xi*5+kh)
-//     y0 = M0+M1+M2,  y1 = M1-M2-M3,   M_xi = sum_{ci,kh} U_xi[co,ci,kh] * V_xi[ci,kh]
-// GEMM view per xi: M = Cout, N = tau (pairs of output samples), K = (ci, kh).  The LDS image and the
-// direct-to-LDS staging are those of the direct kernel (plain strips of the input tile + halo cells): the input
-// transform is applied when the B fragment is formed -- three ds_reads (d0 | d1,d2 as one b64 | d3) and four
-// VALU ops feed four MFMAs -- so x traffic and LDS footprint do not grow; only the weight tile does (20 vs 15 taps).
-// Epilogue: output transform in registers, both samples of a pair stored as one float2.
+// Once a direct-form kernel (aid_conv_dma.hip) keeps the fp32 matrix pipe busy at the sustained clock, the only way to
+// go faster in exact-fp32 arithmetic is to issue FEWER MFMAs: F(4,3) computes four neighbouring outputs of the 3-tap
+// (kw) correlation from 6 products instead of 12.  GEMM view per transform index xi: M = Cout, N = groups of 4 output
+// samples, K = (ci, kh); weights are pre-packed on the host as 30 "taps" xi*5+kh (pack_conv_weight_wino).
+//   conv53_wino4_kernel : input transform applied when the B fragment is formed (plain activations in LDS)
+//   conv53_wino4v_kernel: Winograd-domain input written by the producer pass (aid_scale_act wino=1), triple-buffered
 #include "aid_common.h"
-#ifndef WINO_EXP
-#define WINO_EXP 0     // experiment gates (tools/wino_exp.sh): 1 no DMA, 2 no barrier, 4 no transform, 8 no LDS reads, 16 no setprio
-#endif
 #include <type_traits>
 #include <stdlib.h>
 
@@ -44,278 +36,10 @@ __device__ float4 g_aid_zero_page_w[16];   // (device symbols are per translatio
 #define AID_VMCNT(n) ((((n) & 15) | (7 << 4) | (15 << 8) | ((((n) >> 4) & 3) << 14)))
 #define AID_LGKMCNT0 (15 | (7 << 4) | (0 << 8) | (3 << 14))
 
-#ifndef AID_SPREAD
-#define AID_SPREAD 0
-#endif
-#if AID_SPREAD == 0
-#define AID_SPREAD_RULE(i, s, n) ((i) % (n) == (s))
-#elif AID_SPREAD == 1
-#define AID_SPREAD_RULE(i, s, n) ((i) / 2 == (s))
-#elif AID_SPREAD == 2
-#define AID_SPREAD_RULE(i, s, n) (((i) % ((n) - 1)) + 1 == (s))
-#else
-#define AID_SPREAD_RULE(i, s, n) ((s) == 0)
-#endif
 template <typename F, int... I>
 __device__ __forceinline__ void aid_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, typename F>
 __device__ __forceinline__ void aid_static_for(F&& f) { aid_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-
-// MT m-tiles (32 cout) x NTT tau-tiles (32 tau = 64 outputs) per wave; WGM x WGN waves; N_BLK = 64*NTT*WGN outputs
-template <int MT, int NTT, int WGM, int WGN, int RMAX, int KC, int MINW>
-__global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino_kernel(const ConvWinoDev a) {
-    constexpr int KH = 5, NXI = 4, TAPS = NXI * KH;     // 20 transformed taps
-    constexpr int NW = WGM * WGN;
-    constexpr int NTHREADS = 64 * NW;
-    constexpr int M_BLK = 32 * MT * WGM;
-    constexpr int N_BLK = 64 * NTT * WGN;               // output samples per tile
-    constexpr int HALO = 2 * RMAX;
-    constexpr int XB = N_BLK + HALO;
-    constexpr int XSZ = KC * KH * XB;
-    constexpr int WROW = (M_BLK % 64 == 0) ? M_BLK : ((M_BLK + 63) / 64) * 64;
-    constexpr int WSZ_RAW = TAPS * KC * WROW;
-    constexpr int WSZ = ((WSZ_RAW + 255) / 256) * 256;
-    constexpr int BUFSZ = XSZ + WSZ;
-    constexpr int NXP = KC * KH * (N_BLK / 256);
-    constexpr int NWP = WSZ / 256;
-    constexpr int NP = NXP + NWP;
-    constexpr int PPW = (NP + NW - 1) / NW;
-    constexpr int HQ = (2 * KC * KH * RMAX + NTHREADS - 1) / NTHREADS;
-    constexpr int NSTEP = KH * (KC / 2);                // (kh, ci-pair) steps per chunk, 4*MT*NTT MFMAs each
-    static_assert(N_BLK % 256 == 0, "x tile must be whole 1-KiB pieces");
-
-    const aid_conv2d_params& p = a.p;
-    const int TT = 1 << a.tt_log2;
-    const int ROWS = 1 << a.rows_log2;
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    int* rowinfo = (int*)(smem + 2 * BUFSZ);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN;
-    const int wn = wave % WGN;
-
-    const int tile_t = blockIdx.x % a.tiles_t;
-    const int rg = blockIdx.x / a.tiles_t;
-    const int row0 = rg << a.rows_log2;
-    const int t0 = tile_t << a.tt_log2;
-    const int m0 = blockIdx.y * M_BLK;
-
-    for (int r = tid; r < ROWS; r += NTHREADS) {
-        const int rid = row0 + r;
-        int b = -1, f = 0;
-        if (rid < a.nrows) { b = rid / p.F; f = rid - b * p.F; }
-        rowinfo[2 * r] = b;
-        rowinfo[2 * r + 1] = f;
-    }
-    __syncthreads();
-
-    // ---- DMA piece descriptors (identical scheme to conv53_dma_kernel; weights use the 20-tap Winograd pack) ----
-    const float* psrc[PPW];
-    int pstride[PPW], plds[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int pc = wave + i * NW;
-        psrc[i] = a.zero; pstride[i] = 0; plds[i] = -1;
-        if (pc < NXP) {
-            const int blk = pc / (N_BLK / 256), sub = pc % (N_BLK / 256);
-            const int ci = blk / KH, kh = blk % KH;
-            const int n = sub * 256 + 4 * lane;
-            const int rr = n >> a.tt_log2, tt = n & (TT - 1);
-            const int b = rowinfo[2 * rr];
-            const int fi = rowinfo[2 * rr + 1] + (kh - KH / 2) * p.dilF;
-            plds[i] = blk * XB + sub * 256;
-            if (b >= 0 && fi >= 0 && fi < p.F && t0 + tt < p.T) {
-                psrc[i] = p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + t0 + tt;
-                pstride[i] = (int)(KC * p.x.sC);
-            }
-        } else if (pc < NP) {
-            const int wp_ = pc - NXP;
-            const int e = wp_ * 256 + 4 * lane;
-            const int row = e / WROW, col = e % WROW;
-            const int tap = row / KC, ci = row % KC;
-            plds[i] = XSZ + wp_ * 256;
-            if (col < M_BLK && e < WSZ_RAW) {
-                psrc[i] = p.wp_wino + ((int64_t)tap * p.Cin_pad + ci) * p.Cout_pad + m0 + col;
-                pstride[i] = KC * p.Cout_pad;
-            }
-        }
-    }
-    const int nhalo = 2 * KC * KH * ROWS;
-    const float* hsrc[HQ];
-    int hstride[HQ], hlds[HQ];
-#pragma unroll
-    for (int i = 0; i < HQ; ++i) {
-        const int h = tid + i * NTHREADS;
-        hsrc[i] = a.zero; hstride[i] = 0; hlds[i] = -1;
-        if (h < nhalo) {
-            const int side = h & 1;
-            const int rr = (h >> 1) & (ROWS - 1);
-            const int blk = (h >> 1) >> a.rows_log2;
-            const int ci = blk / KH, kh = blk % KH;
-            const int b = rowinfo[2 * rr];
-            const int fi = rowinfo[2 * rr + 1] + (kh - KH / 2) * p.dilF;
-            const int t = side ? (t0 + TT) : (t0 - 1);
-            hlds[i] = blk * XB + N_BLK + rr * 2 + side;
-            if (b >= 0 && fi >= 0 && fi < p.F && t >= 0 && t < p.T) {
-                hsrc[i] = p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + t;
-                hstride[i] = (int)(KC * p.x.sC);
-            }
-        }
-    }
-    // ---- operand addresses -----------------------------------------------------------------------------------------
-    const int half = lane >> 5;
-    const int ttau_log2 = a.tt_log2 - 1;                 // tau per row = TT/2
-    int vD0[NTT], vD12[NTT], vD3[NTT];                   // float offsets of d0 | (d1,d2) | d3 inside a (ci,kh) block
-#pragma unroll
-    for (int j = 0; j < NTT; ++j) {
-        const int nt = (wn * NTT + j) * 32 + (lane & 31);            // tau index inside the tile
-        const int rr = nt >> ttau_log2, tau = nt & ((TT >> 1) - 1);
-        const int n = rr * TT + 2 * tau;                             // core position of d1
-        vD12[j] = half * KH * XB + n;
-        vD0[j] = half * KH * XB + ((tau == 0) ? (N_BLK + rr * 2) : (n - 1));
-        vD3[j] = half * KH * XB + ((2 * tau + 2 >= TT) ? (N_BLK + rr * 2 + 1) : (n + 2));
-    }
-    int vA[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) vA[i] = XSZ + half * WROW + (wm * MT + i) * 32 + (lane & 31);
-
-    f32x16 acc[MT][NTT][NXI];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NTT; ++j)
-#pragma unroll
-            for (int x = 0; x < NXI; ++x)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][x][r] = 0.f;
-
-    float hv[HQ];
-    auto issue_dma = [&](int ch, float* buf) {
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            if (plds[i] >= 0) {
-                const float* src = psrc[i] + (int64_t)ch * pstride[i];
-                GLDS16W(src, buf + plds[i]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < HQ; ++i) hv[i] = hsrc[i][(int64_t)ch * hstride[i]];
-    };
-    auto write_halo = [&](float* buf) {
-#pragma unroll
-        for (int i = 0; i < HQ; ++i)
-            if (hlds[i] >= 0) buf[hlds[i]] = hv[i];
-    };
-
-    issue_dma(0, smem);
-    write_halo(smem);
-    __syncthreads();
-
-    auto chunk = [&](auto curc, int ch) {
-        constexpr int cur = decltype(curc)::value;
-        const float* Bf = smem + cur * BUFSZ;
-        float* Nx = smem + (cur ^ 1) * BUFSZ;
-        const bool more = (ch + 1) < a.nchunks;
-        if (more) issue_dma(ch + 1, Nx);
-        // raw samples of step s+1 are fetched while the MFMAs of step s run
-        float d0[2][NTT], d3[2][NTT];
-        float2 d12[2][NTT];
-        float av[2][MT][NXI];
-        auto load_step = [&](int s, int buf) {
-            const int kh = s / (KC / 2), cp = s % (KC / 2);
-            const int xo = (2 * cp * KH + kh) * XB;
-#pragma unroll
-            for (int j = 0; j < NTT; ++j) {
-                d0[buf][j] = Bf[vD0[j] + xo];
-                d12[buf][j] = *reinterpret_cast<const float2*>(Bf + vD12[j] + xo);
-                d3[buf][j] = Bf[vD3[j] + xo];
-            }
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int x = 0; x < NXI; ++x)
-                    av[buf][i][x] = Bf[vA[i] + ((x * KH + kh) * KC + 2 * cp) * WROW];
-        };
-        load_step(0, 0);
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-            if (s == 0) __builtin_amdgcn_s_setprio(3);
-            else if (s == (NSTEP + 3) / 4) __builtin_amdgcn_s_setprio(2);
-            else if (s == (NSTEP + 1) / 2) __builtin_amdgcn_s_setprio(1);
-            else if (s == (3 * NSTEP + 3) / 4) __builtin_amdgcn_s_setprio(0);
-            if (s + 1 < NSTEP) load_step(s + 1, (s + 1) & 1);
-            const int bq = s & 1;
-#pragma unroll
-            for (int j = 0; j < NTT; ++j) {
-                const float d1 = d12[bq][j].x, d2 = d12[bq][j].y;
-                const float V[NXI] = {d0[bq][j] - d2, d1 + d2, d2 - d1, d1 - d3[bq][j]};
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int x = 0; x < NXI; ++x)
-                        acc[i][j][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[bq][i][x], V[x], acc[i][j][x], 0, 0, 0);
-            }
-        }
-        if (more) write_halo(Nx);
-        __syncthreads();
-    };
-    for (int ch = 0; ch < a.nchunks; ch += 2) {
-        chunk(std::integral_constant<int, 0>{}, ch);
-        if (ch + 1 < a.nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
-    }
-    __builtin_amdgcn_s_setprio(0);
-
-    // ---- epilogue: output transform, then the usual gate / dGELU / residual, two samples per lane ----------------------
-#pragma unroll
-    for (int j = 0; j < NTT; ++j) {
-        const int nt = (wn * NTT + j) * 32 + (lane & 31);
-        const int rr = nt >> ttau_log2, tau = nt & ((TT >> 1) - 1);
-        const int b = rowinfo[2 * rr];
-        const int f = rowinfo[2 * rr + 1];
-        const int t = t0 + 2 * tau;
-        if (b < 0 || t >= p.T) continue;                 // T is even: both samples of the pair are in range together
-        const int64_t ybase = (int64_t)b * p.y.sB + (int64_t)f * p.y.sF + t;
-        const int64_t rbase = p.res.p ? ((int64_t)b * p.res.sB + (int64_t)f * p.res.sF + t) : 0;
-        const int64_t abase = p.aux.p ? ((int64_t)b * p.aux.sB + (int64_t)f * p.aux.sF + t) : 0;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int mbase = m0 + (wm * MT + i) * 32 + 4 * (lane >> 5);
-#pragma unroll
-            for (int r0 = 0; r0 < 16; r0 += 8) {         // two batches of 8 rows: gather, then compute + store
-                float2 rv[8], uv[8];
-                float sv[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int r = r0 + q;
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    const bool ok = m < p.Cout;
-                    rv[q] = (ok && p.res.p) ? *reinterpret_cast<const float2*>(p.res.p + rbase + (int64_t)m * p.res.sC) : make_float2(0.f, 0.f);
-                    sv[q] = (ok && p.out_scale) ? p.out_scale[(int64_t)b * p.out_scale_ld + m] : 1.f;
-                    if (ok && p.epi == 1) {
-                        const float as = p.aux_scale[(int64_t)b * p.aux_scale_ld + m];
-                        const float2 u = *reinterpret_cast<const float2*>(p.aux.p + abase + (int64_t)m * p.aux.sC);
-                        uv[q] = make_float2(u.x * as, u.y * as);
-                    } else uv[q] = make_float2(0.f, 0.f);
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int r = r0 + q;
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    if (m >= p.Cout) continue;
-                    float y0 = (acc[i][j][0][r] + acc[i][j][1][r] + acc[i][j][2][r]) * sv[q];
-                    float y1 = (acc[i][j][1][r] - acc[i][j][2][r] - acc[i][j][3][r]) * sv[q];
-                    if (p.epi == 1) { y0 *= aid_dgelu(uv[q].x); y1 *= aid_dgelu(uv[q].y); }
-                    y0 += p.res_scale * rv[q].x;
-                    y1 += p.res_scale * rv[q].y;
-                    *reinterpret_cast<float2*>(p.y.p + ybase + (int64_t)m * p.y.sC) = make_float2(p.alpha * y0, p.alpha * y1);
-                }
-            }
-        }
-    }
-}
 
 // ---- F(4,3): 6 products per 4 outputs (2x fewer MFMAs than direct).  tau now indexes GROUPS of 4 output samples:
 //   V = B^T d (d = 6 samples 4g-1 .. 4g+4):  V0 = 4d0-5d2+d4, V1 = (d3+d4)-4(d1+d2), V2 = (d4-d3)+4(d1-d2),
@@ -496,9 +220,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4_kernel(cons
         const float* Bf = cur ? sbuf1 : sbuf0;
         float* Nx = cur ? sbuf0 : sbuf1;
         const bool more = (ch + 1) < a.nchunks;
-#if !(WINO_EXP & 1)
         if (more) issue_dma(ch + 1, Nx);
-#endif
         // raw samples of step s+1 are fetched while the MFMAs of step s run
         float d0[2][NTT], d3[2][NTT];
         float4 d12[2][NTT];
@@ -521,28 +243,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4_kernel(cons
         load_step(0, 0);
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
-#if !(WINO_EXP & 16)
             if (s == 0) __builtin_amdgcn_s_setprio(3);
             else if (s == (NSTEP + 3) / 4) __builtin_amdgcn_s_setprio(2);
             else if (s == (NSTEP + 1) / 2) __builtin_amdgcn_s_setprio(1);
             else if (s == (3 * NSTEP + 3) / 4) __builtin_amdgcn_s_setprio(0);
-#endif
-#if !(WINO_EXP & 8)
             if (s + 1 < NSTEP) load_step(s + 1, (s + 1) & 1);
             const int bq = s & 1;
-#else
-            const int bq = 0;
-#endif
 #pragma unroll
             for (int j = 0; j < NTT; ++j) {
                 const float e0 = d0[bq][j], e1 = d12[bq][j].x, e2 = d12[bq][j].y, e3 = d12[bq][j].z, e4 = d12[bq][j].w, e5 = d3[bq][j];
                 const float s12 = e1 + e2, m12 = e1 - e2, m42 = e4 - e2, m31 = e3 - e1;
-#if !(WINO_EXP & 4)
                 const float V[NXI] = {4.f * e0 - 5.f * e2 + e4, (e3 + e4) - 4.f * s12, (e4 - e3) + 4.f * m12,
                                       m42 + 2.f * m31, m42 - 2.f * m31, 4.f * e1 - 5.f * e3 + e5};
-#else
-                const float V[NXI] = {e0, e1, e2, e3, e4, e5 + s12 * 0.f + m12 * 0.f + m42 * 0.f + m31 * 0.f};
-#endif
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -550,12 +262,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4_kernel(cons
                         acc[i][j][x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[bq][i][x], V[x], acc[i][j][x], 0, 0, 0);
             }
         }
-#if !(WINO_EXP & 1)
         if (more) write_halo(Nx);
-#endif
-#if !(WINO_EXP & 2)
         __syncthreads();
-#endif
     };
     for (int ch = 0; ch < a.nchunks; ch += 2) {
         chunk(std::integral_constant<int, 0>{}, ch);
@@ -794,7 +502,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
     // pieces i with i % NSTEP == s are issued at k-step s
     auto issue_step = [&](auto sc, int ch, float* buf) {
         aid_static_for<PPW>([&](auto ic) {
-            if constexpr (AID_SPREAD_RULE(decltype(ic)::value, decltype(sc)::value, NSTEP)) issue_piece(ic, ch, buf);
+            if constexpr (decltype(ic)::value % NSTEP == decltype(sc)::value) issue_piece(ic, ch, buf);
         });
     };
 
@@ -831,9 +539,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
             else if (s == (NSTEP + 3) / 4) __builtin_amdgcn_s_setprio(2);
             else if (s == (NSTEP + 1) / 2) __builtin_amdgcn_s_setprio(1);
             else if (s == (3 * NSTEP + 3) / 4) __builtin_amdgcn_s_setprio(0);
-#if !(WINO_EXP & 1)
             if (more) issue_step(sc, ch + 2, Nx);        // this step's share of the loads of chunk ch+2
-#endif
             if (s + 1 < NSTEP) load_step(s + 1, (s + 1) & 1);
             constexpr int bq = s & 1;
 #pragma unroll
@@ -848,17 +554,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
         // (`mine` instructions of this wave, issued during this chunk) stay in flight.  __syncthreads() would drain them
         // (its release fence waits for every outstanding VMEM store, LDS-DMA included), so the barrier is spelled out.
         asm volatile("" ::: "memory");
-#if !(WINO_EXP & 64)
         if (more) {
             if (mine == PPW) __builtin_amdgcn_s_waitcnt(AID_VMCNT(PPW)); else __builtin_amdgcn_s_waitcnt(AID_VMCNT(PPW - 1));
         } else {
             __builtin_amdgcn_s_waitcnt(AID_VMCNT(0));
         }
-#endif
         __builtin_amdgcn_s_waitcnt(AID_LGKMCNT0);        // this wave's reads of the buffer that is overwritten next
-#if !(WINO_EXP & 2)
         __builtin_amdgcn_s_barrier();
-#endif
         asm volatile("" ::: "memory");
     };
     for (int ch = 0; ch < a.nchunks; ch += 3) {
@@ -963,43 +665,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
 }
 
 template <int MT, int NTT, int WGM, int WGN, int RMAX, int KC, int MINW = 1>
-static int launch_wino(const aid_conv2d_params* p, hipStream_t st) {
-    constexpr int M_BLK = 32 * MT * WGM;
-    constexpr int N_BLK = 64 * NTT * WGN;
-    constexpr int WROW = (M_BLK % 64 == 0) ? M_BLK : ((M_BLK + 63) / 64) * 64;
-    static const float* zero = nullptr;
-    if (!zero) {
-        void* z = nullptr;
-        if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_aid_zero_page_w)) != hipSuccess) { aid_set_error("aid_conv2d: zero page lookup failed"); return AID_E_LAUNCH; }
-        zero = (const float*)z;
-    }
-    ConvWinoDev a;
-    a.p = *p;
-    a.zero = zero;
-    int TT = aid_pow2ceil(p->T);
-    if (TT > N_BLK) TT = N_BLK;
-    a.tt_log2 = aid_ilog2(TT);
-    const int ROWS = N_BLK / TT;
-    if (ROWS > RMAX) return 1000;
-    a.rows_log2 = aid_ilog2(ROWS);
-    a.tiles_t = aid_cdiv(p->T, TT);
-    a.nrows = p->B * p->F;
-    a.nchunks = p->Cin / KC;
-    const int rgroups = aid_cdiv(a.nrows, ROWS);
-    dim3 grid((unsigned)(rgroups * a.tiles_t), (unsigned)(p->Cout_pad / M_BLK));
-    const size_t lds = sizeof(float) * 2 * ((size_t)KC * 5 * (N_BLK + 2 * RMAX) + (size_t)((20 * KC * WROW + 255) / 256) * 256) + sizeof(int) * 2 * ROWS;
-    auto kern = conv53_wino_kernel<MT, NTT, WGM, WGN, RMAX, KC, MINW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), lds, st, a);
-    AID_CHECK_LAUNCH();
-    return AID_OK;
-}
-
-template <int MT, int NTT, int WGM, int WGN, int RMAX, int KC, int MINW = 1>
 static int launch_wino4(const aid_conv2d_params* p, hipStream_t st) {
     constexpr int M_BLK = 32 * MT * WGM;
     constexpr int N_BLK = 128 * NTT * WGN;
@@ -1024,13 +689,9 @@ static int launch_wino4(const aid_conv2d_params* p, hipStream_t st) {
     const int rgroups = aid_cdiv(a.nrows, ROWS);
     dim3 grid((unsigned)(rgroups * a.tiles_t), (unsigned)(p->Cout_pad / M_BLK));
     auto kern = conv53_wino4_kernel<MT, NTT, WGM, WGN, RMAX, KC, MINW>;      // LDS is static (see the kernel)
-    static int xcd = -1;
-    if (xcd < 0) { const char* e = getenv("AID_CONV_XCD"); xcd = e ? atoi(e) : 1; }
-    a.nx = (int)grid.x; a.ny = (int)grid.y; a.per_xcd = 0;
-    if (xcd) {
-        a.per_xcd = (a.nx * a.ny + 7) / 8;
-        grid = dim3((unsigned)(8 * a.per_xcd), 1);
-    }
+    a.nx = (int)grid.x; a.ny = (int)grid.y;
+    a.per_xcd = (a.nx * a.ny + 7) / 8;                  // XCD-aware 1-D grid (see the kernel)
+    grid = dim3((unsigned)(8 * a.per_xcd), 1);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), 0, st, a);
     AID_CHECK_LAUNCH();
     return AID_OK;
@@ -1061,13 +722,9 @@ static int launch_wino4v(const aid_conv2d_params* p, hipStream_t st) {
     const int rgroups = aid_cdiv(a.nrows, ROWS);
     dim3 grid((unsigned)(rgroups * a.tiles_t), (unsigned)(p->Cout_pad / M_BLK));
     auto kern = conv53_wino4v_kernel<MT, NTT, WGM, WGN, RMAX, KC, MINW>;      // LDS is static (see the kernel)
-    static int xcd = -1;
-    if (xcd < 0) { const char* e = getenv("AID_CONV_XCD"); xcd = e ? atoi(e) : 1; }
-    a.nx = (int)grid.x; a.ny = (int)grid.y; a.per_xcd = 0;
-    if (xcd) {
-        a.per_xcd = (a.nx * a.ny + 7) / 8;
-        grid = dim3((unsigned)(8 * a.per_xcd), 1);
-    }
+    a.nx = (int)grid.x; a.ny = (int)grid.y;
+    a.per_xcd = (a.nx * a.ny + 7) / 8;                  // XCD-aware 1-D grid (see the kernel)
+    grid = dim3((unsigned)(8 * a.per_xcd), 1);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), 0, st, a);
     AID_CHECK_LAUNCH();
     return AID_OK;
@@ -1079,9 +736,7 @@ static int wino_tile_n(int B, int Cout_pad, int F, int T) {
     if (Cout_pad % 64) return 512;
     int TT = aid_pow2ceil(T); if (TT > 512) TT = 512;
     const int64_t tiles = (int64_t)aid_cdiv((int64_t)B * F, 512 / TT) * aid_cdiv(T, TT) * (Cout_pad / 64);
-    static int thr = -1;
-    if (thr < 0) { const char* e = getenv("AID_WINO_SMALL_GRID"); thr = e ? atoi(e) : 160; }     // measured: B=1 +12 %, B=2 neutral, B>=4 never triggers on the shipped networks
-    return (tiles <= thr && aid_pow2ceil(T) >= 16) ? 256 : 512;
+    return (tiles <= 160 && aid_pow2ceil(T) >= 16) ? 256 : 512;     // measured: B=1 +12 %, B=2 neutral, B>=4 never triggers on the shipped networks
 }
 
 static bool wino_v_shape_ok(int Cin, int Cout, int T) {
@@ -1118,7 +773,7 @@ static int conv53_wino_v(const aid_conv2d_params* p, hipStream_t st) {
     AID_REQUIRE(al4(p->x) && al4(p->y) && (!p->res.p || al4(p->res)) && (!p->aux.p || al4(p->aux)), "aid_conv2d: x_wino views must be 16-byte aligned");
     int rc;
     if (p->Cout_pad % 64 == 0 && wino_tile_n(p->B, p->Cout_pad, p->F, p->T) == 256)
-                               rc = launch_wino4v<1, 1, 2, 2, 16, 2, 2>(p, st);     // 64 x 256, 4 waves: small grids
+                               rc = launch_wino4v<1, 1, 2, 2, 16, 2, 1>(p, st);     // 64 x 256, 4 waves (one per SIMD: 92 KB of LDS): small grids
     else if (p->Cout_pad % 64 == 0) rc = launch_wino4v<1, 1, 2, 4, 16, 2, 2>(p, st);     // 64 x 512, 8 waves
     else { aid_set_error("aid_conv2d: x_wino needs a 64-wide Cout tile (the 96-wide tile keeps the in-kernel transform: measured 5 % faster there)"); return AID_E_BADARG; }
     AID_REQUIRE(rc != 1000, "aid_conv2d: x_wino tile does not fit this T");
@@ -1136,21 +791,15 @@ int aid_conv53_wino_try(const aid_conv2d_params* p, hipStream_t st) {
     if (p->res.p && ((p->res.sB % 2) || (p->res.sC % 2) || (p->res.sF % 2) || (((uintptr_t)p->res.p) & 7))) return 0;
     if (p->aux.p && ((p->aux.sB % 2) || (p->aux.sC % 2) || (p->aux.sF % 2) || (((uintptr_t)p->aux.p) & 7))) return 0;
     if ((int64_t)4 * p->x.sC >= (1LL << 31)) return 0;
+    if (p->wino_taps != 30) return 0;                      // the 30-tap F(4,3) pack is the only Winograd pack
+    if ((p->y.sB % 4) || (p->y.sC % 4) || (p->y.sF % 4) || (((uintptr_t)p->y.p) & 15)) return 0;
+    if (p->res.p && ((p->res.sB % 4) || (p->res.sC % 4) || (p->res.sF % 4) || (((uintptr_t)p->res.p) & 15))) return 0;
+    if (p->aux.p && ((p->aux.sB % 4) || (p->aux.sC % 4) || (p->aux.sF % 4) || (((uintptr_t)p->aux.p) & 15))) return 0;
     int rc;
-    if (p->wino_taps == 30) {                              // F(4,3) pack
-        if ((p->y.sB % 4) || (p->y.sC % 4) || (p->y.sF % 4) || (((uintptr_t)p->y.p) & 15)) return 0;
-        if (p->res.p && ((p->res.sB % 4) || (p->res.sC % 4) || (p->res.sF % 4) || (((uintptr_t)p->res.p) & 15))) return 0;
-        if (p->aux.p && ((p->aux.sB % 4) || (p->aux.sC % 4) || (p->aux.sF % 4) || (((uintptr_t)p->aux.p) & 15))) return 0;
-        if (p->Cout_pad % 64 == 0 && wino_tile_n(p->B, p->Cout_pad, p->F, p->T) == 256)
-                                        rc = launch_wino4<1, 1, 2, 2, 16, 2, 2>(p, st);   // 64 x 256, 4 waves: small grids
-        else if (p->Cout_pad % 64 == 0) rc = launch_wino4<1, 1, 2, 4, 16, 2, 2>(p, st);   // 64 x 512, 8 waves, 1 workgroup / CU
-        else if (p->Cout_pad % 96 == 0) rc = launch_wino4<1, 1, 3, 4, 16, 2, 3>(p, st);   // 96 x 512, 12 waves
-        else return 0;
-        if (rc == 1000) return 0;
-        return rc == AID_OK ? 1 : rc;
-    }
-    if (p->Cout_pad % 64 == 0)                  rc = launch_wino<1, 1, 2, 4, 16, 2, 4>(p, st);   // 64 x 256, 8 waves, KC=2, <=128 VGPRs: 2 workgroups / CU
-    else if (p->Cout_pad % 96 == 0)             rc = launch_wino<1, 1, 3, 4, 16, 2>(p, st);   // 96 x 256, 12 waves, KC=2
+    if (p->Cout_pad % 64 == 0 && wino_tile_n(p->B, p->Cout_pad, p->F, p->T) == 256)
+                                    rc = launch_wino4<1, 1, 2, 2, 16, 2, 2>(p, st);   // 64 x 256, 4 waves: small grids
+    else if (p->Cout_pad % 64 == 0) rc = launch_wino4<1, 1, 2, 4, 16, 2, 2>(p, st);   // 64 x 512, 8 waves, 1 workgroup / CU
+    else if (p->Cout_pad % 96 == 0) rc = launch_wino4<1, 1, 3, 4, 16, 2, 3>(p, st);   // 96 x 512, 12 waves
     else return 0;
     if (rc == 1000) return 0;
     return rc == AID_OK ? 1 : rc;

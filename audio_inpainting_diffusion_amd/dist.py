@@ -6,12 +6,21 @@ rank r simply owns segments [lo_r, hi_r) with per-item RNG seeds derived from th
 Collectives: ONE broadcast of the flat fp32 weight buffer from rank 0 at start-up (745 MB for the 22 kHz
 network) and ONE all-gather of the outputs at the end -- nothing inside the sampling loop.  This replaces the
 reference's dead NCCL scaffold (utils/torch_utils/distributed.py:14-31, never initialised).
-Backend "nccl" is RCCL on ROCm; the same code runs under "gloo" on CPU for the unit tests.
+Backend "nccl" is RCCL on ROCm; the same code runs under "gloo" on CPU for the unit tests, and under "gloo"
+with device tensors when several ranks have to share one GPU (functional runs on a 1-GPU box: RCCL refuses
+two ranks on one device) -- the collectives are then staged through host memory.
+
+``launch_ranks`` is the self-launcher used by ``bench.py --gpus N`` when it was started as a plain ``python``
+process: it re-executes the same command under ``torch.distributed.run`` (one rank per GPU, 127.0.0.1
+rendezvous) and relays rank 0's output.
 """
 from __future__ import annotations
 
 import os
-from typing import List, Tuple
+import socket
+import subprocess
+import sys
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -29,7 +38,10 @@ def init_distributed(backend: str = None) -> Tuple[int, int, int]:
         if backend is None:
             backend = os.environ.get("AID_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+            if torch.cuda.device_count() < min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+                raise RuntimeError(f"RCCL needs one GPU per rank ({torch.cuda.device_count()} visible for "
+                                   f"{world} ranks); set AID_DIST_BACKEND=gloo for a functional shared-GPU run")
+            torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
@@ -46,50 +58,118 @@ def item_seeds(base_seed: int, lo: int, hi: int) -> List[int]:
     return [base_seed + i for i in range(lo, hi)]
 
 
+def _active() -> bool:
+    return dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _host_staged(t: torch.Tensor) -> bool:
+    """gloo cannot run every collective on device memory: stage device tensors through the host for it."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+@torch.no_grad()
+def flatten_parameters_(module: torch.nn.Module) -> torch.Tensor:
+    """Re-home every fp32 parameter and buffer of ``module`` as a view into ONE flat buffer (idempotent) and return
+    that buffer.  The weight broadcast is then a single zero-copy collective on it -- no second 745 MB staging
+    copy -- and in-place loads (``load_state_dict`` copies into ``.data``) keep the views intact."""
+    tensors = [p for p in module.parameters()] + [b for b in module.buffers()]
+    tensors = [t for t in tensors if t.dtype == torch.float32]
+    flat = getattr(module, "_aid_flat", None)
+    if flat is not None and len(tensors) and all(
+            t.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for t in tensors):
+        return flat
+    total = sum(t.numel() for t in tensors)
+    dev = tensors[0].device if tensors else torch.device("cpu")
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        view = flat[off:off + n].view(t.shape)
+        view.copy_(t.data)
+        t.data = view                       # frees the old storage tensor by tensor: peak extra = one tensor
+        off += n
+    module._aid_flat = flat
+    if hasattr(module, "_packed_ver"):      # kernel-side weight packs must be refreshed (network.prepare)
+        module._packed_ver = None
+    return flat
+
+
 @torch.no_grad()
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> int:
-    """Broadcast all parameters and buffers from ``src`` as ONE flat fp32 buffer.  Returns bytes sent."""
-    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
-    if not tensors:
+    """Broadcast all fp32 parameters and buffers from ``src`` as ONE flat buffer, in place.  Returns bytes sent."""
+    flat = flatten_parameters_(module)
+    if flat.numel() == 0:
         return 0
-    flat = torch.cat([t.reshape(-1).float() for t in tensors])
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.broadcast(flat, src=src)
-        off = 0
-        for t in tensors:
-            n = t.numel()
-            t.copy_(flat[off:off + n].reshape(t.shape))
-            off += n
+    if _active():
+        if _host_staged(flat):
+            host = flat.cpu()
+            dist.broadcast(host, src=src)
+            flat.copy_(host)
+        else:
+            dist.broadcast(flat, src=src)
+        if hasattr(module, "_packed_ver"):
+            module._packed_ver = None
     return flat.numel() * 4
 
 
 @torch.no_grad()
 def gather_outputs(local_out: torch.Tensor, n_items: int) -> torch.Tensor:
     """All-gather the per-rank outputs [n_local, L] into [n_items, L] (same on every rank)."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not _active():
         return local_out
     world = dist.get_world_size()
     L = local_out.shape[-1]
     nmax = -(-n_items // world)
-    pad = torch.zeros(nmax, L, dtype=local_out.dtype, device=local_out.device)
-    pad[: local_out.shape[0]] = local_out
+    staged = _host_staged(local_out)
+    work_dev = torch.device("cpu") if staged else local_out.device
+    pad = torch.zeros(nmax, L, dtype=local_out.dtype, device=work_dev)
+    pad[: local_out.shape[0]] = local_out.to(work_dev)
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
     parts = []
     for r in range(world):
         lo, hi = shard_range(n_items, r, world)
         parts.append(bufs[r][: hi - lo])
-    return torch.cat(parts, dim=0)
+    return torch.cat(parts, dim=0).to(local_out.device)
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not _active():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dev = torch.device("cpu") if dist.get_backend() == "gloo" else device
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# self-launch (bench.py --gpus N started as a plain python process)
+# ---------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n: int, argv: Optional[List[str]] = None, timeout: Optional[float] = None) -> int:
+    """Re-execute ``argv`` (default: this process's command line) as ``n`` ranks under ``torch.distributed.run``
+    on this node, 127.0.0.1 rendezvous, one rank per GPU.  When fewer than ``n`` GPUs are visible the ranks share
+    them round-robin and the collectives run on gloo (functional mode, labelled as such by the caller).
+    Returns the launcher's exit code; stdout/stderr of the ranks pass through."""
+    argv = list(sys.argv if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < n:
+        env["AID_DIST_BACKEND"] = "gloo"
+        env["AID_SHARED_GPU"] = str(max(1, ndev))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + argv
+    return subprocess.run(cmd, env=env, timeout=timeout).returncode

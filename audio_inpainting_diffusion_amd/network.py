@@ -21,7 +21,6 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -174,8 +173,6 @@ class _Builder:
         self.gstate = {}       # storage data_ptr -> 'full' (first contribution overwrites the whole tensor: no zero fill,
                                #   no read-modify-write) | 'zero' (touched through partial views: zero-filled, accumulated)
         self.scratch = {}      # shape -> scratch tensor for dgrad outputs awaiting the normalisation backward
-        self.fuse_dot = os.environ.get("AID_FUSE_DOT", "1") != "0"  # <gd, x> partials from the dgrad conv epilogue instead of aid_group_dot
-        self.wino_v = os.environ.get("AID_WINO_V", "1") != "0"      # Winograd-domain conv inputs (see _wino_input); 0 = in-kernel transform
 
     # ---- gradient storage: one flat buffer per activation storage, views share strides/offsets ------------
     def G(self, t):
@@ -251,7 +248,7 @@ class _Builder:
         if F == 1 and kh == 1 and epi == 0:              # qk projections: few columns, long K -> split-K scratch (aid_kernels.h)
             ws = self._scratch(("ws", 8 * B * cout * T))
             p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
-        assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] in (20, 30) and wpw.shape[1:] == wp.shape[1:]))
+        assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] == 30 and wpw.shape[1:] == wp.shape[1:]))
         # algorithmic HBM bytes: x once, residual / aux once, y once, weights once
         nb = 4 * (B * F * T * (cin + cout * (1 + (res is not None) + (aux is not None))) + cin * cout * kh * kw)
         self.plan.add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, ws, flops=2 * B * F * T * cin * cout * kh * kw,
@@ -268,7 +265,7 @@ class _Builder:
     def _wino_input(self, cin, cout, T, wp, wpw):
         """True when the pre-pass should write the F(4,3) input transform (aid_scale_act wino=1 -> aid_conv2d x_wino=1):
         measured +5-8 % on the 64-wide M tiles, -5 % on the 96-wide one (12 waves, 123 KB of LDS), which stays in-kernel."""
-        return (self.wino_v and wpw is not None and wpw.shape[0] == 30 and wp.shape[2] % 64 == 0
+        return (wpw is not None and wpw.shape[0] == 30 and wp.shape[2] % 64 == 0
                 and bool(_lib.lib().aid_conv2d_wino_input_supported(cin, cout, T)))
 
     def conv(self, x, y, wp, cin, cout, kh=1, kw=1, dil=1, in_scale=None, act=0, out_scale=None, res=None,
@@ -314,7 +311,7 @@ class _Builder:
                 gd = self._scratch(x.shape)
                 # <gd, x> per (sample, group): folded into the dgrad conv's epilogue when it runs on the F(4,3) kernels
                 nd = 0
-                if self.fuse_dot and act and kh == 5 and gsc is None and wpwT is not None and wpwT.shape[0] == 30:
+                if act and kh == 5 and gsc is None and wpwT is not None and wpwT.shape[0] == 30:
                     nd = int(_lib.lib().aid_conv2d_dot_partials(B, cout, cin, F, T))
                 dws = self._dot_ws(nd) if nd else self.stats_ws
                 self._conv_raw(gin, gd, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, None, 1.0, alpha,
@@ -433,7 +430,6 @@ class Unet_CQT_oct_with_attention(nn.Module):
                 _ResBlock(dim_out, 2, 1, (1, 1), E, proj_place="after"),
                 _ResBlock(dim_in, dim_out, self.num_dils[i], (5, 3), E, attention=bool(self.attention_layers[i]), heads=H,
                           fdim=(i + 1) * bpo)]))
-        self.winograd_f4 = os.environ.get("AID_WINOGRAD", "4") != "2"     # F(4,3) by default; AID_WINOGRAD=2 selects F(2,3)
         self._packed: Dict[str, torch.Tensor] = {}
         self._packed_ver = None
         self._states: Dict[int, dict] = {}
@@ -481,8 +477,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
                 put(name, _lib.pack_conv_weight(w))
                 put(name + "#T", _lib.pack_conv_weight(w, transpose=True))
                 if w.dim() == 4 and tuple(w.shape[2:]) == (5, 3) and w.shape[0] >= 64 and w.shape[1] >= 64:
-                    put(name + "#W", _lib.pack_conv_weight_wino(w, f4=self.winograd_f4))     # Winograd packs (F(4,3) or F(2,3))
-                    put(name + "#WT", _lib.pack_conv_weight_wino(w, transpose=True, f4=self.winograd_f4))
+                    put(name + "#W", _lib.pack_conv_weight_wino(w))                 # Winograd F(4,3) packs
+                    put(name + "#WT", _lib.pack_conv_weight_wino(w, transpose=True))
             elif leaf == "gamma":
                 put(name, w.detach().reshape(-1).float())
         # stacked modulation matrix: [affine2, gate2]? then per step [affine.k, gate.k], block after block

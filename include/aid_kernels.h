@@ -32,6 +32,9 @@ extern "C" {
 int aid_abi_version(void);
 /* last HIP error string seen by a launcher in this process (never NULL) */
 const char* aid_last_error(void);
+/* name of the device kernel the most recent aid_conv2d call dispatched to (host-side bookkeeping for measurements;
+   bench.py groups conv launch times per kernel family with it; never NULL) */
+const char* aid_last_kernel(void);
 
 /* ---------------------------------------------------------------------------------------------------
  * 4-D fp32 view: element (b,c,f,t) lives at p[b*sB + c*sC + f*sF + t].
@@ -78,13 +81,12 @@ int aid_group_stats(const aid_group_stats_params* p, void* stream);
  *   epilogue extension for the input-VJP (guidance branch), selected by `epi`:
  *       epi = 0 : as above
  *       epi = 1 : y = alpha * acc * out_scale * gelu'(aux[b,co,f,t] * aux_scale[b,co])   (dGELU epilogue)
- *   Winograd path (5x3, no in-kernel prologue, Cin % 4 == 0, Cout >= 64, even T): when `wp_wino` is given the
- *   launcher uses F(2,3) along T -- U = G w (U0=w0, U1=(w0+w1+w2)/2, U2=(w0-w1+w2)/2, U3=w2, packed as 20 "taps"
- *   xi*KH+kh), V = B^T d formed from the LDS strip at fragment-load time, 4 MFMAs per 2 output samples instead of 6,
- *   y0 = m0+m1+m2, y1 = m1-m2-m3 in the epilogue.  Same fp32 MFMA, 1.5x fewer of them; results differ from the
- *   direct form only by fp32 rounding (tests: <= 2e-6 rel-L2).  F(4,3) (wino_taps = 30): 6 MFMAs per 4 output
- *   samples (2x fewer than direct); U = G w with G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],
- *   [1/24,-1/12,1/6],[0,0,1]]; fp32 error ~2x that of direct accumulation.
+ *   Winograd path (5x3, no in-kernel prologue, Cin % 4 == 0, Cout >= 64, T % 4 == 0): when `wp_wino` is given the
+ *   launcher uses F(4,3) along T -- 6 MFMAs per 4 output samples (2x fewer than the direct form).  U = G w with
+ *   G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]] packed as 30 "taps"
+ *   xi*KH+kh; V = B^T d either formed from the LDS strip at fragment-load time or supplied by the caller (x_wino);
+ *   output transform in the epilogue.  Same exact-fp32 MFMA; results differ from the direct form only by fp32
+ *   rounding (tests: <= 2e-6 rel-L2, about 2x the error of direct accumulation).
  *   weights are PRE-PACKED by the host: wp[KH*KW][Cin_pad][Cout_pad], cout contiguous, zero padded
  *   (Cin_pad % 32 == 0, Cout_pad a multiple of the M tile the launcher picks for Cout) -- see aid_conv2d_pack_dims.
  * ------------------------------------------------------------------------------------------------- */
@@ -99,8 +101,8 @@ typedef struct {
     int KH, KW, dilF;
     int act, epi;
     float alpha, res_scale;
-    const float* wp_wino;     /* optional: Winograd pack of the same 5x3 weights: F(2,3) = 20 taps, F(4,3) = 30 taps (see below) */
-    int wino_taps;            /* 20 or 30 (0 when wp_wino is NULL) */
+    const float* wp_wino;     /* optional: Winograd F(4,3) pack of the same 5x3 weights, 30 taps (see above) */
+    int wino_taps;            /* 30 (0 when wp_wino is NULL) */
     int x_wino;               /* 1: `x` is the F(4,3) INPUT TRANSFORM of the activations, written by aid_scale_act(wino=1):
                                  [B, Cin, F, 6, T/4] (sF = 6*T/4 ...), V = B^T d per group of 4 samples; needs wp_wino with 30 taps
                                  and aid_conv2d_wino_input_supported(...) != 0.  The kernel then stages and multiplies only. */
@@ -179,9 +181,9 @@ int aid_modulation(const aid_modulation_params* p, void* stream);
 /* ---------------------------------------------------------------------------------------------------
  * CQT (octave-mode NSGT).  replaces the external cqt_nsgt_pytorch calls CQT_nsgt.fwd / .bwd /
  * .apply_hpf_DC (call sites unet...py:743,841; testing/edm_sampler_inpainting.py:63,123).
- * The length-L real FFTs on either side are done by the caller (rocFFT through torch.fft in round 1).
+ * The length-L real FFTs on either side are aid_fft_pass (mixed-radix Stockham, one launch per radix; below).
  *
- * Band table (device, built once by the host from audio-inpainting-diffusion_amd/cqt.py):
+ * Band table (device, built once by the host from audio_inpainting_diffusion_amd/cqt.py):
  *   band k of octave o:  centre bin rc[k], window length Lg[k], window samples g[goff[k] .. goff[k]+Lg[k])
  *   (analysis window) or the dual window times M_k (synthesis), sampled at offsets j = -Lg/2 .. Lg-Lg/2-1.
  *

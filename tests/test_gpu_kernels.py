@@ -117,7 +117,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("wino", [0, 20, 30])
+@pytest.mark.parametrize("wino", [0, 30])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d(L, case, wino):
     B, Cin, Cout, Fd, T, KH, KW, dil, pro, epi = case
@@ -154,7 +154,7 @@ def test_conv2d(L, case, wino):
     if wino:
         if (KH, KW) != (5, 3) or pro or Cin % 4 or Cout < 64:
             pytest.skip("Winograd path needs a plain-copy 5x3 conv with Cin % 4 == 0 and Cout >= 64")
-        wpw = L.pack_conv_weight_wino(wd, f4=(wino == 30))
+        wpw = L.pack_conv_weight_wino(wd)
         p.wp_wino, p.wino_taps = wpw.data_ptr(), wino
     L.call("aid_conv2d", p)
     torch.cuda.synchronize()
@@ -199,7 +199,7 @@ def test_conv2d_winograd_domain_input(L, case):
     Vref = torch.einsum("xk,bcfgk->bcfxg", BT, d).reshape(B, Cin, Fd, 6 * G)
     assert rel_l2(xv.cpu(), Vref) < 1e-6
     # (2) the convolution on it
-    wp, wpw = L.pack_conv_weight(wd), L.pack_conv_weight_wino(wd, f4=True)
+    wp, wpw = L.pack_conv_weight(wd), L.pack_conv_weight_wino(wd)
     y = torch.empty(B, Cout, Fd, T, device=DEV)
     p = L.Conv2dParams()
     resd = None if res is None else res.to(DEV)
@@ -445,7 +445,7 @@ def test_conv2d_dispatch_fuzz(L):
         p.alpha, p.res_scale = alpha, res_scale
         p.x_wino = int(xw)
         if wino:
-            wpw = L.pack_conv_weight_wino(wd, f4=True)
+            wpw = L.pack_conv_weight_wino(wd)
             p.wp_wino, p.wino_taps = wpw.data_ptr(), 30
         ws = None
         if Fd == 1 and not k53:

@@ -211,7 +211,7 @@ def test_conv_epilogue_dot_partials(L, case):
     aux = _rand(B, Cout, Fd, T, seed=42)
     asc = 1.0 + 0.3 * _rand(B, Cout, seed=43)
     gd, wd, auxd, ascd = g.to(DEV), w.to(DEV), aux.to(DEV), asc.to(DEV)
-    wp, wpw = L.pack_conv_weight(wd), L.pack_conv_weight_wino(wd, f4=True)
+    wp, wpw = L.pack_conv_weight(wd), L.pack_conv_weight_wino(wd)
     y = torch.empty(B, Cout, Fd, T, device=DEV)
     ws = torch.full((B * 8 * (P + 1),), float("nan"), device=DEV, dtype=torch.float64)
     p = L.Conv2dParams()

@@ -38,8 +38,7 @@ def main():
     p.KH, p.KW, p.dilF, p.act, p.epi = KH, KW, dil, act, 0
     p.alpha, p.res_scale = 1 / math.sqrt(2), 1.0
     if os.environ.get('PROBE_WINO', '0') != '0' and KH == 5:
-        f4 = os.environ.get('PROBE_WINO') == '30'
-        wpw = L.pack_conv_weight_wino(w, f4=f4)
+        wpw = L.pack_conv_weight_wino(w)
         p.wp_wino, p.wino_taps = wpw.data_ptr(), wpw.shape[0]
     if os.environ.get('PROBE_V', '0') != '0':         # Winograd-domain input written by aid_scale_act(wino=1)
         assert L.lib().aid_conv2d_wino_input_supported(Cin, Cout, T)

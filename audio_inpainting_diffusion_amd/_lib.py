@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AID_LIB_PATH") or os.path.join(_HERE, "libaid_hip.so")      # override: kernel experiments only
 AID_CQT_MAX_OCT = 12
 AID_STATS_SPLIT = 32
+AID_ATTN_MAX_T = 128          # aid_time_attention: one workgroup holds a whole [T, T] score tile
 
 
 class AidError(RuntimeError):

@@ -154,7 +154,8 @@ class _Plan:
                 e0.record()
                 rc = fn(addr, stream)
                 e1.record()
-                timing.append((e0, e1, flops, self._cur_descr(fn, addr), self.opbytes.get(addr, 0)))
+                timing.append((e0, e1, flops, self._cur_descr(fn, addr), self.opbytes.get(addr, 0),
+                               _lib.lib().aid_last_kernel().decode()))
             else:
                 rc = fn(addr, stream)
             if rc != 0:
@@ -469,6 +470,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
                 self._packed[key].copy_(t)
             else:
                 self._packed[key] = t.clone()
+                self._states.clear()             # cached launch plans hold raw pointers into the replaced pack
 
         sd = dict(self.named_parameters())
         for name, w in sd.items():
@@ -571,6 +573,13 @@ class Unet_CQT_oct_with_attention(nn.Module):
         for i in range(1, n):
             assert Tl[i] * 2 == Tl[i - 1], "octave lengths must halve per level (unet...py:768-774,786)"
         Fl = [(i + 1) * bpo for i in range(n)]
+        for i in range(n):
+            if self.attention_layers[i] and Tl[i] > _lib.AID_ATTN_MAX_T:
+                raise NotImplementedError(f"attention at level {i} has T={Tl[i]} > {_lib.AID_ATTN_MAX_T} (aid_time_attention limit)")
+        for nm in ("downsamplerT", "upsamplerT"):
+            k = getattr(self, nm).kernel.detach().float().cpu()
+            if not torch.allclose(k, torch.tensor(_CUBIC), atol=1e-7):
+                raise NotImplementedError(f"{nm}.kernel differs from the reference's cubic FIR (unet...py:514-515), which aid_resample hard-wires")
         st = dict(B=B)
         bd = _Builder(self, B, dev)
         st["sigma"] = bd.buf(B)
@@ -648,11 +657,16 @@ class Unet_CQT_oct_with_attention(nn.Module):
         st["builder"] = bd            # the input-VJP plan is emitted lazily (first guided evaluation)
         return st
 
+    MAX_CACHED_STATES = 2      # launch plans kept alive (each owns all activations / gradients of its batch size: ~61 GB at B=8 guided)
+
     def _state(self, B: int):
         self.prepare()
-        st = self._states.get(B)
+        st = self._states.pop(B, None)
         if st is None:
-            st = self._states[B] = self._build_state(B)
+            while len(self._states) >= self.MAX_CACHED_STATES:          # least recently used first (dicts keep insertion order)
+                self._states.pop(next(iter(self._states)))
+            st = self._build_state(B)
+        self._states[B] = st                                            # (re)insert as most recently used
         return st
 
     # ---------------------------------------------------------------------------------------------------
@@ -752,8 +766,13 @@ class Unet_CQT_oct_with_attention(nn.Module):
         x_hat = tr.irfft(Y)
         g = torch.empty_like(x_hat)
         norm = torch.empty(B, device=x.device, dtype=torch.float32)
+        if not (y.is_cuda and y.dtype == torch.float32 and y.is_contiguous() and tuple(y.shape) == (B, L)):
+            raise _lib.AidError("denoise_guided: y must be a contiguous float32 GPU tensor of shape [B, L]")
         if degradation is None:
             m = mask if mask.dim() == 2 else mask.reshape(1, -1)
+            if not (m.is_cuda and m.dtype == torch.float32 and m.stride(-1) == 1 and m.shape[-1] == L and m.shape[0] in (1, B)):
+                raise _lib.AidError("denoise_guided: mask must be a float32 GPU tensor [1|B, L] with unit inner stride "
+                                    "(Sampler.setup_inpainting normalises it)")
             sp = _lib.GuidanceSeedParams(x_hat.data_ptr(), y.data_ptr(), m.data_ptr(), m.stride(0) if m.shape[0] > 1 else 0,
                                          g.data_ptr(), norm.data_ptr(), B, L)
             _lib.call("aid_guidance_seed", sp)

@@ -154,7 +154,12 @@ class Sampler:
         B, L = x.shape
         xnext = torch.empty_like(x)
         dout = torch.empty_like(x) if mode == 0 else None
-        proj = self.data_consistency and self.y is not None
+        # guided branch: project only with data_consistency.type == "always" (:100); replacement branch (xi == 0):
+        # at EVERY evaluation whatever the type (:141-147) -- like the reference, which fails there when no projection
+        # was ever defined (data_consistency.use False, :338)
+        proj = self.y is not None and (self.data_consistency or self.xi == 0)
+        if proj and not (self.data_consistency or self.data_consistency_end):
+            raise AttributeError("proj_convex_set is undefined: the replacement branch (xi = 0) needs tester.data_consistency.use")
         if proj and self.spectral is not None:                     # y + x_hat - A(x_hat)   (:360)
             x_hat, proj = self.spectral.project(x_hat, self.y), False
         xh_out = torch.empty_like(x) if (self.trace is not None or self.rid) else None
@@ -240,23 +245,40 @@ class Sampler:
             return x.detach(), r["denoised"], r["grads"], r["grad_update"], r["pocs"], r["xt"], r["xt2"], state["t"]
         return x.detach()
 
+    def setup_inpainting(self, y_masked, mask):
+        """Install observations y_masked[B,L] and mask[1|B,L] (any dtype / device / strides) for the time-domain
+        degradation; ``predict`` / ``begin`` + ``step`` then run the loop."""
+        if mask.dim() == 1:
+            mask = mask.reshape(1, -1)
+        dev = y_masked.device
+        self.y = y_masked.contiguous().float()
+        self.mask = mask.to(dev, torch.float32).contiguous()         # read as a raw float* by aid_guidance_seed
+        if self.mask.shape[-1] != self.y.shape[-1] or self.mask.shape[0] not in (1, self.y.shape[0]):
+            raise ValueError(f"mask {tuple(mask.shape)} does not match observations {tuple(y_masked.shape)}")
+        self.spectral = None
+        self.smask = None
+        if self.data_consistency or self.data_consistency_end:
+            sm = prepare_smooth_mask(mask, self.args.tester.data_consistency.hann_size) if self.smooth else mask
+            self.smask = sm.to(dev, torch.float32).contiguous()
+
     def predict_inpainting(self, y_masked, mask):
         """y_masked[B,L], mask[1|B,L] -> inpainted [B,L] on y_masked.device   (:327-346)"""
-        self.mask = mask.to(y_masked.device)
-        self.spectral = None
-        self.y = y_masked.contiguous().float()
-        if self.data_consistency or self.data_consistency_end:
-            sm = prepare_smooth_mask(mask, self.args.tester.data_consistency.hann_size) if self.smooth else mask.float()
-            self.smask = sm.to(y_masked.device).contiguous()
+        self.setup_inpainting(y_masked, mask)
         return self.predict(self.y.shape, self.y.device)
+
+    def setup_spectrogram_inpainting(self, y, mask, observed_is_clean=False):
+        """Install the STFT-domain degradation (mask[F,T] or [B,F,T]).  observed_is_clean: ``y`` is the clean signal
+        and the observation is A(y) (what the tester computes before calling predict_spectrogram_inpainting)."""
+        st = self.args.tester.spectrogram_inpainting.stft
+        y = y.contiguous().float()
+        self.mask = self.smask = None
+        self.spectral = SpectralMask(mask, y.shape[-1], st.n_fft, st.hop_length, st.win_length, st.window, y.device)
+        self.y = self.spectral.apply(y) if observed_is_clean else y
 
     def predict_spectrogram_inpainting(self, y_masked, mask):
         """y_masked[B,L], mask[F,T] (or [B,F,T]) over the STFT of tester.spectrogram_inpainting.stft -> [B,L]
         (:348-364): degradation = STFT-domain masking, projection y + x - A(x)."""
-        st = self.args.tester.spectrogram_inpainting.stft
-        self.y = y_masked.contiguous().float()
-        self.mask = self.smask = None
-        self.spectral = SpectralMask(mask, self.y.shape[-1], st.n_fft, st.hop_length, st.win_length, st.window, self.y.device)
+        self.setup_spectrogram_inpainting(y_masked, mask)
         return self.predict(self.y.shape, self.y.device)
 
 

@@ -55,10 +55,13 @@ def spectral_mask_apply(x: torch.Tensor, mask: torch.Tensor, n_fft=1024, hop=256
 
 class OracleSampler:
     def __init__(self, model, edm, T=35, order=2, xi=0.25, norm=2, data_consistency=True, smooth=True,
-                 hann_size=50, filter_out_cqt_DC_Nyq=True, audio_len=None):
+                 hann_size=50, filter_out_cqt_DC_Nyq=True, audio_len=None, dc_type="always"):
         self.model, self.edm = model, edm
         self.nb_steps, self.order, self.xi, self.norm = T, order, xi, norm
-        self.data_consistency, self.smooth, self.hann_size = data_consistency, smooth, hann_size
+        # (:22-24) data_consistency.use and type == "always" | "end"
+        self.data_consistency = bool(data_consistency) and dc_type == "always"
+        self.data_consistency_end = bool(data_consistency) and dc_type == "end"
+        self.smooth, self.hann_size = smooth, hann_size
         self.filter_hpf = filter_out_cqt_DC_Nyq
         self.audio_len = audio_len
         self.trace = None
@@ -87,8 +90,12 @@ class OracleSampler:
         else:
             with torch.no_grad():
                 x_hat = self.edm.denoiser(x, self.model, sig)
-        if self.data_consistency:
-            x_hat = self.project(x_hat)                                                     # (:100, :343 / :360)
+        if self.data_consistency or self.xi == 0:
+            # guided branch: only with type "always" (:100); replacement branch: at EVERY evaluation, whatever the
+            # type (:141-147) -- the reference raises AttributeError there when no projection was ever defined
+            if not (self.data_consistency or self.data_consistency_end):
+                raise AttributeError("proj_convex_set is undefined: data_consistency.use is False (:338)")
+            x_hat = self.project(x_hat)                                                     # (:100, :146, :343 / :360)
         self._rid_pocs = x_hat.detach().clone()
         if self.trace is not None:
             self.trace.append(x_hat.detach().clone())
@@ -105,7 +112,7 @@ class OracleSampler:
         self.y, self.mask = y_masked, mask
         self.degradation = lambda x: self.mask * x
         self.project = lambda x: self.smask * self.y + (1 - self.smask) * x
-        if self.data_consistency:
+        if self.data_consistency or self.data_consistency_end:
             self.smask = smooth_mask_rows(mask, self.hann_size) if self.smooth else mask
         return self._predict(seeds, record)
 
@@ -155,6 +162,8 @@ class OracleSampler:
                 x = x + h * d
             if rid:
                 R["xt2"][i] = x
+        if self.data_consistency_end:                                                       # (:252)
+            x = self.project(x)
         if rid:                                                                             # (:260)
             return x.detach(), R["denoised"], R["grads"], R["grad_update"], R["pocs"], R["xt"], R["xt2"], t
         return x.detach()

@@ -19,6 +19,7 @@ Fixtures written (inputs + reference outputs only -- data, not code):
                      (weights are regenerated from the seeded initialiser, seed stored)
   edm_schedule.npz   create_schedule / get_gamma for T in {35,36,70,128} with the tester parameters
   sampler_toy.npz    full sampler trajectories (reference Sampler + EDM driving a toy denoiser)
+  sampler_dc.npz         data_consistency.type = 'end' / 'always' on both branches (guided, replacement)
   sampler_rid.npz        rid=True: the sampler's per-step debug buffers (denoised, grads, grad_update, pocs, xt, xt2, t)
   sampler_spectral.npz   spectrogram inpainting: apply_spectral_mask + full trajectories (guided / replacement)
   unet_full_cfgA.npz (--full) full-size 22.05 kHz network output for the seeded weights/input (B=1)
@@ -200,6 +201,33 @@ def gen_sampler(out):
     np.savez_compressed(os.path.join(out, "sampler_toy.npz"), **d)
 
 
+def gen_dc(out):
+    """data_consistency.type variants of the reference sampler (edm_sampler_inpainting.py:22-24, :100, :141-147, :252):
+    'end' projects only after the loop on the guided branch, but the replacement branch (xi = 0) projects at EVERY
+    evaluation whatever the type."""
+    import diff_params.edm as E
+    import testing.edm_sampler_inpainting as S
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.init import seeded_normal
+    L, T = 2048, 5
+    d = {"L": np.array(L), "T": np.array(T)}
+    net = _ToyNet(L)
+    for tag, xi, dctype, seed in (("g_end", 0.25, "end", 0), ("r_end", 0.0, "end", 1), ("g_always", 0.25, "always", 2)):
+        args = make_args(audio_len=L, T=T, xi=xi)
+        args.tester.data_consistency.type = dctype
+        args.tester.data_consistency.hann_size = 20
+        smp = S.Sampler(model=net, diff_params=E.EDM(args), args=args, rid=False)
+        y = torch.from_numpy(seeded_normal(4, seed, L)).reshape(1, L) * 0.063
+        mask = torch.ones(1, L)
+        mask[:, 800:1100] = 0
+        torch.manual_seed(seed)
+        x = smp.predict_inpainting(y * mask, mask)
+        d[f"{tag}.y"], d[f"{tag}.mask"], d[f"{tag}.out"] = (y * mask).numpy(), mask.numpy(), x.numpy()
+        d[f"{tag}.meta"] = np.array([xi, seed, 1.0 if dctype == "end" else 0.0], dtype=np.float64)
+        print("dc", tag, "out rms", float(x.pow(2).mean().sqrt()))
+    np.savez_compressed(os.path.join(out, "sampler_dc.npz"), **d)
+
+
 def gen_rid(out):
     """rid=True: the reference sampler's per-step debug buffers (edm_sampler_inpainting.py:185-191, :217-226, :255-260)."""
     import diff_params.edm as E
@@ -279,11 +307,12 @@ if __name__ == "__main__":
     a = ap.parse_args()
     _setup_imports()
     torch.set_grad_enabled(True)
-    todo = a.only.split(",") if a.only else ["ops", "unet", "edm", "sampler", "spectral", "rid"] + (["full"] if a.full else [])
+    todo = a.only.split(",") if a.only else ["ops", "unet", "edm", "sampler", "spectral", "rid", "dc"] + (["full"] if a.full else [])
     if "ops" in todo: gen_ops(HERE)
     if "unet" in todo: gen_unet_small(HERE)
     if "edm" in todo: gen_edm(HERE)
     if "sampler" in todo: gen_sampler(HERE)
     if "spectral" in todo: gen_spectral(HERE)
     if "rid" in todo: gen_rid(HERE)
+    if "dc" in todo: gen_dc(HERE)
     if "full" in todo: gen_full(HERE)

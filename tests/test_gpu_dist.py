@@ -1,0 +1,182 @@
+"""Multi-GPU path on ONE GPU: world-size independence of a sampler run, and the self-launching bench entry point.
+
+RCCL refuses two ranks on one device, so on a 1-GPU box the two ranks share cuda:0 and the collectives run on the
+gloo backend (staged through host memory by dist.py) -- the sharding, per-item seeds, weight broadcast and output
+gather are the same code the 8-GPU run uses (BASELINE.json configs[2])."""
+import ast
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, ROOT, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup(dev, seed_offset=0, T=2, xi=0.25):
+    from audio_inpainting_diffusion_amd.config import small_args
+    from audio_inpainting_diffusion_amd.init import seeded_init_
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    z = np.load(os.path.join(GOLDEN, "unet_small_a.npz"))
+    kw = ast.literal_eval(str(z["cfg"]))
+    args = small_args(**kw)
+    args.tester.T, args.tester.posterior_sampling.xi = T, xi
+    args.tester.data_consistency.hann_size = 20
+    net = Unet_CQT_oct_with_attention(args, torch.device(dev))
+    seeded_init_(net, int(z["seed"]) + seed_offset, gate_scale=10.0, affine_scale=10.0)
+    return net, args, kw
+
+
+def _segments(n, L):
+    from audio_inpainting_diffusion_amd.init import seeded_normal
+    y = torch.stack([torch.from_numpy(seeded_normal(31, g, L)) for g in range(n)]) * 0.063
+    mask = torch.ones(1, L)
+    mask[:, 1800:2300] = 0
+    return y, mask
+
+
+def _sample(net, args, y, mask, seeds, dev):
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.sampler import Sampler
+    smp = Sampler(model=net, diff_params=EDM(args), args=args)
+    smp.seeds = seeds
+    return smp.predict_inpainting((y * mask).to(dev), mask.to(dev))
+
+
+def _worker(rank, world, port, n_items, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      AID_DIST_BACKEND="gloo")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from audio_inpainting_diffusion_amd import dist as D
+    r, _, w = D.init_distributed()
+    torch.cuda.set_device(0)
+    net, args, kw = _setup("cuda:0", seed_offset=rank)      # ranks start with DIFFERENT weights: the broadcast must fix that
+    nbytes = D.broadcast_parameters(net, src=0)
+    y, mask = _segments(n_items, kw["audio_len"])
+    lo, hi = D.shard_range(n_items, r, w)
+    out = _sample(net, args, y[lo:hi], mask, D.item_seeds(500, lo, hi), "cuda:0")
+    allout = D.gather_outputs(out, n_items)
+    D.barrier()
+    q.put((rank, nbytes, (lo, hi), allout.cpu().numpy()))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_one_process():
+    """gather(2 ranks x B=2) == single-process B=4 sampler output (guided branch, T=2, small golden network)."""
+    from audio_inpainting_diffusion_amd import dist as D
+    n_items = 4
+    net, args, kw = _setup(DEV)
+    y, mask = _segments(n_items, kw["audio_len"])
+    ref = _sample(net, args, y, mask, D.item_seeds(500, 0, n_items), DEV).cpu()
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert [r[2] for r in res] == [(0, 2), (2, 4)]
+    for rank, nbytes, _, allout in res:
+        e = rel_l2(allout, ref)
+        print(f"rank {rank}: gathered 2x2 segments vs single-process B=4: rel-L2 = {e:.2e} ({nbytes / 1e6:.2f} MB broadcast)")
+        assert allout.shape == tuple(ref.shape) and e < 1e-6
+    assert np.array_equal(res[0][3], res[1][3])
+
+
+def test_flat_parameter_storage_survives_load_and_repack():
+    """flatten_parameters_ re-homes the weights as views of one buffer; loading a state_dict afterwards must keep the
+    views and refresh the kernel-side packs."""
+    from audio_inpainting_diffusion_amd import dist as D
+    net, args, kw = _setup(DEV)
+    z = np.load(os.path.join(GOLDEN, "unet_small_a.npz"))
+    x, cn = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["cnoise"]).to(DEV)
+    with torch.no_grad():
+        y0 = net(x, cn)
+    flat = D.flatten_parameters_(net)
+    assert all(p.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in net.parameters())
+    assert D.flatten_parameters_(net) is flat                # idempotent
+    with torch.no_grad():
+        assert torch.equal(net(x, cn), y0)
+    other, _, _ = _setup(DEV, seed_offset=7)
+    with torch.no_grad():
+        y_other = other(x, cn)
+    net.load_state_dict(other.state_dict())
+    assert all(p.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in net.parameters())
+    with torch.no_grad():
+        assert torch.equal(net(x, cn), y_other)
+
+
+def test_bench_self_launches_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` started as a plain process must spawn its own ranks (functional mode on a 1-GPU box)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "1", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["config"]["functional_shared_gpu"] == (torch.cuda.device_count() < 2)
+    assert j["roofline"]["frac"] is not None and 0 < j["roofline"]["frac"] < 1.0
+    print("bench --gpus 2 (self-launched):", j["value"], "evals/s;", j["config"]["parallelism"])
+
+
+@pytest.mark.parametrize("xi,dctype", [(0.25, "end"), (0.0, "end"), (0.25, "always")])
+def test_sampler_data_consistency_types_vs_oracle(xi, dctype):
+    """data_consistency.type on the GPU sampler against the oracle (itself pinned by tests/golden/sampler_dc.npz)."""
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.sampler import Sampler
+    from oracle.edm import OracleEDM
+    from oracle.nsgt_cqt import OracleCQT
+    from oracle.sampler import OracleSampler
+    from oracle.unet import OracleUnet
+    net, args, kw = _setup(DEV, T=3, xi=xi)
+    args.tester.data_consistency.type = dctype
+    Ls = kw["audio_len"]
+    y, mask = _segments(2, Ls)
+    smp = Sampler(model=net, diff_params=EDM(args), args=args)
+    smp.seeds = [5, 6]
+    # the mask is handed over as float64 with a non-unit stride: the sampler must normalise it
+    mask_odd = torch.stack([mask.double(), mask.double()], dim=-1)[..., 0]
+    assert mask_odd.stride(-1) == 2
+    out = smp.predict_inpainting((y * mask).to(DEV), mask_odd.to(DEV))
+    cqt = OracleCQT(kw["num_octs"], kw["bins_per_oct"], "oct", ("kaiser", 1), kw["fs"], Ls)
+    orc = OracleUnet(kw["num_octs"], kw["bins_per_oct"], cqt).load_state_dict(net.state_dict())
+    osmp = OracleSampler(orc, OracleEDM(), T=3, xi=xi, hann_size=20, audio_len=Ls, dc_type=dctype)
+    ref = osmp.predict_inpainting(y * mask, mask, seeds=[5, 6])
+    e = rel_l2(out.cpu(), ref)
+    print(f"xi={xi} type={dctype}: final rel-L2 vs oracle = {e:.2e}")
+    assert e < 5e-4
+    if dctype == "end" or xi == 0.0:
+        assert float((out.cpu() - y)[:, :1700].abs().max()) < 1e-5        # projected after the loop / at every evaluation
+
+
+def test_replacement_branch_without_projection_raises():
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.sampler import Sampler
+    net, args, kw = _setup(DEV, T=2, xi=0.0)
+    args.tester.data_consistency.use = False
+    y, mask = _segments(1, kw["audio_len"])
+    smp = Sampler(model=net, diff_params=EDM(args), args=args)
+    with pytest.raises(AttributeError):
+        smp.predict_inpainting((y * mask).to(DEV), mask.to(DEV))

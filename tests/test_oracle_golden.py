@@ -117,6 +117,26 @@ def test_sampler_trajectories(tag):
     assert rel_l2(out, z[tag + ".out"]) < 1e-5
 
 
+@pytest.mark.parametrize("tag", ["g_end", "r_end", "g_always"])
+def test_sampler_data_consistency_types_match_reference(tag):
+    """data_consistency.type 'end' vs 'always' (edm_sampler_inpainting.py:22-24): the guided branch projects per
+    evaluation only with 'always' (:100), the replacement branch ALWAYS (:141-147), 'end' projects after the loop (:252)."""
+    z = np.load(os.path.join(GOLDEN, "sampler_dc.npz"))
+    L, T = int(z["L"]), int(z["T"])
+    xi, seed, is_end = z[tag + ".meta"]
+    s = OracleSampler(_Toy(L), OracleEDM(), T=T, xi=float(xi), hann_size=20, audio_len=L, dc_type="end" if is_end else "always")
+    torch.manual_seed(int(seed))
+    out = s.predict_inpainting(torch.from_numpy(z[tag + ".y"]), torch.from_numpy(z[tag + ".mask"]))
+    assert rel_l2(out, z[tag + ".out"]) < 1e-5
+
+
+def test_replacement_branch_without_projection_raises_like_the_reference():
+    L = 2048
+    s = OracleSampler(_Toy(L), OracleEDM(), T=2, xi=0.0, data_consistency=False, audio_len=L)
+    with pytest.raises(AttributeError):
+        s.predict_inpainting(torch.zeros(1, L), torch.ones(1, L))
+
+
 def test_sampler_batch_items_are_independent():
     """Per-item semantics: a B=2 run with per-item seeds equals two B=1 runs (guided branch included)."""
     L, T = 2048, 4

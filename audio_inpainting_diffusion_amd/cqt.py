@@ -16,6 +16,7 @@ networks/unet_cqt_oct_with_projattention_adaLN_2.py:620 (mode="oct", Kaiser wind
 from __future__ import annotations
 
 import ctypes
+from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -42,25 +43,90 @@ def fft_radices(n: int):
     return out
 
 
+@dataclass(frozen=True)
+class CQTRules:
+    """The frame-design choices that the reference's external package (``cqt_nsgt_pytorch``, absent here) fixes and the
+    call sites do not: each is ONE switch, so that a maintainer who has the package can pin the transform by running
+    tests/golden/make_cqt_golden.py there and selecting the rule set the conformance test (tests/test_cqt_conformance.py)
+    reports -- through ``network.cqt.rules=<preset name>`` in the config or by changing ``RULES_DEFAULT``.
+
+    (The frequency grid itself is fixed: f_k = fmin*2^(k/bpo), fmin = (fs/2)/2^n, the last band one step below Nyquist --
+    the only grid with exactly ``bins_per_oct`` bands per octave AND all emitted bands inside (0, fs/2).  The dump script
+    stores the package's ``frqs`` so that a different grid shows up as such.)
+    band0_len        length of the lowest constant-Q band: "constq" = b_0*(r - 1/r), r = 2^(1/bpo) (ours);
+                     "f_over_q" = b_0/q with q = sqrt(r)/(r-1)/2 (the sliCQ rule of the NSGT toolbox);
+                     "to_dc" = b_1 - 0 (textbook neighbours rule: breaks the U-Net's octave halving, kept for the test)
+    last_len         highest constant-Q band: "neighbours" = L/2 - b_{K-2} (ours) | "f_over_q" = b_{K-1}/q
+    nyq_len          Nyquist band: "gap" = 2*(L/2 - b_{K-1}) (ours) | "f_over_q" = b_{K-1}/q
+    window_sampling  "integer": w((j)/(M/2)) at integer offsets j about the centre (ours);
+                     "half_sample_odd": odd-length windows sampled at j - 1/2 (a periodic window of odd length rolled by M//2)
+    centre_rounding  "nearest" | "even" (round(b/2)*2, the sliCQ convention)
+    """
+    band0_len: str = "constq"
+    last_len: str = "neighbours"
+    nyq_len: str = "gap"
+    window_sampling: str = "integer"
+    centre_rounding: str = "nearest"
+
+
+RULES_DEFAULT = CQTRules()
+RULE_PRESETS = {
+    "default": RULES_DEFAULT,
+    # our best recollection of the NSGT toolbox's sliCQ window rule (f/q for the first / last / Nyquist bands)
+    "nsgt_f_over_q": CQTRules(band0_len="f_over_q", last_len="f_over_q", nyq_len="f_over_q"),
+    "nsgt_f_over_q_periodic": CQTRules(band0_len="f_over_q", last_len="f_over_q", nyq_len="f_over_q", window_sampling="half_sample_odd"),
+}
+
+
+def resolve_rules(rules) -> CQTRules:
+    if rules is None:
+        return RULES_DEFAULT
+    if isinstance(rules, CQTRules):
+        return rules
+    if isinstance(rules, str):
+        return RULE_PRESETS[rules]
+    return CQTRules(**dict(rules))
+
+
+def frame_design(numocts: int, binsoct: int, fs: float, L: int, rules: CQTRules):
+    """Band centres (float DFT bins), rounded centres and window lengths of [DC, K constant-Q bands, Nyquist]."""
+    K = numocts * binsoct
+    k = np.arange(K, dtype=np.float64)
+    r = 2.0 ** (1.0 / binsoct)
+    f = (fs / 2.0) / 2.0 ** numocts * r ** k
+    b = f * L / fs
+    q = np.sqrt(r) / (r - 1.0) / 2.0
+    nyq = L / 2.0
+    centre = np.concatenate(([0.0], b, [nyq]))
+    Lg = np.empty(K + 2, dtype=np.float64)
+    Lg[0] = 2.0 * b[0]
+    Lg[1] = {"constq": b[0] * (r - 1.0 / r), "f_over_q": b[0] / q, "to_dc": b[1]}[rules.band0_len]
+    Lg[2:K + 1] = centre[3:K + 2] - centre[1:K]
+    if rules.last_len == "f_over_q":
+        Lg[K] = b[K - 1] / q
+    elif rules.last_len != "neighbours":
+        raise ValueError(rules.last_len)
+    Lg[K + 1] = {"gap": 2.0 * (nyq - b[K - 1]), "f_over_q": b[K - 1] / q}[rules.nyq_len]
+    Lg = np.maximum(np.round(Lg).astype(np.int64), 4)
+    if rules.centre_rounding == "nearest":
+        rc = np.round(centre).astype(np.int64)
+    elif rules.centre_rounding == "even":
+        rc = (np.round(centre / 2.0) * 2).astype(np.int64)
+    else:
+        raise ValueError(rules.centre_rounding)
+    return centre, rc, Lg
+
+
 class CQTPlan:
-    def __init__(self, numocts: int, binsoct: int, fs: float, audio_len: int, window=("kaiser", 1.0)):
+    def __init__(self, numocts: int, binsoct: int, fs: float, audio_len: int, window=("kaiser", 1.0), rules=None):
         L = int(audio_len)
         if L % 2:
             raise ValueError("audio_len must be even")
         self.numocts, self.binsoct, self.fs, self.L = int(numocts), int(binsoct), float(fs), L
         self.Lh = L // 2 + 1
+        self.rules = rules = resolve_rules(rules)
         K = self.K = self.numocts * self.binsoct
-        k = np.arange(K, dtype=np.float64)
-        b = (self.fs / 2.0) / 2.0 ** self.numocts * 2.0 ** (k / self.binsoct) * L / self.fs
-        centre = np.concatenate(([0.0], b, [L / 2.0]))
-        ratio = 2.0 ** (1.0 / self.binsoct) - 2.0 ** (-1.0 / self.binsoct)
-        Lg = np.empty(K + 2, dtype=np.int64)
-        Lg[0] = np.round(2.0 * b[0])
-        Lg[1] = np.round(b[0] * ratio)
-        Lg[2:K + 1] = np.round(centre[3:K + 2] - centre[1:K])
-        Lg[K + 1] = np.round(2.0 * (L / 2.0 - b[K - 1]))
-        Lg = np.maximum(Lg, 4)
-        rc = np.round(centre).astype(np.int64)
+        centre, rc, Lg = frame_design(self.numocts, self.binsoct, self.fs, L, rules)
         self.Lg_all, self.rc_all = Lg, rc
 
         if isinstance(window, (tuple, list)) and window[0] == "kaiser":
@@ -73,7 +139,13 @@ class CQTPlan:
         # one concatenated offset axis j for all bands
         off = np.concatenate([np.arange(-(m // 2), m - m // 2) for m in Lg])
         band = np.repeat(np.arange(K + 2), Lg)
-        r = 2.0 * off / Lg[band]
+        if rules.window_sampling == "half_sample_odd":
+            off_w = off - 0.5 * (Lg[band] % 2)
+        elif rules.window_sampling == "integer":
+            off_w = off.astype(np.float64)
+        else:
+            raise ValueError(rules.window_sampling)
+        r = 2.0 * off_w / Lg[band]
         if beta is not None:
             g = np.i0(beta * np.sqrt(np.clip(1.0 - r * r, 0.0, None))) / np.i0(beta)
         else:
@@ -108,9 +180,13 @@ class CQTPlan:
         self.ws_per_b = int(self.Tk.astype(np.int64).sum())
         lo = self.rc.astype(np.int64) - self.Lg // 2
         hi = lo + self.Lg - 1
-        assert np.all(np.diff(lo) >= 0) and np.all(np.diff(hi) >= 0), "band edges must be monotone"
-        assert lo[0] > 0 and hi[-1] < L // 2, "emitted bands must stay inside (0, L/2)"
-        assert np.all(self.Lg <= self.Tk), "painless condition violated"
+        if not (np.all(np.diff(lo) >= 0) and np.all(np.diff(hi) >= 0)):
+            raise NotImplementedError("CQT rules give non-monotone band edges (the HIP overlap-add gather needs monotone edges)")
+        if not (lo[0] > 0 and hi[-1] < L // 2):
+            raise NotImplementedError("CQT rules put an emitted band across DC or Nyquist; the HIP gather only implements bands "
+                                      "inside (0, L/2) (oracle/nsgt_cqt.py handles the wrapped case)")
+        if not np.all(self.Lg <= self.Tk):
+            raise NotImplementedError("painless condition violated (a window is longer than its octave's time length)")
         v = np.arange(self.Lh)
         kfirst = np.searchsorted(hi, v, side="left")
         kend = np.searchsorted(lo, v, side="right")
@@ -135,9 +211,9 @@ class CQTransform:
     """Device transform with the call surface of the reference's ``CQT_nsgt`` (mode="oct")."""
 
     def __init__(self, numocts, binsoct, mode="oct", window=("kaiser", 1.0), fs=44100, audio_len=44100,
-                 dtype=torch.float32, device="cuda"):
+                 dtype=torch.float32, device="cuda", rules=None):
         assert mode == "oct" and dtype == torch.float32
-        self.plan = CQTPlan(numocts, binsoct, fs, audio_len, window)
+        self.plan = CQTPlan(numocts, binsoct, fs, audio_len, window, rules)
         self.device = torch.device(device)
         self.numocts, self.binsoct, self.Ls = int(numocts), int(binsoct), int(audio_len)
         self.size_per_oct = list(self.plan.T_oct)

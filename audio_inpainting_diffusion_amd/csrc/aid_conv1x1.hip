@@ -152,6 +152,7 @@ static int launch_c1(const aid_conv2d_params* p, hipStream_t st) {
     const int64_t pblocks = (a.npos + 4 * 32 * NT - 1) / (4 * 32 * NT);
     hipLaunchKernelGGL((conv1x1_stream_kernel<MT, NT, PF, MINW>), dim3((unsigned)(pblocks * a.mchunks)), dim3(256), 0, st, a);
     AID_CHECK_LAUNCH();
+    aid_note_kernel("conv1x1_stream_kernel");
     return AID_OK;
 }
 

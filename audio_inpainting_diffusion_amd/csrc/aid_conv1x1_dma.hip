@@ -253,6 +253,7 @@ static int launch_c11(const aid_conv2d_params* p, hipStream_t st) {
     a.per_xcd = (a.nx * a.ny + 7) / 8;
     hipLaunchKernelGGL((conv11_dma_kernel<MT, WGM, WGN, RMAX, KC, MINW>), dim3((unsigned)(8 * a.per_xcd)), dim3(64 * WGM * WGN), 0, st, a);
     AID_CHECK_LAUNCH();
+    aid_note_kernel("conv11_dma_kernel");
     return AID_OK;
 }
 

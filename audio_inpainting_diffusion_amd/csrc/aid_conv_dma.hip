@@ -298,6 +298,7 @@ static int launch_dma(const aid_conv2d_params* p, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), lds, st, a);
     AID_CHECK_LAUNCH();
+    aid_note_kernel("conv53_dma_kernel");
     return AID_OK;
 }
 

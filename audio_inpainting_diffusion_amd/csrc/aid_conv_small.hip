@@ -149,6 +149,7 @@ static int launch_cs(K kern, const aid_conv2d_params* p, hipStream_t st) {
     const int rpb = 256 / lpr;
     hipLaunchKernelGGL(kern, dim3((unsigned)(aid_cdiv(a.nrows, rpb) * a.tiles)), dim3(256), 0, st, a);
     AID_CHECK_LAUNCH();
+    aid_note_kernel("conv_small_kernel");
     return AID_OK;
 }
 

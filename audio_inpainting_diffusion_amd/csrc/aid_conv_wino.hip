@@ -694,6 +694,7 @@ static int launch_wino4(const aid_conv2d_params* p, hipStream_t st) {
     grid = dim3((unsigned)(8 * a.per_xcd), 1);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), 0, st, a);
     AID_CHECK_LAUNCH();
+    aid_note_kernel(M_BLK == 96 ? "conv53_wino4_kernel(96)" : ((M_BLK == 64 && N_BLK == 256) ? "conv53_wino4_kernel(64x256)" : "conv53_wino4_kernel"));
     return AID_OK;
 }
 
@@ -727,6 +728,7 @@ static int launch_wino4v(const aid_conv2d_params* p, hipStream_t st) {
     grid = dim3((unsigned)(8 * a.per_xcd), 1);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), 0, st, a);
     AID_CHECK_LAUNCH();
+    aid_note_kernel((M_BLK == 64 && N_BLK == 256) ? "conv53_wino4v_kernel(64x256)" : "conv53_wino4v_kernel");
     return AID_OK;
 }
 

@@ -405,7 +405,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
         win = ("kaiser", float(net.cqt.beta)) if net.cqt.window == "kaiser" else net.cqt.window
         self.CQTransform = CQTransform(self.num_octs, self.bins_per_oct, mode="oct", window=win,
                                        fs=args.exp.sample_rate, audio_len=args.exp.audio_len, dtype=torch.float32,
-                                       device=self.device)
+                                       device=self.device, rules=net.cqt.get("rules") if hasattr(net.cqt, "get") else None)
         n, E, bpo, H = self.num_octs, self.emb_dim, self.bins_per_oct, self.heads
         self.embedding = _Embedding(E)
         self.downsamplerT, self.upsamplerT = _Kernel(), _Kernel()

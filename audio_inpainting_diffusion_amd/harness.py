@@ -12,13 +12,34 @@ No device code here; everything numerical happens in the sampler / network.
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import Optional, List, Sequence, Tuple
 
 import torch
 
 
-def load_checkpoint(net, state, key: str = "ema") -> Tuple[int, str]:
-    """Returns (iteration stored in the checkpoint or 0, strategy used: 'strict' | 'non-strict' | 'shape-matched')."""
+def cqt_is_pinned() -> bool:
+    """True when a dump of the real ``cqt_nsgt_pytorch`` (tests/golden/cqt_ref_*.npz, made by tests/golden/make_cqt_golden.py)
+    sits next to this checkout -- the conformance tests then hold our CQT to the package the checkpoints were trained with."""
+    import glob
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return bool(glob.glob(os.path.join(root, "tests", "golden", "cqt_ref_*.npz")))
+
+
+def load_checkpoint(net, state, key: str = "ema", cqt_pinned: Optional[bool] = None) -> Tuple[int, str]:
+    """Returns (iteration stored in the checkpoint or 0, strategy used: 'strict' | 'non-strict' | 'shape-matched').
+
+    Trained weights only mean something on the transform they were trained with.  The reference's CQT is the external
+    package ``cqt_nsgt_pytorch``; ours follows the same call contract but its frame design is pinned to the package only
+    once the conformance fixtures exist.  Until then this function warns, loudly."""
+    import warnings
+    if cqt_pinned is None:
+        cqt_pinned = cqt_is_pinned()
+    if not cqt_pinned and hasattr(net, "CQTransform") and hasattr(net.CQTransform, "plan"):
+        warnings.warn("loading trained weights into the MI355X network while its CQT is NOT pinned to cqt_nsgt_pytorch "
+                      f"(rules {net.CQTransform.plan.rules}): outputs are not comparable with the reference until "
+                      "tests/golden/make_cqt_golden.py has been run where the package is installed and "
+                      "tests/test_cqt_conformance.py passes", RuntimeWarning, stacklevel=2)
     if isinstance(state, (str, bytes)) or hasattr(state, "__fspath__"):
         state = torch.load(state, map_location="cpu")
     it = int(state["it"]) if "it" in state else 0

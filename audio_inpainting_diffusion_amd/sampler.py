@@ -63,6 +63,7 @@ class Sampler:
         self.spectral = None
         self.seeds: Optional[List[int]] = None      # per-item RNG seeds; None -> global torch CPU generator
         self.trace = None                           # set to [] to record every projected x_hat (tests)
+        self.trace_in = None                        # set to [] to record (x, t) handed to every denoiser evaluation (teacher-forced tests)
         self.n_evals = 0
 
     def update_diff_params(self):
@@ -95,6 +96,8 @@ class Sampler:
         B = x.shape[0]
         dp = self.diff_params
         self.n_evals += B
+        if self.trace_in is not None:
+            self.trace_in.append((x.clone(), float(t_i)))
         if self.y is not None and self.xi > 0:
             return self._denoise_guided(x, t_i)
         hpf = bool(self.y is None and self.args.tester.filter_out_cqt_DC_Nyq)   # (:122-123) unconditional only

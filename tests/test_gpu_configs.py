@@ -71,3 +71,68 @@ def test_config4_cfgB_batch4_guided_evaluation_vs_oracle_autograd():
     e1, e2 = rel_l2(xh[b:b + 1].cpu(), xh_ref.detach()), rel_l2(g[b:b + 1].cpu(), g_ref)
     print(f"config 4 (cfg-B, B=4) item {b}: x_hat rel-L2 = {e1:.3e}, rec_grads rel-L2 = {e2:.3e}")
     assert e1 < 1e-4 and e2 < 1e-4 and abs(float(nrm[b].cpu()) - float(norm)) < 1e-4 * float(norm)
+
+
+def test_config1_batch8_teacher_forced_heun_steps_vs_oracle():
+    """BASELINE.json configs[1] at FULL size and batch 8, guided branch: two Heun steps (four denoiser evaluations) of the
+    GPU sampler; every evaluation's projected x_hat is compared, teacher-forced (the oracle is fed the GPU trajectory's own
+    inputs), with the CPU oracle for two of the eight items.  Covers the sampler <-> network plumbing at the benchmarked
+    batch size (per-item guidance norms, schedule scalars, projection) that single-evaluation tests do not."""
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
+    from audio_inpainting_diffusion_amd.masks import mask_from_args
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    from audio_inpainting_diffusion_amd.sampler import Sampler
+    from oracle.edm import OracleEDM
+    from oracle.nsgt_cqt import OracleCQT
+    from oracle.sampler import OracleSampler, smooth_mask_rows
+    from oracle.unet import OracleUnet
+    args = make_args("maestro22k", T=36, gap_ms=300.0, xi=0.25)
+    net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(DEV)), 0, gate_scale=10.0, affine_scale=10.0)
+    B, Ls = 8, args.exp.audio_len
+    mask = mask_from_args(args)
+    assert int((mask == 0).sum()) == 6615
+    y = torch.stack([torch.from_numpy(seeded_normal(51, b, Ls)) for b in range(B)]) * 0.063 * mask
+    smp = Sampler(model=net, diff_params=EDM(args), args=args)
+    smp.seeds = list(range(70, 70 + B))
+    smp.setup_inpainting(y.to(DEV), mask)
+    smp.trace, smp.trace_in = [], []
+    state = smp.begin((B, Ls), torch.device(DEV))
+    for i in range(2):
+        smp.step(state, i)
+    assert len(smp.trace) == len(smp.trace_in) == 4
+    items = [1, 6]
+    orc = OracleUnet(7, 64, OracleCQT(7, 64, "oct", ("kaiser", 1), 22050, Ls)).load_state_dict(net.state_dict())
+    osmp = OracleSampler(orc, OracleEDM(), T=36, xi=0.25, hann_size=50, audio_len=Ls)
+    osmp.y, osmp.mask = y[items], mask
+    osmp.smask = smooth_mask_rows(mask, 50)
+    for k, ((xin, t), xh) in enumerate(zip(smp.trace_in, smp.trace)):
+        osmp.trace = []
+        osmp.get_score(xin[items].cpu(), torch.tensor(t, dtype=torch.float32))
+        e = rel_l2(xh[items].cpu(), osmp.trace[0])
+        print(f"configs[1] B=8, evaluation {k} (t={t:.4f}), items {items}: projected x_hat rel-L2 vs oracle = {e:.3e}")
+        assert e < 1e-4
+
+
+def test_cfgB_44k_8s_368368_forward_vs_oracle():
+    """The 44.1 kHz network on its 8-second segments (conf/exp/musicnet44k_8s.yaml: L=368368, octave lengths 64..8192)."""
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    from oracle.nsgt_cqt import OracleCQT
+    from oracle.unet import OracleUnet
+    Ls = 368368
+    args = make_args("musicnet44k", audio_len=Ls, T=128, gap_ms=1500.0)
+    net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(DEV)), 1, gate_scale=10.0, affine_scale=10.0)
+    x = torch.from_numpy(seeded_normal(12, 0, Ls)).reshape(1, Ls) * 0.5
+    cn = torch.tensor([[-0.2]])
+    with torch.no_grad():
+        yv = net(x.to(DEV), cn.to(DEV)).cpu()
+    orc = OracleUnet(8, 64, OracleCQT(8, 64, "oct", ("kaiser", 1), 44100, Ls)).load_state_dict(net.state_dict())
+    with torch.no_grad():
+        ref = orc(x, cn)
+    e = rel_l2(yv, ref)
+    print(f"cfg-B L=368368: rel-L2 vs oracle = {e:.3e}; GFLOP/eval = {net.flops_per_eval(1) / 1e9:.1f}")
+    assert e < 1e-4
+    assert abs(net.flops_per_eval(1) / 3.181e12 - 1) < 0.02      # SURVEY.md section 8d: 3.181 TFLOP

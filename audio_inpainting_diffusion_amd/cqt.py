@@ -253,10 +253,12 @@ class CQTransform:
         out = torch.empty(B, self.plan.Lh, 2, device=x.device, dtype=torch.float32)
         return torch.view_as_complex(self._fft(x.contiguous().float(), B, 1, 2, -1.0, 1.0, out))
 
-    def irfft(self, Y: torch.Tensor) -> torch.Tensor:
-        """Y[B,L/2+1] complex -> [B,L] real  (= torch.fft.irfft(Y, n=L))"""
+    def irfft(self, Y: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Y[B,L/2+1] complex -> [B,L] real  (= torch.fft.irfft(Y, n=L)); ``out``: optional contiguous [B,L] float32 destination"""
         B = Y.shape[0]
-        out = torch.empty(B, self.plan.L, device=Y.device, dtype=torch.float32)
+        if out is None:
+            out = torch.empty(B, self.plan.L, device=Y.device, dtype=torch.float32)
+        assert out.is_contiguous() and tuple(out.shape) == (B, self.plan.L) and out.dtype == torch.float32
         return self._fft(torch.view_as_real(Y.contiguous()), B, 2, 1, +1.0, 1.0 / self.plan.L, out)
 
     # ---- planar API used by the network ----------------------------------------------------------------

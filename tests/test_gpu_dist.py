@@ -180,3 +180,33 @@ def test_replacement_branch_without_projection_raises():
     smp = Sampler(model=net, diff_params=EDM(args), args=args)
     with pytest.raises(AttributeError):
         smp.predict_inpainting((y * mask).to(DEV), mask.to(DEV))
+
+
+def test_sub_batch_streams_are_bit_identical_to_one_stream():
+    """network.denoise / denoise_guided cut a batch into sub-batches on concurrent HIP streams: same bits as one stream."""
+    from oracle.edm import OracleEDM
+    net, args, kw = _setup(DEV)
+    B, Ls = 7, kw["audio_len"]
+    y, mask = _segments(B, Ls)
+    g0 = torch.Generator().manual_seed(2)
+    x = (torch.randn(B, Ls, generator=g0) * 0.4).to(DEV)
+    edm = OracleEDM()
+    s = torch.rand(B, 1, generator=g0) * 0.8 + 0.05
+    v = lambda t: t.reshape(-1).to(DEV).contiguous()
+    co = (v(edm.cnoise(s)), v(edm.cin(s)), v(edm.cskip(s)), v(edm.cout(s)))
+    masks = torch.ones(B, Ls)
+    for b in range(B):
+        masks[b, 1000 + 100 * b: 1400 + 100 * b] = 0
+    yd, md = (y * masks).to(DEV).contiguous(), masks.to(DEV)
+    res = {}
+    for n in (1, 2, 3):
+        net.split_streams = n
+        assert len(net.states_of(B)) == n
+        for _ in range(2):                                   # second pass re-uses the launch plans
+            res[n] = (net.denoise(x, *co, True), *net.denoise_guided(x, *co, True, yd, md))
+    torch.cuda.synchronize()
+    for n in (2, 3):
+        for a_, b_ in zip(res[1], res[n]):
+            assert torch.equal(a_, b_)
+    net.split_streams = None
+    assert net._n_split(8) == 3 and net._n_split(4) == 2 and net._n_split(2) == 1

@@ -735,6 +735,46 @@ class Unet_CQT_oct_with_attention(nn.Module):
         Y = self.CQTransform.synthesis_spectrum(st["octs_out"])
         return self.CQTransform.irfft(Y)
 
+    # ---------------------------------------------------------------------------------------------------
+    # HIP-graph replay of launch-bound evaluations.  A fused evaluation is ~1000 (forward) / ~1900 (guided) kernel
+    # launches from pre-filled parameter structs; at B <= 3 the GPU finishes them faster than the host can issue them
+    # (the reference's testers run B = 1).  The first call of a configuration runs eagerly (lazy plan construction, table
+    # uploads, hipFuncSetAttribute), the second captures the same call sequence on torch's capture stream with static
+    # input / output buffers, later calls copy the inputs in and replay.  Sub-batch streams (B >= 4) stay eager.
+    # ---------------------------------------------------------------------------------------------------
+    use_graphs = True
+    GRAPH_MAX_B = 3
+    GRAPH_MAX_PER_STATE = 4
+
+    def _graph_ok(self, B, st):
+        if not (self.use_graphs and B <= self.GRAPH_MAX_B and self._n_split(B) == 1):
+            return False
+        plans = [st["plan_body"]] + ([st["plan_bwd"]] if "plan_bwd" in st else [])
+        return all(pl.timing is None for pl in plans)
+
+    def _graph_run(self, st, key, inputs, fn):
+        """inputs: dict name -> tensor copied into static buffers; fn(static inputs dict) -> tuple of output tensors.
+        Returns clones of the static outputs."""
+        graphs = st.setdefault("graphs", {})
+        ent = graphs.get(key)
+        if ent is None:                                   # first call: eager (builds lazily created plans / tables)
+            graphs[key] = {"seen": 1}
+            while len(graphs) > self.GRAPH_MAX_PER_STATE:
+                graphs.pop(next(iter(graphs)))
+            return fn(inputs)
+        if "graph" not in ent:                            # second call: capture
+            static = {k: v.clone() for k, v in inputs.items()}
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = fn(static)
+            ent.update(graph=g, static=static, outs=outs)
+        else:
+            for k, v in inputs.items():
+                ent["static"][k].copy_(v)
+        ent["graph"].replay()
+        return tuple(o.clone() for o in ent["outs"])
+
     @torch.no_grad()
     def denoise(self, x, cnoise, cin, cskip, cout, hpf: bool):
         """Fused EDM denoiser  D(x) = [hpf](cskip*x + cout*F(cin*x, cnoise))  (diff_params/edm.py:133-148 and,
@@ -743,7 +783,12 @@ class Unet_CQT_oct_with_attention(nn.Module):
         B, L = x.shape
         x = x.contiguous()
         if self._n_split(B) == 1:
-            return self._denoise_one(x, cnoise, cin, cskip, cout, hpf, self._state(B))
+            st = self._state(B)
+            if self._graph_ok(B, st):
+                ins = dict(x=x, cnoise=cnoise.reshape(-1), cin=cin.reshape(-1), cskip=cskip.reshape(-1), cout=cout.reshape(-1))
+                return self._graph_run(st, ("fwd", bool(hpf)), ins,
+                                       lambda t: (self._denoise_one(t["x"], t["cnoise"], t["cin"], t["cskip"], t["cout"], hpf, st),))[0]
+            return self._denoise_one(x, cnoise, cin, cskip, cout, hpf, st)
         n, bounds, streams = self._split_plan(B)
         out = torch.empty(B, L, device=x.device, dtype=torch.float32)
         cur = torch.cuda.current_stream()
@@ -810,7 +855,13 @@ class Unet_CQT_oct_with_attention(nn.Module):
         if not (y.is_cuda and y.dtype == torch.float32 and y.is_contiguous() and tuple(y.shape) == (B, L)):
             raise _lib.AidError("denoise_guided: y must be a contiguous float32 GPU tensor of shape [B, L]")
         if degradation is not None or self._n_split(B) == 1:       # (operator objects keep per-batch scratch: one stream)
-            return self._denoise_guided_one(x, cnoise, cin, cskip, cout, hpf, y, mask, degradation, self._state(B))
+            st = self._state(B)
+            if degradation is None and self._graph_ok(B, st):
+                ins = dict(x=x, cnoise=cnoise.reshape(-1), cin=cin.reshape(-1), cskip=cskip.reshape(-1), cout=cout.reshape(-1))
+                key = ("guided", bool(hpf), y.data_ptr(), mask.data_ptr(), tuple(mask.shape))       # y / mask are read in place
+                return self._graph_run(st, key, ins, lambda t: self._denoise_guided_one(
+                    t["x"], t["cnoise"], t["cin"], t["cskip"], t["cout"], hpf, y, mask, None, st))
+            return self._denoise_guided_one(x, cnoise, cin, cskip, cout, hpf, y, mask, degradation, st)
         m = mask if mask.dim() == 2 else mask.reshape(1, -1)
         n, bounds, streams = self._split_plan(B)
         x_hat = torch.empty(B, L, device=x.device, dtype=torch.float32)

@@ -203,7 +203,9 @@ def main():
         smp.step(state, i)
     n_split = 1 if (a.task == "spectrogram" and a.xi > 0) else net._n_split(B)     # (operator objects keep the guided evaluation on one stream)
     timing = []
-    if n_split == 1:                                   # one stream: per-launch HIP events inside the timed region
+    graphs = bool(net.use_graphs and B <= net.GRAPH_MAX_B and n_split == 1)     # small batches replay a captured HIP graph
+    separate = n_split > 1 or graphs                   # per-launch HIP events cannot be taken inside the product schedule
+    if not separate:                                   # one stream, eager launches: per-launch HIP events inside the timed region
         for pl in net.timed_plans(B, a.xi > 0):
             pl.timing = timing
     torch.cuda.synchronize()
@@ -219,12 +221,13 @@ def main():
     wall = D.max_over_ranks(wall, dev)
     assert torch.isfinite(state["x"]).all()
     roofline_pass = "per-launch HIP events inside the timed region (single stream)"
-    if n_split > 1:
+    if separate:
         # The product schedule runs %d sub-batches on concurrent HIP streams: kernels of different sub-batches overlap, so a
         # launch's start-to-end time in the timed region is not the kernel's speed.  Kernel speeds are measured right after
         # it: the SAME sampler continues for one warm-up and one measured Heun step with the network forced onto one stream.
-        roofline_pass = ("separate single-stream pass: 1 warm-up + 1 measured Heun step (steps %d, %d of the same run) right after the timed "
-                         "region, whose %d sub-batch streams overlap kernels" % (a.warmup + a.steps, a.warmup + a.steps + 1, n_split))
+        roofline_pass = ("separate single-stream pass of eager launches: 1 warm-up + 1 measured Heun step (steps %d, %d of the same run) right after "
+                         "the timed region, %s" % (a.warmup + a.steps, a.warmup + a.steps + 1,
+                                                    "which replays a captured HIP graph per evaluation" if graphs else "whose %d sub-batch streams overlap kernels" % n_split))
         assert a.warmup + a.steps + 2 <= T - 1
         net.split_streams = 1
         smp.step(state, a.warmup + a.steps)
@@ -272,7 +275,7 @@ def main():
                        "network": "unet_cqt_oct_with_attention %s, %.1f M params, random-init (seeded)" % ("44.1 kHz 8-octave" if a.workload == "musicnet44k" else "7-octave", sum(p.numel() for p in net.parameters()) / 1e6),
                        "parallelism": "segments sharded %d-way, one process per GPU, weights broadcast once in place (%.0f MB in %.3f s, %s), no collective in the loop"
                                       % (world, nbytes / 1e6, t_bcast, (torch.distributed.get_backend() if world > 1 else "single process")),
-                       "sub_batch_streams": n_split, "functional_shared_gpu": bool(shared)},
+                       "sub_batch_streams": n_split, "hip_graph_replay": graphs, "functional_shared_gpu": bool(shared)},
             "roofline": {"bound": "mfma", "kernel": dom_name, "measured_in": roofline_pass,
                          "definition": "achieved = MFMA FLOPs the dominant kernel issues per launch / its average launch duration (HIP events in the timed region); "
                                        "Winograd F(4,3) issues half of the direct-form FLOPs; algorithmic_tflops = direct-form FLOPs / the same time",
@@ -282,7 +285,7 @@ def main():
                          "traffic": None, "traffic_from_profile": _profile_traffic(),
                          "share_of_conv_time": round(dom.get("time_ms", 0.0) / max(conv_ms, 1e-9), 3),
                          "all_conv": {"launches": len(timing), "executed_mfma_tflops": round(exe / sec / 1e12, 2), "frac_of_fp32_mfma_peak": round(exe / sec / 1e12 / PEAK_F32_MFMA, 4),
-                                      "algorithmic_tflops": round(alg / sec / 1e12, 2), "conv_time_fraction_of_wall": round(sec / (wall_serial if n_split > 1 else wall), 3),
+                                      "algorithmic_tflops": round(alg / sec / 1e12, 2), "conv_time_fraction_of_wall": round(sec / (wall_serial if separate else wall), 3),
                                       "single_stream_ms_per_step": round(1e3 * wall_serial, 2)},
                          "families": fams},
         }

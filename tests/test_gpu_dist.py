@@ -210,3 +210,44 @@ def test_sub_batch_streams_are_bit_identical_to_one_stream():
             assert torch.equal(a_, b_)
     net.split_streams = None
     assert net._n_split(8) == 3 and net._n_split(4) == 2 and net._n_split(2) == 1
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_hip_graph_replay_equals_eager_launches(B):
+    """Small batches replay a captured HIP graph of the evaluation (network._graph_run): same bits as eager launches, for
+    changing inputs, on the forward-only and the guided entry points and through a whole sampler run."""
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.sampler import Sampler
+    from oracle.edm import OracleEDM
+    net, args, kw = _setup(DEV, T=3, xi=0.25)
+    Ls = kw["audio_len"]
+    y, mask = _segments(B, Ls)
+    yd, md = (y * mask).to(DEV).contiguous(), mask.to(DEV)
+    edm = OracleEDM()
+    v = lambda t: t.reshape(-1).to(DEV).contiguous()
+    g0 = torch.Generator().manual_seed(5)
+    calls = []
+    for _ in range(4):
+        x = (torch.randn(B, Ls, generator=g0) * 0.4).to(DEV)
+        s = torch.rand(B, 1, generator=g0) * 0.8 + 0.05
+        calls.append((x, (v(edm.cnoise(s)), v(edm.cin(s)), v(edm.cskip(s)), v(edm.cout(s)))))
+    out = {}
+    for mode in (False, True):
+        net.use_graphs = mode
+        net._states.clear()
+        out[mode] = [(net.denoise(x, *co, False), *net.denoise_guided(x, *co, True, yd, md)) for x, co in calls]
+        if mode:
+            st = net._state(B)
+            assert sum("graph" in e for e in st["graphs"].values()) == 2        # captured on the second call, replayed after
+    torch.cuda.synchronize()
+    for ea, gr in zip(out[False], out[True]):
+        for a_, b_ in zip(ea, gr):
+            assert torch.equal(a_, b_)
+    res = {}
+    for mode in (False, True):
+        net.use_graphs = mode
+        net._states.clear()
+        smp = Sampler(model=net, diff_params=EDM(args), args=args)
+        smp.seeds = list(range(40, 40 + B))
+        res[mode] = smp.predict_inpainting(yd, md)
+    assert torch.equal(res[False], res[True])

@@ -76,5 +76,13 @@ def run(gates=(0, 1, 2, 3)):
             print(f"gate {g}:", (out.stdout.strip().splitlines() or [out.stderr[-300:]])[-1], flush=True)
 
 
+def run96():
+    for shape in ("8 96 96 192 512 5 3 4", "8 96 96 128 1024 5 3 2", "8 96 96 256 256 5 3 8"):
+        for v in ("0", "1"):
+            env = dict(os.environ, PROBE_WINO="30", PROBE_V=v)
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "conv_probe.py")] + shape.split() + ["20", "-1"], env=env, capture_output=True, text=True)
+            print(f"x_wino={v}:", (out.stdout.strip().splitlines() or [out.stderr[-300:]])[-1], flush=True)
+
+
 if __name__ == "__main__":
-    {"build": build, "run": run, "run0": lambda: run((0,)), "run45": lambda: run((0, 1, 4, 5))}[sys.argv[1]]()
+    {"build": build, "run": run, "run0": lambda: run((0,)), "run45": lambda: run((0, 1, 4, 5)), "run96": lambda: run96()}[sys.argv[1]]()

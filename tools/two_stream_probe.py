@@ -40,6 +40,7 @@ def run_split():
         lo, hi = bounds[i], bounds[i + 1]
         streams[i].wait_stream(cur)
         with torch.cuda.stream(streams[i]):
+            nets[i].split_streams = 1
             outs.append(nets[i].denoise_guided(x[lo:hi].contiguous(), *coeffs(hi - lo), True, y[lo:hi].contiguous(), mask))
     for st in streams:
         cur.wait_stream(st)
@@ -54,5 +55,22 @@ for name, fn in (("single stream B=%d" % B, run_single), ("%d streams, split %s"
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     print(f"{name}: {dt * 1e3:.1f} ms per guided evaluation of {B} segments = {B / dt:.2f} evals/s", flush=True)
+# free-running variant: every sub-batch runs all its evaluations on its own stream, one join at the very end
+def run_free(k):
+    cur = torch.cuda.current_stream()
+    for i in range(nsplit):
+        streams[i].wait_stream(cur)
+    for _ in range(k):
+        for i in range(nsplit):
+            lo, hi = bounds[i], bounds[i + 1]
+            with torch.cuda.stream(streams[i]):
+                nets[i].split_streams = 1
+                nets[i].denoise_guided(x[lo:hi].contiguous(), *coeffs(hi - lo), True, y[lo:hi].contiguous(), mask)
+    for st in streams:
+        cur.wait_stream(st)
+run_free(1); torch.cuda.synchronize()
+t0 = time.perf_counter(); run_free(reps); torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / reps
+print(f"{nsplit} free-running streams (no join between evaluations): {dt * 1e3:.1f} ms per guided evaluation of {B} segments = {B / dt:.2f} evals/s", flush=True)
 ra = run_single(); rb = run_split(); torch.cuda.synchronize()
 print("max |x_hat diff| split vs single:", float((torch.cat([o[0] for o in rb]) - ra[0]).abs().max()))

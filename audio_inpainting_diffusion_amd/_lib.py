@@ -55,7 +55,7 @@ class ResampleParams(C.Structure):
 
 class AttentionParams(C.Structure):
     _fields_ = [("qk", C.c_void_p), ("v", C.c_void_p), ("out", C.c_void_p), ("probs", C.c_void_p),
-                ("B", C.c_int), ("H", C.c_int), ("F", C.c_int), ("T", C.c_int), ("scale", C.c_float)]
+                ("B", C.c_int), ("H", C.c_int), ("F", C.c_int), ("T", C.c_int), ("scale", C.c_float), ("bias", C.c_void_p)]
 
 
 class EmbedParams(C.Structure):
@@ -189,7 +189,7 @@ def lib():
             if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials"):
                 getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, name).restype = C.c_int
-        if L.aid_abi_version() != 2:
+        if L.aid_abi_version() != 3:
             raise AidError("ABI version mismatch")
         _lib = L
     return _lib

@@ -107,7 +107,7 @@ def make_args(name: str = "maestro22k", audio_len: int = 184184, T: int = 36, ga
 
 
 def small_args(num_octs=4, bins_per_oct=8, Ns=(8, 8, 16, 16), num_dils=(1, 2, 2, 3), attention=(0, 0, 1, 1, 1),
-               audio_len=4096, fs=22050, emb_dim=32, T=4, xi=0.0) -> Cfg:
+               audio_len=4096, fs=22050, emb_dim=32, T=4, xi=0.0, use_fencoding=False, bias_qkv=False, use_rel_pos=False) -> Cfg:
     """Reduced-size network of the same family, for parity tests that finish in seconds on CPU."""
     a = make_args("maestro22k", audio_len=audio_len, T=T, xi=xi)
     a.network.Ns, a.network.num_dils = list(Ns), list(num_dils)
@@ -115,5 +115,7 @@ def small_args(num_octs=4, bins_per_oct=8, Ns=(8, 8, 16, 16), num_dils=(1, 2, 2,
     a.network.emb_dim = emb_dim
     a.network.depth = num_octs
     a.network.cqt.num_octs, a.network.cqt.bins_per_oct = num_octs, bins_per_oct
+    a.network.use_fencoding = bool(use_fencoding)
+    a.network.attention_dict.bias_qkv, a.network.attention_dict.use_rel_pos = bool(bias_qkv), bool(use_rel_pos)
     a.exp.sample_rate = fs
     return a

@@ -93,6 +93,15 @@ __global__ __launch_bounds__(256) void time_attention_kernel(const aid_attention
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     }
+    if (p.bias && n < T && m0 < T) {                        // sim = (q k^T + bias[h][n][m]) * scale   (use_rel_pos, unet...py:364-366)
+        const float* brow = p.bias + ((int64_t)h * T + n) * T;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int mb = m0 + 8 * q + 4 * half;
+            const float4 bb = att_ld4(brow, mb, T, mb < T, vec && ((((uintptr_t)p.bias) & 15) == 0));
+            acc[4 * q] += bb.x; acc[4 * q + 1] += bb.y; acc[4 * q + 2] += bb.z; acc[4 * q + 3] += bb.w;
+        }
+    }
     // ---- softmax over the keys of query n: registers -> half-waves (shuffle) -> waves (LDS) ----------------------------
     float mx = -3.0e38f;
 #pragma unroll

@@ -11,6 +11,8 @@ imported reference, so weights are produced by a counter-based generator (splitm
   * ``affine*.weight``        : as a plain weight, times ``affine_scale``    (reference 1.0)
   * ``embedding.RFF_freq``    : 16 * N(0,1)                                   (:176-177)
   * ``*.gamma`` = 1, ``*.bias`` = 0 (init_bias=0, :34), resampler ``kernel`` buffers = cubic taps (:514-515)
+  * optional switches: ``attn_block.qk.bias`` (bias_qkv) U(-0.5,0.5); ``rel_pos.relative_attention_bias.weight`` (use_rel_pos) as a
+    plain weight; ``freq_encodings.*.RFF_freq`` 16*N(0,1) and ``.embeddings`` U(-1,1) (use_fencoding)
 
 Parity tests use gate_scale ~ 10 and affine_scale ~ 10 so that every conv / attention branch contributes
 O(1) to the output (with the reference's 1e-7 gates a broken kernel would be invisible at 1e-4 rel-L2).
@@ -64,7 +66,11 @@ def seeded_tensor(name: str, shape: Tuple[int, ...], index: int, seed: int, gate
     if leaf == "gamma":
         return torch.ones(shape, dtype=torch.float32)
     if leaf == "bias":
+        if name.split(".")[-2:-1] == ["qk"]:          # attention_dict.bias_qkv: a zero bias would make the switch untestable
+            return torch.from_numpy((0.5 * (2.0 * _uniform01(seed, index, n) - 1.0)).astype(np.float32)).reshape(shape)
         return torch.zeros(shape, dtype=torch.float32)
+    if leaf == "embeddings":                          # use_fencoding: sin / cos tables (any values in [-1, 1] exercise the path)
+        return torch.from_numpy((2.0 * _uniform01(seed, index, n) - 1.0).astype(np.float32)).reshape(shape)
     if leaf == "kernel":
         return torch.tensor(_CUBIC, dtype=torch.float32).reshape(shape)
     if leaf == "RFF_freq":

@@ -73,22 +73,59 @@ class _Embedding(nn.Module):
                                   _Weight([emb_dim, 256], 256, s, emb_dim)])
 
 
-class _Attn(nn.Module):
-    """TimeAttentionBlock parameters (unet...py:315-323)."""
+class _RelPos(nn.Module):
+    """RelativePositionBias parameters (unet...py:266-273): an nn.Embedding(num_buckets, heads) table."""
 
-    def __init__(self, nin, heads, fdim):
+    def __init__(self, num_buckets, max_distance, heads):
+        super().__init__()
+        self.num_buckets, self.max_distance = int(num_buckets), int(max_distance)
+        self.relative_attention_bias = _Weight([num_buckets, heads], heads, 1.0)
+
+    def bias_table(self, T: int) -> torch.Tensor:
+        """[H, T, T] additive logit bias (RelativePositionBias.forward, unet...py:275-312).  The bucket indices are computed with
+        CPU torch ops in the reference's own operation order (float32 log, truncation), then gathered on the weight's device."""
+        nb = self.num_buckets // 2
+        pos = torch.arange(T, dtype=torch.long)
+        rel = pos[None, :] - pos[:, None]
+        ret = (rel >= 0).to(torch.long) * nb
+        n = torch.abs(rel)
+        max_exact = nb // 2
+        val_if_large = max_exact + (torch.log(n.float() / max_exact) / math.log(self.max_distance / max_exact) * (nb - max_exact)).long()
+        val_if_large = torch.min(val_if_large, torch.full_like(val_if_large, nb - 1))
+        bucket = ret + torch.where(n < max_exact, n, val_if_large)
+        w = self.relative_attention_bias.weight.detach().float()
+        return w[bucket.to(w.device)].permute(2, 0, 1).contiguous()
+
+
+class _FreqEnc(nn.Module):
+    """AddFreqEncodingRFF parameters (unet...py:213-232): a frozen [1, 2N, F] sin/cos table concatenated to an octave's input."""
+
+    def __init__(self, f_dim, N):
+        super().__init__()
+        self.RFF_freq = nn.Parameter(16 * torch.randn([1, N]), requires_grad=False)
+        table = 2 * math.pi * torch.arange(f_dim)[None, None, :] * self.RFF_freq.unsqueeze(-1)
+        self.embeddings = nn.Parameter(torch.cat([torch.sin(table), torch.cos(table)], dim=1), requires_grad=False)
+
+
+class _Attn(nn.Module):
+    """TimeAttentionBlock parameters (unet...py:315-336)."""
+
+    def __init__(self, nin, heads, fdim, bias_qkv=False, rel_pos=None):
         super().__init__()
         s = math.sqrt(1 / 3)
         n = heads * fdim
-        self.qk = _Weight([2 * n, n, 1], n, s)
+        self.qk = _Weight([2 * n, n, 1], n, s, bias_len=2 * n if bias_qkv else 0)
         self.proj_in = _Weight([heads, nin, 1, 1], nin, s)
         self.proj_out = _Weight([nin, heads, 1, 1], heads, s)
+        if rel_pos is not None:
+            self.rel_pos = _RelPos(*rel_pos, heads)
 
 
 class _ResBlock(nn.Module):
     """ResnetBlock parameters (unet...py:383-448)."""
 
-    def __init__(self, dim, dim_out, num_dils, kernel_size, emb_dim, proj_place="before", attention=False, heads=8, fdim=0):
+    def __init__(self, dim, dim_out, num_dils, kernel_size, emb_dim, proj_place="before", attention=False, heads=8, fdim=0,
+                 bias_qkv=False, rel_pos=None):
         super().__init__()
         self.dim, self.dim_out, self.num_dils, self.ks, self.proj_place = dim, dim_out, num_dils, tuple(kernel_size), proj_place
         self.has_attn, self.heads, self.fdim = attention, heads, fdim
@@ -110,7 +147,7 @@ class _ResBlock(nn.Module):
             self.norm2 = _Gamma(N)
             self.affine2 = _Weight([N, emb_dim], emb_dim, s, N)
             self.gate2 = _Weight([N, emb_dim], emb_dim, z, N)
-            self.attn_block = _Attn(N, heads, fdim)
+            self.attn_block = _Attn(N, heads, fdim, bias_qkv, rel_pos)
 
 
 # =========================================================================================================
@@ -270,7 +307,7 @@ class _Builder:
                 and bool(_lib.lib().aid_conv2d_wino_input_supported(cin, cout, T)))
 
     def conv(self, x, y, wp, cin, cout, kh=1, kw=1, dil=1, in_scale=None, act=0, out_scale=None, res=None,
-             res_scale=1.0, alpha=1.0, wpT=None, norm_stats=None, wpw=None, wpwT=None):
+             res_scale=1.0, alpha=1.0, wpT=None, norm_stats=None, wpw=None, wpwT=None, res_nograd=False):
         """Forward conv + registration of its input-VJP.  ``norm_stats``: the (mean, 1/(std+eps)) buffer when
         ``in_scale`` was produced by ``stats`` from this same ``x`` (the scale then depends on x)."""
         if act and kh > 1:
@@ -291,7 +328,7 @@ class _Builder:
             gy = self.G(y)
             B, _, F, T = x.shape
             fused_res = (norm_stats is not None) and (res is x)
-            if res is not None and not fused_res:
+            if res is not None and not fused_res and not res_nograd:
                 gr = self.G(res)
                 if self._gacc(res):
                     self.add2_raw(gr, gy, gr, 1.0, alpha * res_scale)
@@ -350,6 +387,18 @@ class _Builder:
                     self.add2_raw(gy, None, gt, c, 0.0)
         self.bwd.append(bw)
 
+    def copy(self, u, y):
+        """y = u (strided views), with its VJP"""
+        self.add2_raw(u, None, y, 1.0, 0.0)
+
+        def bw():
+            gy, gu = self.G(y), self.G(u)
+            if self._gacc(u):
+                self.add2_raw(gu, gy, gu, 1.0, 1.0)
+            else:
+                self.add2_raw(gy, None, gu, 1.0, 0.0)
+        self.bwd.append(bw)
+
     def _resample_raw(self, x, y, up, adjoint=0, accumulate=0):
         B, Cc, F, T = x.shape
         p = _lib.ResampleParams(_lib.view4(x), _lib.view4(y), B, Cc, F, T, int(up), int(adjoint), int(accumulate))
@@ -359,12 +408,12 @@ class _Builder:
         self._resample_raw(x, y, up)
         self.bwd.append(lambda: self._resample_raw(self.G(y), self.G(x), up, adjoint=1, accumulate=1 if self._gacc(x) else 0))
 
-    def attention(self, qk, v, out, heads, F, T):
+    def attention(self, qk, v, out, heads, F, T, bias=None):
         B = v.shape[0]
         probs = self.buf(B, heads, T, T)
         scale = float(F) ** -0.5
-        p = _lib.AttentionParams(qk.data_ptr(), v.data_ptr(), out.data_ptr(), probs.data_ptr(), B, heads, F, T, scale)
-        self.plan.add("aid_time_attention", p, qk, v, out, probs, flops=4 * B * heads * T * T * F)
+        p = _lib.AttentionParams(qk.data_ptr(), v.data_ptr(), out.data_ptr(), probs.data_ptr(), B, heads, F, T, scale, _lib.ptr(bias))
+        self.plan.add("aid_time_attention", p, qk, v, out, probs, bias, flops=4 * B * heads * T * T * F)
 
         def bw():
             gq, gv, go = self.G(qk), self.G(v), self.G(out)
@@ -389,11 +438,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
         self.bins_per_oct = int(net.cqt.bins_per_oct)
         self.emb_dim = int(net.emb_dim)
         has_attn = any(int(v) for v in net.attention_layers)
-        # use_rel_pos / bias_qkv only exist inside TimeAttentionBlock: the shipped no-attention configuration
-        # (conf/network/paper_1912_unet_cqt_oct_noattention_adaln.yaml, attention_layers all 0) sets use_rel_pos: True
-        if not net.use_norm or net.use_fencoding or (has_attn and (net.attention_dict.use_rel_pos or net.attention_dict.bias_qkv)):
-            raise NotImplementedError("only use_norm=True, use_fencoding=False, use_rel_pos=False, bias_qkv=False "
-                                      "(the shipped configurations) are built")
+        if not net.use_norm:
+            raise NotImplementedError("use_norm=False is not built (every shipped configuration normalises)")
         if net.bottleneck_type != "res_dil_convs":
             raise NotImplementedError("bottleneck type not implemented")   # same error as unet...py:694
         self.heads = int(net.attention_dict.num_heads)
@@ -408,6 +454,15 @@ class Unet_CQT_oct_with_attention(nn.Module):
                                        device=self.device, rules=net.cqt.get("rules") if hasattr(net.cqt, "get") else None)
         n, E, bpo, H = self.num_octs, self.emb_dim, self.bins_per_oct, self.heads
         self.embedding = _Embedding(E)
+        ad = net.attention_dict
+        akw = dict(heads=H, bias_qkv=bool(ad.bias_qkv),
+                   rel_pos=(int(ad.rel_pos_num_buckets), int(ad.rel_pos_max_distance)) if ad.use_rel_pos else None)
+        self.use_fencoding = bool(net.use_fencoding)
+        self.n_fenc = 32                                 # N_freq_encoding (unet...py:627)
+        if self.use_fencoding:                           # registered between `embedding` and the resamplers, as in the reference (:629)
+            self.freq_encodings = nn.ModuleList([_FreqEnc(bpo, self.n_fenc) for _ in range(n)])
+        Nin = 2 * self.n_fenc + 2 if self.use_fencoding else 2
+        self.Nin = Nin
         self.downsamplerT, self.upsamplerT = _Kernel(), _Kernel()
         self.downs, self.middle, self.ups = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
         s = math.sqrt(1 / 3)
@@ -415,22 +470,22 @@ class Unet_CQT_oct_with_attention(nn.Module):
             dim_in = self.Ns[i] if i == 0 else self.Ns[i - 1]
             dim_out = self.Ns[i]
             self.downs.append(nn.ModuleList([
-                _ResBlock(2, dim_in, 1, (1, 1), E),
+                _ResBlock(Nin, dim_in, 1, (1, 1), E),
                 _Weight([dim_out, 2, 5, 3], 2 * 15, s),
-                _ResBlock(dim_in, dim_out, self.num_dils[i], (5, 3), E, attention=bool(self.attention_layers[i]), heads=H,
-                          fdim=(i + 1) * bpo)]))
+                _ResBlock(dim_in, dim_out, self.num_dils[i], (5, 3), E, attention=bool(self.attention_layers[i]),
+                          fdim=(i + 1) * bpo, **akw)]))
         for _ in range(self.num_bottleneck_layers):
             self.middle.append(nn.ModuleList([
                 _ResBlock(self.Ns[-1], 2, 1, (1, 1), E, proj_place="after"),
                 _ResBlock(self.Ns[-1], self.Ns[-1], self.num_dils[-1], (5, 3), E, attention=bool(self.attention_layers[-1]),
-                          heads=H, fdim=n * bpo)]))
+                          fdim=n * bpo, **akw)]))
         for i in range(n - 1, -1, -1):
             dim_in = self.Ns[i] * 2
             dim_out = self.Ns[i] if i == 0 else self.Ns[i - 1]
             self.ups.append(nn.ModuleList([
                 _ResBlock(dim_out, 2, 1, (1, 1), E, proj_place="after"),
-                _ResBlock(dim_in, dim_out, self.num_dils[i], (5, 3), E, attention=bool(self.attention_layers[i]), heads=H,
-                          fdim=(i + 1) * bpo)]))
+                _ResBlock(dim_in, dim_out, self.num_dils[i], (5, 3), E, attention=bool(self.attention_layers[i]),
+                          fdim=(i + 1) * bpo, **akw)]))
         self._packed: Dict[str, torch.Tensor] = {}
         self._packed_ver = None
         self._states: Dict[tuple, dict] = {}
@@ -497,6 +552,20 @@ class Unet_CQT_oct_with_attention(nn.Module):
                 rows.append(w.detach().float())
                 biases.append(b.detach().float())
                 off += w.shape[0]
+        Toct = self.CQTransform.plan.T_oct
+        for pfx, blk in self._resblocks():
+            if not blk.has_attn:
+                continue
+            T = Toct[self.num_octs - blk.fdim // self.bins_per_oct]           # time length of the level this block sits on
+            ab = blk.attn_block
+            if hasattr(ab.qk, "bias"):                                         # bias_qkv: the conv's residual input, broadcast over T
+                put(pfx + "attn_block.qk.bias#T", ab.qk.bias.detach().float()[:, None].expand(-1, T))
+            if hasattr(ab, "rel_pos"):                                         # use_rel_pos: additive logit bias [H, T, T]
+                put(pfx + "attn_block.rel_pos#table", ab.rel_pos.bias_table(T))
+        if self.use_fencoding:
+            for i, fe in enumerate(self.freq_encodings):
+                put(f"#fenc.{i}", fe.embeddings.detach().float().reshape(2 * self.n_fenc, self.bins_per_oct))
+            self._states.clear()                                                # (the tables are copied into the input buffers at plan build)
         put("#modW", torch.cat(rows, 0))
         put("#modB", torch.cat(biases, 0))
         self._mod_layout, self._mod_total = layout, off
@@ -529,10 +598,12 @@ class Unet_CQT_oct_with_attention(nn.Module):
             bd.conv(x, xp, W[pfx + "attn_block.proj_in.weight"], N, H, in_scale=sc, wpT=W[pfx + "attn_block.proj_in.weight#T"],
                     norm_stats=stb)
             qk = bd.buf(B, 2 * H * F, 1, T)
+            qb = W.get(pfx + "attn_block.qk.bias#T")                         # bias_qkv (unet...py:321): rides on the conv's residual input
             bd.conv(xp.view(B, H * F, 1, T), qk, W[pfx + "attn_block.qk.weight"], H * F, 2 * H * F,
-                    wpT=W[pfx + "attn_block.qk.weight#T"])
+                    wpT=W[pfx + "attn_block.qk.weight#T"],
+                    res=None if qb is None else qb.view(1, 2 * H * F, 1, T).expand(B, -1, -1, -1), res_nograd=True)
             att = bd.buf(B, H, F, T)
-            bd.attention(qk, xp, att, H, F, T)
+            bd.attention(qk, xp, att, H, F, T, bias=W.get(pfx + "attn_block.rel_pos#table"))  # use_rel_pos (:364)
             x1 = bd.buf(B, N, F, T)
             bd.conv(att, x1, W[pfx + "attn_block.proj_out.weight"], H, N, out_scale=self._mod(st, pfx + "gate2"), res=x,
                     alpha=RSQRT2, wpT=W[pfx + "attn_block.proj_out.weight#T"])
@@ -599,7 +670,18 @@ class Unet_CQT_oct_with_attention(nn.Module):
 
         # -- buffers the CQT analysis writes (octave o feeds level n-1-o) ----------------------------------------
         pyrL = bd.buf(B, 2, n * bpo, Tl[n - 1])     # pyramid input of the deepest level = cat(C_{n-1}, pyr_{n-2}) (:773)
-        octs_in = [pyrL[:, :, :bpo, :] if o == 0 else bd.buf(B, 2, bpo, Toct[o]) for o in range(n)]
+        if self.use_fencoding:
+            # AddFreqEncodingRFF (:253-263, :754-756): octave o's init block sees [C (2 channels), 2N frozen sin/cos rows]; the
+            # table is copied once into channels 2.. of a (2 + 2N)-channel input buffer, the CQT analysis writes channels 0..1
+            cin_full = []
+            for o in range(n):
+                t = bd.buf(B, self.Nin, bpo, Toct[o])
+                t[:, 2:] = W[f"#fenc.{n - 1 - o}"].view(1, 2 * self.n_fenc, bpo, 1)      # (freq_encodings[i] belongs to level i = n-1-o)
+                cin_full.append(t)
+            octs_in = [t[:, :2] for t in cin_full]
+        else:
+            cin_full = None
+            octs_in = [pyrL[:, :, :bpo, :] if o == 0 else bd.buf(B, 2, bpo, Toct[o]) for o in range(n)]
         st["octs_in"] = octs_in
         D = [bd.buf(B, 2 * Ns[i], Fl[i], Tl[i]) for i in range(n)]                       # cat(X, skip) along C (:814)
         Xb = [bd.buf(B, Ns[i] if i == 0 else Ns[i - 1], Fl[i], Tl[i]) for i in range(n)]   # cat(C2, X) along F (:770)
@@ -607,7 +689,10 @@ class Unet_CQT_oct_with_attention(nn.Module):
         pyr_prev = None
         for i in range(n):
             Cin = octs_in[n - 1 - i]
-            self._emit_resblock(bd, st, f"downs.{i}.0.", self.downs[i][0], Cin, Xb[i][:, :, :bpo, :])
+            self._emit_resblock(bd, st, f"downs.{i}.0.", self.downs[i][0], Cin if cin_full is None else cin_full[n - 1 - i],
+                                Xb[i][:, :, :bpo, :])
+            if cin_full is not None and i == n - 1:          # the deepest octave is also the first rows of the pyramid input (:773)
+                bd.copy(Cin, pyrL[:, :, :bpo, :])
             if i < n - 1:
                 pyr = pyrL[:, :, bpo:, :] if i == n - 2 else bd.buf(B, 2, Fl[i], Tl[i] // 2)
                 bd.resample(Cin, pyr[:, :, :bpo, :], up=0)

@@ -177,6 +177,8 @@ def main():
     net = Unet_CQT_oct_with_attention(args, dev)
     if a.streams:
         net.split_streams = a.streams
+    elif a.task == "spectrogram" and a.xi > 0:
+        net.split_streams = 1                      # the STFT-mask operator keeps per-batch scratch: the guided evaluation stays on one stream
     if rank == 0:
         seeded_init_(net, 0)                       # reference-scale gates (1e-7), like a fresh reference network
     D.barrier()
@@ -201,7 +203,7 @@ def main():
     state = smp.begin((B, L), dev)
     for i in range(a.warmup):
         smp.step(state, i)
-    n_split = 1 if (a.task == "spectrogram" and a.xi > 0) else net._n_split(B)     # (operator objects keep the guided evaluation on one stream)
+    n_split = net._n_split(B)
     timing = []
     graphs = bool(net.use_graphs and B <= net.GRAPH_MAX_B and n_split == 1)     # small batches replay a captured HIP graph
     separate = n_split > 1 or graphs                   # per-launch HIP events cannot be taken inside the product schedule

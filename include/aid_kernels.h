@@ -28,7 +28,7 @@ extern "C" {
 #define AID_E_BADARG (-1)   /* unsupported shape / null pointer / misaligned stride */
 #define AID_E_LAUNCH (-2)   /* hipLaunchKernel reported an error                    */
 
-#define AID_ABI_VERSION 2
+#define AID_ABI_VERSION 3
 int aid_abi_version(void);
 /* last HIP error string seen by a launcher in this process (never NULL) */
 const char* aid_last_error(void);
@@ -146,11 +146,14 @@ int aid_resample(const aid_resample_params* p, void* stream);
  *   v  : [B, H, F, T]  (the projected input itself, unet...py:353)
  *   out: [B, H, F, T]
  *   T <= 128.  If `probs` is non-NULL the softmax matrix [B,H,T,T] is also written (saved for the VJP).
+ *   QK^T, PV and the VJP products run on v_mfma_f32_32x32x2_f32; the softmax reduces over registers, one wavefront shuffle and LDS.
  * ------------------------------------------------------------------------------------------------- */
 typedef struct {
     const float* qk; const float* v; float* out; float* probs;
     int B, H, F, T;
     float scale;
+    const float* bias;        /* optional [H, T, T] additive logit bias, applied BEFORE the scale: softmax((q k^T + bias) * scale)
+                                 -- the relative-position bias of attention_dict.use_rel_pos (unet...py:266-312,364); NULL: none */
 } aid_attention_params;
 int aid_time_attention(const aid_attention_params* p, void* stream);
 

@@ -60,16 +60,34 @@ def resample_up(x: torch.Tensor) -> torch.Tensor:
     return F.conv_transpose1d(xp, k, stride=2, padding=7).reshape(*sh[:-1], -1)
 
 
-def time_attention(sd, p: str, x: torch.Tensor, heads: int) -> torch.Tensor:
+def relative_position_bias(weight: torch.Tensor, T: int, max_distance: int = 64) -> torch.Tensor:
+    """RelativePositionBias.forward(T, T) (unet...py:266-312): T5-style bucketed bias, weight[num_buckets, H] -> [1,H,T,T]."""
+    num_buckets = weight.shape[0] // 2
+    q_pos = torch.arange(T, dtype=torch.long)
+    rel = q_pos[None, :] - q_pos[:, None]                            # k_pos - q_pos            (:300-302)
+    ret = (rel >= 0).to(torch.long) * num_buckets
+    n = torch.abs(rel)
+    max_exact = num_buckets // 2
+    is_small = n < max_exact
+    val_if_large = max_exact + (torch.log(n.float() / max_exact) / math.log(max_distance / max_exact) * (num_buckets - max_exact)).long()
+    val_if_large = torch.min(val_if_large, torch.full_like(val_if_large, num_buckets - 1))
+    bucket = ret + torch.where(is_small, n, val_if_large)
+    return weight[bucket].permute(2, 0, 1).unsqueeze(0)             # "m n h -> 1 h m n"     (:309-311)
+
+
+def time_attention(sd, p: str, x: torch.Tensor, heads: int, rel_pos_max_distance: int = 64) -> torch.Tensor:
     """TimeAttentionBlock.forward (unet...py:338-380).  x[B,C,F,T] -> [B,C,F,T]."""
     B, C, Fd, T = x.shape
     xp = F.conv2d(x, sd[p + "proj_in.weight"])                      # [B,H,F,T]
     xf = xp.reshape(B, heads * Fd, T)
     v = xp.permute(0, 1, 3, 2)                                      # [B,H,T,F]
-    qk = F.conv1d(xf, sd[p + "qk.weight"])                          # [B,2*H*F,T]
+    qk = F.conv1d(xf, sd[p + "qk.weight"], sd.get(p + "qk.bias"))   # [B,2*H*F,T]   (bias: attention_dict.bias_qkv, :321)
     qk = qk.reshape(B, heads, 2 * Fd, T).permute(0, 1, 3, 2)        # b (h d) t -> b h t d
     q, k = qk[..., :Fd], qk[..., Fd:]
-    sim = torch.einsum("bhnd,bhmd->bhnm", q, k) * (float(Fd) ** -0.5)
+    sim = torch.einsum("bhnd,bhmd->bhnm", q, k)
+    if p + "rel_pos.relative_attention_bias.weight" in sd:          # attention_dict.use_rel_pos (:364): added BEFORE the scale
+        sim = sim + relative_position_bias(sd[p + "rel_pos.relative_attention_bias.weight"], T, rel_pos_max_distance)
+    sim = sim * (float(Fd) ** -0.5)
     attn = sim.softmax(dim=-1)
     out = torch.einsum("bhnm,bhmd->bhnd", attn, v).permute(0, 1, 3, 2)  # [B,H,F,T]
     return F.conv2d(out, sd[p + "proj_out.weight"])
@@ -121,7 +139,11 @@ class OracleUnet:
         X = pyr = None
         for i in range(n):
             C = torch.view_as_real(X_list[-1 - i].squeeze(1)).permute(0, 3, 1, 2).contiguous()  # [B,2,bpo,T]
-            C2 = resnet_block(sd, f"downs.{i}.0.", C, emb, self.heads)
+            Cin = C
+            if f"freq_encodings.{i}.embeddings" in sd:                # use_fencoding (:754-756, AddFreqEncodingRFF.forward :253-263)
+                e = sd[f"freq_encodings.{i}.embeddings"]                  # [1, 2N, bpo]
+                Cin = torch.cat((C, e[:, :, :, None].expand(C.shape[0], -1, -1, C.shape[-1])), dim=1)
+            C2 = resnet_block(sd, f"downs.{i}.0.", Cin, emb, self.heads)
             if i == 0:
                 X, pyr = C2, resample_down(C)
             elif i < n - 1:

@@ -121,6 +121,9 @@ def gen_unet_small(out):
                   audio_len=4096, fs=22050, emb_dim=32),
         "b": dict(num_octs=7, bins_per_oct=8, Ns=(8, 8, 16, 16, 16, 32, 32), num_dils=(2, 3, 4, 5, 6, 7, 7),
                   attention=(0, 0, 0, 0, 1, 1, 1, 1), audio_len=16384, fs=22050, emb_dim=64),
+        # the optional switches no shipped configuration turns on (unet...py:213-312,321,364,625-632,754-756)
+        "c": dict(num_octs=4, bins_per_oct=8, Ns=(8, 8, 16, 16), num_dils=(1, 2, 2, 3), attention=(0, 0, 1, 1, 1),
+                  audio_len=4096, fs=22050, emb_dim=32, use_fencoding=True, bias_qkv=True, use_rel_pos=True),
     }
     for tag, kw in cfgs.items():
         args = small_args(**kw)

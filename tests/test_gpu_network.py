@@ -30,7 +30,7 @@ def _net_from_golden(tag):
     return net, z, kw, args
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_unet_small_vs_reference_golden(tag):
     net, z, kw, _ = _net_from_golden(tag)
     with torch.no_grad():

@@ -130,7 +130,7 @@ def _setup(tag="a"):
     return net, orc, z, kw, args
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_network_vjp_vs_oracle_autograd(tag):
     """torch.autograd.grad through the drop-in network (autograd bridge -> hand-written VJP plan) vs the oracle."""
     net, orc, z, kw, _ = _setup(tag)

@@ -55,7 +55,7 @@ def test_resnet_block(ops, tag):
     assert rel_l2(y, ops[tag + ".y"]) < TOL
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_unet_small(tag):
     from audio_inpainting_diffusion_amd.init import seeded_state_dict
     z = np.load(os.path.join(GOLDEN, f"unet_small_{tag}.npz"))

@@ -4,7 +4,7 @@ runs, as MI355X_MICROARCH.md prescribes).   usage: conv_traffic.py <dir with fet
 import collections, csv, glob, json, sys
 
 CONV = ("conv53_wino4v_kernel", "conv53_wino4_kernel", "conv_mfma_kernel", "conv1x1_stream_kernel", "conv11_dma_kernel", "conv_small_cout_kernel",
-        "conv_small_cin_kernel", "conv53_dma_kernel", "conv53_wino_kernel")
+        "conv_small_cin_kernel", "conv53_dma_kernel")
 
 def avg(d, counter):
     f = glob.glob(d + "/*counter_collection.csv")[0]
@@ -22,11 +22,12 @@ def avg(d, counter):
 
 fetch, nf, pf = avg(sys.argv[1], "FETCH_SIZE")
 write, nw, pw = avg(sys.argv[2], "WRITE_SIZE")
-out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline",
+out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --streams 1",
        "kernel": "all aid_conv2d kernels (" + ", ".join(sorted(pf)) + ")", "launches": nf,
        "FETCH_SIZE_kb_avg_per_launch": round(fetch, 1), "WRITE_SIZE_kb_avg_per_launch": round(write, 1),
        "per_kernel_FETCH_SIZE_kb_avg": {k: round(v[0], 1) for k, v in pf.items()}, "per_kernel_WRITE_SIZE_kb_avg": {k: round(v[0], 1) for k, v in pw.items()},
        "correction": "gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide (16 B/lane) coalesced reads -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncorrected",
+       "per_kernel_hbm_bytes_corrected": {k: int((2 * pf[k][0] + pw.get(k, [0.0])[0]) * 1024) for k in pf},
        "hbm_bytes_per_conv_launch_corrected": int((2 * fetch + write) * 1024), "hbm_bytes_per_conv_launch_raw": int((fetch + write) * 1024)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))

@@ -156,11 +156,62 @@ class StftParams(C.Structure):
                 ("n_fft", C.c_int), ("hop", C.c_int), ("n_frames", C.c_int), ("adjoint", C.c_int)]
 
 
+class WgradParams(C.Structure):
+    _fields_ = [("gy", View), ("x", View), ("P", C.c_void_p),
+                ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("F", C.c_int), ("T", C.c_int), ("KH", C.c_int), ("KW", C.c_int),
+                ("dilF", C.c_int), ("S", C.c_int), ("alpha", C.c_float)]
+
+
+class WgradReduceParams(C.Structure):
+    _fields_ = [("P", C.c_void_p), ("W", C.c_void_p), ("gate", C.c_void_p), ("gate_ld", C.c_int64),
+                ("in_scale", C.c_void_p), ("in_scale_ld", C.c_int64), ("dW", C.c_void_p), ("dgate", C.c_void_p), ("dgate_ld", C.c_int64),
+                ("B", C.c_int), ("S", C.c_int), ("Cout", C.c_int), ("Cin", C.c_int), ("K", C.c_int), ("accumulate", C.c_int)]
+
+
+class ChannelDotParams(C.Structure):
+    _fields_ = [("u", View), ("v", View), ("out", C.c_void_p), ("out_ld", C.c_int64),
+                ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int)]
+
+
+class ScaleBwdParams(C.Structure):
+    _fields_ = [("S", C.c_void_p), ("S_ld", C.c_int64), ("scale", C.c_void_p), ("scale_ld", C.c_int64), ("gamma", C.c_void_p),
+                ("mod", C.c_void_p), ("mod_ld", C.c_int64), ("stats", C.c_void_p), ("dgamma", C.c_void_p), ("dmod", C.c_void_p),
+                ("dmod_ld", C.c_int64), ("B", C.c_int), ("C", C.c_int), ("groups", C.c_int), ("accumulate", C.c_int)]
+
+
+class ModulationBwdParams(C.Structure):
+    _fields_ = [("dmod", C.c_void_p), ("emb", C.c_void_p), ("W", C.c_void_p), ("dW", C.c_void_p), ("dbias", C.c_void_p),
+                ("demb", C.c_void_p), ("B", C.c_int), ("E", C.c_int), ("N", C.c_int), ("accumulate", C.c_int)]
+
+
+class EmbedBwdParams(C.Structure):
+    _fields_ = [("fwd", EmbedParams), ("demb", C.c_void_p), ("dw0", C.c_void_p), ("db0", C.c_void_p), ("dw1", C.c_void_p),
+                ("db1", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p), ("accumulate", C.c_int)]
+
+
+class AdamParams(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("gscale", C.c_void_p),
+                ("n", C.c_int64), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("bias1", C.c_float), ("bias2_sqrt", C.c_float)]
+
+
+class EmaParams(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("n", C.c_int64), ("rate", C.c_float)]
+
+
+class SumsqParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("ws", C.c_void_p), ("out", C.c_void_p), ("n", C.c_int64), ("max_norm", C.c_float)]
+
+
+AID_SUMSQ_BLOCKS = 512
+
 EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_stats", "aid_conv2d", "aid_conv2d_pack_dims", "aid_resample",
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
-           "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials"]
+           "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials",
+           "aid_conv2d_wgrad", "aid_wgrad_reduce", "aid_channel_dot", "aid_scale_bwd", "aid_modulation_bwd", "aid_embed_bwd",
+           "aid_adam", "aid_ema", "aid_sumsq"]
 
 _lib = None
 

@@ -1,0 +1,410 @@
+// Parameter-gradient kernels of the training step (diff_params/edm.py:166-193 loss_fn,
+// training/trainer.py:253-304 train_step / update_ema).  The activation gradients come from the input-VJP plan that the
+// guidance branch already runs; these kernels add what only training needs:
+//
+//   aid_conv2d_wgrad   P[b,s][co][ci][tap] = alpha * sum_{f,t} gy[b,co,f,t] * in[b,ci,f+(kh-KH/2)*dil,t+kw-KW/2]
+//                      per-(sample, row-split) partial weight gradients on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32):
+//                      M = 32 output channels, N = 32 input channels, K = positions (t); one accumulator tile per tap, the
+//                      taps of a layer spread over the 4 waves of a workgroup.  gy and the KH dilated input rows of a 64-sample
+//                      chunk are staged in LDS (rows padded to an odd length: the transposed fragment reads are conflict-free).
+//   aid_wgrad_reduce   dW[co,ci,tap] += sum_b gate[b,co] * in_scale[b,ci] * sum_s P ;
+//                      dgate[b,co]   = sum_{ci,tap} W[co,ci,tap] * in_scale[b,ci] * sum_s P      (= alpha <gy, conv output>: the
+//                      gate's gradient needs the un-gated conv output, which the forward never stores -- it is recovered from the
+//                      per-sample partials instead of recomputing the convolution)
+//   aid_channel_dot    S[b,c] = sum_{f,t} u*v  (per channel; fp64 accumulation)     -> gradient of the per-(b,c) norm/adaLN scale
+//   aid_scale_bwd      S / scale -> d gamma[c] (accumulated over b), d affine[b,c] (into the modulation-gradient row)
+//   aid_modulation_bwd / aid_embed_bwd   the stacked affine/gate Linears and the RFF-MLP, backwards
+//   aid_adam / aid_ema / aid_sumsq       fused optimiser update, EMA update and gradient-norm partials over flat buffers
+// Everything is deterministic (fixed summation orders, no atomics).
+#include "aid_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define WG_TC 64                 // positions (t) per staged chunk
+#define WG_LDA (WG_TC + 1)       // gy rows in LDS
+#define WG_LDB (WG_TC + 3)       // input rows in LDS: one halo sample each side (KW <= 3) + pad to an odd length
+#define WG_MAXKH 5
+#define WG_MAXTAPS 15
+
+struct WgDev {
+    aid_conv2d_wgrad_params p;
+    int co_tiles, ci_tiles;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgDev a) {
+    const aid_conv2d_wgrad_params& p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = (blockIdx.x % a.co_tiles) * 32;
+    const int ci0 = (blockIdx.x / a.co_tiles) * 32;
+    const int b = blockIdx.y / p.S, s = blockIdx.y - b * p.S;
+    const int f_lo = (int)(((int64_t)p.F * s) / p.S), f_hi = (int)(((int64_t)p.F * (s + 1)) / p.S);
+    const int KH = p.KH, KW = p.KW, ntaps = KH * KW;
+    const int kwc = KW / 2, khc = KH / 2;
+
+    __shared__ float gyT[32 * WG_LDA];
+    __shared__ float xT[WG_MAXKH * 32 * WG_LDB];
+
+    // taps of this wave: wave, wave + 4, wave + 8, wave + 12
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    int tkh[4], tkw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int tap = wave + 4 * q; tkh[q] = tap / KW; tkw[q] = tap - tkh[q] * KW; }
+
+    const bool vec = ((p.T & 3) == 0) && ((p.gy.sB | p.gy.sC | p.gy.sF | p.x.sB | p.x.sC | p.x.sF) & 3) == 0 &&
+                     ((((uintptr_t)p.gy.p) | ((uintptr_t)p.x.p)) & 15) == 0;
+    for (int f = f_lo; f < f_hi; ++f) {
+        for (int t0 = 0; t0 < p.T; t0 += WG_TC) {
+            __syncthreads();                                  // (previous chunk's fragment reads are done)
+            // ---- stage gy[b, co0.., f, t0..t0+63] ----------------------------------------------------------------------
+            for (int e = tid; e < 32 * (WG_TC / 4); e += 256) {
+                const int row = e / (WG_TC / 4), q4 = e - row * (WG_TC / 4);
+                const int co = co0 + row, t = t0 + 4 * q4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (co < p.Cout && t < p.T) {
+                    const float* src = p.gy.p + (int64_t)b * p.gy.sB + (int64_t)co * p.gy.sC + (int64_t)f * p.gy.sF + t;
+                    if (vec && t + 3 < p.T) v = *reinterpret_cast<const float4*>(src);
+                    else { v.x = src[0]; if (t + 1 < p.T) v.y = src[1]; if (t + 2 < p.T) v.z = src[2]; if (t + 3 < p.T) v.w = src[3]; }
+                }
+                float* d = gyT + row * WG_LDA + 4 * q4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+            // ---- stage the KH dilated input rows, one halo sample each side ------------------------------------------------
+            for (int e = tid; e < KH * 32 * (WG_TC / 4); e += 256) {
+                const int q4 = e % (WG_TC / 4);
+                const int rk = e / (WG_TC / 4);
+                const int row = rk % 32, kh = rk / 32;
+                const int ci = ci0 + row, fi = f + (kh - khc) * p.dilF, t = t0 + 4 * q4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ci < p.Cin && fi >= 0 && fi < p.F && t < p.T) {
+                    const float* src = p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + t;
+                    if (vec && t + 3 < p.T) v = *reinterpret_cast<const float4*>(src);
+                    else { v.x = src[0]; if (t + 1 < p.T) v.y = src[1]; if (t + 2 < p.T) v.z = src[2]; if (t + 3 < p.T) v.w = src[3]; }
+                }
+                float* d = xT + (kh * 32 + row) * WG_LDB + 1 + 4 * q4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+            for (int e = tid; e < KH * 32 * 2; e += 256) {
+                const int side = e & 1, rk = e >> 1;
+                const int row = rk % 32, kh = rk / 32;
+                const int ci = ci0 + row, fi = f + (kh - khc) * p.dilF;
+                const int t = side ? (t0 + WG_TC) : (t0 - 1);
+                float v = 0.f;
+                if (ci < p.Cin && fi >= 0 && fi < p.F && t >= 0 && t < p.T)
+                    v = p.x.p[(int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + t];
+                xT[(kh * 32 + row) * WG_LDB + (side ? (WG_TC + 1) : 0)] = v;
+            }
+            __syncthreads();
+            // ---- K loop over the chunk's positions: A = gy^T (rows: co), B = shifted input (cols: ci) ----------------------------
+            const float* ap = gyT + l32 * WG_LDA + half;
+#pragma unroll 4
+            for (int k = 0; k < WG_TC; k += 2) {
+                const float av = ap[k];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (wave + 4 * q < ntaps) {               // (wave-uniform)
+                        const float bv = xT[(tkh[q] * 32 + l32) * WG_LDB + 1 + k + half + tkw[q] - kwc];
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- write the partials P[(b*S+s)][co][ci][tap] ----------------------------------------------------------------------------
+    float* P = p.P + ((int64_t)(b * p.S + s) * p.Cout) * p.Cin * ntaps;
+    const int ci = ci0 + l32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int tap = wave + 4 * q;
+        if (tap >= ntaps || ci >= p.Cin) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < p.Cout) P[((int64_t)co * p.Cin + ci) * ntaps + tap] = p.alpha * acc[q][r];
+        }
+    }
+}
+
+extern "C" int aid_conv2d_wgrad(const aid_conv2d_wgrad_params* p, void* stream) {
+    AID_REQUIRE(p && p->gy.p && p->x.p && p->P, "aid_conv2d_wgrad: null pointer");
+    AID_REQUIRE(p->B > 0 && p->Cin > 0 && p->Cout > 0 && p->F > 0 && p->T > 0 && p->S >= 1 && p->S <= p->F, "aid_conv2d_wgrad: bad shape");
+    AID_REQUIRE(p->KH >= 1 && p->KH <= WG_MAXKH && (p->KW == 1 || p->KW == 3) && p->KH * p->KW <= WG_MAXTAPS && p->KH * p->KW <= 16,
+                "aid_conv2d_wgrad: kernel sizes up to 5x3");
+    WgDev a;
+    a.p = *p;
+    a.co_tiles = aid_cdiv(p->Cout, 32);
+    a.ci_tiles = aid_cdiv(p->Cin, 32);
+    AID_REQUIRE((int64_t)p->B * p->S < 65536, "aid_conv2d_wgrad: too many (sample, split) pairs");
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(a.co_tiles * a.ci_tiles), (unsigned)(p->B * p->S)), dim3(256), 0, (hipStream_t)stream, a);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad_reduce_w_kernel(const aid_wgrad_reduce_params p) {
+    const int64_t n = (int64_t)p.Cout * p.Cin * p.K;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int co = (int)(i / ((int64_t)p.Cin * p.K));
+    const int ci = (int)((i / p.K) % p.Cin);
+    float accv = 0.f;
+    for (int b = 0; b < p.B; ++b) {                         // fixed order: deterministic
+        float sp = 0.f;
+        for (int s = 0; s < p.S; ++s) sp += p.P[((int64_t)(b * p.S + s)) * n + i];
+        const float g = p.gate ? p.gate[(int64_t)b * p.gate_ld + co] : 1.f;
+        const float sc = p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_ld + ci] : 1.f;
+        accv += g * sc * sp;
+    }
+    p.dW[i] = (p.accumulate ? p.dW[i] : 0.f) + accv;
+}
+
+__global__ __launch_bounds__(64) void wgrad_reduce_gate_kernel(const aid_wgrad_reduce_params p) {
+    const int b = blockIdx.y, co = blockIdx.x, lane = threadIdx.x;
+    const int64_t row = (int64_t)p.Cin * p.K;
+    const int64_t n = (int64_t)p.Cout * row;
+    double accv = 0.0;
+    for (int64_t j = lane; j < row; j += 64) {
+        const int ci = (int)(j / p.K);
+        float sp = 0.f;
+        for (int s = 0; s < p.S; ++s) sp += p.P[((int64_t)(b * p.S + s)) * n + (int64_t)co * row + j];
+        const float sc = p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_ld + ci] : 1.f;
+        accv += (double)(p.W[(int64_t)co * row + j] * sc) * (double)sp;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) accv += __shfl_down(accv, o, 64);
+    if (lane == 0) p.dgate[(int64_t)b * p.dgate_ld + co] = (float)accv;
+}
+
+extern "C" int aid_wgrad_reduce(const aid_wgrad_reduce_params* p, void* stream) {
+    AID_REQUIRE(p && p->P && p->dW, "aid_wgrad_reduce: null pointer");
+    AID_REQUIRE(!p->dgate || p->W, "aid_wgrad_reduce: dgate needs the weights");
+    const int64_t n = (int64_t)p->Cout * p->Cin * p->K;
+    hipLaunchKernelGGL(wgrad_reduce_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
+    AID_CHECK_LAUNCH();
+    if (p->dgate) {
+        hipLaunchKernelGGL(wgrad_reduce_gate_kernel, dim3((unsigned)p->Cout, (unsigned)p->B), dim3(64), 0, (hipStream_t)stream, *p);
+        AID_CHECK_LAUNCH();
+    }
+    return AID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void channel_dot_kernel(const aid_channel_dot_params p) {
+    const int bc = blockIdx.x, b = bc / p.C, c = bc - b * p.C;
+    const int tid = threadIdx.x;
+    const int64_t n = (int64_t)p.F * p.T;
+    const float* u = p.u.p + (int64_t)b * p.u.sB + (int64_t)c * p.u.sC;
+    const float* v = p.v.p + (int64_t)b * p.v.sB + (int64_t)c * p.v.sC;
+    double s = 0.0;
+    for (int64_t i = tid; i < n; i += 256) {
+        const int f = (int)(i / p.T), t = (int)(i - (int64_t)f * p.T);
+        s += (double)u[(int64_t)f * p.u.sF + t] * (double)v[(int64_t)f * p.v.sF + t];
+    }
+    __shared__ double red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) p.out[(int64_t)b * p.out_ld + c] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+extern "C" int aid_channel_dot(const aid_channel_dot_params* p, void* stream) {
+    AID_REQUIRE(p && p->u.p && p->v.p && p->out, "aid_channel_dot: null pointer");
+    hipLaunchKernelGGL(channel_dot_kernel, dim3((unsigned)(p->B * p->C)), dim3(256), 0, (hipStream_t)stream, *p);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}
+
+// d scale[b,c] = S[b,c] / scale[b,c];  scale = gamma_c (1 + a[b,c]) inv[b,g]
+__global__ __launch_bounds__(256) void scale_bwd_kernel(const aid_scale_bwd_params p) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.C) return;
+    const int g = c / (p.C / p.groups);
+    const float gam = p.gamma[c];
+    float dg = 0.f;
+    for (int b = 0; b < p.B; ++b) {
+        const float sc = p.scale[(int64_t)b * p.scale_ld + c];
+        const float ds = (sc != 0.f) ? p.S[(int64_t)b * p.S_ld + c] / sc : 0.f;
+        const float inv = p.stats[((int64_t)b * p.groups + g) * 2 + 1];
+        const float a1 = 1.f + (p.mod ? p.mod[(int64_t)b * p.mod_ld + c] : 0.f);
+        dg += ds * a1 * inv;
+        if (p.dmod) p.dmod[(int64_t)b * p.dmod_ld + c] = ds * gam * inv;
+    }
+    p.dgamma[c] = (p.accumulate ? p.dgamma[c] : 0.f) + dg;
+}
+
+extern "C" int aid_scale_bwd(const aid_scale_bwd_params* p, void* stream) {
+    AID_REQUIRE(p && p->S && p->scale && p->gamma && p->stats && p->dgamma, "aid_scale_bwd: null pointer");
+    AID_REQUIRE(p->groups > 0 && (p->C % p->groups) == 0, "aid_scale_bwd: C must be a multiple of groups");
+    hipLaunchKernelGGL(scale_bwd_kernel, dim3((unsigned)aid_cdiv(p->C, 256)), dim3(256), 0, (hipStream_t)stream, *p);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// mod[b,j] = emb[b,:] . W[j,:] + bias[j]   ->   dW[j,e] = sum_b dmod[b,j] emb[b,e],  dbias[j] = sum_b dmod[b,j],
+//                                              demb[b,e] = sum_j dmod[b,j] W[j,e]
+__global__ __launch_bounds__(256) void modulation_bwd_w_kernel(const aid_modulation_bwd_params p) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)p.N * p.E) return;
+    const int j = (int)(i / p.E), e = (int)(i - (int64_t)j * p.E);
+    float accv = 0.f;
+    for (int b = 0; b < p.B; ++b) accv += p.dmod[(int64_t)b * p.N + j] * p.emb[(int64_t)b * p.E + e];
+    p.dW[i] = (p.accumulate ? p.dW[i] : 0.f) + accv;
+    if (e == 0) {
+        float sb = 0.f;
+        for (int b = 0; b < p.B; ++b) sb += p.dmod[(int64_t)b * p.N + j];
+        p.dbias[j] = (p.accumulate ? p.dbias[j] : 0.f) + sb;
+    }
+}
+
+__global__ __launch_bounds__(256) void modulation_bwd_e_kernel(const aid_modulation_bwd_params p) {
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.E) return;
+    float accv = 0.f;
+    for (int j = 0; j < p.N; ++j) accv += p.dmod[(int64_t)b * p.N + j] * p.W[(int64_t)j * p.E + e];
+    p.demb[(int64_t)b * p.E + e] = accv;
+}
+
+extern "C" int aid_modulation_bwd(const aid_modulation_bwd_params* p, void* stream) {
+    AID_REQUIRE(p && p->dmod && p->emb && p->W && p->dW && p->dbias && p->demb, "aid_modulation_bwd: null pointer");
+    hipLaunchKernelGGL(modulation_bwd_w_kernel, dim3((unsigned)(((int64_t)p->N * p->E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
+    AID_CHECK_LAUNCH();
+    hipLaunchKernelGGL(modulation_bwd_e_kernel, dim3((unsigned)aid_cdiv(p->E, 256), (unsigned)p->B), dim3(256), 0, (hipStream_t)stream, *p);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}
+
+// RFF-MLP backward: one workgroup walks the samples in order (deterministic accumulation); the forward activations are
+// recomputed per sample in LDS exactly as aid_embed computes them.
+#define EMB_MAX 1024
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const aid_embed_bwd_params q) {
+    const aid_embed_params& p = q.fwd;
+    __shared__ float x0[EMB_MAX], a0[EMB_MAX], a1[EMB_MAX], g2[EMB_MAX], g1[EMB_MAX], g0[EMB_MAX];
+    const int tid = threadIdx.x;
+    const int d0 = 2 * p.rff;
+    for (int b = 0; b < p.B; ++b) {
+        const float s = p.sigma[b];
+        for (int i = tid; i < p.rff; i += 256) {
+            const float ang = 2.0f * 3.14159265358979323846f * s * p.rff_freq[i];
+            x0[i] = sinf(ang);
+            x0[p.rff + i] = cosf(ang);
+        }
+        __syncthreads();
+        for (int o = tid; o < p.h0; o += 256) {
+            float accv = p.b0[o];
+            for (int i = 0; i < d0; ++i) accv += x0[i] * p.w0[(int64_t)o * d0 + i];
+            a0[o] = fmaxf(accv, 0.f);
+        }
+        __syncthreads();
+        for (int o = tid; o < p.h1; o += 256) {
+            float accv = p.b1[o];
+            for (int i = 0; i < p.h0; ++i) accv += a0[i] * p.w1[(int64_t)o * p.h0 + i];
+            a1[o] = fmaxf(accv, 0.f);
+        }
+        __syncthreads();
+        // layer 2 (output E): the forward output is emb = relu(z2); g2 = demb * (emb > 0)
+        for (int o = tid; o < p.E; o += 256) g2[o] = (p.emb[(int64_t)b * p.E + o] > 0.f) ? q.demb[(int64_t)b * p.E + o] : 0.f;
+        __syncthreads();
+        for (int64_t i = tid; i < (int64_t)p.E * p.h1; i += 256) q.dw2[i] = ((b || q.accumulate) ? q.dw2[i] : 0.f) + g2[i / p.h1] * a1[i % p.h1];
+        for (int o = tid; o < p.E; o += 256) q.db2[o] = ((b || q.accumulate) ? q.db2[o] : 0.f) + g2[o];
+        for (int i = tid; i < p.h1; i += 256) {
+            float accv = 0.f;
+            for (int o = 0; o < p.E; ++o) accv += g2[o] * p.w2[(int64_t)o * p.h1 + i];
+            g1[i] = (a1[i] > 0.f) ? accv : 0.f;
+        }
+        __syncthreads();
+        for (int64_t i = tid; i < (int64_t)p.h1 * p.h0; i += 256) q.dw1[i] = ((b || q.accumulate) ? q.dw1[i] : 0.f) + g1[i / p.h0] * a0[i % p.h0];
+        for (int o = tid; o < p.h1; o += 256) q.db1[o] = ((b || q.accumulate) ? q.db1[o] : 0.f) + g1[o];
+        for (int i = tid; i < p.h0; i += 256) {
+            float accv = 0.f;
+            for (int o = 0; o < p.h1; ++o) accv += g1[o] * p.w1[(int64_t)o * p.h0 + i];
+            g0[i] = (a0[i] > 0.f) ? accv : 0.f;
+        }
+        __syncthreads();
+        for (int64_t i = tid; i < (int64_t)p.h0 * d0; i += 256) q.dw0[i] = ((b || q.accumulate) ? q.dw0[i] : 0.f) + g0[i / d0] * x0[i % d0];
+        for (int o = tid; o < p.h0; o += 256) q.db0[o] = ((b || q.accumulate) ? q.db0[o] : 0.f) + g0[o];
+        __syncthreads();
+    }
+}
+
+extern "C" int aid_embed_bwd(const aid_embed_bwd_params* q, void* stream) {
+    AID_REQUIRE(q && q->demb && q->dw0 && q->dw1 && q->dw2 && q->db0 && q->db1 && q->db2 && q->fwd.emb, "aid_embed_bwd: null pointer");
+    AID_REQUIRE(2 * q->fwd.rff <= EMB_MAX && q->fwd.h0 <= EMB_MAX && q->fwd.h1 <= EMB_MAX && q->fwd.E <= EMB_MAX, "aid_embed_bwd: layer too wide");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *q);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// torch.optim.Adam (no weight decay, no amsgrad): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)          gscale: gradient-clipping coefficient (1 = none)
+__global__ __launch_bounds__(256) void adam_kernel(const aid_adam_params p) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const float g = p.grad[i] * (p.gscale ? *p.gscale : 1.f);
+    const float m = p.beta1 * p.m[i] + (1.f - p.beta1) * g;
+    const float v = p.beta2 * p.v[i] + (1.f - p.beta2) * g * g;
+    p.m[i] = m;
+    p.v[i] = v;
+    const float denom = sqrtf(v) / p.bias2_sqrt + p.eps;
+    p.param[i] -= (p.lr / p.bias1) * (m / denom);
+}
+
+extern "C" int aid_adam(const aid_adam_params* p, void* stream) {
+    AID_REQUIRE(p && p->param && p->grad && p->m && p->v && p->n > 0, "aid_adam: null pointer");
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}
+
+// dst = dst * rate + src * (1 - rate)      (trainer.py:288-304)
+__global__ __launch_bounds__(256) void ema_kernel(const aid_ema_params p) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    p.dst[i] = p.dst[i] * p.rate + p.src[i] * (1.f - p.rate);
+}
+
+extern "C" int aid_ema(const aid_ema_params* p, void* stream) {
+    AID_REQUIRE(p && p->dst && p->src && p->n > 0, "aid_ema: null pointer");
+    hipLaunchKernelGGL(ema_kernel, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}
+
+// partial sums of squares (fp64) in nblk blocks, then one block folds them into out[0] = sum, out[1] = clip coefficient
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const aid_sumsq_params p, int nblk) {
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < p.n; i += (int64_t)nblk * 256) { const double v = p.x[i]; s += v * v; }
+    __shared__ double red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) p.ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(64) void sumsq_final_kernel(const aid_sumsq_params p, int nblk) {
+    if (threadIdx.x) return;
+    double s = 0.0;
+    for (int i = 0; i < nblk; ++i) s += p.ws[i];
+    const float nrm = (float)sqrt(s);
+    p.out[0] = nrm;
+    p.out[1] = (p.max_norm > 0.f) ? fminf(1.f, p.max_norm / (nrm + 1e-6f)) : 1.f;   // torch.nn.utils.clip_grad_norm_
+}
+
+extern "C" int aid_sumsq(const aid_sumsq_params* p, void* stream) {
+    AID_REQUIRE(p && p->x && p->ws && p->out && p->n > 0, "aid_sumsq: null pointer");
+    const int nblk = AID_SUMSQ_BLOCKS;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *p, nblk);
+    AID_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, *p, nblk);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}

@@ -200,8 +200,13 @@ class _Plan:
 
 
 class _Builder:
-    def __init__(self, net, B, device):
+    def __init__(self, net, B, device, train=False):
         self.net, self.B, self.device = net, B, device
+        self.train = bool(train)   # also emit parameter-gradient ops into the backward plan (training step)
+        self.S_of = {}             # scale tensor data_ptr -> [B,C] buffer holding sum_{f,t} (dL/d(x*scale) * scale) * x
+        self.mod = self.dmod = None   # [B, sum N] modulation vectors and their gradient (set by the network before emission)
+        self.pgrad = None          # name -> gradient view (flat gradient buffer laid out like the flat parameter buffer)
+        self.params = None         # name -> parameter tensor (its own layout)
         self.plan = _Plan()
         self.nbytes = 0
         self.stats_ws = torch.empty(B * 8 * _lib.AID_STATS_SPLIT * 2, device=device, dtype=torch.float64)
@@ -254,13 +259,59 @@ class _Builder:
         return t
 
     # ---- op emitters ---------------------------------------------------------------------------------
-    def stats(self, x, gamma, mod, scale, stats=None):
+    def stats(self, x, gamma, mod, scale, stats=None, gname=None):
         """group statistics of x -> per-(b,c) scale (+ saved mean / inverse std for the VJP)."""
         B, Cc, F, T = x.shape
         p = _lib.GroupStatsParams(_lib.view4(x), B, Cc, F, T, 8, gamma.data_ptr(), _lib.ptr(mod),
                                   0 if mod is None else mod.stride(0), 1e-7, scale.data_ptr(), _lib.ptr(stats),
                                   self.stats_ws.data_ptr())
         self.plan.add("aid_group_stats", p, x, gamma, mod, scale, stats)
+        if self.train and gname is not None:
+            def bw():                                   # gradient of scale = gamma (1 + affine) / (std + eps) w.r.t. gamma and the affine vector
+                S = self.S_of.pop(scale.data_ptr(), None)
+                if S is None:
+                    return
+                dm = self.dmod_like(mod)
+                sp = _lib.ScaleBwdParams(S.data_ptr(), S.stride(0), scale.data_ptr(), scale.stride(0), gamma.data_ptr(), _lib.ptr(mod),
+                                         0 if mod is None else mod.stride(0), stats.data_ptr(), self.pgrad[gname].data_ptr(),
+                                         _lib.ptr(dm), 0 if dm is None else dm.stride(0), B, Cc, 8, 1)
+                self.plan.add("aid_scale_bwd", sp, S, scale, gamma, mod, stats, dm)
+            self.bwd.append(bw)
+
+    def dmod_like(self, view):
+        """the slice of the modulation-gradient buffer that corresponds to a slice ``view`` of the modulation buffer"""
+        if view is None:
+            return None
+        off = (view.data_ptr() - self.mod.data_ptr()) // 4
+        assert 0 <= off < self.mod.shape[1] and view.stride(0) == self.mod.stride(0)
+        return self.dmod[:, off:off + view.shape[1]]
+
+    def _train_conv(self, x, gy, gd, wname, cin, cout, kh, kw, dil, in_scale, act, out_scale, alpha):
+        """Parameter-gradient ops of one conv (weight, gate vector, and the <dL/du * scale, x> sums its input scale needs)."""
+        B, _, F, T = gy.shape
+        K = kh * kw
+        xin, isc = x, in_scale
+        if act:                                           # the conv saw gelu(x * scale): recompute it (one pass) into scratch
+            xin = self._scratch(("hw",) + tuple(x.shape))
+            sp = _lib.ScaleActParams(_lib.view4(x), _lib.view4(xin), in_scale.data_ptr(), in_scale.stride(0), B, cin, F, T, 1, 0)
+            self.plan.add("aid_scale_act", sp, x, xin, in_scale)
+            isc = None
+        tiles = -(-cout // 32) * -(-cin // 32)
+        S = max(1, min(F, -(-1024 // (tiles * B))))
+        P = self._scratch(("P", B * S * cout * cin * K))
+        wp = _lib.WgradParams(_lib.view4(gy), _lib.view4(xin), P.data_ptr(), B, cin, cout, F, T, kh, kw, dil, S, alpha)
+        self.plan.add("aid_conv2d_wgrad", wp, gy, xin, P, flops=2 * B * F * T * cin * cout * K)
+        W = self.params[wname]
+        dg = self.dmod_like(out_scale)
+        rp = _lib.WgradReduceParams(P.data_ptr(), W.data_ptr(), _lib.ptr(out_scale), 0 if out_scale is None else out_scale.stride(0),
+                                    _lib.ptr(isc), 0 if isc is None else isc.stride(0), self.pgrad[wname].data_ptr(), _lib.ptr(dg),
+                                    0 if dg is None else dg.stride(0), B, S, cout, cin, K, 1)
+        self.plan.add("aid_wgrad_reduce", rp, P, W, out_scale, isc, dg)
+        if in_scale is not None and gd is not None:       # gd = dL/d(x*scale) * scale  ->  S[b,c] = sum gd * x  (aid_scale_bwd divides by scale)
+            Sb = self.buf(B, cin)
+            cp = _lib.ChannelDotParams(_lib.view4(gd), _lib.view4(x), Sb.data_ptr(), Sb.stride(0), B, cin, F, T)
+            self.plan.add("aid_channel_dot", cp, gd, x, Sb)
+            self.S_of[in_scale.data_ptr()] = Sb
 
     def _conv_raw(self, x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha, epi=0,
                   aux=None, aux_scale=None, wpw=None, x_wino=False, dot=None):
@@ -307,7 +358,7 @@ class _Builder:
                 and bool(_lib.lib().aid_conv2d_wino_input_supported(cin, cout, T)))
 
     def conv(self, x, y, wp, cin, cout, kh=1, kw=1, dil=1, in_scale=None, act=0, out_scale=None, res=None,
-             res_scale=1.0, alpha=1.0, wpT=None, norm_stats=None, wpw=None, wpwT=None, res_nograd=False):
+             res_scale=1.0, alpha=1.0, wpT=None, norm_stats=None, wpw=None, wpwT=None, res_nograd=False, wname=None):
         """Forward conv + registration of its input-VJP.  ``norm_stats``: the (mean, 1/(std+eps)) buffer when
         ``in_scale`` was produced by ``stats`` from this same ``x`` (the scale then depends on x)."""
         if act and kh > 1:
@@ -358,6 +409,8 @@ class _Builder:
                 if not nd:
                     dp = _lib.GroupDotParams(_lib.view4(gd), _lib.view4(x), B, cin, F, T, 8, self.stats_ws.data_ptr())
                     self.plan.add("aid_group_dot", dp, gd, x)
+                if self.train and wname is not None:
+                    self._train_conv(x, gy, gd, wname, cin, cout, kh, kw, dil, in_scale, act, out_scale, alpha)
                 npar = _lib.NormBwdParams(_lib.view4(gd), _lib.view4(x), _lib.view4(gy if fused_res else None), _lib.view4(self.G(x)),
                                           B, cin, F, T, 8, norm_stats.data_ptr(), dws.data_ptr(), 1e-7,
                                           alpha * res_scale, 1 if self._gacc(x) else 0, nd)
@@ -366,6 +419,9 @@ class _Builder:
                 gx = self.G(x)
                 self._conv_raw(gin, gx, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, gx if self._gacc(x) else None, 1.0 / alpha, alpha,
                                epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None)
+                if self.train and wname is not None:
+                    assert in_scale is None, "a scaled conv input without its statistics buffer has no parameter-gradient path"
+                    self._train_conv(x, gy, None, wname, cin, cout, kh, kw, dil, None, act, out_scale, alpha)
         self.bwd.append(bw)
 
 
@@ -588,53 +644,53 @@ class Unet_CQT_oct_with_attention(nn.Module):
         x = xin
         if hasattr(blk, "proj_in"):
             x = bd.buf(B, N, F, T)
-            bd.conv(xin, x, W[pfx + "proj_in.weight"], blk.dim, N, wpT=W[pfx + "proj_in.weight#T"])
+            bd.conv(xin, x, W[pfx + "proj_in.weight"], blk.dim, N, wpT=W[pfx + "proj_in.weight#T"], wname=pfx + "proj_in.weight")
         if blk.has_attn:
             H = blk.heads
             assert F == blk.fdim, "attention block built for a different number of frequency rows"
             sc, stb = bd.buf(B, N), bd.buf(B, 8, 2)
-            bd.stats(x, W[pfx + "norm2.gamma"], self._mod(st, pfx + "affine2"), sc, stb)
+            bd.stats(x, W[pfx + "norm2.gamma"], self._mod(st, pfx + "affine2"), sc, stb, gname=pfx + "norm2.gamma")
             xp = bd.buf(B, H, F, T)
             bd.conv(x, xp, W[pfx + "attn_block.proj_in.weight"], N, H, in_scale=sc, wpT=W[pfx + "attn_block.proj_in.weight#T"],
-                    norm_stats=stb)
+                    norm_stats=stb, wname=pfx + "attn_block.proj_in.weight")
             qk = bd.buf(B, 2 * H * F, 1, T)
             qb = W.get(pfx + "attn_block.qk.bias#T")                         # bias_qkv (unet...py:321): rides on the conv's residual input
             bd.conv(xp.view(B, H * F, 1, T), qk, W[pfx + "attn_block.qk.weight"], H * F, 2 * H * F,
                     wpT=W[pfx + "attn_block.qk.weight#T"],
-                    res=None if qb is None else qb.view(1, 2 * H * F, 1, T).expand(B, -1, -1, -1), res_nograd=True)
+                    res=None if qb is None else qb.view(1, 2 * H * F, 1, T).expand(B, -1, -1, -1), res_nograd=True, wname=pfx + "attn_block.qk.weight")
             att = bd.buf(B, H, F, T)
             bd.attention(qk, xp, att, H, F, T, bias=W.get(pfx + "attn_block.rel_pos#table"))  # use_rel_pos (:364)
             x1 = bd.buf(B, N, F, T)
             bd.conv(att, x1, W[pfx + "attn_block.proj_out.weight"], H, N, out_scale=self._mod(st, pfx + "gate2"), res=x,
-                    alpha=RSQRT2, wpT=W[pfx + "attn_block.proj_out.weight#T"])
+                    alpha=RSQRT2, wpT=W[pfx + "attn_block.proj_out.weight#T"], wname=pfx + "attn_block.proj_out.weight")
             x = x1
         kh, kw = blk.ks
         for k in range(blk.num_dils):
             sc, stb = bd.buf(B, N), bd.buf(B, 8, 2)
-            bd.stats(x, W[pfx + f"norm.{k}.gamma"], self._mod(st, pfx + f"affine.{k}"), sc, stb)
+            bd.stats(x, W[pfx + f"norm.{k}.gamma"], self._mod(st, pfx + f"affine.{k}"), sc, stb, gname=pfx + f"norm.{k}.gamma")
             xn = bd.buf(B, N, F, T)
             bd.conv(x, xn, W[pfx + f"H.{k}.weight"], N, N, kh, kw, dil=(2 ** k if kh > 1 else 1), in_scale=sc, act=1,
                     out_scale=self._mod(st, pfx + f"gate.{k}"), res=x, alpha=RSQRT2, wpT=W[pfx + f"H.{k}.weight#T"],
-                    norm_stats=stb, wpw=W.get(pfx + f"H.{k}.weight#W"), wpwT=W.get(pfx + f"H.{k}.weight#WT"))
+                    norm_stats=stb, wpw=W.get(pfx + f"H.{k}.weight#W"), wpwT=W.get(pfx + f"H.{k}.weight#WT"), wname=pfx + f"H.{k}.weight")
             x = xn
         if blk.proj_place == "after":
             assert hasattr(blk, "proj_out") and hasattr(blk, "res_conv")
             t1 = bd.buf(B, blk.dim_out, F, T)
             if prev_out is not None:   # (Xout + OutBlock(X))/sqrt2 folded in (unet...py:817)
                 bd.conv(xin, t1, W[pfx + "res_conv.weight"], blk.dim, blk.dim_out, res=prev_out, res_scale=SQRT2,
-                        wpT=W[pfx + "res_conv.weight#T"])
+                        wpT=W[pfx + "res_conv.weight#T"], wname=pfx + "res_conv.weight")
                 a2 = 0.5
             else:
-                bd.conv(xin, t1, W[pfx + "res_conv.weight"], blk.dim, blk.dim_out, wpT=W[pfx + "res_conv.weight#T"])
+                bd.conv(xin, t1, W[pfx + "res_conv.weight"], blk.dim, blk.dim_out, wpT=W[pfx + "res_conv.weight#T"], wname=pfx + "res_conv.weight")
                 a2 = RSQRT2
-            bd.conv(x, yout, W[pfx + "proj_out.weight"], N, blk.dim_out, res=t1, alpha=a2, wpT=W[pfx + "proj_out.weight#T"])
+            bd.conv(x, yout, W[pfx + "proj_out.weight"], N, blk.dim_out, res=t1, alpha=a2, wpT=W[pfx + "proj_out.weight#T"], wname=pfx + "proj_out.weight")
         elif hasattr(blk, "res_conv"):
             bd.conv(xin, yout, W[pfx + "res_conv.weight"], blk.dim, blk.dim_out, res=x, alpha=RSQRT2,
-                    wpT=W[pfx + "res_conv.weight#T"])
+                    wpT=W[pfx + "res_conv.weight#T"], wname=pfx + "res_conv.weight")
         else:
             bd.add2(x, xin, yout, RSQRT2, RSQRT2)
 
-    def _build_state(self, B: int):
+    def _build_state(self, B: int, train: bool = False):
         self.prepare()
         dev = next(self.parameters()).device
         n, bpo, Ns = self.num_octs, self.bins_per_oct, self.Ns
@@ -652,10 +708,28 @@ class Unet_CQT_oct_with_attention(nn.Module):
             if not torch.allclose(k, torch.tensor(_CUBIC), atol=1e-7):
                 raise NotImplementedError(f"{nm}.kernel differs from the reference's cubic FIR (unet...py:514-515), which aid_resample hard-wires")
         st = dict(B=B)
-        bd = _Builder(self, B, dev)
+        bd = _Builder(self, B, dev, train=train)
         st["sigma"] = bd.buf(B)
         st["emb"] = bd.buf(B, self.emb_dim)
         st["mod"] = bd.buf(B, self._mod_total)
+        bd.mod = st["mod"]
+        if train:
+            if self.use_fencoding or any(hasattr(b.attn_block, "rel_pos") or hasattr(b.attn_block.qk, "bias")
+                                         for _, b in self._resblocks() if b.has_attn):
+                raise NotImplementedError("the training step covers the shipped configurations (no fencoding / bias_qkv / rel_pos)")
+            from .dist import flatten_parameters_
+            flat = flatten_parameters_(self)                       # parameters as views of ONE buffer: the optimiser walks it flat
+            st["gflat"] = torch.zeros_like(flat)
+            names = [k for k, v in self.named_parameters() if v.dtype == torch.float32] + \
+                    [k for k, v in self.named_buffers() if v.dtype == torch.float32]
+            tens = [v for v in self.parameters() if v.dtype == torch.float32] + [v for v in self.buffers() if v.dtype == torch.float32]
+            bd.params, bd.pgrad, off = {}, {}, 0
+            for k, v in zip(names, tens):
+                assert v.data_ptr() == flat.data_ptr() + 4 * off, "parameter is not where the flat buffer says it is"
+                bd.params[k] = v
+                bd.pgrad[k] = st["gflat"][off:off + v.numel()].view(v.shape)
+                off += v.numel()
+            bd.dmod = st["dmod"] = torch.zeros_like(st["mod"])
         W = self._packed
         # -- plan 0: embedding + all modulation vectors ----------------------------------------------------
         p0 = _Plan()
@@ -663,6 +737,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
                               W["#emb.w1"].data_ptr(), W["#emb.b1"].data_ptr(), W["#emb.w2"].data_ptr(), W["#emb.b2"].data_ptr(),
                               st["emb"].data_ptr(), B, W["#emb.freq"].numel(), W["#emb.w0"].shape[0], W["#emb.w1"].shape[0], self.emb_dim)
         p0.add("aid_embed", ep)
+        st["embed_params"] = ep
         mp = _lib.ModulationParams(st["emb"].data_ptr(), W["#modW"].data_ptr(), W["#modB"].data_ptr(), st["mod"].data_ptr(), B,
                                    self.emb_dim, self._mod_total)
         p0.add("aid_modulation", mp)
@@ -706,10 +781,10 @@ class Unet_CQT_oct_with_attention(nn.Module):
             if i < n - 1:
                 Xd = bd.buf(B, Ns[i], Fl[i], Tl[i] // 2)
                 bd.resample(hs, Xd, up=0)
-                bd.conv(pyr, Xb[i + 1][:, :, bpo:, :], wpyr, 2, Ns[i], 5, 3, dil=1, res=Xd, alpha=RSQRT2, wpT=wpyrT)   # (:794)
+                bd.conv(pyr, Xb[i + 1][:, :, bpo:, :], wpyr, 2, Ns[i], 5, 3, dil=1, res=Xd, alpha=RSQRT2, wpT=wpyrT, wname=f"downs.{i}.1.weight")   # (:794)
             else:
                 Xmid = bd.buf(B, Ns[i], Fl[i], Tl[i])
-                bd.conv(pyr, Xmid, wpyr, 2, Ns[i], 5, 3, dil=1, res=hs, alpha=RSQRT2, wpT=wpyrT)
+                bd.conv(pyr, Xmid, wpyr, 2, Ns[i], 5, 3, dil=1, res=hs, alpha=RSQRT2, wpT=wpyrT, wname=f"downs.{i}.1.weight")
             pyr_prev = pyr
         # -- bottleneck (:800-804) --------------------------------------------------------------------------------
         Xcur = Xmid
@@ -757,7 +832,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
         self._states[group] = grp                                       # (re)insert as most recently used
         st = grp.get((B, slot))
         if st is None:
-            st = grp[(B, slot)] = self._build_state(B)
+            st = grp[(B, slot)] = self._build_state(B, train=(group[1] == "train"))
         return st
 
     # ---------------------------------------------------------------------------------------------------
@@ -994,6 +1069,72 @@ class Unet_CQT_oct_with_attention(nn.Module):
         self._body_vjp(st, tr.spectrum_scale(Gh, tab["w_over_L"], per_item=cout))
         S = tr.analysis_adjoint(st["gin"], in_scale=cin, X=Gh, cskip=cskip)
         return x_hat, tr.irfft(S, out=None if outs is None else outs[1]), norm
+
+    # ---------------------------------------------------------------------------------------------------
+    # training step support: loss + parameter gradients on the same kernels
+    # ---------------------------------------------------------------------------------------------------
+    def train_state(self, B: int):
+        return self._state(B, 0, (B, "train"))
+
+    def _tail_plan(self, st):
+        """modulation / embedding backward + hand-out of the stacked modulation gradients to the individual Linears."""
+        if "plan_tail" in st:
+            return st["plan_tail"]
+        bd, W, E, B = st["builder"], self._packed, self.emb_dim, st["B"]
+        N = self._mod_total
+        st["dWm"], st["dbm"] = bd.buf(N, E), bd.buf(N)
+        st["demb"] = bd.buf(B, E)
+        pl = _Plan()
+        mp = _lib.ModulationBwdParams(st["dmod"].data_ptr(), st["emb"].data_ptr(), W["#modW"].data_ptr(), st["dWm"].data_ptr(),
+                                      st["dbm"].data_ptr(), st["demb"].data_ptr(), B, E, N, 0)
+        pl.add("aid_modulation_bwd", mp)
+        g = bd.pgrad
+        ep = _lib.EmbedBwdParams(st["embed_params"], st["demb"].data_ptr(),
+                                 g["embedding.MLP.0.weight"].data_ptr(), g["embedding.MLP.0.bias"].data_ptr(),
+                                 g["embedding.MLP.1.weight"].data_ptr(), g["embedding.MLP.1.bias"].data_ptr(),
+                                 g["embedding.MLP.2.weight"].data_ptr(), g["embedding.MLP.2.bias"].data_ptr(), 0)
+        pl.add("aid_embed_bwd", ep)
+        st["plan_tail"] = pl
+        return pl
+
+    @torch.no_grad()
+    def loss_and_grads(self, inputs: torch.Tensor, cnoise: torch.Tensor, target: torch.Tensor, hpf_error: bool = False):
+        """error = net(inputs, cnoise) - target  [-> apply_hpf_DC(error) if hpf_error, edm.py:180-187];  loss = mean(error**2)
+        (trainer.py:262-263).  Fills the flat gradient buffer of the training state (``train_state(B)['gflat']``, laid out like
+        the flat parameter buffer) with d loss / d parameter, all through HIP kernels.  Returns (loss [device scalar], error**2)."""
+        self._check_input(inputs)
+        B, L = inputs.shape
+        st = self.train_state(B)
+        tr = self.CQTransform
+        tab = tr._tables(inputs.device)
+        x = inputs.detach().contiguous().float()
+        tr.analysis(x, st["octs_in"])
+        self._run_body(st, cnoise)
+        est = tr.irfft(tr.synthesis_spectrum(st["octs_out"]))
+        err = torch.empty_like(est)
+        minus1 = torch.full((B,), -1.0, device=x.device)
+        _lib.call("aid_axpby", _lib.AxpbyParams(est.data_ptr(), target.contiguous().float().data_ptr(), err.data_ptr(), None, minus1.data_ptr(), B, L))
+        if hpf_error:
+            err = tr._hpf(err)
+        rn = torch.empty(B, device=x.device, dtype=torch.float32)
+        _lib.call("aid_row_norm", _lib.RowNormParams(err.data_ptr(), rn.data_ptr(), B, L))
+        loss = (rn * rn).sum() / (B * L)
+        # seed: d loss / d estimate = 2 error / (B L)   (through the self-adjoint DC/Nyquist projector once more if it was applied)
+        g = torch.empty_like(err)
+        coef = torch.full((B,), 2.0 / (B * L), device=x.device)
+        _lib.call("aid_axpby", _lib.AxpbyParams(err.data_ptr(), None, g.data_ptr(), coef.data_ptr(), None, B, L))
+        Gh = tr.rfft(g)
+        if hpf_error:
+            Gh = tr.spectrum_scale(Gh, tab["hpf"])
+        st["gflat"].zero_()
+        st["dmod"].zero_()
+        self._body_vjp(st, tr.spectrum_scale(Gh, tab["w_over_L"]))
+        self._tail_plan(st).run()
+        gp = st["builder"].pgrad
+        for key, (off, n) in self._mod_layout.items():               # stacked [sum N, E] rows -> the Linears' own gradient tensors
+            gp[key + ".weight"].copy_(st["dWm"][off:off + n])
+            gp[key + ".bias"].copy_(st["dbm"][off:off + n])
+        return loss, err * err
 
     def _ones_row(self, L, device):
         o = getattr(self, "_ones_cache", None)

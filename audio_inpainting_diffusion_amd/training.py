@@ -1,0 +1,110 @@
+"""Training step on the MI355X kernels.
+
+Mirrors what the reference does per iteration (training/trainer.py:253-304 ``train_step`` / ``update_ema`` with
+diff_params/edm.py:150-193 ``prepare_train_preconditioning`` / ``loss_fn``):
+
+    sigma ~ sample_ptrain_safe(B) ; noise = randn * sigma
+    input = c_in (x + noise) ; target = (x - c_skip (x + noise)) / c_out ; error = net(input, c_noise) - target
+    loss = mean(error**2) ; loss.backward() ; lr ramp-up ; clip_grad_norm_ ; Adam.step() ; EMA update
+
+Host side (this file): the O(B) scalar work and the RNG, in the reference's float32 torch arithmetic.  Device side: the
+network forward, the activation-gradient plan the guidance branch already uses, and the parameter-gradient / optimiser
+kernels of csrc/aid_train.hip -- no torch.autograd, no torch.optim on the path.  Parameters, gradients, Adam moments and the
+EMA copy are flat fp32 buffers (dist.flatten_parameters_), so optimiser, EMA and gradient clipping are three launches.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .dist import flatten_parameters_
+
+
+def sample_ptrain_safe(edm, N: int, generator=None) -> torch.Tensor:
+    """EDM.sample_ptrain_safe (edm.py:76-85): sigma on the sampling schedule's warp with exponent ro_train."""
+    a = torch.rand(N, generator=generator)
+    return (edm.sigma_max ** (1 / edm.ro_train) + a * (edm.sigma_min ** (1 / edm.ro_train) - edm.sigma_max ** (1 / edm.ro_train))) ** edm.ro_train
+
+
+def prepare_train_preconditioning(edm, x: torch.Tensor, sigma: torch.Tensor, noise: Optional[torch.Tensor] = None):
+    """edm.py:150-163: (c_in (x+n), target, c_noise); sigma [B,1] on x.device; noise defaults to randn * sigma (CPU RNG like the reference)."""
+    if noise is None:
+        noise = torch.randn(x.shape).to(x.device) * sigma
+    cskip, cout, cin, cnoise = edm.cskip(sigma), edm.cout(sigma), edm.cin(sigma), edm.cnoise(sigma)
+    target = (1 / cout) * (x - cskip * (x + noise))
+    return cin * (x + noise), target, cnoise
+
+
+class Trainer:
+    """The per-iteration part of the reference ``Trainer`` (optimizer conf/exp/*.yaml:12-19,62-69)."""
+
+    def __init__(self, net, edm, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, lr_rampup_it=10000, use_grad_clip=True, max_grad_norm=1.0,
+                 ema_rate=0.9999, ema_rampup=10000, batch=4, use_cqt_DC_correction=False):
+        self.net, self.edm = net, edm
+        self.lr, self.beta1, self.beta2, self.eps = float(lr), float(beta1), float(beta2), float(eps)
+        self.lr_rampup_it, self.use_grad_clip, self.max_grad_norm = lr_rampup_it, bool(use_grad_clip), float(max_grad_norm)
+        self.ema_rate, self.ema_rampup, self.batch = float(ema_rate), ema_rampup, int(batch)
+        self.hpf_error = bool(use_cqt_DC_correction)
+        self.flat = flatten_parameters_(net)
+        self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.ema = self.flat.clone()                                   # EMA of every parameter, same flat layout (trainer.py:66-68 deepcopy)
+        self.ws = torch.zeros(_lib.AID_SUMSQ_BLOCKS, device=self.flat.device, dtype=torch.float64)
+        self.gstat = torch.zeros(2, device=self.flat.device, dtype=torch.float32)      # (gradient norm, clipping coefficient)
+        self.it = 0                                                     # iterations done; the t of Adam's bias correction is it + 1
+        self.steps = 0
+
+    # -----------------------------------------------------------------------------------------------------------------------
+    def loss_and_grads(self, audio: torch.Tensor, sigma: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
+        """EDM.loss_fn (edm.py:166-193) + loss.backward(): returns (loss, error**2, sigma); gradients land in the state's flat buffer."""
+        B = audio.shape[0]
+        if sigma is None:
+            sigma = sample_ptrain_safe(self.edm, B)
+        sigma = sigma.reshape(B, 1).to(audio.device)
+        inp, target, cnoise = prepare_train_preconditioning(self.edm, audio, sigma, noise)
+        loss, err2 = self.net.loss_and_grads(inp, cnoise, target, hpf_error=self.hpf_error)
+        return loss, err2, sigma
+
+    def grads(self, B: int) -> torch.Tensor:
+        return self.net.train_state(B)["gflat"]
+
+    def optimizer_step(self, B: int):
+        """lr ramp-up (trainer.py:270-274), clip_grad_norm_ (:277-278), Adam.step (:281)."""
+        g = self.grads(B)
+        n = g.numel()
+        lr = self.lr * min(self.it / max(self.lr_rampup_it, 1e-8), 1) if self.it <= self.lr_rampup_it else self.lr
+        _lib.call("aid_sumsq", _lib.SumsqParams(g.data_ptr(), self.ws.data_ptr(), self.gstat.data_ptr(), n,
+                                                self.max_grad_norm if self.use_grad_clip else 0.0))
+        self.steps += 1
+        t = self.steps
+        _lib.call("aid_adam", _lib.AdamParams(self.flat.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                              self.gstat[1:].data_ptr(), n, lr, self.beta1, self.beta2, self.eps,
+                                              1.0 - self.beta1 ** t, math.sqrt(1.0 - self.beta2 ** t)))
+        self.net._packed_ver = None          # parameters changed behind torch's version counters: refresh the kernel-side packs
+
+    def update_ema(self):
+        """trainer.py:288-304"""
+        t = self.it * self.batch
+        rate = float(min(max(t / self.ema_rampup, 0.0), self.ema_rate)) if t < self.ema_rampup else self.ema_rate
+        _lib.call("aid_ema", _lib.EmaParams(self.ema.data_ptr(), self.flat.data_ptr(), self.flat.numel(), rate))
+
+    def train_step(self, audio: torch.Tensor, sigma=None, noise=None):
+        """One iteration (num_accumulation_rounds = 1): returns the loss (device scalar)."""
+        loss, _, _ = self.loss_and_grads(audio, sigma, noise)
+        self.optimizer_step(audio.shape[0])
+        self.update_ema()                     # (training_loop: train_step, update_ema, then it += 1; trainer.py:366-368)
+        self.it += 1
+        return loss
+
+    def ema_state_dict(self):
+        """state_dict-shaped view of the EMA buffer (what the reference checkpoints as 'ema')."""
+        out, off = {}, 0
+        sd = self.net.state_dict()
+        names = [k for k, v in self.net.named_parameters() if v.dtype == torch.float32] + [k for k, v in self.net.named_buffers() if v.dtype == torch.float32]
+        for k in names:
+            n = sd[k].numel()
+            out[k] = self.ema[off:off + n].view(sd[k].shape)
+            off += n
+        return out

@@ -411,6 +411,93 @@ typedef struct {
 } aid_add2_params;
 int aid_add2(const aid_add2_params* p, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Training step: parameter gradients, optimiser, EMA.
+ *   replaces: torch.autograd through the network inside EDM.loss_fn (diff_params/edm.py:166-193), torch.optim.Adam.step,
+ *             clip_grad_norm_ and Trainer.update_ema (training/trainer.py:253-304).
+ * The activation gradients are those of the input-VJP plan (aid_conv2d on transposed weights, aid_norm_bwd, ...); the entry
+ * points below add the parameter gradients.  All reductions have a fixed order (no atomics).
+ *
+ * aid_conv2d_wgrad : P[(b*S+s)][co][ci][tap] = alpha * sum_{f in split s, t} gy[b,co,f,t] * x[b,ci,f+(kh-KH/2)*dilF,t+kw-KW/2]
+ *                    (zero padding; tap = kh*KW+kw) -- per-(sample, row split) partial weight gradients on fp32 MFMA.
+ *                    `x` is the conv's input as the forward saw it (for an activated layer: the aid_scale_act output).
+ * aid_wgrad_reduce : dW[co,ci,tap] (+)= sum_b gate[b,co] * in_scale[b,ci] * sum_s P      (gate / in_scale NULL -> 1)
+ *                    dgate[b,co]    = sum_{ci,tap} W[co,ci,tap] * in_scale[b,ci] * sum_s P   (= alpha * <gy, ungated conv output>)
+ *                    W, dW in the parameter's own layout [Cout][Cin][KH*KW].
+ * aid_channel_dot  : out[b,c] = sum_{f,t} u*v
+ * aid_scale_bwd    : scale[b,c] = gamma[c] (1 + mod[b,c]) inv[b,g]:  ds = S/scale;  dgamma[c] (+)= sum_b ds (1+mod) inv;
+ *                    dmod[b,c] = ds gamma inv          (stats: [B, groups, 2] (mean, inv) of aid_group_stats)
+ * aid_modulation_bwd / aid_embed_bwd : backward of aid_modulation / aid_embed (parameter gradients + d emb)
+ * aid_adam         : torch.optim.Adam update over a flat buffer (bias1 = 1-beta1^t, bias2_sqrt = sqrt(1-beta2^t), gscale: optional
+ *                    device scalar multiplying the gradient = the clipping coefficient written by aid_sumsq)
+ * aid_ema          : dst = dst*rate + src*(1-rate)
+ * aid_sumsq        : out[0] = ||x||_2, out[1] = min(1, max_norm / (||x|| + 1e-6)) (1 when max_norm <= 0); ws: AID_SUMSQ_BLOCKS doubles
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    aid_view gy, x;
+    float* P;
+    int B, Cin, Cout, F, T, KH, KW, dilF;
+    int S;
+    float alpha;
+} aid_conv2d_wgrad_params;
+int aid_conv2d_wgrad(const aid_conv2d_wgrad_params* p, void* stream);
+
+typedef struct {
+    const float* P; const float* W;
+    const float* gate; int64_t gate_ld;
+    const float* in_scale; int64_t in_scale_ld;
+    float* dW; float* dgate; int64_t dgate_ld;
+    int B, S, Cout, Cin, K, accumulate;
+} aid_wgrad_reduce_params;
+int aid_wgrad_reduce(const aid_wgrad_reduce_params* p, void* stream);
+
+typedef struct {
+    aid_view u, v;
+    float* out; int64_t out_ld;
+    int B, C, F, T;
+} aid_channel_dot_params;
+int aid_channel_dot(const aid_channel_dot_params* p, void* stream);
+
+typedef struct {
+    const float* S; int64_t S_ld;
+    const float* scale; int64_t scale_ld;
+    const float* gamma; const float* mod; int64_t mod_ld;
+    const float* stats;
+    float* dgamma; float* dmod; int64_t dmod_ld;
+    int B, C, groups, accumulate;
+} aid_scale_bwd_params;
+int aid_scale_bwd(const aid_scale_bwd_params* p, void* stream);
+
+typedef struct {
+    const float* dmod; const float* emb; const float* W;
+    float* dW; float* dbias; float* demb;
+    int B, E, N, accumulate;
+} aid_modulation_bwd_params;
+int aid_modulation_bwd(const aid_modulation_bwd_params* p, void* stream);
+
+typedef struct {
+    aid_embed_params fwd;              /* the forward's parameters (emb = its output) */
+    const float* demb;                 /* [B, E] */
+    float* dw0; float* db0; float* dw1; float* db1; float* dw2; float* db2;
+    int accumulate;
+} aid_embed_bwd_params;
+int aid_embed_bwd(const aid_embed_bwd_params* p, void* stream);
+
+typedef struct {
+    float* param; const float* grad; float* m; float* v;
+    const float* gscale;
+    int64_t n;
+    float lr, beta1, beta2, eps, bias1, bias2_sqrt;
+} aid_adam_params;
+int aid_adam(const aid_adam_params* p, void* stream);
+
+typedef struct { float* dst; const float* src; int64_t n; float rate; } aid_ema_params;
+int aid_ema(const aid_ema_params* p, void* stream);
+
+#define AID_SUMSQ_BLOCKS 512
+typedef struct { const float* x; double* ws; float* out; int64_t n; float max_norm; } aid_sumsq_params;
+int aid_sumsq(const aid_sumsq_params* p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

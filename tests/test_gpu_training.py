@@ -1,0 +1,152 @@
+"""Training step on the HIP kernels against torch.autograd / torch.optim over the CPU oracle.
+
+ * parameter gradients of mean((net(input, c_noise) - target)**2) for EVERY tensor of the state_dict, vs autograd through the
+   oracle U-Net (which is pinned to the reference by tests/golden/unet_small_*.npz);
+ * aid_sumsq / aid_adam / aid_ema vs clip_grad_norm_ + torch.optim.Adam + the reference's EMA rule;
+ * two whole iterations (EDM preconditioning, loss, backward, lr ramp-up, clipping, Adam, EMA) vs the same loop on the oracle."""
+import ast
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _setup(tag="a"):
+    from audio_inpainting_diffusion_amd.config import small_args
+    from audio_inpainting_diffusion_amd.init import seeded_init_
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    from oracle.nsgt_cqt import OracleCQT
+    from oracle.unet import OracleUnet
+    z = np.load(os.path.join(GOLDEN, f"unet_small_{tag}.npz"))
+    kw = ast.literal_eval(str(z["cfg"]))
+    args = small_args(**kw)
+    net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(DEV)), int(z["seed"]), gate_scale=10.0, affine_scale=10.0)
+    cqt = OracleCQT(kw["num_octs"], kw["bins_per_oct"], "oct", ("kaiser", 1), kw["fs"], kw["audio_len"])
+    orc = OracleUnet(kw["num_octs"], kw["bins_per_oct"], cqt).load_state_dict(net.state_dict())
+    return net, orc, z, kw, args
+
+
+def _oracle_grads(orc, x, cn, target, hpf=False):
+    for v in orc.sd.values():
+        v.requires_grad_(True)
+        v.grad = None
+    y = orc(x, cn)
+    err = y - target
+    if hpf:
+        err = orc.CQTransform.apply_hpf_DC(err)
+    loss = (err ** 2).mean()
+    loss.backward()
+    g = {k: (v.grad.clone() if v.grad is not None else torch.zeros_like(v)) for k, v in orc.sd.items()}
+    for v in orc.sd.values():
+        v.requires_grad_(False)
+    return float(loss), g
+
+
+@pytest.mark.parametrize("tag,hpf", [("a", False), ("b", False), ("a", True)])
+def test_parameter_gradients_vs_oracle_autograd(tag, hpf):
+    net, orc, z, kw, _ = _setup(tag)
+    x, cn = torch.from_numpy(z["x"]), torch.from_numpy(z["cnoise"])
+    target = torch.randn(x.shape, generator=torch.Generator().manual_seed(5)) * 0.2
+    loss, err2 = net.loss_and_grads(x.to(DEV), cn.to(DEV), target.to(DEV), hpf_error=hpf)
+    ref_loss, ref = _oracle_grads(orc, x, cn, target, hpf)
+    assert abs(float(loss) - ref_loss) < 1e-5 * abs(ref_loss)
+    got = {k: v.detach().cpu() for k, v in net.train_state(x.shape[0])["builder"].pgrad.items()}
+    tot_num = tot_den = 0.0
+    worst = ("", 0.0)
+    gmax = max(float(v.norm()) for v in ref.values())
+    for k, r in ref.items():
+        if k.endswith("RFF_freq") or k.endswith("kernel"):
+            assert float(got[k].abs().max()) == 0.0              # frozen tensors
+            continue
+        d = float((got[k].double() - r.double()).norm())
+        tot_num += d * d
+        tot_den += float(r.double().norm()) ** 2
+        e = d / (float(r.norm()) + 1e-6 * gmax)
+        if e > worst[1]:
+            worst = (k, e)
+    tot = math.sqrt(tot_num / tot_den)
+    print(f"parameter gradients ({tag}, hpf={hpf}): all tensors together rel-L2 = {tot:.2e}; worst tensor {worst[0]} {worst[1]:.2e}; loss {float(loss):.6f}")
+    assert tot < 1e-4 and worst[1] < 1e-3
+
+
+def test_optimizer_and_ema_kernels_vs_torch():
+    from audio_inpainting_diffusion_amd import _lib as L
+    n = 100003
+    g0 = torch.Generator().manual_seed(1)
+    p0 = torch.randn(n, generator=g0)
+    ema0 = p0.clone()
+    pd, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    ws = torch.zeros(L.AID_SUMSQ_BLOCKS, device=DEV, dtype=torch.float64)
+    gst = torch.zeros(2, device=DEV)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pr], lr=2e-4, betas=(0.9, 0.999), eps=1e-8)
+    for t in range(1, 5):
+        g = torch.randn(n, generator=g0) * (3.0 if t % 2 else 1e-3)        # clipped on odd steps only
+        gd = g.to(DEV)
+        L.call("aid_sumsq", L.SumsqParams(gd.data_ptr(), ws.data_ptr(), gst.data_ptr(), n, 1.0))
+        L.call("aid_adam", L.AdamParams(pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), gst[1:].data_ptr(), n, 2e-4, 0.9, 0.999, 1e-8,
+                                        1.0 - 0.9 ** t, math.sqrt(1.0 - 0.999 ** t)))
+        pr.grad = g.clone()
+        nrm = torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        assert abs(float(gst[0]) - float(nrm)) < 1e-5 * float(nrm)
+        assert rel_l2(pd.cpu(), pr.detach()) < 1e-6 and rel_l2(pd.cpu() - p0, pr.detach() - p0) < 1e-4     # (the deltas are ~1e-4 of the values)
+    ema = ema0.to(DEV)
+    L.call("aid_ema", L.EmaParams(ema.data_ptr(), pd.data_ptr(), n, 0.75))
+    assert rel_l2(ema.cpu(), ema0 * 0.75 + pd.cpu() * 0.25) < 1e-6
+
+
+def test_two_training_iterations_vs_oracle_loop():
+    """trainer.py:253-304 on the small network: same sigma / noise on both sides; loss values, EMA and parameters after two steps."""
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.training import Trainer, prepare_train_preconditioning
+    net, orc, z, kw, args = _setup("a")
+    edm = EDM(args)
+    tr = Trainer(net, edm, lr=2e-3, lr_rampup_it=2, max_grad_norm=1.0, ema_rate=0.9, ema_rampup=8, batch=2)
+    B, Ls = 2, kw["audio_len"]
+    g0 = torch.Generator().manual_seed(9)
+    keys = list(orc.sd.keys())
+    params = [torch.nn.Parameter(orc.sd[k].clone()) for k in keys]
+    trainable = [p for k, p in zip(keys, params) if not (k.endswith("RFF_freq") or k.endswith("kernel"))]
+    opt = torch.optim.Adam(trainable, lr=2e-3, betas=(0.9, 0.999), eps=1e-8)
+    ema_ref = {k: orc.sd[k].clone() for k in keys}
+    losses, ref_losses = [], []
+    for it in range(3):
+        audio = torch.randn(B, Ls, generator=g0) * 0.063
+        sigma = (torch.rand(B, 1, generator=g0) * 0.5 + 0.05)
+        noise = torch.randn(B, Ls, generator=g0) * sigma
+        losses.append(float(tr.train_step(audio.to(DEV), sigma, noise.to(DEV))))
+        # ---- the reference's iteration on the oracle --------------------------------------------------------------------
+        orc.sd = {k: p for k, p in zip(keys, params)}
+        inp, target, cnoise = prepare_train_preconditioning(edm, audio, sigma, noise)
+        opt.zero_grad()
+        loss = ((orc(inp, cnoise) - target) ** 2).mean()
+        loss.backward()
+        for gpar in opt.param_groups:
+            gpar["lr"] = 2e-3 * min(it / max(2, 1e-8), 1)
+        torch.nn.utils.clip_grad_norm_(trainable, 1.0)
+        opt.step()
+        t = it * 2
+        s = float(np.clip(t / 8, 0.0, 0.9)) if t < 8 else 0.9
+        with torch.no_grad():
+            for k, p in zip(keys, params):
+                ema_ref[k].copy_(ema_ref[k] * s + p * (1 - s))
+        ref_losses.append(float(loss))
+    print("losses", losses, "oracle", ref_losses)
+    for a_, b_ in zip(losses, ref_losses):
+        assert abs(a_ - b_) < 1e-4 * abs(b_)
+    sd = net.state_dict()
+    num = math.sqrt(sum(float((sd[k].cpu() - params[i].detach()).norm()) ** 2 for i, k in enumerate(keys)))
+    den = math.sqrt(sum(float(params[i].detach().norm()) ** 2 for i in range(len(keys))))
+    print(f"parameters after 3 iterations: rel-L2 vs oracle loop = {num / den:.2e}")
+    assert num / den < 1e-4
+    ema = tr.ema_state_dict()
+    num = math.sqrt(sum(float((ema[k].cpu() - ema_ref[k]).norm()) ** 2 for k in keys))
+    assert num / den < 1e-4

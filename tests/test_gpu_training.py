@@ -150,3 +150,41 @@ def test_two_training_iterations_vs_oracle_loop():
     ema = tr.ema_state_dict()
     num = math.sqrt(sum(float((ema[k].cpu() - ema_ref[k]).norm()) ** 2 for k in keys))
     assert num / den < 1e-4
+
+
+def test_full_size_parameter_gradients_vs_oracle_autograd():
+    """Full-size 22.05 kHz network (186 M parameters), B=1: loss and a spread of parameter gradients (first / deep 5x3 weights,
+    qk projection, 1x1 projections, norm gammas, affine / gate Linears, embedding MLP) vs torch.autograd over the CPU oracle."""
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    from oracle.nsgt_cqt import OracleCQT
+    from oracle.unet import OracleUnet
+    args = make_args("maestro22k")
+    net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(DEV)), 0, gate_scale=10.0, affine_scale=10.0)
+    Ls = args.exp.audio_len
+    x = torch.from_numpy(seeded_normal(61, 0, Ls)).reshape(1, Ls) * 0.5
+    target = torch.from_numpy(seeded_normal(62, 0, Ls)).reshape(1, Ls) * 0.3
+    cn = torch.tensor([[-0.45]])
+    loss, _ = net.loss_and_grads(x.to(DEV), cn.to(DEV), target.to(DEV))
+    got = net.train_state(1)["builder"].pgrad
+    orc = OracleUnet(7, 64, OracleCQT(7, 64, "oct", ("kaiser", 1), 22050, Ls)).load_state_dict(net.state_dict())
+    ref_loss, ref = _oracle_grads(orc, x, cn, target)
+    assert abs(float(loss) - ref_loss) < 1e-5 * abs(ref_loss)
+    keys = ["downs.0.0.proj_in.weight", "downs.0.2.H.1.weight", "downs.0.1.weight", "downs.3.2.H.4.weight", "downs.6.2.H.6.weight",
+            "downs.5.2.attn_block.qk.weight", "downs.4.2.attn_block.proj_in.weight", "downs.4.2.attn_block.proj_out.weight",
+            "middle.0.1.H.3.weight", "middle.0.0.proj_out.weight", "middle.0.0.res_conv.weight", "ups.0.1.H.0.weight", "ups.6.1.H.1.weight",
+            "ups.3.0.proj_out.weight", "downs.2.2.norm.1.gamma", "downs.6.2.norm2.gamma", "downs.1.2.affine.2.weight", "downs.1.2.affine.2.bias",
+            "ups.2.1.gate.3.weight", "ups.2.1.gate.3.bias", "downs.6.2.gate2.weight", "embedding.MLP.0.weight", "embedding.MLP.2.bias"]
+    worst = 0.0
+    for k in keys:
+        e = rel_l2(got[k].cpu(), ref[k])
+        worst = max(worst, e)
+        print(f"  {k:44s} rel-L2 {e:.2e}")
+        assert e < 1e-4, k
+    train = [k for k in ref if not (k.endswith("RFF_freq") or k.endswith("kernel"))]      # (frozen in the reference: requires_grad=False / buffers)
+    assert all(float(got[k].abs().max()) == 0.0 for k in ref if k not in train)
+    num = math.sqrt(sum(float((got[k].cpu().double() - ref[k].double()).norm()) ** 2 for k in train))
+    den = math.sqrt(sum(float(ref[k].double().norm()) ** 2 for k in train))
+    print(f"full-size parameter gradients: loss {float(loss):.6f} (oracle {ref_loss:.6f}); all trainable tensors together rel-L2 = {num / den:.2e}; worst listed {worst:.2e}")
+    assert num / den < 1e-4

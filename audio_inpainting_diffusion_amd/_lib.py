@@ -181,7 +181,8 @@ class ScaleBwdParams(C.Structure):
 
 class ModulationBwdParams(C.Structure):
     _fields_ = [("dmod", C.c_void_p), ("emb", C.c_void_p), ("W", C.c_void_p), ("dW", C.c_void_p), ("dbias", C.c_void_p),
-                ("demb", C.c_void_p), ("B", C.c_int), ("E", C.c_int), ("N", C.c_int), ("accumulate", C.c_int)]
+                ("demb", C.c_void_p), ("B", C.c_int), ("E", C.c_int), ("N", C.c_int), ("accumulate", C.c_int),
+                ("part", C.c_void_p), ("part_floats", C.c_int64)]
 
 
 class EmbedBwdParams(C.Structure):

@@ -31,84 +31,103 @@ struct WgDev {
     int co_tiles, ci_tiles;
 };
 
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgDev a) {
+#define WG_CO 64                 // output channels per workgroup tile (two 32-row MFMA tiles share every B fragment)
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgDev a) {
     const aid_conv2d_wgrad_params& p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int co0 = (blockIdx.x % a.co_tiles) * 32;
+    const int co0 = (blockIdx.x % a.co_tiles) * WG_CO;
     const int ci0 = (blockIdx.x / a.co_tiles) * 32;
     const int b = blockIdx.y / p.S, s = blockIdx.y - b * p.S;
     const int f_lo = (int)(((int64_t)p.F * s) / p.S), f_hi = (int)(((int64_t)p.F * (s + 1)) / p.S);
     const int KH = p.KH, KW = p.KW, ntaps = KH * KW;
     const int kwc = KW / 2, khc = KH / 2;
 
-    __shared__ float gyT[32 * WG_LDA];
+    __shared__ float gyT[WG_CO * WG_LDA];
     __shared__ float xT[WG_MAXKH * 32 * WG_LDB];
 
-    // taps of this wave: wave, wave + 4, wave + 8, wave + 12
-    f32x16 acc[4];
+    // taps of this wave: wave, wave + 4, wave + 8, wave + 12; two accumulator tiles (co0.., co0+32..) per tap
+    f32x16 acc[4][2];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][i][r] = 0.f;
     int tkh[4], tkw[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const int tap = wave + 4 * q; tkh[q] = tap / KW; tkw[q] = tap - tkh[q] * KW; }
 
     const bool vec = ((p.T & 3) == 0) && ((p.gy.sB | p.gy.sC | p.gy.sF | p.x.sB | p.x.sC | p.x.sF) & 3) == 0 &&
                      ((((uintptr_t)p.gy.p) | ((uintptr_t)p.x.p)) & 15) == 0;
-    for (int f = f_lo; f < f_hi; ++f) {
-        for (int t0 = 0; t0 < p.T; t0 += WG_TC) {
-            __syncthreads();                                  // (previous chunk's fragment reads are done)
-            // ---- stage gy[b, co0.., f, t0..t0+63] ----------------------------------------------------------------------
-            for (int e = tid; e < 32 * (WG_TC / 4); e += 256) {
-                const int row = e / (WG_TC / 4), q4 = e - row * (WG_TC / 4);
-                const int co = co0 + row, t = t0 + 4 * q4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (co < p.Cout && t < p.T) {
-                    const float* src = p.gy.p + (int64_t)b * p.gy.sB + (int64_t)co * p.gy.sC + (int64_t)f * p.gy.sF + t;
-                    if (vec && t + 3 < p.T) v = *reinterpret_cast<const float4*>(src);
-                    else { v.x = src[0]; if (t + 1 < p.T) v.y = src[1]; if (t + 2 < p.T) v.z = src[2]; if (t + 3 < p.T) v.w = src[3]; }
+    // one input row (32 channels x 64 samples + the two halo samples) into ring slot `slot`
+    auto stage_row = [&](int fi, int slot, int t0) {
+        for (int e = tid; e < 32 * (WG_TC / 4); e += 256) {
+            const int row = e / (WG_TC / 4), q4 = e - row * (WG_TC / 4);
+            const int ci = ci0 + row, t = t0 + 4 * q4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci < p.Cin && fi >= 0 && fi < p.F && t < p.T) {
+                const float* src = p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + t;
+                if (vec && t + 3 < p.T) v = *reinterpret_cast<const float4*>(src);
+                else { v.x = src[0]; if (t + 1 < p.T) v.y = src[1]; if (t + 2 < p.T) v.z = src[2]; if (t + 3 < p.T) v.w = src[3]; }
+            }
+            float* d = xT + (slot * 32 + row) * WG_LDB + 1 + 4 * q4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        if (KW > 1 && tid < 64) {
+            const int side = tid & 1, row = tid >> 1;
+            const int ci = ci0 + row;
+            const int t = side ? (t0 + WG_TC) : (t0 - 1);
+            float v = 0.f;
+            if (ci < p.Cin && fi >= 0 && fi < p.F && t >= 0 && t < p.T)
+                v = p.x.p[(int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + t];
+            xT[(slot * 32 + row) * WG_LDB + (side ? (WG_TC + 1) : 0)] = v;
+        }
+    };
+    // Rows are walked along the dilation sub-lattice (f, f + dil, f + 2 dil, ...): consecutive steps share KH-1 of their KH
+    // input rows, which stay in a ring of LDS slots -- one new row is staged per step instead of KH.
+    const int dil = (KH > 1) ? p.dilF : 1;
+    const int tc = (p.T < WG_TC) ? ((p.T + 3) & ~3) : WG_TC;     // positions actually walked per chunk (short levels: T = 32)
+    for (int t0 = 0; t0 < p.T; t0 += WG_TC) {
+        for (int res = 0; res < dil; ++res) {
+            int f = f_lo + ((res - f_lo) % dil + dil) % dil;            // first row of this residue class inside the split
+            for (int n = 0; f < f_hi; f += dil, ++n) {
+                __syncthreads();                              // (previous step's fragment reads are done)
+                // ---- stage gy[b, co0.., f, t0..t0+63] ------------------------------------------------------------------
+                for (int e = tid; e < WG_CO * (WG_TC / 4); e += 256) {
+                    const int row = e / (WG_TC / 4), q4 = e - row * (WG_TC / 4);
+                    const int co = co0 + row, t = t0 + 4 * q4;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (co < p.Cout && t < p.T) {
+                        const float* src = p.gy.p + (int64_t)b * p.gy.sB + (int64_t)co * p.gy.sC + (int64_t)f * p.gy.sF + t;
+                        if (vec && t + 3 < p.T) v = *reinterpret_cast<const float4*>(src);
+                        else { v.x = src[0]; if (t + 1 < p.T) v.y = src[1]; if (t + 2 < p.T) v.z = src[2]; if (t + 3 < p.T) v.w = src[3]; }
+                    }
+                    float* d = gyT + row * WG_LDA + 4 * q4;
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
                 }
-                float* d = gyT + row * WG_LDA + 4 * q4;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-            // ---- stage the KH dilated input rows, one halo sample each side ------------------------------------------------
-            for (int e = tid; e < KH * 32 * (WG_TC / 4); e += 256) {
-                const int q4 = e % (WG_TC / 4);
-                const int rk = e / (WG_TC / 4);
-                const int row = rk % 32, kh = rk / 32;
-                const int ci = ci0 + row, fi = f + (kh - khc) * p.dilF, t = t0 + 4 * q4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ci < p.Cin && fi >= 0 && fi < p.F && t < p.T) {
-                    const float* src = p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + t;
-                    if (vec && t + 3 < p.T) v = *reinterpret_cast<const float4*>(src);
-                    else { v.x = src[0]; if (t + 1 < p.T) v.y = src[1]; if (t + 2 < p.T) v.z = src[2]; if (t + 3 < p.T) v.w = src[3]; }
+                // ---- input rows: chain row m = n + kh lives in slot m % KH --------------------------------------------------
+                if (n == 0) {
+                    for (int kh = 0; kh < KH; ++kh) stage_row(f + (kh - khc) * dil, kh % KH, t0);
+                } else {
+                    stage_row(f + (KH - 1 - khc) * dil, (n + KH - 1) % KH, t0);
                 }
-                float* d = xT + (kh * 32 + row) * WG_LDB + 1 + 4 * q4;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-            for (int e = tid; e < KH * 32 * 2; e += 256) {
-                const int side = e & 1, rk = e >> 1;
-                const int row = rk % 32, kh = rk / 32;
-                const int ci = ci0 + row, fi = f + (kh - khc) * p.dilF;
-                const int t = side ? (t0 + WG_TC) : (t0 - 1);
-                float v = 0.f;
-                if (ci < p.Cin && fi >= 0 && fi < p.F && t >= 0 && t < p.T)
-                    v = p.x.p[(int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + t];
-                xT[(kh * 32 + row) * WG_LDB + (side ? (WG_TC + 1) : 0)] = v;
-            }
-            __syncthreads();
-            // ---- K loop over the chunk's positions: A = gy^T (rows: co), B = shifted input (cols: ci) ----------------------------
-            const float* ap = gyT + l32 * WG_LDA + half;
-#pragma unroll 4
-            for (int k = 0; k < WG_TC; k += 2) {
-                const float av = ap[k];
+                __syncthreads();
+                // ---- K loop over the chunk's positions: A = gy^T (rows: co), B = shifted input (cols: ci) ------------------------
+                int boff[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (wave + 4 * q < ntaps) {               // (wave-uniform)
-                        const float bv = xT[(tkh[q] * 32 + l32) * WG_LDB + 1 + k + half + tkw[q] - kwc];
-                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[q], 0, 0, 0);
+                for (int q = 0; q < 4; ++q) boff[q] = (((n + tkh[q]) % KH) * 32 + l32) * WG_LDB + 1 + half + tkw[q] - kwc;
+                const float* ap = gyT + l32 * WG_LDA + half;
+                for (int k = 0; k < tc; k += 2) {
+                    const float a0 = ap[k], a1 = ap[32 * WG_LDA + k];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (wave + 4 * q < ntaps) {           // (wave-uniform)
+                            const float bv = xT[boff[q] + k];
+                            acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[q][0], 0, 0, 0);
+                            acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[q][1], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -122,10 +141,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgDev a) {
         const int tap = wave + 4 * q;
         if (tap >= ntaps || ci >= p.Cin) continue;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (co < p.Cout) P[((int64_t)co * p.Cin + ci) * ntaps + tap] = p.alpha * acc[q][r];
-        }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < p.Cout) P[((int64_t)co * p.Cin + ci) * ntaps + tap] = p.alpha * acc[q][i][r];
+            }
     }
 }
 
@@ -136,7 +157,7 @@ extern "C" int aid_conv2d_wgrad(const aid_conv2d_wgrad_params* p, void* stream) 
                 "aid_conv2d_wgrad: kernel sizes up to 5x3");
     WgDev a;
     a.p = *p;
-    a.co_tiles = aid_cdiv(p->Cout, 32);
+    a.co_tiles = aid_cdiv(p->Cout, WG_CO);
     a.ci_tiles = aid_cdiv(p->Cin, 32);
     AID_REQUIRE((int64_t)p->B * p->S < 65536, "aid_conv2d_wgrad: too many (sample, split) pairs");
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(a.co_tiles * a.ci_tiles), (unsigned)(p->B * p->S)), dim3(256), 0, (hipStream_t)stream, a);
@@ -262,12 +283,24 @@ __global__ __launch_bounds__(256) void modulation_bwd_w_kernel(const aid_modulat
     }
 }
 
-__global__ __launch_bounds__(256) void modulation_bwd_e_kernel(const aid_modulation_bwd_params p) {
+// demb[b,e] = sum_j dmod[b,j] W[j,e]: one workgroup per (row chunk of 128 j, sample), partial sums to `part`, then a fixed-order fold
+#define MODB_CH 128
+__global__ __launch_bounds__(256) void modulation_bwd_e_kernel(const aid_modulation_bwd_params p, float* __restrict__ part, int nchunk) {
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int j0 = ch * MODB_CH, j1 = min(p.N, j0 + MODB_CH);
+    for (int e = threadIdx.x; e < p.E; e += 256) {
+        float accv = 0.f;
+        for (int j = j0; j < j1; ++j) accv += p.dmod[(int64_t)b * p.N + j] * p.W[(int64_t)j * p.E + e];
+        part[((int64_t)b * nchunk + ch) * p.E + e] = accv;
+    }
+}
+
+__global__ __launch_bounds__(256) void modulation_bwd_e_fold_kernel(const aid_modulation_bwd_params p, const float* __restrict__ part, int nchunk) {
     const int b = blockIdx.y;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= p.E) return;
     float accv = 0.f;
-    for (int j = 0; j < p.N; ++j) accv += p.dmod[(int64_t)b * p.N + j] * p.W[(int64_t)j * p.E + e];
+    for (int ch = 0; ch < nchunk; ++ch) accv += part[((int64_t)b * nchunk + ch) * p.E + e];
     p.demb[(int64_t)b * p.E + e] = accv;
 }
 
@@ -275,7 +308,12 @@ extern "C" int aid_modulation_bwd(const aid_modulation_bwd_params* p, void* stre
     AID_REQUIRE(p && p->dmod && p->emb && p->W && p->dW && p->dbias && p->demb, "aid_modulation_bwd: null pointer");
     hipLaunchKernelGGL(modulation_bwd_w_kernel, dim3((unsigned)(((int64_t)p->N * p->E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
     AID_CHECK_LAUNCH();
-    hipLaunchKernelGGL(modulation_bwd_e_kernel, dim3((unsigned)aid_cdiv(p->E, 256), (unsigned)p->B), dim3(256), 0, (hipStream_t)stream, *p);
+    const int nchunk = aid_cdiv(p->N, MODB_CH);
+    AID_REQUIRE(p->part && p->part_floats >= (int64_t)p->B * nchunk * p->E, "aid_modulation_bwd: `part` scratch must hold B * ceil(N/128) * E floats");
+    hipLaunchKernelGGL(modulation_bwd_e_kernel, dim3((unsigned)nchunk, (unsigned)p->B), dim3(256), 0, (hipStream_t)stream, *p, p->part, nchunk);
+    AID_CHECK_LAUNCH();
+    hipLaunchKernelGGL(modulation_bwd_e_fold_kernel, dim3((unsigned)aid_cdiv(p->E, 256), (unsigned)p->B), dim3(256), 0, (hipStream_t)stream, *p,
+                       (const float*)p->part, nchunk);
     AID_CHECK_LAUNCH();
     return AID_OK;
 }

@@ -296,7 +296,7 @@ class _Builder:
             sp = _lib.ScaleActParams(_lib.view4(x), _lib.view4(xin), in_scale.data_ptr(), in_scale.stride(0), B, cin, F, T, 1, 0)
             self.plan.add("aid_scale_act", sp, x, xin, in_scale)
             isc = None
-        tiles = -(-cout // 32) * -(-cin // 32)
+        tiles = -(-cout // 64) * -(-cin // 32)
         S = max(1, min(F, -(-1024 // (tiles * B))))
         P = self._scratch(("P", B * S * cout * cin * K))
         wp = _lib.WgradParams(_lib.view4(gy), _lib.view4(xin), P.data_ptr(), B, cin, cout, F, T, kh, kw, dil, S, alpha)
@@ -1085,8 +1085,9 @@ class Unet_CQT_oct_with_attention(nn.Module):
         st["dWm"], st["dbm"] = bd.buf(N, E), bd.buf(N)
         st["demb"] = bd.buf(B, E)
         pl = _Plan()
+        st["mpart"] = bd.buf(B * (-(-N // 128)) * E)
         mp = _lib.ModulationBwdParams(st["dmod"].data_ptr(), st["emb"].data_ptr(), W["#modW"].data_ptr(), st["dWm"].data_ptr(),
-                                      st["dbm"].data_ptr(), st["demb"].data_ptr(), B, E, N, 0)
+                                      st["dbm"].data_ptr(), st["demb"].data_ptr(), B, E, N, 0, st["mpart"].data_ptr(), st["mpart"].numel())
         pl.add("aid_modulation_bwd", mp)
         g = bd.pgrad
         ep = _lib.EmbedBwdParams(st["embed_params"], st["demb"].data_ptr(),

@@ -472,6 +472,7 @@ typedef struct {
     const float* dmod; const float* emb; const float* W;
     float* dW; float* dbias; float* demb;
     int B, E, N, accumulate;
+    float* part; int64_t part_floats;   /* scratch: B * ceil(N/128) * E floats (partial sums of demb, folded in a fixed order) */
 } aid_modulation_bwd_params;
 int aid_modulation_bwd(const aid_modulation_bwd_params* p, void* stream);
 

@@ -5,8 +5,10 @@ diff_params/edm.py:55-64), ``get_gamma`` (:38-53), ``sample_prior`` (:87-95), ``
 (:97-128) and ``denoiser`` (:133-148).  Everything here is O(T) or O(B) scalar work that stays on the host in
 float32 torch arithmetic, bit-identical to the reference (pinned by tests/golden/edm_schedule.npz); the
 per-sample tensor work is done by the HIP kernels (the network's fused ``denoise`` entry folds c_in into the
-CQT analysis and c_skip / c_out into the synthesis spectrum).  The training-only members (``loss_fn``,
-``sample_ptrain*``) are out of scope.
+CQT analysis and c_skip / c_out into the synthesis spectrum).  The training members ``sample_ptrain_safe`` (:76-85),
+``prepare_train_preconditioning`` (:150-163) and ``loss_fn`` (:166-193) are mirrored too: with the MI355X network in
+``train()`` mode its forward is differentiable w.r.t. the parameters (autograd.TrainFn), so the reference's own
+``loss.backward(); optimizer.step()`` works unchanged; ``training.Trainer`` is the all-HIP path (no torch.optim).
 """
 from __future__ import annotations
 
@@ -60,3 +62,26 @@ class EDM:
         if len(sigma.shape) == 1:
             sigma = sigma.unsqueeze(-1)
         return self.cskip(sigma) * xn + self.cout(sigma) * net(self.cin(sigma) * xn, self.cnoise(sigma))
+
+    # ---- training (edm.py:76-85, :150-193) ----------------------------------------------------------------------------------
+    def sample_ptrain_safe(self, N):
+        a = torch.rand(N)
+        return (self.sigma_max ** (1 / self.ro_train) + a * (self.sigma_min ** (1 / self.ro_train) - self.sigma_max ** (1 / self.ro_train))) ** self.ro_train
+
+    def prepare_train_preconditioning(self, x, sigma):
+        noise = self.sample_prior(x.shape, sigma)
+        cskip, cout, cin, cnoise = self.cskip(sigma), self.cout(sigma), self.cin(sigma), self.cnoise(sigma)
+        target = (1 / cout) * (x - cskip * (x + noise))
+        return cin * (x + noise), target, cnoise
+
+    def loss_fn(self, net, x):
+        """(error**2, sigma) exactly as the reference returns them (the caller takes ``.mean()`` and calls ``backward()``)."""
+        sigma = self.sample_ptrain_safe(x.shape[0]).unsqueeze(-1).to(x.device)
+        inp, target, cnoise = self.prepare_train_preconditioning(x, sigma)
+        error = net(inp, cnoise) - target
+        try:                                   # as the reference (:180-187): it reads args.net.use_cqt_DC_correction inside a bare
+            if self.args.net.use_cqt_DC_correction:    # try -- no shipped config has an `args.net`, so the correction never runs there either
+                error = net.CQTransform.apply_hpf_DC(error)
+        except Exception:
+            pass
+        return error ** 2, sigma

@@ -881,8 +881,11 @@ class Unet_CQT_oct_with_attention(nn.Module):
         """inputs[B,L] (time domain), sigma[B,1] (= c_noise) -> [B,L]     (unet...py:730-845)"""
         self._check_input(inputs)
         if torch.is_grad_enabled() and inputs.requires_grad:
-            from .autograd import DenoiserFn   # input-VJP through the same kernels (guidance branch)
-            return DenoiserFn.apply(inputs, sigma, self)
+            from .autograd import DenoiserFn   # input-VJP through the same kernels (guidance branch; the reference's tester leaves
+            return DenoiserFn.apply(inputs, sigma, self)          # the network in train() mode, so this case comes first)
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            from .autograd import TrainFn      # training: gradients w.r.t. the parameters through the same kernels
+            return TrainFn.apply(inputs, sigma, self, *self.parameters())
         return self._forward_impl(inputs, sigma)
 
     @torch.no_grad()
@@ -1099,34 +1102,24 @@ class Unet_CQT_oct_with_attention(nn.Module):
         return pl
 
     @torch.no_grad()
-    def loss_and_grads(self, inputs: torch.Tensor, cnoise: torch.Tensor, target: torch.Tensor, hpf_error: bool = False):
-        """error = net(inputs, cnoise) - target  [-> apply_hpf_DC(error) if hpf_error, edm.py:180-187];  loss = mean(error**2)
-        (trainer.py:262-263).  Fills the flat gradient buffer of the training state (``train_state(B)['gflat']``, laid out like
-        the flat parameter buffer) with d loss / d parameter, all through HIP kernels.  Returns (loss [device scalar], error**2)."""
+    def _train_forward(self, inputs, sigma):
+        """forward on the training state (its backward plan also carries the parameter-gradient ops)"""
         self._check_input(inputs)
-        B, L = inputs.shape
+        st = self.train_state(inputs.shape[0])
+        x = inputs.detach().contiguous().float()
+        self.CQTransform.analysis(x, st["octs_in"])
+        self._run_body(st, sigma)
+        return self.CQTransform.irfft(self.CQTransform.synthesis_spectrum(st["octs_out"]))
+
+    @torch.no_grad()
+    def _train_backward(self, g_out, need_input=False):
+        """g_out[B,L] = d loss / d network output of the LAST _train_forward -> fills the flat gradient buffer; returns
+        (d loss / d inputs or None, [gradient view per parameter, in self.parameters() order])."""
+        B = g_out.shape[0]
         st = self.train_state(B)
         tr = self.CQTransform
-        tab = tr._tables(inputs.device)
-        x = inputs.detach().contiguous().float()
-        tr.analysis(x, st["octs_in"])
-        self._run_body(st, cnoise)
-        est = tr.irfft(tr.synthesis_spectrum(st["octs_out"]))
-        err = torch.empty_like(est)
-        minus1 = torch.full((B,), -1.0, device=x.device)
-        _lib.call("aid_axpby", _lib.AxpbyParams(est.data_ptr(), target.contiguous().float().data_ptr(), err.data_ptr(), None, minus1.data_ptr(), B, L))
-        if hpf_error:
-            err = tr._hpf(err)
-        rn = torch.empty(B, device=x.device, dtype=torch.float32)
-        _lib.call("aid_row_norm", _lib.RowNormParams(err.data_ptr(), rn.data_ptr(), B, L))
-        loss = (rn * rn).sum() / (B * L)
-        # seed: d loss / d estimate = 2 error / (B L)   (through the self-adjoint DC/Nyquist projector once more if it was applied)
-        g = torch.empty_like(err)
-        coef = torch.full((B,), 2.0 / (B * L), device=x.device)
-        _lib.call("aid_axpby", _lib.AxpbyParams(err.data_ptr(), None, g.data_ptr(), coef.data_ptr(), None, B, L))
-        Gh = tr.rfft(g)
-        if hpf_error:
-            Gh = tr.spectrum_scale(Gh, tab["hpf"])
+        tab = tr._tables(g_out.device)
+        Gh = tr.rfft(g_out.detach().float().contiguous())
         st["gflat"].zero_()
         st["dmod"].zero_()
         self._body_vjp(st, tr.spectrum_scale(Gh, tab["w_over_L"]))
@@ -1135,6 +1128,32 @@ class Unet_CQT_oct_with_attention(nn.Module):
         for key, (off, n) in self._mod_layout.items():               # stacked [sum N, E] rows -> the Linears' own gradient tensors
             gp[key + ".weight"].copy_(st["dWm"][off:off + n])
             gp[key + ".bias"].copy_(st["dbm"][off:off + n])
+        gin = tr.irfft(tr.analysis_adjoint(st["gin"])) if need_input else None
+        return gin, [gp[k] if p.requires_grad else None for k, p in self.named_parameters()]
+
+    @torch.no_grad()
+    def loss_and_grads(self, inputs: torch.Tensor, cnoise: torch.Tensor, target: torch.Tensor, hpf_error: bool = False):
+        """error = net(inputs, cnoise) - target  [-> apply_hpf_DC(error) if hpf_error, edm.py:180-187];  loss = mean(error**2)
+        (trainer.py:262-263).  Fills the flat gradient buffer of the training state (``train_state(B)['gflat']``, laid out like
+        the flat parameter buffer) with d loss / d parameter, all through HIP kernels.  Returns (loss [device scalar], error**2)."""
+        B, L = inputs.shape
+        tr = self.CQTransform
+        est = self._train_forward(inputs, cnoise)
+        err = torch.empty_like(est)
+        minus1 = torch.full((B,), -1.0, device=est.device)
+        _lib.call("aid_axpby", _lib.AxpbyParams(est.data_ptr(), target.contiguous().float().data_ptr(), err.data_ptr(), None, minus1.data_ptr(), B, L))
+        if hpf_error:
+            err = tr._hpf(err)
+        rn = torch.empty(B, device=est.device, dtype=torch.float32)
+        _lib.call("aid_row_norm", _lib.RowNormParams(err.data_ptr(), rn.data_ptr(), B, L))
+        loss = (rn * rn).sum() / (B * L)
+        # seed: d loss / d estimate = 2 error / (B L)   (through the self-adjoint DC/Nyquist projector once more if it was applied)
+        g = torch.empty_like(err)
+        coef = torch.full((B,), 2.0 / (B * L), device=est.device)
+        _lib.call("aid_axpby", _lib.AxpbyParams(err.data_ptr(), None, g.data_ptr(), coef.data_ptr(), None, B, L))
+        if hpf_error:
+            g = tr._hpf(g)
+        self._train_backward(g)
         return loss, err * err
 
     def _ones_row(self, L, device):

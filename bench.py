@@ -43,7 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA = 157.3          # TFLOP/s, dense fp32 matrix (MI355X_MICROARCH.md)
-WINO_KERNELS = ("conv53_wino4v_kernel", "conv53_wino4_kernel")     # F(4,3): executed MFMA FLOPs = 1/2 of the direct form
+WINO_KERNELS = ("conv53_wino4r_kernel", "conv53_wino4v_kernel", "conv53_wino4_kernel")     # F(4,3): executed MFMA FLOPs = 1/2 of the direct form
 
 
 def cpu_model() -> str:

@@ -119,7 +119,7 @@ int aid_conv2d(const aid_conv2d_params* p, void* stream);
 /* non-zero when a 5x3 layer of this shape can take Winograd-domain input (x_wino = 1) */
 int aid_conv2d_wino_input_supported(int Cin, int Cout, int T);
 /* number of per-tile partial dots per (sample, group) the F(4,3) epilogue writes for this shape; 0 = not supported */
-int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T);
+int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino);
 /* padded dims the packed weight buffer must have for a given (Cin, Cout) */
 void aid_conv2d_pack_dims(int Cin, int Cout, int* Cin_pad, int* Cout_pad);
 

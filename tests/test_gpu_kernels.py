@@ -454,7 +454,7 @@ def test_conv2d_dispatch_fuzz(L):
         P = 0
         dws = None
         if wino and epi and not use_res:
-            P = int(L.lib().aid_conv2d_dot_partials(B, Cin, Cout, Fd, T))
+            P = int(L.lib().aid_conv2d_dot_partials(B, Cin, Cout, Fd, T, dil, int(xw)))
             if P:
                 dws = torch.full((B * 8 * (P + 1),), float("nan"), device=DEV, dtype=torch.float64)
                 p.dot_ws, p.dot_n = dws.data_ptr(), P

@@ -204,7 +204,7 @@ def test_conv_epilogue_dot_partials(L, case):
     """dgrad conv with the dGELU epilogue + dot_ws: the per-tile partials of <y, aux> per (sample, channel group) that
     replace the aid_group_dot pass, on the in-kernel-transform and the Winograd-domain-input F(4,3) kernels."""
     B, Cin, Cout, Fd, T, dil, xw = case
-    P = L.lib().aid_conv2d_dot_partials(B, Cin, Cout, Fd, T)
+    P = L.lib().aid_conv2d_dot_partials(B, Cin, Cout, Fd, T, dil, xw)
     assert P > 0
     g = _rand(B, Cin, Fd, T, seed=40)
     w = _rand(Cout, Cin, 5, 3, seed=41, scale=1.0 / math.sqrt(Cin * 15))

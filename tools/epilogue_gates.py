@@ -84,5 +84,17 @@ def run96():
             print(f"x_wino={v}:", (out.stdout.strip().splitlines() or [out.stderr[-300:]])[-1], flush=True)
 
 
+def runr():
+    """product library vs the experimental row-shared kernel (tools/exp/libaid_wino4r.so) on the main x_wino shapes"""
+    shapes = SHAPES + ["8 256 256 448 32 5 3 64", "8 256 256 384 64 5 3 1", "8 128 128 384 64 5 3 8", "8 64 64 128 1024 5 3 2"]
+    for shape in shapes:
+        for name, libp in (("product ", None), ("wino4r  ", os.path.join(EXP, "libaid_wino4r.so"))):
+            env = dict(os.environ, PROBE_WINO="30", PROBE_V="1")
+            if libp:
+                env["AID_LIB_PATH"] = libp
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "conv_probe.py")] + shape.split() + ["20", "-1"], env=env, capture_output=True, text=True)
+            print(name, (out.stdout.strip().splitlines() or [out.stderr[-300:]])[-1], flush=True)
+
+
 if __name__ == "__main__":
-    {"build": build, "run": run, "run0": lambda: run((0,)), "run45": lambda: run((0, 1, 4, 5)), "run96": lambda: run96()}[sys.argv[1]]()
+    {"build": build, "run": run, "run0": lambda: run((0,)), "run45": lambda: run((0, 1, 4, 5)), "run96": lambda: run96(), "runr": lambda: runr()}[sys.argv[1]]()

@@ -1017,15 +1017,15 @@ class Unet_CQT_oct_with_attention(nn.Module):
         x = x.contiguous()
         if not (y.is_cuda and y.dtype == torch.float32 and y.is_contiguous() and tuple(y.shape) == (B, L)):
             raise _lib.AidError("denoise_guided: y must be a contiguous float32 GPU tensor of shape [B, L]")
-        if degradation is not None or self._n_split(B) == 1:       # (operator objects keep per-batch scratch: one stream)
-            st = self._state(B)
+        if (degradation is not None and not getattr(degradation, "shared_mask", False)) or self._n_split(B) == 1:
+            st = self._state(B)                                      # (per-item operator masks: one stream)
             if degradation is None and self._graph_ok(B, st):
                 ins = dict(x=x, cnoise=cnoise.reshape(-1), cin=cin.reshape(-1), cskip=cskip.reshape(-1), cout=cout.reshape(-1))
                 key = ("guided", bool(hpf), y.data_ptr(), mask.data_ptr(), tuple(mask.shape))       # y / mask are read in place
                 return self._graph_run(st, key, ins, lambda t: self._denoise_guided_one(
                     t["x"], t["cnoise"], t["cin"], t["cskip"], t["cout"], hpf, y, mask, None, st))
             return self._denoise_guided_one(x, cnoise, cin, cskip, cout, hpf, y, mask, degradation, st)
-        m = mask if mask.dim() == 2 else mask.reshape(1, -1)
+        m = None if degradation is not None else (mask if mask.dim() == 2 else mask.reshape(1, -1))
         n, bounds, streams = self._split_plan(B)
         x_hat = torch.empty(B, L, device=x.device, dtype=torch.float32)
         grads = torch.empty(B, L, device=x.device, dtype=torch.float32)
@@ -1036,7 +1036,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
             streams[i].wait_stream(cur)
             with torch.cuda.stream(streams[i]):
                 self._denoise_guided_one(x[lo:hi], cnoise[lo:hi], cin[lo:hi], cskip[lo:hi], cout[lo:hi], hpf, y[lo:hi],
-                                         m[lo:hi] if m.shape[0] > 1 else m, None, self._state(hi - lo, i, (B, n)),
+                                         None if m is None else (m[lo:hi] if m.shape[0] > 1 else m), degradation, self._state(hi - lo, i, (B, n)),
                                          outs=(x_hat[lo:hi], grads[lo:hi], norm[lo:hi]))
         for st_ in streams:
             cur.wait_stream(st_)

@@ -69,9 +69,10 @@ class SpectralMask:
 
     def _params(self, x, out, adjoint, c0=1.0, add1=None, add2=None):
         B = x.shape[0]
-        fr = self._frames.get(B)
+        key = (B, torch.cuda.current_stream().cuda_stream)          # (sub-batches on concurrent streams must not share the frame scratch)
+        fr = self._frames.get(key)
         if fr is None:
-            fr = self._frames[B] = torch.empty(B, self.n_frames, self.n_fft, device=x.device, dtype=torch.float32)
+            fr = self._frames[key] = torch.empty(B, self.n_frames, self.n_fft, device=x.device, dtype=torch.float32)
         if self.mask.shape[0] not in (1, B):
             raise _lib.AidError("per-item spectral masks must match the batch size")
         return _lib.StftParams(x.data_ptr(), fr.data_ptr(), out.data_ptr(), self.window.data_ptr(), self.twiddle.data_ptr(),
@@ -88,6 +89,11 @@ class SpectralMask:
         _lib.call("aid_stft_frames", p)
         _lib.call("aid_stft_ola", p)
         return out
+
+    @property
+    def shared_mask(self) -> bool:
+        """one mask for every item (sub-batches can then use this operator concurrently)"""
+        return self.mask.shape[0] == 1
 
     def apply(self, x):
         """A(x)"""

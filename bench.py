@@ -177,8 +177,6 @@ def main():
     net = Unet_CQT_oct_with_attention(args, dev)
     if a.streams:
         net.split_streams = a.streams
-    elif a.task == "spectrogram" and a.xi > 0:
-        net.split_streams = 1                      # the STFT-mask operator keeps per-batch scratch: the guided evaluation stays on one stream
     if rank == 0:
         seeded_init_(net, 0)                       # reference-scale gates (1e-7), like a fresh reference network
     D.barrier()

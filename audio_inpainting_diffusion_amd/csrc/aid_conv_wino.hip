@@ -672,28 +672,33 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
 // and one workgroup's prologue / epilogue (24 us per tile that the one-workgroup-per-CU kernel exposes, profiles/r02_epilogue_gates.txt)
 // runs under the other's K loop.  Layout of the x region per input channel: [slot 0..RA+3][xi 0..5][TT/4 groups]; output row j reads
 // slot j + kh.  Requires F % dilF == 0 (rows of a residue class: F/dilF).
+// Large dilations leave few rows per residue class (F/dilF = 28, 14, 7 on the deepest level): there a tile takes RA rows of each of NC
+// ADJACENT residue classes (NC x RA x TT = 256 positions, NC (RA + 4) staged rows), so that RA divides the class without padding rows.
 struct ConvWinoRDev {
     aid_conv2d_params p;
     const float* zero;
-    int nchunks, quads, ttiles, ny, per_xcd, ntiles;
+    int nchunks, quads, ttiles, ny, per_xcd, ntiles, rgroups;
 };
 
-template <int TT, int NBUF>
-__global__ __launch_bounds__(256, NBUF == 2 ? 3 : 2) void conv53_wino4r_kernel(const ConvWinoRDev a) {
+template <int TT, int NC>
+__global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDev a) {
     constexpr int KH = 5, NXI = 6, TAPS = NXI * KH, KC = 2;
     constexpr int NW = 4, WGN = 2;
     constexpr int M_BLK = 64, N_BLK = 256;
     constexpr int GPR = TT / 4;                         // groups of 4 outputs per row
-    constexpr int RA = N_BLK / TT;                      // output rows per tile (4 or 8)
-    constexpr int NSLOT = RA + KH - 1;                  // staged input rows per channel
+    constexpr int RA = N_BLK / (TT * NC);               // output rows per residue class and tile
+    constexpr int CSLOT = RA + KH - 1;                  // staged input rows per channel and class
+    constexpr int NSLOT = NC * CSLOT;
     constexpr int XCI = NSLOT * NXI * GPR;              // floats per input channel in the x region
     constexpr int XSZ = ((KC * XCI + 255) / 256) * 256;
     constexpr int WROW = M_BLK;
     constexpr int WSZ = TAPS * KC * WROW;               // 3840 floats = 15 pieces
     constexpr int BUFSZ = XSZ + WSZ;
+    constexpr int NBUF = (3 * BUFSZ * 4 * 2 <= 160 * 1024) ? 3 : 2;    // three buffers while two workgroups still fit a CU (NBUF 2 vs 3 measured +-1 %)
     constexpr int NXP = XSZ / 256, NWP = WSZ / 256, NP = NXP + NWP;
     constexpr int PPW = (NP + NW - 1) / NW;
     constexpr int NSTEP = KH;
+    static_assert(RA >= 1 && RA * NC * TT == N_BLK, "tile shape");
     static_assert(WSZ % 256 == 0 && GPR % 4 == 0 && NP > (PPW - 1) * NW, "piece bookkeeping");
 
     const aid_conv2d_params& p = a.p;
@@ -707,15 +712,16 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 3 : 2) void conv53_wino4r_kernel(c
     const int wm = wave / WGN, wn = wave % WGN;
     const int half = lane >> 5;
 
-    // XCD-aware logical tile (see conv53_wino4v_kernel); order: Cout tile fastest, then t tile, quad, residue class, sample
+    // XCD-aware logical tile (see conv53_wino4v_kernel); order: Cout tile fastest, then t tile, quad, residue-class group, sample
     const int Lt = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
     if (Lt >= a.ntiles) return;
     int rest = Lt;
     const int by = rest % a.ny; rest /= a.ny;
     const int tile_t = rest % a.ttiles; rest /= a.ttiles;
     const int q = rest % a.quads; rest /= a.quads;
-    const int res = rest % p.dilF;
-    const int b = rest / p.dilF;
+    const int rg = rest % a.rgroups;
+    const int b = rest / a.rgroups;
+    const int res = rg * NC;                             // first residue class of this tile
     const int t0 = tile_t * TT;
     const int m0 = by * M_BLK;
     const int nrow = p.F / p.dilF;                       // rows of one residue class
@@ -732,9 +738,10 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 3 : 2) void conv53_wino4r_kernel(c
             const int eg = pc * 256 + 4 * lane;
             const int ci = eg / XCI, e = eg % XCI;
             const int slot = e / (NXI * GPR), xi = (e / GPR) % NXI, gl = e % GPR;
-            const int jr = j0 + slot - (KH / 2);         // sub-lattice row index of this slot
+            const int cls = slot / CSLOT;
+            const int jr = j0 + (slot % CSLOT) - (KH / 2);   // sub-lattice row index of this slot
             if (ci < KC && jr >= 0 && jr < nrow && t0 + 4 * gl < p.T) {
-                const int fi = res + jr * p.dilF;
+                const int fi = res + cls + jr * p.dilF;
                 psrc[i] = p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + (int64_t)xi * (p.T >> 2) + (t0 >> 2) + gl;
                 pstride[i] = (int)(KC * p.x.sC);
             }
@@ -749,8 +756,9 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 3 : 2) void conv53_wino4r_kernel(c
     }
     // ---- operand addresses: lane's group g of this wave's 32 -> output row j = g / GPR, group tau = g % GPR -------------------------
     const int g = wn * 32 + (lane & 31);
-    const int jl = g / GPR, tau = g % GPR;
-    const int vB = half * XCI + jl * NXI * GPR + tau;    // + (kh * NXI + xi) * GPR : slot jl + kh, plane xi
+    const int rl = g / GPR, tau = g % GPR;               // row of the tile: class rl / RA, sub-lattice row rl % RA
+    const int cl = rl / RA, jl = rl % RA;
+    const int vB = half * XCI + (cl * CSLOT + jl) * NXI * GPR + tau;    // + (kh * NXI + xi) * GPR : slot jl + kh of the class, plane xi
     const int vA = XSZ + half * WROW + wm * 32 + (lane & 31);
 
     f32x16 acc[NXI];
@@ -830,7 +838,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 3 : 2) void conv53_wino4r_kernel(c
     // ---- epilogue (as conv53_wino4v_kernel; this lane's output row: sub-lattice row j0 + jl) -----------------------------------------
     float dsum[4] = {0.f, 0.f, 0.f, 0.f};
     const int jr_o = j0 + jl;
-    const int f_o = res + jr_o * p.dilF;
+    const int f_o = res + cl + jr_o * p.dilF;
     const int t_o = t0 + 4 * tau;
     const bool ok_o = jr_o < nrow && t_o < p.T;
     const int mbase = m0 + wm * 32 + 4 * half;
@@ -897,7 +905,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 3 : 2) void conv53_wino4r_kernel(c
                         const int mrow = m0 + (w / WGN) * 32 + 4 * h + 8 * qq;
                         if (mrow / cpg == grp) sacc += red[(w * 2 + h) * 4 + qq];
                     }
-            const int ptile = (res * a.quads + q) * a.ttiles + tile_t;
+            const int ptile = (rg * a.quads + q) * a.ttiles + tile_t;
             p.dot_ws[((int64_t)b * 8 + grp) * p.dot_n + ptile] = (double)sacc;
         }
     }
@@ -972,16 +980,21 @@ static int launch_wino4v(const aid_conv2d_params* p, hipStream_t st) {
 }
 
 // row-shared kernel: eligibility + launch.  Returns 1000 when the shape is better served by the 64 x 512 kernel.
-static int wino4r_geometry(const aid_conv2d_params* p, int* TTo, int* quads, int* ttiles) {
+// Picks the fewest residue classes per tile (least staging) whose rows-per-class RA wastes at most 10 % of a tile on padding rows.
+static int wino4r_geometry(const aid_conv2d_params* p, int* TTo, int* NCo, int* quads, int* ttiles) {
     if (p->dilF < 1 || (p->F % p->dilF) || p->Cout_pad % 64) return 0;
     const int TT = p->T >= 64 ? 64 : 32;
     if (p->T % TT) return 0;
-    const int RA = 256 / TT;
     const int nrow = p->F / p->dilF;
-    const int qd = (nrow + RA - 1) / RA;
-    if ((int64_t)qd * RA * 10 > (int64_t)nrow * 11) return 0;          // more than 10 % of the rows of a tile would be padding
-    *TTo = TT; *quads = qd; *ttiles = p->T / TT;
-    return 1;
+    for (int NC = 1; NC * TT <= 256; NC *= 2) {
+        if (p->dilF % NC) break;
+        const int RA = 256 / (TT * NC);
+        const int qd = (nrow + RA - 1) / RA;
+        if ((int64_t)qd * RA * 10 > (int64_t)nrow * 11) continue;     // more than 10 % of the rows of a tile would be padding
+        *TTo = TT; *NCo = NC; *quads = qd; *ttiles = p->T / TT;
+        return 1;
+    }
+    return 0;
 }
 
 static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
@@ -991,22 +1004,32 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
         if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_aid_zero_page_w)) != hipSuccess) { aid_set_error("aid_conv2d: zero page lookup failed"); return AID_E_LAUNCH; }
         zero = (const float*)z;
     }
-    int TT, quads, ttiles;
-    if (!wino4r_geometry(p, &TT, &quads, &ttiles)) return 1000;
+    int TT, NC, quads, ttiles;
+    if (!wino4r_geometry(p, &TT, &NC, &quads, &ttiles)) return 1000;
     ConvWinoRDev a;
     a.p = *p;
     a.zero = zero;
     a.nchunks = p->Cin / 2;
     a.quads = quads; a.ttiles = ttiles;
+    a.rgroups = p->dilF / NC;
     a.ny = p->Cout_pad / 64;
-    a.ntiles = p->B * p->dilF * quads * ttiles * a.ny;
+    a.ntiles = p->B * a.rgroups * quads * ttiles * a.ny;
     a.per_xcd = (a.ntiles + 7) / 8;
     const dim3 grid((unsigned)(8 * a.per_xcd));
-    // NBUF = 3 (two workgroups per CU); NBUF = 2 with three workgroups per CU measured the same (+-1 %, profiles/r02_wino4r_probe.txt)
-    if (TT == 64) hipLaunchKernelGGL((conv53_wino4r_kernel<64, 3>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv53_wino4r_kernel<32, 3>), grid, dim3(256), 0, st, a);
+#define AID_W4R(TTv, NCv) hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv>), grid, dim3(256), 0, st, a)
+    switch (TT * 16 + NC) {
+        case 64 * 16 + 1: AID_W4R(64, 1); break;
+        case 64 * 16 + 2: AID_W4R(64, 2); break;
+        case 64 * 16 + 4: AID_W4R(64, 4); break;
+        case 32 * 16 + 1: AID_W4R(32, 1); break;
+        case 32 * 16 + 2: AID_W4R(32, 2); break;
+        case 32 * 16 + 4: AID_W4R(32, 4); break;
+        case 32 * 16 + 8: AID_W4R(32, 8); break;
+        default: aid_set_error("aid_conv2d: row-shared tile shape not instantiated"); return AID_E_BADARG;
+    }
+#undef AID_W4R
     AID_CHECK_LAUNCH();
-    aid_note_kernel("conv53_wino4r_kernel");
+    aid_note_kernel(NC == 1 ? "conv53_wino4r_kernel" : "conv53_wino4r_kernel(multi-class)");
     return AID_OK;
 }
 
@@ -1038,8 +1061,8 @@ extern "C" int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, i
     if (x_wino && wino_v_shape_ok(Cin, Cout, T)) {           // the row-shared kernel takes the launch when its geometry fits
         aid_conv2d_params q{};
         q.B = B; q.Cin = Cin; q.Cout = Cout; q.F = F; q.T = T; q.dilF = dilF; q.Cout_pad = cop;
-        int TT, quads, ttiles;
-        if (wino4r_geometry(&q, &TT, &quads, &ttiles)) return dilF * quads * ttiles;
+        int TT, NC, quads, ttiles;
+        if (wino4r_geometry(&q, &TT, &NC, &quads, &ttiles)) return (dilF / NC) * quads * ttiles;
     }
     const int nblk = wino_tile_n(B, cop, F, T);
     int TT = aid_pow2ceil(T);

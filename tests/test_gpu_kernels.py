@@ -170,6 +170,13 @@ WINO_V_CASES = [
     (2, 256, 256, 24, 32, 64, 1, True),      # ROWS = 16, dilation larger than F
     (3, 64, 128, 9, 48, 1, 0, False),        # T not a power of two (zero-page groups), odd rows
     (2, 64, 64, 128, 512, 4, 1, True),       # 256 tiles of 512 positions: the full-grid 64 x 512 configuration (smaller launches take 64 x 256)
+    # row-shared kernel, several residue classes per tile (few rows per class): <TT, NC>
+    (2, 64, 64, 56, 32, 2, 1, True),         # <32, 2>: 28 rows per class, 4 rows x 2 classes
+    (1, 128, 64, 56, 32, 4, 0, True),        # <32, 4>: 14 rows per class, 2 rows x 4 classes
+    (2, 64, 128, 56, 32, 8, 1, True),        # <32, 8>: 7 rows per class, one row of 8 classes
+    (1, 64, 64, 40, 64, 4, 1, False),        # <64, 2>: 10 rows per class
+    (2, 64, 64, 20, 128, 4, 0, True),        # <64, 4>: 5 rows per class, two t tiles
+    (1, 256, 256, 448, 32, 16, 1, True),     # the deepest level of the shipped network (28 rows per class)
 ]
 
 

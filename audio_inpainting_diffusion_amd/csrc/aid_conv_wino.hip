@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
     constexpr int NG = N_BLK / 4;                       // groups of 4 outputs per tile = length of one V plane in LDS
     constexpr int XB = NXI * NG;                        // a (ci,kh) block: six planes [xi][group]
     constexpr int XSZ = KC * KH * XB;
-    constexpr int WROW = (M_BLK % 64 == 0) ? M_BLK : ((M_BLK + 63) / 64) * 64;
+    constexpr int WROW = M_BLK;                         // (96-wide tiles: no padding, 3 x 54 KB of LDS)
     constexpr int WSZ_RAW = TAPS * KC * WROW;
     constexpr int WSZ = ((WSZ_RAW + 255) / 256) * 256;
     constexpr int BUFSZ = XSZ + WSZ;
@@ -678,13 +678,17 @@ struct ConvWinoRDev {
     aid_conv2d_params p;
     const float* zero;
     int nchunks, quads, ttiles, ny, per_xcd, ntiles, rgroups;
+    int m_base, m_stride;      // Cout tile `by` starts at m_base + by * m_stride
+    int dot_all, dot_base;     // 96-channel layers (two launches): every launch writes all eight groups of its own partial slots
 };
 
-template <int TT, int NC>
+// WGM = 2: 64 output channels x 256 positions; WGM = 1: 32 output channels x 512 positions (the remainder tile of 96-channel layers,
+// whose first 64 channels take the 64-wide tile: four waves per workgroup either way, one per SIMD)
+template <int TT, int NC, int WGM>
 __global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDev a) {
     constexpr int KH = 5, NXI = 6, TAPS = NXI * KH, KC = 2;
-    constexpr int NW = 4, WGN = 2;
-    constexpr int M_BLK = 64, N_BLK = 256;
+    constexpr int NW = 4, WGN = NW / WGM;
+    constexpr int M_BLK = 32 * WGM, N_BLK = 128 * WGN;
     constexpr int GPR = TT / 4;                         // groups of 4 outputs per row
     constexpr int RA = N_BLK / (TT * NC);               // output rows per residue class and tile
     constexpr int CSLOT = RA + KH - 1;                  // staged input rows per channel and class
@@ -692,14 +696,15 @@ __global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDe
     constexpr int XCI = NSLOT * NXI * GPR;              // floats per input channel in the x region
     constexpr int XSZ = ((KC * XCI + 255) / 256) * 256;
     constexpr int WROW = M_BLK;
-    constexpr int WSZ = TAPS * KC * WROW;               // 3840 floats = 15 pieces
+    constexpr int WSZ_RAW = TAPS * KC * WROW;           // 64 channels: 3840 floats = 15 pieces; 32: 1920 -> 8 pieces (the last half used)
+    constexpr int WSZ = ((WSZ_RAW + 255) / 256) * 256;
     constexpr int BUFSZ = XSZ + WSZ;
     constexpr int NBUF = (3 * BUFSZ * 4 * 2 <= 160 * 1024) ? 3 : 2;    // three buffers while two workgroups still fit a CU (NBUF 2 vs 3 measured +-1 %)
     constexpr int NXP = XSZ / 256, NWP = WSZ / 256, NP = NXP + NWP;
     constexpr int PPW = (NP + NW - 1) / NW;
     constexpr int NSTEP = KH;
     static_assert(RA >= 1 && RA * NC * TT == N_BLK, "tile shape");
-    static_assert(WSZ % 256 == 0 && GPR % 4 == 0 && NP > (PPW - 1) * NW, "piece bookkeeping");
+    static_assert(WROW % 4 == 0 && GPR % 4 == 0 && NP > (PPW - 1) * NW, "piece bookkeeping");
 
     const aid_conv2d_params& p = a.p;
     __shared__ __attribute__((aligned(16))) float sbuf0[BUFSZ];
@@ -723,7 +728,7 @@ __global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDe
     const int b = rest / a.rgroups;
     const int res = rg * NC;                             // first residue class of this tile
     const int t0 = tile_t * TT;
-    const int m0 = by * M_BLK;
+    const int m0 = a.m_base + by * a.m_stride;
     const int nrow = p.F / p.dilF;                       // rows of one residue class
     const int j0 = q * RA;                               // first sub-lattice row of this tile
 
@@ -750,8 +755,10 @@ __global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDe
             const int row = e / WROW, col = e % WROW;
             const int tap = row / KC, ci = row % KC;
             plds[i] = XSZ + (pc - NXP) * 256;
-            psrc[i] = p.wp_wino + ((int64_t)tap * p.Cin_pad + ci) * p.Cout_pad + m0 + col;
-            pstride[i] = KC * p.Cout_pad;
+            if (e < WSZ_RAW) {
+                psrc[i] = p.wp_wino + ((int64_t)tap * p.Cin_pad + ci) * p.Cout_pad + m0 + col;
+                pstride[i] = KC * p.Cout_pad;
+            }
         }
     }
     // ---- operand addresses: lane's group g of this wave's 32 -> output row j = g / GPR, group tau = g % GPR -------------------------
@@ -896,16 +903,16 @@ __global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDe
         }
         __syncthreads();
         const int cpg = p.Cout >> 3;
-        const int grp = m0 / cpg + tid;
-        if (tid < M_BLK / cpg && grp < 8) {
+        const int grp = a.dot_all ? tid : m0 / cpg + tid;    // dot_all: zeros for the groups this Cout tile does not touch
+        if (tid < (a.dot_all ? 8 : M_BLK / cpg) && grp < 8) {
             float sacc = 0.f;
             for (int w = 0; w < NW; ++w)
                 for (int h = 0; h < 2; ++h)
                     for (int qq = 0; qq < 4; ++qq) {
                         const int mrow = m0 + (w / WGN) * 32 + 4 * h + 8 * qq;
-                        if (mrow / cpg == grp) sacc += red[(w * 2 + h) * 4 + qq];
+                        if (mrow < p.Cout && mrow / cpg == grp) sacc += red[(w * 2 + h) * 4 + qq];
                     }
-            const int ptile = (rg * a.quads + q) * a.ttiles + tile_t;
+            const int ptile = a.dot_base + (rg * a.quads + q) * a.ttiles + tile_t;
             p.dot_ws[((int64_t)b * 8 + grp) * p.dot_n + ptile] = (double)sacc;
         }
     }
@@ -975,26 +982,37 @@ static int launch_wino4v(const aid_conv2d_params* p, hipStream_t st) {
     grid = dim3((unsigned)(8 * a.per_xcd), 1);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), 0, st, a);
     AID_CHECK_LAUNCH();
-    aid_note_kernel((M_BLK == 64 && N_BLK == 256) ? "conv53_wino4v_kernel(64x256)" : "conv53_wino4v_kernel");
+    aid_note_kernel((M_BLK == 64 && N_BLK == 256) ? "conv53_wino4v_kernel(64x256)" : (M_BLK == 96 ? "conv53_wino4v_kernel(96)" : "conv53_wino4v_kernel"));
     return AID_OK;
 }
 
-// row-shared kernel: eligibility + launch.  Returns 1000 when the shape is better served by the 64 x 512 kernel.
+// row-shared kernel: eligibility + launch.  Returns 1000 when the shape is better served by the 64|96 x 512 kernel.
 // Picks the fewest residue classes per tile (least staging) whose rows-per-class RA wastes at most 10 % of a tile on padding rows.
-static int wino4r_geometry(const aid_conv2d_params* p, int* TTo, int* NCo, int* quads, int* ttiles) {
-    if (p->dilF < 1 || (p->F % p->dilF) || p->Cout_pad % 64) return 0;
+// npos: positions per tile (256 for the 64-channel tile, 512 for the 32-channel remainder tile of 96-channel layers).
+static int wino4r_tile(const aid_conv2d_params* p, int npos, int max_nc, int* TTo, int* NCo, int* quads, int* ttiles) {
+    if (p->dilF < 1 || (p->F % p->dilF)) return 0;
     const int TT = p->T >= 64 ? 64 : 32;
     if (p->T % TT) return 0;
     const int nrow = p->F / p->dilF;
-    for (int NC = 1; NC * TT <= 256; NC *= 2) {
+    for (int NC = 1; NC * TT <= 256 && NC <= max_nc; NC *= 2) {
         if (p->dilF % NC) break;
-        const int RA = 256 / (TT * NC);
+        const int RA = npos / (TT * NC);
         const int qd = (nrow + RA - 1) / RA;
         if ((int64_t)qd * RA * 10 > (int64_t)nrow * 11) continue;     // more than 10 % of the rows of a tile would be padding
         *TTo = TT; *NCo = NC; *quads = qd; *ttiles = p->T / TT;
         return 1;
     }
     return 0;
+}
+
+struct Wino4rPlan { int TT, NC, quads, ttiles; };
+// plan[0]: the 64-channel tiles; plan[1] (96-channel layers only): the 32-channel remainder tiles.  Returns the number of launches (0: not eligible).
+static int wino4r_geometry(const aid_conv2d_params* p, Wino4rPlan plan[2]) {
+    if (p->Cout_pad % 64 == 0) return wino4r_tile(p, 256, 8, &plan[0].TT, &plan[0].NC, &plan[0].quads, &plan[0].ttiles) ? 1 : 0;
+    if (p->Cout_pad % 96) return 0;
+    if (!wino4r_tile(p, 256, 8, &plan[0].TT, &plan[0].NC, &plan[0].quads, &plan[0].ttiles)) return 0;
+    if (!wino4r_tile(p, 512, 2, &plan[1].TT, &plan[1].NC, &plan[1].quads, &plan[1].ttiles) || plan[1].TT != 64) return 0;
+    return 2;
 }
 
 static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
@@ -1004,32 +1022,45 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
         if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_aid_zero_page_w)) != hipSuccess) { aid_set_error("aid_conv2d: zero page lookup failed"); return AID_E_LAUNCH; }
         zero = (const float*)z;
     }
-    int TT, NC, quads, ttiles;
-    if (!wino4r_geometry(p, &TT, &NC, &quads, &ttiles)) return 1000;
-    ConvWinoRDev a;
-    a.p = *p;
-    a.zero = zero;
-    a.nchunks = p->Cin / 2;
-    a.quads = quads; a.ttiles = ttiles;
-    a.rgroups = p->dilF / NC;
-    a.ny = p->Cout_pad / 64;
-    a.ntiles = p->B * a.rgroups * quads * ttiles * a.ny;
-    a.per_xcd = (a.ntiles + 7) / 8;
-    const dim3 grid((unsigned)(8 * a.per_xcd));
-#define AID_W4R(TTv, NCv) hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv>), grid, dim3(256), 0, st, a)
-    switch (TT * 16 + NC) {
-        case 64 * 16 + 1: AID_W4R(64, 1); break;
-        case 64 * 16 + 2: AID_W4R(64, 2); break;
-        case 64 * 16 + 4: AID_W4R(64, 4); break;
-        case 32 * 16 + 1: AID_W4R(32, 1); break;
-        case 32 * 16 + 2: AID_W4R(32, 2); break;
-        case 32 * 16 + 4: AID_W4R(32, 4); break;
-        case 32 * 16 + 8: AID_W4R(32, 8); break;
-        default: aid_set_error("aid_conv2d: row-shared tile shape not instantiated"); return AID_E_BADARG;
-    }
+    Wino4rPlan plan[2];
+    const int nl = wino4r_geometry(p, plan);
+    if (!nl) return 1000;
+    const bool m96 = nl == 2;
+    int dot_base = 0;
+    for (int l = 0; l < nl; ++l) {
+        const Wino4rPlan& g = plan[l];
+        ConvWinoRDev a;
+        a.p = *p;
+        a.zero = zero;
+        a.nchunks = p->Cin / 2;
+        a.quads = g.quads; a.ttiles = g.ttiles;
+        a.rgroups = p->dilF / g.NC;
+        a.ny = m96 ? p->Cout_pad / 96 : p->Cout_pad / 64;
+        a.m_base = l == 0 ? 0 : 64;
+        a.m_stride = m96 ? 96 : 64;
+        a.dot_all = m96 ? 1 : 0;
+        a.dot_base = dot_base;
+        dot_base += a.rgroups * g.quads * g.ttiles;
+        a.ntiles = p->B * a.rgroups * g.quads * g.ttiles * a.ny;
+        a.per_xcd = (a.ntiles + 7) / 8;
+        const dim3 grid((unsigned)(8 * a.per_xcd));
+#define AID_W4R(TTv, NCv, WGMv) hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv>), grid, dim3(256), 0, st, a)
+        switch ((l * 128 + g.TT) * 16 + g.NC) {
+            case 64 * 16 + 1: AID_W4R(64, 1, 2); break;
+            case 64 * 16 + 2: AID_W4R(64, 2, 2); break;
+            case 64 * 16 + 4: AID_W4R(64, 4, 2); break;
+            case 32 * 16 + 1: AID_W4R(32, 1, 2); break;
+            case 32 * 16 + 2: AID_W4R(32, 2, 2); break;
+            case 32 * 16 + 4: AID_W4R(32, 4, 2); break;
+            case 32 * 16 + 8: AID_W4R(32, 8, 2); break;
+            case (128 + 64) * 16 + 1: AID_W4R(64, 1, 1); break;
+            case (128 + 64) * 16 + 2: AID_W4R(64, 2, 1); break;
+            default: aid_set_error("aid_conv2d: row-shared tile shape not instantiated"); return AID_E_BADARG;
+        }
 #undef AID_W4R
-    AID_CHECK_LAUNCH();
-    aid_note_kernel(NC == 1 ? "conv53_wino4r_kernel" : "conv53_wino4r_kernel(multi-class)");
+        AID_CHECK_LAUNCH();
+    }
+    aid_note_kernel(m96 ? "conv53_wino4r_kernel(64+32)" : (plan[0].NC == 1 ? "conv53_wino4r_kernel" : "conv53_wino4r_kernel(multi-class)"));
     return AID_OK;
 }
 
@@ -1045,7 +1076,7 @@ static int wino_tile_n(int B, int Cout_pad, int F, int T) {
 static bool wino_v_shape_ok(int Cin, int Cout, int T) {
     int cip, cop;
     aid_conv2d_pack_dims(Cin, Cout, &cip, &cop);
-    return (Cin % 4) == 0 && Cout >= 64 && (cop % 64) == 0 && (T % 16) == 0 && T >= 32;
+    return (Cin % 4) == 0 && Cout >= 64 && ((cop % 64) == 0 || (cop % 96) == 0) && (T % 16) == 0 && T >= 32;
 }
 
 extern "C" int aid_conv2d_wino_input_supported(int Cin, int Cout, int T) { return wino_v_shape_ok(Cin, Cout, T) ? 1 : 0; }
@@ -1061,8 +1092,11 @@ extern "C" int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, i
     if (x_wino && wino_v_shape_ok(Cin, Cout, T)) {           // the row-shared kernel takes the launch when its geometry fits
         aid_conv2d_params q{};
         q.B = B; q.Cin = Cin; q.Cout = Cout; q.F = F; q.T = T; q.dilF = dilF; q.Cout_pad = cop;
-        int TT, NC, quads, ttiles;
-        if (wino4r_geometry(&q, &TT, &NC, &quads, &ttiles)) return (dilF / NC) * quads * ttiles;
+        Wino4rPlan plan[2];
+        const int nl = wino4r_geometry(&q, plan);
+        int n = 0;
+        for (int l = 0; l < nl; ++l) n += (dilF / plan[l].NC) * plan[l].quads * plan[l].ttiles;
+        if (nl) return n;
     }
     const int nblk = wino_tile_n(B, cop, F, T);
     int TT = aid_pow2ceil(T);
@@ -1086,7 +1120,8 @@ static int conv53_wino_v(const aid_conv2d_params* p, hipStream_t st) {
     if (p->Cout_pad % 64 == 0 && wino_tile_n(p->B, p->Cout_pad, p->F, p->T) == 256)
                                rc = launch_wino4v<1, 1, 2, 2, 16, 2, 1>(p, st);     // 64 x 256, 4 waves (one per SIMD: 92 KB of LDS): small grids
     else if (p->Cout_pad % 64 == 0) rc = launch_wino4v<1, 1, 2, 4, 16, 2, 2>(p, st);     // 64 x 512, 8 waves
-    else { aid_set_error("aid_conv2d: x_wino needs a 64-wide Cout tile (the 96-wide tile keeps the in-kernel transform: measured 5 % faster there)"); return AID_E_BADARG; }
+    else if (p->Cout_pad % 96 == 0) rc = launch_wino4v<1, 1, 3, 4, 16, 2, 3>(p, st);     // 96 x 512, 12 waves (geometries the row-shared kernel declines)
+    else { aid_set_error("aid_conv2d: x_wino needs a 64- or 96-wide Cout tile"); return AID_E_BADARG; }
     AID_REQUIRE(rc != 1000, "aid_conv2d: x_wino tile does not fit this T");
     return rc;
 }

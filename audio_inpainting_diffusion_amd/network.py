@@ -353,8 +353,8 @@ class _Builder:
 
     def _wino_input(self, cin, cout, T, wp, wpw):
         """True when the pre-pass should write the F(4,3) input transform (aid_scale_act wino=1 -> aid_conv2d x_wino=1):
-        measured +5-8 % on the 64-wide M tiles, -5 % on the 96-wide one (12 waves, 123 KB of LDS), which stays in-kernel."""
-        return (wpw is not None and wpw.shape[0] == 30 and wp.shape[2] % 64 == 0
+        every 5x3 layer with Cin % 4 == 0, a 64- or 96-multiple Cout pack and T % 16 == 0, T >= 32 (the library answers)."""
+        return (wpw is not None and wpw.shape[0] == 30
                 and bool(_lib.lib().aid_conv2d_wino_input_supported(cin, cout, T)))
 
     def conv(self, x, y, wp, cin, cout, kh=1, kw=1, dil=1, in_scale=None, act=0, out_scale=None, res=None,

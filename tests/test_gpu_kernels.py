@@ -177,6 +177,11 @@ WINO_V_CASES = [
     (1, 64, 64, 40, 64, 4, 1, False),        # <64, 2>: 10 rows per class
     (2, 64, 64, 20, 128, 4, 0, True),        # <64, 4>: 5 rows per class, two t tiles
     (1, 256, 256, 448, 32, 16, 1, True),     # the deepest level of the shipped network (28 rows per class)
+    # 96 output channels: 64-channel tiles + 32-channel x 512-position remainder tiles (two launches)
+    (1, 96, 96, 32, 256, 2, 1, True),
+    (2, 64, 96, 48, 64, 2, 0, False),        # remainder tile over two residue classes <64, 2, 1>
+    (2, 96, 96, 20, 256, 4, 1, True),        # 5 rows per class: the row-shared kernel declines -> 96 x 512 tiles
+    (2, 64, 96, 16, 32, 2, 0, False),        # T = 32: no remainder-tile instance -> 96 x 512 tiles
 ]
 
 

@@ -200,7 +200,8 @@ def test_full_size_guided_evaluation_vs_oracle_autograd():
 
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 16, 64, 2, 1), (1, 96, 96, 16, 128, 4, 0), (1, 128, 256, 16, 32, 8, 1), (2, 256, 128, 32, 256, 1, 1),
-                                  (2, 64, 64, 56, 32, 4, 1), (1, 128, 128, 40, 64, 4, 1), (1, 64, 64, 56, 32, 8, 1)])
+                                  (2, 64, 64, 56, 32, 4, 1), (1, 128, 128, 40, 64, 4, 1), (1, 64, 64, 56, 32, 8, 1),
+                                  (2, 96, 96, 32, 128, 2, 1), (1, 96, 96, 20, 256, 4, 1)])
 def test_conv_epilogue_dot_partials(L, case):
     """dgrad conv with the dGELU epilogue + dot_ws: the per-tile partials of <y, aux> per (sample, channel group) that
     replace the aid_group_dot pass, on the in-kernel-transform and the Winograd-domain-input F(4,3) kernels."""

@@ -40,9 +40,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgDev a) {
     const int co0 = (blockIdx.x % a.co_tiles) * WG_CO;
     const int ci0 = (blockIdx.x / a.co_tiles) * 32;
     const int b = blockIdx.y / p.S, s = blockIdx.y - b * p.S;
-    const int f_lo = (int)(((int64_t)p.F * s) / p.S), f_hi = (int)(((int64_t)p.F * (s + 1)) / p.S);
     const int KH = p.KH, KW = p.KW, ntaps = KH * KW;
     const int kwc = KW / 2, khc = KH / 2;
+    const bool two = co0 + 32 < p.Cout;                   // the second 32-row tile has rows (96 channels: the last tile is half empty)
 
     __shared__ float gyT[WG_CO * WG_LDA];
     __shared__ float xT[WG_MAXKH * 32 * WG_LDB];
@@ -61,77 +61,130 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgDev a) {
 
     const bool vec = ((p.T & 3) == 0) && ((p.gy.sB | p.gy.sC | p.gy.sF | p.x.sB | p.x.sC | p.x.sF) & 3) == 0 &&
                      ((((uintptr_t)p.gy.p) | ((uintptr_t)p.x.p)) & 15) == 0;
-    // one input row (32 channels x 64 samples + the two halo samples) into ring slot `slot`
-    auto stage_row = [&](int fi, int slot, int t0) {
-        for (int e = tid; e < 32 * (WG_TC / 4); e += 256) {
-            const int row = e / (WG_TC / 4), q4 = e - row * (WG_TC / 4);
-            const int ci = ci0 + row, t = t0 + 4 * q4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ci < p.Cin && fi >= 0 && fi < p.F && t < p.T) {
-                const float* src = p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + t;
-                if (vec && t + 3 < p.T) v = *reinterpret_cast<const float4*>(src);
-                else { v.x = src[0]; if (t + 1 < p.T) v.y = src[1]; if (t + 2 < p.T) v.z = src[2]; if (t + 3 < p.T) v.w = src[3]; }
-            }
-            float* d = xT + (slot * 32 + row) * WG_LDB + 1 + 4 * q4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    auto ld4 = [&](const float* base, bool ok, int t) {   // four consecutive samples t..t+3 of one row (zero outside)
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && t < p.T) {
+            const float* src = base + t;
+            if (vec && t + 3 < p.T) v = *reinterpret_cast<const float4*>(src);
+            else { v.x = src[0]; if (t + 1 < p.T) v.y = src[1]; if (t + 2 < p.T) v.z = src[2]; if (t + 3 < p.T) v.w = src[3]; }
         }
-        if (KW > 1 && tid < 64) {
-            const int side = tid & 1, row = tid >> 1;
-            const int ci = ci0 + row;
-            const int t = side ? (t0 + WG_TC) : (t0 - 1);
-            float v = 0.f;
-            if (ci < p.Cin && fi >= 0 && fi < p.F && t >= 0 && t < p.T)
-                v = p.x.p[(int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + t];
-            xT[(slot * 32 + row) * WG_LDB + (side ? (WG_TC + 1) : 0)] = v;
+        return v;
+    };
+    // This thread's share of a step's staging: gy 64 rows x 16 float4 -> 4 per thread; one input row 32 x 16 float4 -> 2 per thread (+ halo)
+    const int q4 = tid & 15, srow = tid >> 4;             // float4 column, base row (rows srow + 16 i)
+    auto load_gy = [&](int f, int t0, float4 (&g)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = co0 + srow + 16 * i;
+            g[i] = ld4(p.gy.p + (int64_t)b * p.gy.sB + (int64_t)co * p.gy.sC + (int64_t)f * p.gy.sF, co < p.Cout, t0 + 4 * q4);
         }
     };
-    // Rows are walked along the dilation sub-lattice (f, f + dil, f + 2 dil, ...): consecutive steps share KH-1 of their KH
-    // input rows, which stay in a ring of LDS slots -- one new row is staged per step instead of KH.
+    auto store_gy = [&](const float4 (&g)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float* d = gyT + (srow + 16 * i) * WG_LDA + 4 * q4;
+            d[0] = g[i].x; d[1] = g[i].y; d[2] = g[i].z; d[3] = g[i].w;
+        }
+    };
+    auto load_row = [&](int fi, int t0, float4 (&x)[2], float& hl) {
+        const bool fok = fi >= 0 && fi < p.F;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ci = ci0 + srow + 16 * i;
+            x[i] = ld4(p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF, fok && ci < p.Cin, t0 + 4 * q4);
+        }
+        hl = 0.f;
+        if (KW > 1 && tid < 64) {
+            const int side = tid & 1, ci = ci0 + (tid >> 1);
+            const int t = side ? (t0 + WG_TC) : (t0 - 1);
+            if (ci < p.Cin && fok && t >= 0 && t < p.T) hl = p.x.p[(int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + t];
+        }
+    };
+    auto store_row = [&](int slot, const float4 (&x)[2], float hl) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float* d = xT + (slot * 32 + srow + 16 * i) * WG_LDB + 1 + 4 * q4;
+            d[0] = x[i].x; d[1] = x[i].y; d[2] = x[i].z; d[3] = x[i].w;
+        }
+        if (KW > 1 && tid < 64) xT[(slot * 32 + (tid >> 1)) * WG_LDB + ((tid & 1) ? (WG_TC + 1) : 0)] = hl;
+    };
+
+    // ---- the step sequence ------------------------------------------------------------------------------------------------------
+    // One step = one output row f x one chunk of 64 positions.  Rows are walked along the dilation sub-lattice (f, f + dil, ...): consecutive
+    // steps of such a chain share KH-1 of their KH input rows, which stay in a ring of LDS slots -- one new row per step.  Order: chunk, residue
+    // class, row of the class; the S splits of a sample cut this sequence (nct * F steps) into equal contiguous parts, so large dilations
+    // keep their chains (a split that starts inside a chain stages all KH rows once).
     const int dil = (KH > 1) ? p.dilF : 1;
+    const int nct = (p.T + WG_TC - 1) / WG_TC;
     const int tc = (p.T < WG_TC) ? ((p.T + 3) & ~3) : WG_TC;     // positions actually walked per chunk (short levels: T = 32)
-    for (int t0 = 0; t0 < p.T; t0 += WG_TC) {
-        for (int res = 0; res < dil; ++res) {
-            int f = f_lo + ((res - f_lo) % dil + dil) % dil;            // first row of this residue class inside the split
-            for (int n = 0; f < f_hi; f += dil, ++n) {
-                __syncthreads();                              // (previous step's fragment reads are done)
-                // ---- stage gy[b, co0.., f, t0..t0+63] ------------------------------------------------------------------
-                for (int e = tid; e < WG_CO * (WG_TC / 4); e += 256) {
-                    const int row = e / (WG_TC / 4), q4 = e - row * (WG_TC / 4);
-                    const int co = co0 + row, t = t0 + 4 * q4;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (co < p.Cout && t < p.T) {
-                        const float* src = p.gy.p + (int64_t)b * p.gy.sB + (int64_t)co * p.gy.sC + (int64_t)f * p.gy.sF + t;
-                        if (vec && t + 3 < p.T) v = *reinterpret_cast<const float4*>(src);
-                        else { v.x = src[0]; if (t + 1 < p.T) v.y = src[1]; if (t + 2 < p.T) v.z = src[2]; if (t + 3 < p.T) v.w = src[3]; }
+    const int qd = p.F / dil, rem = p.F - qd * dil;             // classes res < rem have qd + 1 rows, the others qd
+    const int64_t total = (int64_t)nct * p.F;
+    const int g_lo = (int)((total * s) / p.S), g_hi = (int)((total * (s + 1)) / p.S);
+    int c = g_lo / p.F, res, n;
+    {
+        const int r = g_lo - c * p.F;
+        if (r < rem * (qd + 1)) { res = r / (qd + 1); n = r - res * (qd + 1); }
+        else { const int r2 = r - rem * (qd + 1); res = rem + r2 / qd; n = r2 - (res - rem) * qd; }
+    }
+    float4 pg[4], px[2];
+    float ph = 0.f;
+    bool have = false;                                    // pg / px / ph hold the next step's gy tile and new input row
+    bool start = true;                                    // this step stages all KH rows (chain start, or first step of the split)
+    for (int g = g_lo; g < g_hi; ++g) {
+        const int f = res + n * dil, t0 = c * WG_TC;
+        __syncthreads();                                  // (previous step's fragment reads are done)
+        if (!have) load_gy(f, t0, pg);
+        store_gy(pg);
+        if (start) {
+            for (int kh = 0; kh < KH; ++kh) {
+                load_row(f + (kh - khc) * dil, t0, px, ph);
+                store_row((n + kh) % KH, px, ph);
+            }
+        } else {
+            store_row((n + KH - 1) % KH, px, ph);
+        }
+        __syncthreads();
+        // ---- next step; its loads are issued now and land in registers while this step multiplies -------------------------------
+        int n2 = n + 1, res2 = res, c2 = c;
+        if (n2 >= qd + (res < rem ? 1 : 0)) { n2 = 0; ++res2; if (res2 >= dil || res2 >= p.F) { res2 = 0; ++c2; } }
+        const bool chain = n2 != 0;
+        have = g + 1 < g_hi;
+        if (have) {
+            const int f2 = res2 + n2 * dil;
+            load_gy(f2, c2 * WG_TC, pg);
+            if (chain) load_row(f2 + (KH - 1 - khc) * dil, c2 * WG_TC, px, ph);
+        }
+        // ---- K loop over the chunk's positions: A = gy^T (rows: co), B = shifted input (cols: ci) ------------------------------------
+        int boff[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) boff[q] = (((n + tkh[q]) % KH) * 32 + l32) * WG_LDB + 1 + half + tkw[q] - kwc;
+        const float* ap = gyT + l32 * WG_LDA + half;
+        if (two) {
+            for (int k = 0; k < tc; k += 2) {
+                const float a0 = ap[k], a1 = ap[32 * WG_LDA + k];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (wave + 4 * q < ntaps) {           // (wave-uniform)
+                        const float bv = xT[boff[q] + k];
+                        acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[q][0], 0, 0, 0);
+                        acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[q][1], 0, 0, 0);
                     }
-                    float* d = gyT + row * WG_LDA + 4 * q4;
-                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
                 }
-                // ---- input rows: chain row m = n + kh lives in slot m % KH --------------------------------------------------
-                if (n == 0) {
-                    for (int kh = 0; kh < KH; ++kh) stage_row(f + (kh - khc) * dil, kh % KH, t0);
-                } else {
-                    stage_row(f + (KH - 1 - khc) * dil, (n + KH - 1) % KH, t0);
-                }
-                __syncthreads();
-                // ---- K loop over the chunk's positions: A = gy^T (rows: co), B = shifted input (cols: ci) ------------------------
-                int boff[4];
+            }
+        } else {
+            for (int k = 0; k < tc; k += 2) {
+                const float a0 = ap[k];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) boff[q] = (((n + tkh[q]) % KH) * 32 + l32) * WG_LDB + 1 + half + tkw[q] - kwc;
-                const float* ap = gyT + l32 * WG_LDA + half;
-                for (int k = 0; k < tc; k += 2) {
-                    const float a0 = ap[k], a1 = ap[32 * WG_LDA + k];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (wave + 4 * q < ntaps) {           // (wave-uniform)
-                            const float bv = xT[boff[q] + k];
-                            acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[q][0], 0, 0, 0);
-                            acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[q][1], 0, 0, 0);
-                        }
+                for (int q = 0; q < 4; ++q) {
+                    if (wave + 4 * q < ntaps) {
+                        const float bv = xT[boff[q] + k];
+                        acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[q][0], 0, 0, 0);
                     }
                 }
             }
         }
+        start = !chain;
+        n = n2; res = res2; c = c2;
     }
     // ---- write the partials P[(b*S+s)][co][ci][tap] ----------------------------------------------------------------------------
     float* P = p.P + ((int64_t)(b * p.S + s) * p.Cout) * p.Cin * ntaps;
@@ -153,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgDev a) {
 extern "C" int aid_conv2d_wgrad(const aid_conv2d_wgrad_params* p, void* stream) {
     AID_REQUIRE(p && p->gy.p && p->x.p && p->P, "aid_conv2d_wgrad: null pointer");
     AID_REQUIRE(p->B > 0 && p->Cin > 0 && p->Cout > 0 && p->F > 0 && p->T > 0 && p->S >= 1 && p->S <= p->F, "aid_conv2d_wgrad: bad shape");
+    AID_REQUIRE((int64_t)p->F * aid_cdiv(p->T, WG_TC) < (1LL << 30), "aid_conv2d_wgrad: too many steps");
     AID_REQUIRE(p->KH >= 1 && p->KH <= WG_MAXKH && (p->KW == 1 || p->KW == 3) && p->KH * p->KW <= WG_MAXTAPS && p->KH * p->KW <= 16,
                 "aid_conv2d_wgrad: kernel sizes up to 5x3");
     WgDev a;

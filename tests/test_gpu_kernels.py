@@ -505,3 +505,46 @@ def test_polyphase_resampler_vs_oracle(L, ratio):
         assert out.shape == (2, 65536) and rel_l2(out, O.resample_batch(a.double(), 44100, 22050, 65536)) < 2e-6
         out = resample_batch(a.to(DEV), torch.tensor([48000, 48000]), 22050, 65536).cpu()
         assert rel_l2(out, O.resample_batch(a.double(), 48000, 22050, 65536)) < 2e-6
+
+
+WGRAD_CASES = [
+    # B, Cin, Cout, F, T, KH, KW, dil, S
+    (2, 64, 64, 12, 64, 5, 3, 2, 1),        # one chunk, chains of 6 rows
+    (2, 64, 96, 10, 128, 5, 3, 1, 3),       # 96 output channels (half-empty second tile), splits cutting chains, two chunks
+    (1, 40, 72, 9, 50, 5, 3, 4, 2),         # ragged channels, T % 4 != 0 (scalar loads), F % dil != 0
+    (2, 32, 64, 6, 32, 5, 3, 16, 2),        # T = 32 (short chunk), dilation larger than F
+    (1, 128, 128, 14, 200, 5, 3, 2, 5),     # T = 3 chunks + remainder, four tiles
+    (3, 96, 8, 7, 64, 1, 1, 1, 2),          # 1x1, few output channels
+    (2, 2, 64, 8, 96, 5, 3, 2, 8),          # pyramid projection 2 -> C, S = F
+    (1, 64, 64, 28, 32, 5, 3, 8, 4),        # deep-level shape: several residue classes per split
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv2d_wgrad_partials(L, case):
+    """aid_conv2d_wgrad: per-(sample, split) partial weight gradients; their sum over the splits against the fp64 definition
+    dW[b,co,ci,kh,kw] = alpha * sum_{f,t} gy[b,co,f,t] * x[b,ci,f+(kh-KH/2)*dil,t+kw-KW/2]."""
+    B, Cin, Cout, Fd, T, KH, KW, dil, S = case
+    gy = _rand(B, Cout, Fd, T, seed=70)
+    x = _rand(B, Cin, Fd, T, seed=71)
+    alpha = 0.75
+    ph, pw = (KH // 2) * dil, KW // 2
+    xp = F.pad(x.double(), (pw, pw, ph, ph))
+    ref = torch.zeros(B, Cout, Cin, KH, KW, dtype=torch.float64)
+    for kh in range(KH):
+        for kw in range(KW):
+            ref[:, :, :, kh, kw] = alpha * torch.einsum("boft,bift->boi", gy.double(), xp[:, :, kh * dil:kh * dil + Fd, kw:kw + T])
+    # strided views (the network hands over channel slices of wider buffers)
+    gbig = torch.full((B, Cout + 3, Fd, T), 7.0, device=DEV)
+    xbig = torch.full((B, Cin + 5, Fd, T), 7.0, device=DEV)
+    gd, xd = gbig[:, 2:2 + Cout], xbig[:, 4:4 + Cin]
+    gd.copy_(gy.to(DEV)); xd.copy_(x.to(DEV))
+    K = KH * KW
+    P = torch.full((B * S * Cout * Cin * K + 16,), float("nan"), device=DEV)
+    p = L.WgradParams(L.view4(gd), L.view4(xd), P.data_ptr(), B, Cin, Cout, Fd, T, KH, KW, dil, S, alpha)
+    L.call("aid_conv2d_wgrad", p)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(P[B * S * Cout * Cin * K:]).all()), "wrote past the partial buffer"
+    got = P[:B * S * Cout * Cin * K].cpu().double().reshape(B, S, Cout, Cin, KH, KW).sum(1)
+    assert bool(torch.isfinite(got).all())
+    assert rel_l2(got, ref) < 2e-6

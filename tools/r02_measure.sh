@@ -25,5 +25,5 @@ done
 python tools/conv_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/r02_conv_traffic.json > /dev/null
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 # PMC: matrix-pipe occupancy of the dominant kernel on its main shapes
-for shape in "8 256 256 384 64 5 3 4" "8 256 256 448 32 5 3 4" "8 128 128 320 128 5 3 4" "8 64 64 64 2048 5 3 1"; do tools/pmc_conv.sh "$shape" 1; done > $O/r02_wino4v_pmc.txt 2>&1
-tools/pmc_conv.sh "8 96 96 192 512 5 3 4" 0 >> $O/r02_wino4v_pmc.txt 2>&1
+for shape in "8 256 256 384 64 5 3 4" "8 256 256 448 32 5 3 4" "8 128 128 320 128 5 3 4" "8 64 64 64 2048 5 3 1"; do tools/pmc_conv.sh "$shape" 1; done > $O/r02_wino_pmc.txt 2>&1
+tools/pmc_conv.sh "8 96 96 192 512 5 3 4" 1 >> $O/r02_wino_pmc.txt 2>&1

@@ -2,7 +2,7 @@
 // training/trainer.py:253-304 train_step / update_ema).  The activation gradients come from the input-VJP plan that the
 // guidance branch already runs; these kernels add what only training needs:
 //
-//   aid_conv2d_wgrad   P[b,s][co][ci][tap] = alpha * sum_{f,t} gy[b,co,f,t] * in[b,ci,f+(kh-KH/2)*dil,t+kw-KW/2]
+//   aid_conv2d_wgrad   P[b,s][co][tap][ci] = alpha * sum_{f,t} gy[b,co,f,t] * in[b,ci,f+(kh-KH/2)*dil,t+kw-KW/2]
 //                      per-(sample, row-split) partial weight gradients on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32):
 //                      M = 32 output channels, N = 32 input channels, K = positions (t); one accumulator tile per tap, the
 //                      taps of a layer spread over the 4 waves of a workgroup.  gy and the KH dilated input rows of a 64-sample
@@ -31,9 +31,17 @@ struct WgDev {
     int co_tiles, ci_tiles;
 };
 
+#define WG_NW 8                  // waves per workgroup
+#define WG_QPW 2                 // taps per wave (WG_NW * WG_QPW >= 15)
+#define WG_THREADS (64 * WG_NW)
 #define WG_CO 64                 // output channels per workgroup tile (two 32-row MFMA tiles share every B fragment)
+#define WG_NS (WG_MAXKH + 1)     // ring slots of input rows: the KH rows of the current step + the new row of the next one
 
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgDev a) {
+// One workgroup per CU (85 KB of LDS, eight waves = two per SIMD).  Staging is asynchronous INSIDE the workgroup: the next step's gy
+// tile and new input row are loaded into registers before the K loop, written to the other gy buffer / the free ring slot half-way
+// through it, and one barrier per step separates the steps.  (Two workgroups per CU with synchronous staging ran in lockstep -- equal
+// step lengths never let their phases drift apart -- so staging time simply added to the MFMA time: profiles/r02_wgrad_gates.txt.)
+__global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const WgDev a) {
     const aid_conv2d_wgrad_params& p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -42,22 +50,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgDev a) {
     const int b = blockIdx.y / p.S, s = blockIdx.y - b * p.S;
     const int KH = p.KH, KW = p.KW, ntaps = KH * KW;
     const int kwc = KW / 2, khc = KH / 2;
+    const int NS = KH + 1;
     const bool two = co0 + 32 < p.Cout;                   // the second 32-row tile has rows (96 channels: the last tile is half empty)
 
-    __shared__ float gyT[WG_CO * WG_LDA];
-    __shared__ float xT[WG_MAXKH * 32 * WG_LDB];
+    __shared__ float gyT0[WG_CO * WG_LDA + 8];            // (+8: the fast path reads one k-step past the chunk)
+    __shared__ float gyT1[WG_CO * WG_LDA + 8];
+    __shared__ float xT[WG_NS * 32 * WG_LDB + 8];
 
-    // taps of this wave: wave, wave + 4, wave + 8, wave + 12; two accumulator tiles (co0.., co0+32..) per tap
-    f32x16 acc[4][2];
+    // taps of this wave: wave, wave + 8; two accumulator tiles (co0.., co0+32..) per tap
+    f32x16 acc[WG_QPW][2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < WG_QPW; ++q)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][i][r] = 0.f;
-    int tkh[4], tkw[4];
+    int tkh[WG_QPW], tkw[WG_QPW];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const int tap = wave + 4 * q; tkh[q] = tap / KW; tkw[q] = tap - tkh[q] * KW; }
+    for (int q = 0; q < WG_QPW; ++q) { const int tap = wave + WG_NW * q; tkh[q] = tap / KW; tkw[q] = tap - tkh[q] * KW; }
 
     const bool vec = ((p.T & 3) == 0) && ((p.gy.sB | p.gy.sC | p.gy.sF | p.x.sB | p.x.sC | p.x.sF) & 3) == 0 &&
                      ((((uintptr_t)p.gy.p) | ((uintptr_t)p.x.p)) & 15) == 0;
@@ -70,50 +80,44 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgDev a) {
         }
         return v;
     };
-    // This thread's share of a step's staging: gy 64 rows x 16 float4 -> 4 per thread; one input row 32 x 16 float4 -> 2 per thread (+ halo)
-    const int q4 = tid & 15, srow = tid >> 4;             // float4 column, base row (rows srow + 16 i)
-    auto load_gy = [&](int f, int t0, float4 (&g)[4]) {
+    // This thread's share of a step's staging: gy 64 rows x 16 float4 -> 2 per thread; one input row 32 x 16 float4 -> 1 per thread (+ halo)
+    const int q4 = tid & 15, srow = tid >> 4;             // float4 column, base row 0..31 (gy rows srow + 32 i)
+    auto load_gy = [&](int f, int t0, float4 (&g)[2]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int co = co0 + srow + 16 * i;
+        for (int i = 0; i < 2; ++i) {
+            const int co = co0 + srow + 32 * i;
             g[i] = ld4(p.gy.p + (int64_t)b * p.gy.sB + (int64_t)co * p.gy.sC + (int64_t)f * p.gy.sF, co < p.Cout, t0 + 4 * q4);
         }
     };
-    auto store_gy = [&](const float4 (&g)[4]) {
+    auto store_gy = [&](float* gyT, const float4 (&g)[2]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float* d = gyT + (srow + 16 * i) * WG_LDA + 4 * q4;
+        for (int i = 0; i < 2; ++i) {
+            float* d = gyT + (srow + 32 * i) * WG_LDA + 4 * q4;
             d[0] = g[i].x; d[1] = g[i].y; d[2] = g[i].z; d[3] = g[i].w;
         }
     };
-    auto load_row = [&](int fi, int t0, float4 (&x)[2], float& hl) {
+    auto load_row = [&](int fi, int t0, float4& x, float& hl) {
         const bool fok = fi >= 0 && fi < p.F;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ci = ci0 + srow + 16 * i;
-            x[i] = ld4(p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF, fok && ci < p.Cin, t0 + 4 * q4);
-        }
+        const int ci = ci0 + srow;
+        x = ld4(p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF, fok && ci < p.Cin, t0 + 4 * q4);
         hl = 0.f;
         if (KW > 1 && tid < 64) {
-            const int side = tid & 1, ci = ci0 + (tid >> 1);
+            const int side = tid & 1, cih = ci0 + (tid >> 1);
             const int t = side ? (t0 + WG_TC) : (t0 - 1);
-            if (ci < p.Cin && fok && t >= 0 && t < p.T) hl = p.x.p[(int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + t];
+            if (cih < p.Cin && fok && t >= 0 && t < p.T) hl = p.x.p[(int64_t)b * p.x.sB + (int64_t)cih * p.x.sC + (int64_t)fi * p.x.sF + t];
         }
     };
-    auto store_row = [&](int slot, const float4 (&x)[2], float hl) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float* d = xT + (slot * 32 + srow + 16 * i) * WG_LDB + 1 + 4 * q4;
-            d[0] = x[i].x; d[1] = x[i].y; d[2] = x[i].z; d[3] = x[i].w;
-        }
+    auto store_row = [&](int slot, const float4& x, float hl) {
+        float* d = xT + (slot * 32 + srow) * WG_LDB + 1 + 4 * q4;
+        d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
         if (KW > 1 && tid < 64) xT[(slot * 32 + (tid >> 1)) * WG_LDB + ((tid & 1) ? (WG_TC + 1) : 0)] = hl;
     };
 
     // ---- the step sequence ------------------------------------------------------------------------------------------------------
     // One step = one output row f x one chunk of 64 positions.  Rows are walked along the dilation sub-lattice (f, f + dil, ...): consecutive
-    // steps of such a chain share KH-1 of their KH input rows, which stay in a ring of LDS slots -- one new row per step.  Order: chunk, residue
-    // class, row of the class; the S splits of a sample cut this sequence (nct * F steps) into equal contiguous parts, so large dilations
-    // keep their chains (a split that starts inside a chain stages all KH rows once).
+    // steps of such a chain share KH-1 of their KH input rows, which stay in a ring of LDS slots (chain row m = n + kh in slot m % NS) -- one
+    // new row per step.  Order: chunk, residue class, row of the class; the S splits of a sample cut this sequence (nct * F steps) into equal
+    // contiguous parts, so large dilations keep their chains (a split that starts inside a chain stages all KH rows once).
     const int dil = (KH > 1) ? p.dilF : 1;
     const int nct = (p.T + WG_TC - 1) / WG_TC;
     const int tc = (p.T < WG_TC) ? ((p.T + 3) & ~3) : WG_TC;     // positions actually walked per chunk (short levels: T = 32)
@@ -126,79 +130,106 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgDev a) {
         if (r < rem * (qd + 1)) { res = r / (qd + 1); n = r - res * (qd + 1); }
         else { const int r2 = r - rem * (qd + 1); res = rem + r2 / qd; n = r2 - (res - rem) * qd; }
     }
-    float4 pg[4], px[2];
+    float4 pg[2], px;
     float ph = 0.f;
-    bool have = false;                                    // pg / px / ph hold the next step's gy tile and new input row
-    bool start = true;                                    // this step stages all KH rows (chain start, or first step of the split)
-    for (int g = g_lo; g < g_hi; ++g) {
-        const int f = res + n * dil, t0 = c * WG_TC;
-        __syncthreads();                                  // (previous step's fragment reads are done)
-        if (!have) load_gy(f, t0, pg);
-        store_gy(pg);
-        if (start) {
-            for (int kh = 0; kh < KH; ++kh) {
-                load_row(f + (kh - khc) * dil, t0, px, ph);
-                store_row((n + kh) % KH, px, ph);
-            }
-        } else {
-            store_row((n + KH - 1) % KH, px, ph);
+    auto stage_chain_start = [&](int f, int t0, int n0) {       // all KH rows of a step (synchronous)
+        for (int kh = 0; kh < KH; ++kh) {
+            load_row(f + (kh - khc) * dil, t0, px, ph);
+            store_row((n0 + kh) % NS, px, ph);
         }
-        __syncthreads();
-        // ---- next step; its loads are issued now and land in registers while this step multiplies -------------------------------
+    };
+    if (g_lo < g_hi) {
+        load_gy(res + n * dil, c * WG_TC, pg);
+        store_gy(gyT0, pg);
+        stage_chain_start(res + n * dil, c * WG_TC, n);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int g = g_lo; g < g_hi; ++g) {
+        // ---- next step: its loads are issued now and land in registers while this step multiplies ---------------------------------------
         int n2 = n + 1, res2 = res, c2 = c;
         if (n2 >= qd + (res < rem ? 1 : 0)) { n2 = 0; ++res2; if (res2 >= dil || res2 >= p.F) { res2 = 0; ++c2; } }
+        const bool have = g + 1 < g_hi;
         const bool chain = n2 != 0;
-        have = g + 1 < g_hi;
+        const int f2 = res2 + n2 * dil;
         if (have) {
-            const int f2 = res2 + n2 * dil;
             load_gy(f2, c2 * WG_TC, pg);
             if (chain) load_row(f2 + (KH - 1 - khc) * dil, c2 * WG_TC, px, ph);
         }
+        const float* gyT = cur ? gyT1 : gyT0;
+        float* gyN = cur ? gyT0 : gyT1;
+        auto store_next = [&]() {
+            if (have) {
+                store_gy(gyN, pg);
+                if (chain) store_row((n2 + KH - 1) % NS, px, ph);
+            }
+        };
         // ---- K loop over the chunk's positions: A = gy^T (rows: co), B = shifted input (cols: ci) ------------------------------------
-        int boff[4];
+        int boff[WG_QPW];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) boff[q] = (((n + tkh[q]) % KH) * 32 + l32) * WG_LDB + 1 + half + tkw[q] - kwc;
+        for (int q = 0; q < WG_QPW; ++q) boff[q] = (((n + tkh[q]) % NS) * 32 + l32) * WG_LDB + 1 + half + tkw[q] - kwc;
         const float* ap = gyT + l32 * WG_LDA + half;
-        if (two) {
-            for (int k = 0; k < tc; k += 2) {
-                const float a0 = ap[k], a1 = ap[32 * WG_LDA + k];
+        if (ntaps == 15 && (tc & 15) == 0) {
+            // 5x3 fast path: every wave runs two taps (wave 7's second is a dummy whose tile is never written: its SIMD slot would idle
+            // otherwise), fragments of k-step j+1 are read while step j multiplies (reads past tc land in the row padding / array tail)
+            const float* bp0 = xT + boff[0];
+            const float* bp1 = xT + boff[1];
+            float av[2][2], bv[2][2];
+            auto ld = [&](int k, int u) {
+                av[u][0] = ap[k];
+                if (two) av[u][1] = ap[32 * WG_LDA + k];
+                bv[u][0] = bp0[k]; bv[u][1] = bp1[k];
+            };
+            ld(0, 0);
+            const int kmid = tc >> 1;
+            for (int k0 = 0; k0 < tc; k0 += 8) {
+                if (k0 == kmid) store_next();
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (wave + 4 * q < ntaps) {           // (wave-uniform)
-                        const float bv = xT[boff[q] + k];
-                        acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[q][0], 0, 0, 0);
-                        acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[q][1], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    ld(k0 + 2 * j + 2, (j + 1) & 1);
+#pragma unroll
+                    for (int q = 0; q < WG_QPW; ++q) {
+                        acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][0], bv[j & 1][q], acc[q][0], 0, 0, 0);
+                        if (two) acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][1], bv[j & 1][q], acc[q][1], 0, 0, 0);
                     }
                 }
             }
         } else {
+            const int kmid = (tc >> 2) << 1;
             for (int k = 0; k < tc; k += 2) {
-                const float a0 = ap[k];
+                if (k == kmid) store_next();
+                const float a0 = ap[k], a1 = ap[32 * WG_LDA + k];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (wave + 4 * q < ntaps) {
-                        const float bv = xT[boff[q] + k];
-                        acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[q][0], 0, 0, 0);
+                for (int q = 0; q < WG_QPW; ++q) {
+                    if (wave + WG_NW * q < ntaps) {       // (wave-uniform)
+                        const float bvv = xT[boff[q] + k];
+                        acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bvv, acc[q][0], 0, 0, 0);
+                        if (two) acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bvv, acc[q][1], 0, 0, 0);
                     }
                 }
             }
         }
-        start = !chain;
+        __syncthreads();                                  // this step's fragment reads and the next step's stores are done
+        if (have && !chain) {                             // the next step starts a chain: its KH rows, synchronously
+            stage_chain_start(f2, c2 * WG_TC, n2);
+            __syncthreads();
+        }
+        cur ^= 1;
         n = n2; res = res2; c = c2;
     }
-    // ---- write the partials P[(b*S+s)][co][ci][tap] ----------------------------------------------------------------------------
-    float* P = p.P + ((int64_t)(b * p.S + s) * p.Cout) * p.Cin * ntaps;
+    // ---- write the partials P[(b*S+s)][co][tap][ci] (ci fastest: every store instruction writes two full 128-byte lines) ---------------
+    float* P = p.P + ((int64_t)(b * p.S + s) * ntaps) * p.Cout * p.Cin;
     const int ci = ci0 + l32;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int tap = wave + 4 * q;
+    for (int q = 0; q < WG_QPW; ++q) {
+        const int tap = wave + WG_NW * q;
         if (tap >= ntaps || ci >= p.Cin) continue;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (co < p.Cout) P[((int64_t)co * p.Cin + ci) * ntaps + tap] = p.alpha * acc[q][i][r];
+                if (co < p.Cout) P[((int64_t)co * ntaps + tap) * p.Cin + ci] = p.alpha * acc[q][i][r];
             }
     }
 }
@@ -214,7 +245,7 @@ extern "C" int aid_conv2d_wgrad(const aid_conv2d_wgrad_params* p, void* stream) 
     a.co_tiles = aid_cdiv(p->Cout, WG_CO);
     a.ci_tiles = aid_cdiv(p->Cin, 32);
     AID_REQUIRE((int64_t)p->B * p->S < 65536, "aid_conv2d_wgrad: too many (sample, split) pairs");
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(a.co_tiles * a.ci_tiles), (unsigned)(p->B * p->S)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(a.co_tiles * a.ci_tiles), (unsigned)(p->B * p->S)), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
     AID_CHECK_LAUNCH();
     return AID_OK;
 }
@@ -222,10 +253,11 @@ extern "C" int aid_conv2d_wgrad(const aid_conv2d_wgrad_params* p, void* stream) 
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void wgrad_reduce_w_kernel(const aid_wgrad_reduce_params p) {
     const int64_t n = (int64_t)p.Cout * p.Cin * p.K;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // index into one partial: [co][tap][ci] (coalesced reads)
     if (i >= n) return;
+    const int ci = (int)(i % p.Cin);
+    const int tap = (int)((i / p.Cin) % p.K);
     const int co = (int)(i / ((int64_t)p.Cin * p.K));
-    const int ci = (int)((i / p.K) % p.Cin);
     float accv = 0.f;
     for (int b = 0; b < p.B; ++b) {                         // fixed order: deterministic
         float sp = 0.f;
@@ -234,50 +266,75 @@ __global__ __launch_bounds__(256) void wgrad_reduce_w_kernel(const aid_wgrad_red
         const float sc = p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_ld + ci] : 1.f;
         accv += g * sc * sp;
     }
-    p.dW[i] = (p.accumulate ? p.dW[i] : 0.f) + accv;
+    const int64_t o = ((int64_t)co * p.Cin + ci) * p.K + tap;       // the parameter's layout [co][ci][tap]
+    p.dW[o] = (p.accumulate ? p.dW[o] : 0.f) + accv;
 }
 
-__global__ __launch_bounds__(64) void wgrad_reduce_gate_kernel(const aid_wgrad_reduce_params p) {
-    const int b = blockIdx.y, co = blockIdx.x, lane = threadIdx.x;
+#define WRG_CHUNK 3840            // floats of a weight row staged per pass (256 input channels x 15 taps)
+__global__ __launch_bounds__(256) void wgrad_reduce_gate_kernel(const aid_wgrad_reduce_params p) {
+    const int b = blockIdx.y, co = blockIdx.x, tid = threadIdx.x;
     const int64_t row = (int64_t)p.Cin * p.K;
     const int64_t n = (int64_t)p.Cout * row;
+    __shared__ float Wl[WRG_CHUNK];
+    __shared__ double red[4];
     double accv = 0.0;
-    for (int64_t j = lane; j < row; j += 64) {
-        const int ci = (int)(j / p.K);
-        float sp = 0.f;
-        for (int s = 0; s < p.S; ++s) sp += p.P[((int64_t)(b * p.S + s)) * n + (int64_t)co * row + j];
-        const float sc = p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_ld + ci] : 1.f;
-        accv += (double)(p.W[(int64_t)co * row + j] * sc) * (double)sp;
+    const int cpc = WRG_CHUNK / p.K;                        // input channels per staged chunk
+    for (int c0 = 0; c0 < p.Cin; c0 += cpc) {
+        const int nc = min(cpc, p.Cin - c0);
+        __syncthreads();
+        for (int e = tid; e < nc * p.K; e += 256) Wl[e] = p.W[(int64_t)co * row + (int64_t)c0 * p.K + e];     // [ci][tap], coalesced
+        __syncthreads();
+        for (int j = tid; j < nc * p.K; j += 256) {         // j = tap * nc + cl: the partials' order ([co][tap][ci]) -> coalesced reads
+            const int tap = j / nc, cl = j - tap * nc, ci = c0 + cl;
+            float sp = 0.f;
+            for (int s = 0; s < p.S; ++s) sp += p.P[((int64_t)(b * p.S + s)) * n + (int64_t)co * row + (int64_t)tap * p.Cin + ci];
+            const float sc = p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_ld + ci] : 1.f;
+            accv += (double)(Wl[cl * p.K + tap] * sc) * (double)sp;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) accv += __shfl_down(accv, o, 64);
-    if (lane == 0) p.dgate[(int64_t)b * p.dgate_ld + co] = (float)accv;
+    if ((tid & 63) == 0) red[tid >> 6] = accv;
+    __syncthreads();
+    if (tid == 0) p.dgate[(int64_t)b * p.dgate_ld + co] = (float)((red[0] + red[1]) + (red[2] + red[3]));
 }
 
 extern "C" int aid_wgrad_reduce(const aid_wgrad_reduce_params* p, void* stream) {
     AID_REQUIRE(p && p->P && p->dW, "aid_wgrad_reduce: null pointer");
     AID_REQUIRE(!p->dgate || p->W, "aid_wgrad_reduce: dgate needs the weights");
+    AID_REQUIRE(p->K >= 1 && p->K <= WRG_CHUNK, "aid_wgrad_reduce: bad tap count");
     const int64_t n = (int64_t)p->Cout * p->Cin * p->K;
     hipLaunchKernelGGL(wgrad_reduce_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
     AID_CHECK_LAUNCH();
     if (p->dgate) {
-        hipLaunchKernelGGL(wgrad_reduce_gate_kernel, dim3((unsigned)p->Cout, (unsigned)p->B), dim3(64), 0, (hipStream_t)stream, *p);
+        hipLaunchKernelGGL(wgrad_reduce_gate_kernel, dim3((unsigned)p->Cout, (unsigned)p->B), dim3(256), 0, (hipStream_t)stream, *p);
         AID_CHECK_LAUNCH();
     }
     return AID_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void channel_dot_kernel(const aid_channel_dot_params p) {
+__global__ __launch_bounds__(256) void channel_dot_kernel(const aid_channel_dot_params p, int vec) {
     const int bc = blockIdx.x, b = bc / p.C, c = bc - b * p.C;
     const int tid = threadIdx.x;
-    const int64_t n = (int64_t)p.F * p.T;
     const float* u = p.u.p + (int64_t)b * p.u.sB + (int64_t)c * p.u.sC;
     const float* v = p.v.p + (int64_t)b * p.v.sB + (int64_t)c * p.v.sC;
     double s = 0.0;
-    for (int64_t i = tid; i < n; i += 256) {
-        const int f = (int)(i / p.T), t = (int)(i - (int64_t)f * p.T);
-        s += (double)u[(int64_t)f * p.u.sF + t] * (double)v[(int64_t)f * p.v.sF + t];
+    if (vec) {                                              // rows of float4 (T % 4 == 0, 16-byte aligned views)
+        const int T4 = p.T >> 2;
+        const int n4 = p.F * T4;
+        for (int i = tid; i < n4; i += 256) {
+            const int f = i / T4, t = (i - f * T4) << 2;
+            const float4 a = *reinterpret_cast<const float4*>(u + (int64_t)f * p.u.sF + t);
+            const float4 w = *reinterpret_cast<const float4*>(v + (int64_t)f * p.v.sF + t);
+            s += (double)(a.x * w.x + a.y * w.y) + (double)(a.z * w.z + a.w * w.w);
+        }
+    } else {
+        const int64_t n = (int64_t)p.F * p.T;
+        for (int64_t i = tid; i < n; i += 256) {
+            const int f = (int)(i / p.T), t = (int)(i - (int64_t)f * p.T);
+            s += (double)u[(int64_t)f * p.u.sF + t] * (double)v[(int64_t)f * p.v.sF + t];
+        }
     }
     __shared__ double red[4];
 #pragma unroll
@@ -289,7 +346,9 @@ __global__ __launch_bounds__(256) void channel_dot_kernel(const aid_channel_dot_
 
 extern "C" int aid_channel_dot(const aid_channel_dot_params* p, void* stream) {
     AID_REQUIRE(p && p->u.p && p->v.p && p->out, "aid_channel_dot: null pointer");
-    hipLaunchKernelGGL(channel_dot_kernel, dim3((unsigned)(p->B * p->C)), dim3(256), 0, (hipStream_t)stream, *p);
+    const int vec = ((p->T & 3) == 0) && ((p->u.sB | p->u.sC | p->u.sF | p->v.sB | p->v.sC | p->v.sF) & 3) == 0 &&
+                    ((((uintptr_t)p->u.p) | ((uintptr_t)p->v.p)) & 15) == 0;
+    hipLaunchKernelGGL(channel_dot_kernel, dim3((unsigned)(p->B * p->C)), dim3(256), 0, (hipStream_t)stream, *p, vec);
     AID_CHECK_LAUNCH();
     return AID_OK;
 }

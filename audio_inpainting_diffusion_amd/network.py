@@ -297,7 +297,7 @@ class _Builder:
             self.plan.add("aid_scale_act", sp, x, xin, in_scale)
             isc = None
         tiles = -(-cout // 64) * -(-cin // 32)
-        S = max(1, min(F, -(-1024 // (tiles * B))))
+        S = max(1, min(F, 1024 // (tiles * B)))           # <= 1024 workgroups: at most four full rounds of one workgroup per CU
         P = self._scratch(("P", B * S * cout * cin * K))
         wp = _lib.WgradParams(_lib.view4(gy), _lib.view4(xin), P.data_ptr(), B, cin, cout, F, T, kh, kw, dil, S, alpha)
         self.plan.add("aid_conv2d_wgrad", wp, gy, xin, P, flops=2 * B * F * T * cin * cout * K)

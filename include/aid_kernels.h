@@ -418,7 +418,7 @@ int aid_add2(const aid_add2_params* p, void* stream);
  * The activation gradients are those of the input-VJP plan (aid_conv2d on transposed weights, aid_norm_bwd, ...); the entry
  * points below add the parameter gradients.  All reductions have a fixed order (no atomics).
  *
- * aid_conv2d_wgrad : P[(b*S+s)][co][ci][tap] = alpha * sum_{f in split s, t} gy[b,co,f,t] * x[b,ci,f+(kh-KH/2)*dilF,t+kw-KW/2]
+ * aid_conv2d_wgrad : P[(b*S+s)][co][tap][ci] = alpha * sum_{f in split s, t} gy[b,co,f,t] * x[b,ci,f+(kh-KH/2)*dilF,t+kw-KW/2]
  *                    (zero padding; tap = kh*KW+kw) -- per-(sample, row split) partial weight gradients on fp32 MFMA.
  *                    `x` is the conv's input as the forward saw it (for an activated layer: the aid_scale_act output).
  * aid_wgrad_reduce : dW[co,ci,tap] (+)= sum_b gate[b,co] * in_scale[b,ci] * sum_s P      (gate / in_scale NULL -> 1)

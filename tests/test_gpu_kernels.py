@@ -545,6 +545,44 @@ def test_conv2d_wgrad_partials(L, case):
     L.call("aid_conv2d_wgrad", p)
     torch.cuda.synchronize()
     assert bool(torch.isnan(P[B * S * Cout * Cin * K:]).all()), "wrote past the partial buffer"
-    got = P[:B * S * Cout * Cin * K].cpu().double().reshape(B, S, Cout, Cin, KH, KW).sum(1)
+    got = P[:B * S * Cout * Cin * K].cpu().double().reshape(B, S, Cout, KH, KW, Cin).sum(1).permute(0, 1, 4, 2, 3)   # [co][tap][ci] -> [co][ci][kh][kw]
     assert bool(torch.isfinite(got).all())
     assert rel_l2(got, ref) < 2e-6
+
+
+@pytest.mark.parametrize("case", [(2, 3, 64, 64, 15), (3, 1, 96, 40, 15), (2, 2, 8, 300, 1), (1, 4, 256, 256, 15)])
+def test_wgrad_reduce_and_gate_gradient(L, case):
+    """aid_wgrad_reduce on partials in the kernel's [co][tap][ci] layout: dW[co,ci,tap] = sum_b gate*in_scale*sum_s P and
+    dgate[b,co] = sum_{ci,tap} W*in_scale*sum_s P, against fp64."""
+    B, S, Cout, Cin, K = case
+    P = _rand(B, S, Cout, K, Cin, seed=80)
+    W = _rand(Cout, Cin, K, seed=81)
+    gate = _rand(B, Cout, seed=82)
+    isc = 1.0 + 0.3 * _rand(B, Cin, seed=83)
+    Ps = P.double().sum(1).permute(0, 1, 3, 2)                                  # [B, co, ci, tap]
+    dW_ref = torch.einsum("bo,bi,boik->oik", gate.double(), isc.double(), Ps)
+    dg_ref = torch.einsum("oik,bi,boik->bo", W.double(), isc.double(), Ps)
+    Pd, Wd, gd_, id_ = P.to(DEV).contiguous(), W.to(DEV).contiguous(), gate.to(DEV), isc.to(DEV)
+    dW = torch.full((Cout, Cin, K), 0.5, device=DEV)
+    dg = torch.empty(B, Cout, device=DEV)
+    p = L.WgradReduceParams(Pd.data_ptr(), Wd.data_ptr(), gd_.data_ptr(), gd_.stride(0), id_.data_ptr(), id_.stride(0),
+                            dW.data_ptr(), dg.data_ptr(), dg.stride(0), B, S, Cout, Cin, K, 1)
+    L.call("aid_wgrad_reduce", p)
+    torch.cuda.synchronize()
+    assert rel_l2(dW.cpu().double() - 0.5, dW_ref) < 2e-6
+    assert rel_l2(dg.cpu().double(), dg_ref) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 5, 12), (1, 64, 7, 256), (2, 8, 3, 10)])
+def test_channel_dot(L, shape):
+    B, C, Fd, T = shape
+    u, v = _rand(B, C, Fd, T, seed=84), _rand(B, C, Fd, T, seed=85)
+    big = torch.full((B, C + 2, Fd, T), 7.0, device=DEV)
+    ud = big[:, 1:1 + C]
+    ud.copy_(u.to(DEV))
+    vd = v.to(DEV)
+    out = torch.empty(B, C, device=DEV)
+    L.call("aid_channel_dot", L.ChannelDotParams(L.view4(ud), L.view4(vd), out.data_ptr(), out.stride(0), B, C, Fd, T))
+    torch.cuda.synchronize()
+    ref = (u.double() * v.double()).sum((2, 3))
+    assert float((out.cpu().double() - ref).abs().max()) < 1e-5 * float(ref.abs().max() + 1)

@@ -30,7 +30,7 @@ class View(C.Structure):
 class GroupStatsParams(C.Structure):
     _fields_ = [("x", View), ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("groups", C.c_int),
                 ("gamma", C.c_void_p), ("mod", C.c_void_p), ("mod_ld", C.c_int64), ("eps", C.c_float),
-                ("scale", C.c_void_p), ("stats", C.c_void_p), ("ws", C.c_void_p)]
+                ("scale", C.c_void_p), ("stats", C.c_void_p), ("ws", C.c_void_p), ("ws_n", C.c_int)]
 
 
 class Conv2dParams(C.Structure):
@@ -45,7 +45,7 @@ class Conv2dParams(C.Structure):
                 ("act", C.c_int), ("epi", C.c_int),
                 ("alpha", C.c_float), ("res_scale", C.c_float), ("wp_wino", C.c_void_p), ("wino_taps", C.c_int),
                 ("x_wino", C.c_int), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
-                ("dot_ws", C.c_void_p), ("dot_n", C.c_int)]
+                ("dot_ws", C.c_void_p), ("dot_n", C.c_int), ("stat_ws", C.c_void_p), ("stat_n", C.c_int)]
 
 
 class ResampleParams(C.Structure):
@@ -206,7 +206,7 @@ class SumsqParams(C.Structure):
 
 AID_SUMSQ_BLOCKS = 512
 
-EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_stats", "aid_conv2d", "aid_conv2d_pack_dims", "aid_resample",
+EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_stats", "aid_conv2d", "aid_conv2d_pack_dims", "aid_conv2d_stat_partials", "aid_resample",
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
@@ -241,7 +241,7 @@ def lib():
             if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials"):
                 getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, name).restype = C.c_int
-        if L.aid_abi_version() != 3:
+        if L.aid_abi_version() != 4:
             raise AidError("ABI version mismatch")
         _lib = L
     return _lib

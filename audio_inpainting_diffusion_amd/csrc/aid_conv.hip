@@ -490,6 +490,10 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     AID_REQUIRE(p->epi == 0 || (p->epi == 1 && p->aux.p && p->aux_scale), "aid_conv2d: epi=1 needs aux + aux_scale");
     AID_REQUIRE((int64_t)p->B * p->in_scale_ld < (1LL << 31), "aid_conv2d: in_scale too large");
     AID_REQUIRE(!p->x_wino || (p->KH == 5 && p->KW == 3 && p->wp_wino), "aid_conv2d: x_wino is a 5x3 Winograd-path input layout");
+    if (p->stat_ws) {
+        AID_REQUIRE(!p->dot_ws && p->epi == 0 && p->x_wino, "aid_conv2d: stat_ws is an option of the forward epilogue on Winograd-domain input");
+        AID_REQUIRE(p->stat_n > 0 && p->stat_n == aid_conv2d_stat_partials(p->B, p->Cin, p->Cout, p->F, p->T, p->dilF, p->x_wino), "aid_conv2d: stat_n != aid_conv2d_stat_partials()");
+    }
     if (p->dot_ws) {
         AID_REQUIRE(p->KH == 5 && p->KW == 3 && p->wp_wino && p->wino_taps == 30 && p->epi == 1 && !p->res.p,
                     "aid_conv2d: dot_ws is an option of the F(4,3) dGELU epilogue");

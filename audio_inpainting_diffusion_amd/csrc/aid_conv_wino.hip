@@ -843,7 +843,8 @@ __global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDe
     }
 
     // ---- epilogue (as conv53_wino4v_kernel; this lane's output row: sub-lattice row j0 + jl) -----------------------------------------
-    float dsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float dsum[4] = {0.f, 0.f, 0.f, 0.f};                // <y, aux> (dot_ws) or sum y (stat_ws) per block of 4 rows
+    float qsum[4] = {0.f, 0.f, 0.f, 0.f};                // sum y^2 (stat_ws)
     const int jr_o = j0 + jl;
     const int f_o = res + cl + jr_o * p.dilF;
     const int t_o = t0 + 4 * tau;
@@ -885,35 +886,42 @@ __global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDe
                 y0 *= p.alpha; y1 *= p.alpha; y2 *= p.alpha; y3 *= p.alpha;
                 *reinterpret_cast<float4*>(p.y.p + ybase + (int64_t)m * p.y.sC) = make_float4(y0, y1, y2, y3);
                 if (p.dot_ws) dsum[r0 >> 2] += (y0 * ur[qq].x + y1 * ur[qq].y) + (y2 * ur[qq].z + y3 * ur[qq].w);
+                if (p.stat_ws) { dsum[r0 >> 2] += (y0 + y1) + (y2 + y3); qsum[r0 >> 2] += (y0 * y0 + y1 * y1) + (y2 * y2 + y3 * y3); }
             }
         }
     }
-    if (p.dot_ws) {                                          // <y, aux> per (sample, channel group): one partial per tile
+    if (p.dot_ws || p.stat_ws) {                             // per (sample, channel group): one partial per tile
+        const bool st = p.stat_ws != nullptr;
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-            float v = dsum[qq];
+            float v = dsum[qq], w = qsum[qq];
 #pragma unroll
-            for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 32);
-            dsum[qq] = v;
+            for (int off = 16; off >= 1; off >>= 1) { v += __shfl_xor(v, off, 32); if (st) w += __shfl_xor(w, off, 32); }
+            dsum[qq] = v; qsum[qq] = w;
         }
         float* red = sbuf0;
         if ((lane & 31) == 0) {
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) red[(wave * 2 + half) * 4 + qq] = dsum[qq];
+            for (int qq = 0; qq < 4; ++qq) { red[(wave * 2 + half) * 4 + qq] = dsum[qq]; red[NW * 8 + (wave * 2 + half) * 4 + qq] = qsum[qq]; }
         }
         __syncthreads();
         const int cpg = p.Cout >> 3;
         const int grp = a.dot_all ? tid : m0 / cpg + tid;    // dot_all: zeros for the groups this Cout tile does not touch
         if (tid < (a.dot_all ? 8 : M_BLK / cpg) && grp < 8) {
-            float sacc = 0.f;
+            float sacc = 0.f, qacc = 0.f;
             for (int w = 0; w < NW; ++w)
                 for (int h = 0; h < 2; ++h)
                     for (int qq = 0; qq < 4; ++qq) {
                         const int mrow = m0 + (w / WGN) * 32 + 4 * h + 8 * qq;
-                        if (mrow < p.Cout && mrow / cpg == grp) sacc += red[(w * 2 + h) * 4 + qq];
+                        if (mrow < p.Cout && mrow / cpg == grp) { sacc += red[(w * 2 + h) * 4 + qq]; qacc += red[NW * 8 + (w * 2 + h) * 4 + qq]; }
                     }
             const int ptile = a.dot_base + (rg * a.quads + q) * a.ttiles + tile_t;
-            p.dot_ws[((int64_t)b * 8 + grp) * p.dot_n + ptile] = (double)sacc;
+            if (st) {
+                double* o = p.stat_ws + (((int64_t)b * 8 + grp) * p.stat_n + ptile) * 2;
+                o[0] = (double)sacc; o[1] = (double)qacc;
+            } else {
+                p.dot_ws[((int64_t)b * 8 + grp) * p.dot_n + ptile] = (double)sacc;
+            }
         }
     }
 }
@@ -1080,6 +1088,23 @@ static bool wino_v_shape_ok(int Cin, int Cout, int T) {
 }
 
 extern "C" int aid_conv2d_wino_input_supported(int Cin, int Cout, int T) { return wino_v_shape_ok(Cin, Cout, T) ? 1 : 0; }
+
+// partials per (sample, group) of the forward (sum, sum of squares) option: the row-shared kernel only
+extern "C" int aid_conv2d_stat_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino) {
+    int cip, cop;
+    aid_conv2d_pack_dims(Cin, Cout, &cip, &cop);
+    if (!x_wino || (Cout % 8) || !wino_v_shape_ok(Cin, Cout, T)) return 0;
+    const int mblk = (cop % 64 == 0) ? 64 : ((cop % 96 == 0) ? 96 : 0);
+    const int cpg = Cout / 8;
+    if (!mblk || (cpg % 4) || (mblk % cpg)) return 0;
+    aid_conv2d_params q{};
+    q.B = B; q.Cin = Cin; q.Cout = Cout; q.F = F; q.T = T; q.dilF = dilF; q.Cout_pad = cop;
+    Wino4rPlan plan[2];
+    const int nl = wino4r_geometry(&q, plan);
+    int n = 0;
+    for (int l = 0; l < nl; ++l) n += (dilF / plan[l].NC) * plan[l].quads * plan[l].ttiles;
+    return n;
+}
 
 // tiles per sample of the F(4,3) kernels (64|96 x 512 tiles) when the per-tile <y, aux> partials are well defined
 extern "C" int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino) {

@@ -54,12 +54,22 @@ __global__ __launch_bounds__(256) void group_stats_partial(const StatsDev a) {
 __global__ __launch_bounds__(256) void group_stats_final(const StatsDev a) {
     const aid_group_stats_params& p = a.p;
     const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double n = (double)a.nrows * (double)p.T;
-    for (int c = threadIdx.x; c < p.C; c += 256) {
-        const int g = c / a.cg;
-        const double* w = p.ws + ((int64_t)(b * p.groups + g) * AID_STATS_SPLIT) * 2;
+    const int nk = p.ws_n > 0 ? p.ws_n : AID_STATS_SPLIT;
+    __shared__ double gsum[64][2];                          // (sum, sum of squares) per group (groups <= 64)
+    for (int g = wave; g < p.groups; g += 4) {              // one wave per group: lane l adds partials l, l+64, ... then a fixed tree
+        const double* w = p.ws + ((int64_t)(b * p.groups + g) * nk) * 2;
         double s = 0.0, ss = 0.0;
-        for (int i = 0; i < AID_STATS_SPLIT; ++i) { s += w[2 * i]; ss += w[2 * i + 1]; }
+        for (int i = lane; i < nk; i += 64) { s += w[2 * i]; ss += w[2 * i + 1]; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { s += __shfl_xor(s, off, 64); ss += __shfl_xor(ss, off, 64); }
+        if (lane == 0) { gsum[g][0] = s; gsum[g][1] = ss; }
+    }
+    __syncthreads();
+    for (int c = tid; c < p.C; c += 256) {
+        const int g = c / a.cg;
+        const double s = gsum[g][0], ss = gsum[g][1];
         const double mean = s / n;
         double var = (ss - n * mean * mean) / (n - 1.0);
         if (var < 0.0) var = 0.0;
@@ -72,11 +82,11 @@ __global__ __launch_bounds__(256) void group_stats_final(const StatsDev a) {
         }
     }
 }
-
 extern "C" int aid_group_stats(const aid_group_stats_params* p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     AID_REQUIRE(p && p->x.p && p->gamma && p->scale && p->ws, "aid_group_stats: null pointer");
-    AID_REQUIRE(p->groups > 0 && p->C % p->groups == 0, "aid_group_stats: C must be divisible by groups");
+    AID_REQUIRE(p->groups > 0 && p->groups <= 64 && p->C % p->groups == 0, "aid_group_stats: C must be divisible by groups (<= 64)");
+    AID_REQUIRE(p->ws_n >= 0, "aid_group_stats: bad ws_n");
     AID_REQUIRE((p->T % 4) == 0 && (p->x.sB % 4) == 0 && (p->x.sC % 4) == 0 && (p->x.sF % 4) == 0 &&
                     (((uintptr_t)p->x.p) & 15) == 0,
                 "aid_group_stats: view must be float4-addressable");
@@ -87,8 +97,10 @@ extern "C" int aid_group_stats(const aid_group_stats_params* p, void* stream) {
     int lpr = aid_pow2ceil(p->T / 4);
     if (lpr > 256) lpr = 256;
     a.lpr_log2 = aid_ilog2(lpr);
-    hipLaunchKernelGGL(group_stats_partial, dim3(p->B * p->groups, AID_STATS_SPLIT), dim3(256), 0, st, a);
-    AID_CHECK_LAUNCH();
+    if (p->ws_n == 0) {
+        hipLaunchKernelGGL(group_stats_partial, dim3(p->B * p->groups, AID_STATS_SPLIT), dim3(256), 0, st, a);
+        AID_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(group_stats_final, dim3(p->B), dim3(256), 0, st, a);
     AID_CHECK_LAUNCH();
     return AID_OK;

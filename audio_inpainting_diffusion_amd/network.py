@@ -211,6 +211,8 @@ class _Builder:
         self.nbytes = 0
         self.stats_ws = torch.empty(B * 8 * _lib.AID_STATS_SPLIT * 2, device=device, dtype=torch.float64)
         self.bwd = []          # closures emitting the VJP ops of each forward op (run in reverse by finish_backward)
+        self._stat_src = {}    # view key of a forward conv output -> (its params struct, partials per (b, group)): see stats()
+        self._in_bwd = False
         self.bplan = None
         self.gmap = {}         # storage data_ptr -> flat gradient storage of the same size
         self.gstate = {}       # storage data_ptr -> 'full' (first contribution overwrites the whole tensor: no zero fill,
@@ -248,8 +250,11 @@ class _Builder:
     def finish_backward(self):
         """Emit the reverse sweep (input-VJP) into ``self.bplan``."""
         fwd_plan, self.plan = self.plan, _Plan()
+        self._in_bwd = True
+        self._stat_src.clear()
         for emit in reversed(self.bwd):
             emit()
+        self._in_bwd = False
         self.bplan, self.plan = self.plan, fwd_plan
         return self.bplan
 
@@ -259,13 +264,34 @@ class _Builder:
         return t
 
     # ---- op emitters ---------------------------------------------------------------------------------
+    @staticmethod
+    def _vkey(t):
+        return (t.data_ptr(), tuple(t.shape), tuple(t.stride()))
+
+    def _wrote(self, t):
+        """a forward op (re)writes t: forget epilogue statistics of any conv output that overlaps it"""
+        if self._in_bwd or not self._stat_src or t is None:
+            return
+        lo = t.data_ptr()
+        hi = lo + 4 * (1 + sum((n - 1) * st for n, st in zip(t.shape, t.stride())))
+        for k in [k for k, v in self._stat_src.items() if not (v[2] <= lo or hi <= k[0])]:
+            del self._stat_src[k]
+
     def stats(self, x, gamma, mod, scale, stats=None, gname=None):
-        """group statistics of x -> per-(b,c) scale (+ saved mean / inverse std for the VJP)."""
+        """group statistics of x -> per-(b,c) scale (+ saved mean / inverse std for the VJP).  When x is the untouched output of a forward
+        conv on the row-shared F(4,3) kernel, that conv's epilogue writes the (sum, sum of squares) partials and the read pass is skipped."""
         B, Cc, F, T = x.shape
+        src = None if self._in_bwd else self._stat_src.pop(self._vkey(x), None)
+        ws, ws_n = self.stats_ws, 0
+        if src is not None:
+            cp, ws_n = src[0], src[1]
+            ws = torch.empty(B * 8 * ws_n * 2, device=self.device, dtype=torch.float64)
+            self.nbytes += ws.numel() * 8
+            cp.stat_ws, cp.stat_n = ws.data_ptr(), ws_n
         p = _lib.GroupStatsParams(_lib.view4(x), B, Cc, F, T, 8, gamma.data_ptr(), _lib.ptr(mod),
                                   0 if mod is None else mod.stride(0), 1e-7, scale.data_ptr(), _lib.ptr(stats),
-                                  self.stats_ws.data_ptr())
-        self.plan.add("aid_group_stats", p, x, gamma, mod, scale, stats)
+                                  ws.data_ptr(), ws_n)
+        self.plan.add("aid_group_stats", p, x, gamma, mod, scale, stats, ws)
         if self.train and gname is not None:
             def bw():                                   # gradient of scale = gamma (1 + affine) / (std + eps) w.r.t. gamma and the affine vector
                 S = self.S_of.pop(scale.data_ptr(), None)
@@ -342,6 +368,12 @@ class _Builder:
         nb = 4 * (B * F * T * (cin + cout * (1 + (res is not None) + (aux is not None))) + cin * cout * kh * kw)
         self.plan.add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, ws, flops=2 * B * F * T * cin * cout * kh * kw,
                       nbytes=nb)
+        self._wrote(y)
+        if not self._in_bwd and x_wino and epi == 0 and dot is None and self.net.epilogue_stats:
+            n = int(_lib.lib().aid_conv2d_stat_partials(B, cin, cout, F, T, dil, 1))
+            if n:                                         # a later stats(y) may ask this conv's epilogue for the partial sums
+                hi = y.data_ptr() + 4 * (1 + sum((m - 1) * st for m, st in zip(y.shape, y.stride())))
+                self._stat_src[self._vkey(y)] = (p, n, hi)
 
     def _dot_ws(self, n):
         """scratch for the per-tile <gd, x> partials written by the conv epilogue: [B*8, n] doubles + B*8 floats (coef)"""
@@ -430,6 +462,7 @@ class _Builder:
         B, Cc, F, T = u.shape
         p = _lib.Add2Params(_lib.view4(u), _lib.view4(v), _lib.view4(y), B, Cc, F, T, a, b)
         self.plan.add("aid_add2", p, u, v, y)
+        self._wrote(y)
 
     def add2(self, u, v, y, a, b):
         self.add2_raw(u, v, y, a, b)
@@ -459,6 +492,7 @@ class _Builder:
         B, Cc, F, T = x.shape
         p = _lib.ResampleParams(_lib.view4(x), _lib.view4(y), B, Cc, F, T, int(up), int(adjoint), int(accumulate))
         self.plan.add("aid_resample", p, x, y)
+        self._wrote(y)
 
     def resample(self, x, y, up):
         self._resample_raw(x, y, up)
@@ -470,6 +504,7 @@ class _Builder:
         scale = float(F) ** -0.5
         p = _lib.AttentionParams(qk.data_ptr(), v.data_ptr(), out.data_ptr(), probs.data_ptr(), B, heads, F, T, scale, _lib.ptr(bias))
         self.plan.add("aid_time_attention", p, qk, v, out, probs, bias, flops=4 * B * heads * T * T * F)
+        self._wrote(out)
 
         def bw():
             gq, gv, go = self.G(qk), self.G(v), self.G(out)
@@ -906,6 +941,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
     # input / output buffers, later calls copy the inputs in and replay.  Sub-batch streams (B >= 4) stay eager.
     # ---------------------------------------------------------------------------------------------------
     use_graphs = True
+    epilogue_stats = True      # forward group statistics from the epilogue of the conv that produces the tensor (row-shared F(4,3) kernel)
     GRAPH_MAX_B = 3
     GRAPH_MAX_PER_STATE = 4
 

@@ -28,7 +28,7 @@ extern "C" {
 #define AID_E_BADARG (-1)   /* unsupported shape / null pointer / misaligned stride */
 #define AID_E_LAUNCH (-2)   /* hipLaunchKernel reported an error                    */
 
-#define AID_ABI_VERSION 3
+#define AID_ABI_VERSION 4
 int aid_abi_version(void);
 /* last HIP error string seen by a launcher in this process (never NULL) */
 const char* aid_last_error(void);
@@ -64,7 +64,9 @@ typedef struct {
     float eps;
     float* scale;              /* [B, C]   out   */
     float* stats;              /* [B, groups, 2] out (mean, 1/(std+eps)) */
-    double* ws;
+    double* ws;                /* scratch: [B*groups][max(ws_n, AID_STATS_SPLIT)][2] doubles */
+    int ws_n;                  /* 0: the kernel reads x and reduces it itself.  > 0: `ws` already holds ws_n partial (sum, sum of squares) pairs per
+                                  (sample, group), written by the epilogue of the aid_conv2d that produced x (its stat_ws / stat_n): the read pass is skipped */
 } aid_group_stats_params;
 int aid_group_stats(const aid_group_stats_params* p, void* stream);
 
@@ -114,12 +116,18 @@ typedef struct {
                                  (sample, channel group of Cout/8) over its tile and writes one partial per tile,
                                  dot_ws[(b*8 + g) * dot_n + tile_in_sample] -- the aid_group_dot pass over the dgrad output
                                  folded into the conv that produces it.  dot_n must equal aid_conv2d_dot_partials(...). */
+    double* stat_ws; int stat_n; /* optional (forward, epi = 0, Winograd-domain input on the row-shared kernel only; not together with dot_ws): the epilogue
+                                 also reduces (sum y, sum y^2) per (sample, channel group of Cout/8) over its tile:
+                                 stat_ws[((b*8 + g) * stat_n + tile) * 2 + {0,1}] -- the read pass of the NEXT layer's aid_group_stats folded into
+                                 the conv that produces its input (aid_group_stats ws_n = stat_n).  stat_n must equal aid_conv2d_stat_partials(...). */
 } aid_conv2d_params;
 int aid_conv2d(const aid_conv2d_params* p, void* stream);
 /* non-zero when a 5x3 layer of this shape can take Winograd-domain input (x_wino = 1) */
 int aid_conv2d_wino_input_supported(int Cin, int Cout, int T);
 /* number of per-tile partial dots per (sample, group) the F(4,3) epilogue writes for this shape; 0 = not supported */
 int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino);
+/* number of per-tile (sum, sum of squares) partials per (sample, group) for stat_ws; 0 = the kernel that takes this shape does not write them */
+int aid_conv2d_stat_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino);
 /* padded dims the packed weight buffer must have for a given (Cin, Cout) */
 void aid_conv2d_pack_dims(int Cin, int Cout, int* Cin_pad, int* Cout_pad);
 

@@ -586,3 +586,50 @@ def test_channel_dot(L, shape):
     torch.cuda.synchronize()
     ref = (u.double() * v.double()).sum((2, 3))
     assert float((out.cpu().double() - ref).abs().max()) < 1e-5 * float(ref.abs().max() + 1)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 24, 128, 2), (1, 128, 256, 16, 64, 4), (2, 96, 96, 32, 128, 2), (1, 64, 128, 56, 32, 8)])
+def test_group_stats_from_conv_epilogue(L, case):
+    """aid_conv2d(stat_ws) on the row-shared F(4,3) kernel + aid_group_stats(ws_n): the per-tile (sum, sum of squares) partials of the conv
+    output replace the read pass; scale and (mean, 1/(std+eps)) agree with the plain two-kernel statistics of the same tensor."""
+    B, Cin, Cout, Fd, T, dil = case
+    P = int(L.lib().aid_conv2d_stat_partials(B, Cin, Cout, Fd, T, dil, 1))
+    assert P > 0
+    x = _rand(B, Cin, Fd, T, seed=90)
+    w = _rand(Cout, Cin, 5, 3, seed=91, scale=1.0 / math.sqrt(Cin * 15))
+    res = _rand(B, Cout, Fd, T, seed=92)
+    gate = _rand(B, Cout, seed=93)
+    xd, wd = x.to(DEV), w.to(DEV)
+    G = T // 4
+    xv = torch.empty(B, Cin, Fd, 6 * G, device=DEV)
+    L.call("aid_scale_act", L.ScaleActParams(L.view4(xd), L.view4(xv), None, 0, B, Cin, Fd, T, 0, 1))
+    wp, wpw = L.pack_conv_weight(wd), L.pack_conv_weight_wino(wd)
+    y = torch.empty(B, Cout, Fd, T, device=DEV)
+    resd, gd = res.to(DEV), gate.to(DEV)
+    ws = torch.full((B * 8 * P * 2 + 4,), float("nan"), device=DEV, dtype=torch.float64)
+    p = L.Conv2dParams()
+    p.x, p.y, p.res, p.aux = L.view4(xv), L.view4(y), L.view4(resd), L.view4(None)
+    p.wp, p.wp_wino, p.wino_taps, p.x_wino = wp.data_ptr(), wpw.data_ptr(), 30, 1
+    p.out_scale, p.out_scale_ld = gd.data_ptr(), gd.stride(0)
+    p.B, p.Cin, p.Cout, p.F, p.T = B, Cin, Cout, Fd, T
+    p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
+    p.KH, p.KW, p.dilF, p.act, p.epi = 5, 3, dil, 0, 0
+    p.alpha, p.res_scale = 1 / math.sqrt(2), 1.0
+    p.stat_ws, p.stat_n = ws.data_ptr(), P
+    L.call("aid_conv2d", p)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(ws[B * 8 * P * 2:]).all()) and bool(torch.isfinite(ws[:B * 8 * P * 2]).all())
+    gamma = (1.0 + 0.1 * _rand(Cout, seed=94)).to(DEV)
+    mod = (0.2 * _rand(B, Cout, seed=95)).to(DEV)
+    out = []
+    for n_, w_ in ((P, ws), (0, torch.empty(B * 8 * L.AID_STATS_SPLIT * 2, device=DEV, dtype=torch.float64))):
+        scale = torch.empty(B, Cout, device=DEV)
+        st = torch.empty(B, 8, 2, device=DEV)
+        sp = L.GroupStatsParams(L.view4(y), B, Cout, Fd, T, 8, gamma.data_ptr(), mod.data_ptr(), mod.stride(0), 1e-7, scale.data_ptr(),
+                                st.data_ptr(), w_.data_ptr(), n_)
+        L.call("aid_group_stats", sp)
+        torch.cuda.synchronize()
+        out.append((scale.cpu(), st.cpu()))
+    assert rel_l2(out[0][0], out[1][0]) < 1e-6
+    assert float((out[0][1][..., 0] - out[1][1][..., 0]).abs().max()) < 1e-6 * float(out[1][1][..., 0].abs().max() + 1)
+    assert rel_l2(out[0][1][..., 1], out[1][1][..., 1]) < 1e-6

@@ -208,6 +208,69 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const NbDev a) {
     *reinterpret_cast<float4*>(o) = r;
 }
 
+// Same pass with the Winograd-domain copy for the dgrad conv of the layer below.  Same thread <-> float4 mapping as norm_bwd_kernel (coalesced
+// 1 KB per wave instruction); the two neighbour samples of a group of four come from the adjacent lanes by wave shuffles (recomputed from scalar
+// loads at the two ends of a wave), and the group's F(4,3) input transform, times wscale[b,c], goes to `wout` (six coalesced plane stores).
+__global__ __launch_bounds__(256) void norm_bwd_wino_kernel(const NbDev a) {
+    const aid_norm_bwd_params& p = a.p;
+    const int tid = threadIdx.x;
+    const int lpr = 1 << a.lpr_log2;
+    const int sub = tid >> a.lpr_log2, lq = tid & (lpr - 1);
+    const int rpb = 256 >> a.lpr_log2;
+    const int tile = blockIdx.x % a.tiles;
+    const int row = (blockIdx.x / a.tiles) * rpb + sub;
+    const int o4 = (tile * lpr + lq) * 4;
+    const bool live = row < a.nrows && o4 < p.T;           // (all lanes stay for the shuffles)
+    const int rw = live ? row : 0;
+    const int f = rw % p.F;
+    const int bc = rw / p.F;
+    const int c = bc % p.C;
+    const int b = bc / p.C;
+    const int bg = b * p.groups + c / a.cg;
+    const float coef = a.coef[bg];
+    const float mean = p.stats[2 * bg];
+    const float* gdr = p.gd.p + (int64_t)b * p.gd.sB + (int64_t)c * p.gd.sC + (int64_t)f * p.gd.sF;
+    const float* xr = p.x.p + (int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)f * p.x.sF;
+    const float* gyr = p.gy.p ? p.gy.p + (int64_t)b * p.gy.sB + (int64_t)c * p.gy.sC + (int64_t)f * p.gy.sF : nullptr;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        const float4 g = *reinterpret_cast<const float4*>(gdr + o4);
+        const float4 x = *reinterpret_cast<const float4*>(xr + o4);
+        r = make_float4(g.x - coef * (x.x - mean), g.y - coef * (x.y - mean), g.z - coef * (x.z - mean), g.w - coef * (x.w - mean));
+        if (gyr) {
+            const float4 y = *reinterpret_cast<const float4*>(gyr + o4);
+            r.x += p.a * y.x; r.y += p.a * y.y; r.z += p.a * y.z; r.w += p.a * y.w;
+        }
+        *reinterpret_cast<float4*>(p.out.p + (int64_t)b * p.out.sB + (int64_t)c * p.out.sC + (int64_t)f * p.out.sF + o4) = r;
+    }
+    // neighbours: sample o4-1 (= .w of the previous group) and o4+4 (= .x of the next group) of the SAME row
+    const int lane = tid & 63;
+    float e0 = __shfl_up(r.w, 1, 64), e5 = __shfl_down(r.x, 1, 64);
+    auto one = [&](int t) {
+        float v = gdr[t] - coef * (xr[t] - mean);
+        if (gyr) v += p.a * gyr[t];
+        return v;
+    };
+    if (live) {
+        if (o4 == 0) e0 = 0.f;                             // the conv's zero padding
+        else if (lane == 0 || lq == 0) e0 = one(o4 - 1);   // previous group lives in another wave / block
+        if (o4 + 4 >= p.T) e5 = 0.f;
+        else if (lane == 63 || lq == lpr - 1) e5 = one(o4 + 4);
+        const float sc = p.wscale ? p.wscale[(int64_t)b * p.wscale_ld + c] : 1.f;
+        e0 *= sc; e5 *= sc;
+        const float e1 = r.x * sc, e2 = r.y * sc, e3 = r.z * sc, e4 = r.w * sc;
+        const float s12 = e1 + e2, m12 = e1 - e2, m42 = e4 - e2, m31 = e3 - e1;
+        const int G = p.T >> 2;
+        float* yr = p.wout.p + (int64_t)b * p.wout.sB + (int64_t)c * p.wout.sC + (int64_t)f * p.wout.sF + (o4 >> 2);
+        yr[0] = 4.f * e0 - 5.f * e2 + e4;
+        yr[G] = (e3 + e4) - 4.f * s12;
+        yr[2 * G] = (e4 - e3) + 4.f * m12;
+        yr[3 * G] = m42 + 2.f * m31;
+        yr[4 * G] = m42 - 2.f * m31;
+        yr[5 * G] = 4.f * e1 - 5.f * e3 + e5;
+    }
+}
+
 extern "C" int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream) {
     AID_REQUIRE(p && p->gd.p && p->x.p && p->out.p && p->stats && p->ws, "aid_norm_bwd: null pointer");
     AID_REQUIRE(p->groups > 0 && p->C % p->groups == 0 && (p->T % 4) == 0, "aid_norm_bwd: bad shape");
@@ -224,6 +287,14 @@ extern "C" int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream) {
     const int rpb = 256 / lpr;
     hipLaunchKernelGGL(norm_bwd_coef, dim3(p->B * p->groups), dim3(64), 0, (hipStream_t)stream, a);
     AID_CHECK_LAUNCH();
+    if (p->wout.p) {
+        AID_REQUIRE((p->T % 16) == 0 && !p->accumulate, "aid_norm_bwd: wout needs T % 16 == 0 and accumulate = 0 (neighbour samples are recomputed)");
+        AID_REQUIRE(p->wout.sF >= 6 * (p->T / 4) && (p->wout.sB % 4) == 0 && (p->wout.sC % 4) == 0 && (p->wout.sF % 4) == 0 && (((uintptr_t)p->wout.p) & 15) == 0,
+                    "aid_norm_bwd: wout rows are [6][T/4], 16-byte aligned");
+        hipLaunchKernelGGL(norm_bwd_wino_kernel, dim3((unsigned)(aid_cdiv(a.nrows, rpb) * a.tiles)), dim3(256), 0, (hipStream_t)stream, a);
+        AID_CHECK_LAUNCH();
+        return AID_OK;
+    }
     hipLaunchKernelGGL(norm_bwd_kernel, dim3((unsigned)(aid_cdiv(a.nrows, rpb) * a.tiles)), dim3(256), 0, (hipStream_t)stream, a);
     AID_CHECK_LAUNCH();
     return AID_OK;

@@ -212,6 +212,8 @@ class _Builder:
         self.stats_ws = torch.empty(B * 8 * _lib.AID_STATS_SPLIT * 2, device=device, dtype=torch.float64)
         self.bwd = []          # closures emitting the VJP ops of each forward op (run in reverse by finish_backward)
         self._stat_src = {}    # view key of a forward conv output -> (its params struct, partials per (b, group)): see stats()
+        self._nb_src = {}      # (reverse sweep) view key of a gradient tensor -> (the aid_norm_bwd params that wrote it last, op index, end address)
+        self._g_last = {}      # (reverse sweep) Winograd-domain gradient scratch data_ptr -> index of the last op that used it
         self._in_bwd = False
         self.bplan = None
         self.gmap = {}         # storage data_ptr -> flat gradient storage of the same size
@@ -252,6 +254,8 @@ class _Builder:
         fwd_plan, self.plan = self.plan, _Plan()
         self._in_bwd = True
         self._stat_src.clear()
+        self._nb_src.clear()
+        self._g_last.clear()
         for emit in reversed(self.bwd):
             emit()
         self._in_bwd = False
@@ -269,13 +273,15 @@ class _Builder:
         return (t.data_ptr(), tuple(t.shape), tuple(t.stride()))
 
     def _wrote(self, t):
-        """a forward op (re)writes t: forget epilogue statistics of any conv output that overlaps it"""
-        if self._in_bwd or not self._stat_src or t is None:
+        """an op (re)writes t: forget what was recorded about overlapping tensors -- forward: the conv whose epilogue could supply the
+        statistics of t; reverse sweep: the aid_norm_bwd that could also write the Winograd-domain copy of t"""
+        d = self._nb_src if self._in_bwd else self._stat_src
+        if not d or t is None:
             return
         lo = t.data_ptr()
         hi = lo + 4 * (1 + sum((n - 1) * st for n, st in zip(t.shape, t.stride())))
-        for k in [k for k, v in self._stat_src.items() if not (v[2] <= lo or hi <= k[0])]:
-            del self._stat_src[k]
+        for k in [k for k, v in d.items() if not (v[2] <= lo or hi <= k[0])]:
+            del d[k]
 
     def stats(self, x, gamma, mod, scale, stats=None, gname=None):
         """group statistics of x -> per-(b,c) scale (+ saved mean / inverse std for the VJP).  When x is the untouched output of a forward
@@ -424,9 +430,16 @@ class _Builder:
                 gw = norm_stats is not None and self._wino_input(cout, cin, gy.shape[3], wpT, wpwT)
                 gshape = (gy.shape[0], cout, gy.shape[2], 6 * (gy.shape[3] // 4)) if gw else tuple(gy.shape)
                 gin = self._scratch(("g",) + gshape)
-                sp = _lib.ScaleActParams(_lib.view4(gy), _lib.view4(gin), out_scale.data_ptr(), out_scale.stride(0), gy.shape[0],
-                                         cout, gy.shape[2], gy.shape[3], 0, int(gw))
-                self.plan.add("aid_scale_act", sp, gy, gin, out_scale)
+                nb = self._nb_src.pop(self._vkey(gy), None) if (gw and self.net.fuse_norm_bwd_wino) else None
+                if nb is not None and nb[1] > self._g_last.get(gin.data_ptr(), -1):
+                    # gy was written last by an aid_norm_bwd and nothing used this scratch since: that pass also writes gin
+                    nb[0].wout, nb[0].wscale, nb[0].wscale_ld = _lib.view4(gin), out_scale.data_ptr(), out_scale.stride(0)
+                    self.plan.keep.extend((gin, out_scale))
+                else:
+                    sp = _lib.ScaleActParams(_lib.view4(gy), _lib.view4(gin), out_scale.data_ptr(), out_scale.stride(0), gy.shape[0],
+                                             cout, gy.shape[2], gy.shape[3], 0, int(gw))
+                    self.plan.add("aid_scale_act", sp, gy, gin, out_scale)
+                self._g_last[gin.data_ptr()] = len(self.plan.ops)      # (the dgrad conv below reads it)
                 gsc = None
             if norm_stats is not None:
                 gd = self._scratch(x.shape)
@@ -447,6 +460,11 @@ class _Builder:
                                           B, cin, F, T, 8, norm_stats.data_ptr(), dws.data_ptr(), 1e-7,
                                           alpha * res_scale, 1 if self._gacc(x) else 0, nd)
                 self.plan.add("aid_norm_bwd", npar, gd, x, gy, norm_stats)
+                gxv = self.G(x)
+                self._wrote(gxv)
+                if npar.accumulate == 0 and x.shape[3] % 16 == 0:
+                    hi = gxv.data_ptr() + 4 * (1 + sum((m - 1) * st for m, st in zip(gxv.shape, gxv.stride())))
+                    self._nb_src[self._vkey(gxv)] = (npar, len(self.plan.ops) - 1, hi)
             else:
                 gx = self.G(x)
                 self._conv_raw(gin, gx, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, gx if self._gacc(x) else None, 1.0 / alpha, alpha,
@@ -514,6 +532,8 @@ class _Builder:
             bp = _lib.AttentionBwdParams(qk.data_ptr(), v.data_ptr(), probs.data_ptr(), go.data_ptr(), gq.data_ptr(), gv.data_ptr(),
                                          B, heads, F, T, scale, 1 if self._gacc(v) else 0, dsws.data_ptr())
             self.plan.add("aid_time_attention_bwd", bp, qk, v, probs, go, gq, gv, dsws, flops=10 * B * heads * T * T * F)
+            self._wrote(gq)
+            self._wrote(gv)
         self.bwd.append(bw)
 
 
@@ -941,6 +961,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
     # input / output buffers, later calls copy the inputs in and replay.  Sub-batch streams (B >= 4) stay eager.
     # ---------------------------------------------------------------------------------------------------
     use_graphs = True
+    fuse_norm_bwd_wino = True  # reverse sweep: aid_norm_bwd also writes the Winograd-domain, gated copy that the dgrad conv below stages
     epilogue_stats = True      # forward group statistics from the epilogue of the conv that produces the tensor (row-shared F(4,3) kernel)
     GRAPH_MAX_B = 3
     GRAPH_MAX_PER_STATE = 4

@@ -144,6 +144,7 @@ def main():
                                                               "configs[3] sweeps 25 / 50 / 100, conf/tester/inpainting_tester_shortgaps.yaml:74-75)")
     ap.add_argument("--streams", type=int, default=0, help="sub-batch HIP streams per evaluation (default: automatic, network._n_split; 1 = plain single-stream schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused-norm-bwd", action="store_true", help="A/B: separate gate / Winograd-transform pre-pass before every dgrad conv")
     ap.add_argument("--no-epilogue-stats", action="store_true", help="A/B: group statistics by their own read pass instead of the conv epilogue")
     ap.add_argument("--conv-table", action="store_true", help="print per-shape conv kernel times (stderr)")
     a = ap.parse_args()
@@ -178,6 +179,8 @@ def main():
     net = Unet_CQT_oct_with_attention(args, dev)
     if a.no_epilogue_stats:
         net.epilogue_stats = False
+    if a.no_fused_norm_bwd:
+        net.fuse_norm_bwd_wino = False
     if a.streams:
         net.split_streams = a.streams
     if rank == 0:

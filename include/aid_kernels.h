@@ -325,6 +325,9 @@ typedef struct {
     float eps, a;
     int accumulate;
     int ws_n;
+    aid_view wout;                /* optional second output (T % 16 == 0): the F(4,3) input transform [B, C, F, 6, T/4] of out * wscale[b,c] -- what
+                                     aid_scale_act(wino=1) would write for the dgrad conv of the layer below (its gate pre-pass folded into this pass) */
+    const float* wscale; int64_t wscale_ld;   /* [B, wscale_ld] or NULL (-> 1) */
 } aid_norm_bwd_params;
 int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream);
 

@@ -283,3 +283,35 @@ def small_xi0(args):
 def L_AidError():
     from audio_inpainting_diffusion_amd._lib import AidError
     return AidError
+
+
+@pytest.mark.parametrize("shape,with_gy", [((2, 16, 5, 32), True), ((1, 64, 7, 256), False), ((2, 8, 3, 16), True)])
+def test_norm_bwd_with_winograd_domain_copy(L, shape, with_gy):
+    """aid_norm_bwd(wout): the plain output equals the plain call's, and wout is the F(4,3) input transform of out * wscale[b,c]
+    (= what aid_scale_act(wino=1) writes from it)."""
+    B, C, Fd, T = shape
+    gd, x, gy = _rand(B, C, Fd, T, seed=60), _rand(B, C, Fd, T, seed=61), _rand(B, C, Fd, T, seed=62)
+    ws_ = (1.0 + 0.5 * _rand(B, C, seed=63)).to(DEV)
+    gdd, xd, gyd = gd.to(DEV), x.to(DEV), gy.to(DEV)
+    stats = torch.empty(B, 8, 2, device=DEV)
+    scale = torch.empty(B, C, device=DEV)
+    gam = torch.ones(C, device=DEV)
+    sws = torch.zeros(B * 8 * (L.AID_STATS_SPLIT + 1) * 2, device=DEV, dtype=torch.float64)
+    L.call("aid_group_stats", L.GroupStatsParams(L.view4(xd), B, C, Fd, T, 8, gam.data_ptr(), None, 0, 1e-7, scale.data_ptr(), stats.data_ptr(), sws.data_ptr()))
+    L.call("aid_group_dot", L.GroupDotParams(L.view4(gdd), L.view4(xd), B, C, Fd, T, 8, sws.data_ptr()))
+    outs = []
+    for fused in (0, 1):
+        out = torch.empty(B, C, Fd, T, device=DEV)
+        wout = torch.full((B, C, Fd, 6 * (T // 4)), float("nan"), device=DEV)
+        p = L.NormBwdParams(L.view4(gdd), L.view4(xd), L.view4(gyd if with_gy else None), L.view4(out), B, C, Fd, T, 8, stats.data_ptr(), sws.data_ptr(),
+                            1e-7, 0.7, 0, 0)
+        if fused:
+            p.wout, p.wscale, p.wscale_ld = L.view4(wout), ws_.data_ptr(), ws_.stride(0)
+        L.call("aid_norm_bwd", p)
+        torch.cuda.synchronize()
+        outs.append((out, wout))
+    assert torch.equal(outs[0][0], outs[1][0])
+    ref = torch.empty_like(outs[1][1])
+    L.call("aid_scale_act", L.ScaleActParams(L.view4(outs[0][0]), L.view4(ref), ws_.data_ptr(), ws_.stride(0), B, C, Fd, T, 0, 1))
+    torch.cuda.synchronize()
+    assert rel_l2(outs[1][1].cpu(), ref.cpu()) < 1e-6            # (same arithmetic; the compiler contracts the two forms differently)

@@ -337,3 +337,9 @@ def test_resampling_kernel_tables_wav_io_and_case_logic(tmp_path):
     assert sr == 22050 and back.shape == (1, 2205) and float((back[0] - sig).abs().max()) < 1.0 / 32767
     loud = write_audio_file(4.0 * sig.reshape(1, -1), 22050, "loud", path=str(tmp_path))      # max >= 1 -> rescaled to peak 1
     assert abs(float(read_wav(loud)[0].max()) - 32767 / 32768) < 1e-4
+
+
+def test_graft_entry_build_checks_the_header_abi_version():
+    """__graft_entry__.build() is what the driver runs: it must compile, load the library and agree with the header's ABI version."""
+    import __graft_entry__ as g
+    g.build()

@@ -11,8 +11,8 @@ run() { python bench.py --no-cpu-baseline "$@" 2>/dev/null; }
   run --workload musicnet44k
   run --workload musicnet44k --xi 0
   run --task spectrogram
-  run --batch 1
-  run --batch 2
+  run --batch 1 --warmup 2
+  run --batch 2 --warmup 2
   run --batch 16 --steps 2
   run --streams 1
   run --streams 2

@@ -315,3 +315,45 @@ def test_norm_bwd_with_winograd_domain_copy(L, shape, with_gy):
     L.call("aid_scale_act", L.ScaleActParams(L.view4(outs[0][0]), L.view4(ref), ws_.data_ptr(), ws_.stride(0), B, C, Fd, T, 0, 1))
     torch.cuda.synchronize()
     assert rel_l2(outs[1][1].cpu(), ref.cpu()) < 1e-6            # (same arithmetic; the compiler contracts the two forms differently)
+
+
+def test_fused_passes_match_the_unfused_schedule_at_full_size():
+    """Statistics from the conv epilogue (aid_conv2d stat_ws) and the Winograd-domain copy written by aid_norm_bwd (wout) against the same
+    network with both switched off (separate read / gate passes): a full-size guided evaluation agrees to rounding, and the fused forms
+    really are in the plans."""
+    import ctypes
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
+    from audio_inpainting_diffusion_amd.masks import long_gap_mask
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    from oracle.edm import OracleEDM
+    args = make_args("maestro22k")
+    Ls = args.exp.audio_len
+    edm = OracleEDM()
+    x = torch.from_numpy(seeded_normal(23, 0, 2 * Ls)).reshape(2, Ls) * 0.3
+    y = torch.from_numpy(seeded_normal(24, 0, 2 * Ls)).reshape(2, Ls) * 0.063
+    mask = long_gap_mask(Ls, 22050, 300)
+    s = torch.tensor([[0.4], [2.0]])
+    v = lambda t: t.reshape(-1).to(DEV).contiguous()
+    res = []
+    for fused in (True, False):
+        net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(DEV)), 0, gate_scale=10.0, affine_scale=10.0)
+        net.epilogue_stats = net.fuse_norm_bwd_wino = fused
+        net.use_graphs = False
+        xh, g, nrm = net.denoise_guided(x.to(DEV), v(edm.cnoise(s)), v(edm.cin(s)), v(edm.cskip(s)), v(edm.cout(s)), True,
+                                        (y * mask).to(DEV), mask.to(DEV))
+        st = net._state(2)
+        n_stat = sum(1 for k in st["plan_body"].keep if isinstance(k, L_mod().GroupStatsParams) and k.ws_n > 0)
+        n_nb = sum(1 for k in st["plan_bwd"].keep if isinstance(k, L_mod().NormBwdParams) and k.wout.p)
+        res.append((xh.cpu(), g.cpu(), nrm.cpu(), n_stat, n_nb))
+        del net
+        torch.cuda.empty_cache()
+    assert res[0][3] >= 40 and res[0][4] >= 40 and res[1][3] == 0 and res[1][4] == 0, (res[0][3:], res[1][3:])
+    e1, e2 = rel_l2(res[0][0], res[1][0]), rel_l2(res[0][1], res[1][1])
+    print(f"fused vs unfused passes: x_hat rel-L2 = {e1:.2e}, rec_grads rel-L2 = {e2:.2e}; statistics from epilogues: {res[0][3]}, fused norm_bwd: {res[0][4]}")
+    assert e1 < 2e-6 and e2 < 2e-5
+
+
+def L_mod():
+    from audio_inpainting_diffusion_amd import _lib
+    return _lib

@@ -34,14 +34,15 @@ struct WgDev {
 #define WG_NW 8                  // waves per workgroup
 #define WG_QPW 2                 // taps per wave (WG_NW * WG_QPW >= 15)
 #define WG_THREADS (64 * WG_NW)
-#define WG_CO 64                 // output channels per workgroup tile (two 32-row MFMA tiles share every B fragment)
 #define WG_NS (WG_MAXKH + 1)     // ring slots of input rows: the KH rows of the current step + the new row of the next one
 
 // One workgroup per CU (85 KB of LDS, eight waves = two per SIMD).  Staging is asynchronous INSIDE the workgroup: the next step's gy
 // tile and new input row are loaded into registers before the K loop, written to the other gy buffer / the free ring slot half-way
 // through it, and one barrier per step separates the steps.  (Two workgroups per CU with synchronous staging ran in lockstep -- equal
 // step lengths never let their phases drift apart -- so staging time simply added to the MFMA time: profiles/r02_wgrad_gates.txt.)
+template <int COB>     // 32-row output-channel blocks per workgroup tile: 2 (64 channels), or 3 for layers whose Cout is an odd multiple of 32 (C = 96)
 __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const WgDev a) {
+    constexpr int WG_CO = 32 * COB;
     const aid_conv2d_wgrad_params& p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -51,18 +52,18 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const WgDev a
     const int KH = p.KH, KW = p.KW, ntaps = KH * KW;
     const int kwc = KW / 2, khc = KH / 2;
     const int NS = KH + 1;
-    const bool two = co0 + 32 < p.Cout;                   // the second 32-row tile has rows (96 channels: the last tile is half empty)
+    const int nco = min(COB, (p.Cout - co0 + 31) / 32);   // 32-row blocks of this tile that have rows (wave-uniform)
 
     __shared__ float gyT0[WG_CO * WG_LDA + 8];            // (+8: the fast path reads one k-step past the chunk)
     __shared__ float gyT1[WG_CO * WG_LDA + 8];
     __shared__ float xT[WG_NS * 32 * WG_LDB + 8];
 
-    // taps of this wave: wave, wave + 8; two accumulator tiles (co0.., co0+32..) per tap
-    f32x16 acc[WG_QPW][2];
+    // taps of this wave: wave, wave + 8; COB accumulator tiles (co0.., co0+32.., ...) per tap
+    f32x16 acc[WG_QPW][COB];
 #pragma unroll
     for (int q = 0; q < WG_QPW; ++q)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < COB; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][i][r] = 0.f;
     int tkh[WG_QPW], tkw[WG_QPW];
@@ -80,18 +81,18 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const WgDev a
         }
         return v;
     };
-    // This thread's share of a step's staging: gy 64 rows x 16 float4 -> 2 per thread; one input row 32 x 16 float4 -> 1 per thread (+ halo)
+    // This thread's share of a step's staging: gy 32 COB rows x 16 float4 -> COB per thread; one input row 32 x 16 float4 -> 1 per thread (+ halo)
     const int q4 = tid & 15, srow = tid >> 4;             // float4 column, base row 0..31 (gy rows srow + 32 i)
-    auto load_gy = [&](int f, int t0, float4 (&g)[2]) {
+    auto load_gy = [&](int f, int t0, float4 (&g)[COB]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < COB; ++i) {
             const int co = co0 + srow + 32 * i;
             g[i] = ld4(p.gy.p + (int64_t)b * p.gy.sB + (int64_t)co * p.gy.sC + (int64_t)f * p.gy.sF, co < p.Cout, t0 + 4 * q4);
         }
     };
-    auto store_gy = [&](float* gyT, const float4 (&g)[2]) {
+    auto store_gy = [&](float* gyT, const float4 (&g)[COB]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < COB; ++i) {
             float* d = gyT + (srow + 32 * i) * WG_LDA + 4 * q4;
             d[0] = g[i].x; d[1] = g[i].y; d[2] = g[i].z; d[3] = g[i].w;
         }
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const WgDev a
         if (r < rem * (qd + 1)) { res = r / (qd + 1); n = r - res * (qd + 1); }
         else { const int r2 = r - rem * (qd + 1); res = rem + r2 / qd; n = r2 - (res - rem) * qd; }
     }
-    float4 pg[2], px;
+    float4 pg[COB], px;
     float ph = 0.f;
     auto stage_chain_start = [&](int f, int t0, int n0) {       // all KH rows of a step (synchronous)
         for (int kh = 0; kh < KH; ++kh) {
@@ -174,10 +175,11 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const WgDev a
             // otherwise), fragments of k-step j+1 are read while step j multiplies (reads past tc land in the row padding / array tail)
             const float* bp0 = xT + boff[0];
             const float* bp1 = xT + boff[1];
-            float av[2][2], bv[2][2];
+            float av[2][COB], bv[2][2];
             auto ld = [&](int k, int u) {
-                av[u][0] = ap[k];
-                if (two) av[u][1] = ap[32 * WG_LDA + k];
+#pragma unroll
+                for (int i = 0; i < COB; ++i)
+                    if (i < nco) av[u][i] = ap[i * 32 * WG_LDA + k];
                 bv[u][0] = bp0[k]; bv[u][1] = bp1[k];
             };
             ld(0, 0);
@@ -189,8 +191,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const WgDev a
                     ld(k0 + 2 * j + 2, (j + 1) & 1);
 #pragma unroll
                     for (int q = 0; q < WG_QPW; ++q) {
-                        acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][0], bv[j & 1][q], acc[q][0], 0, 0, 0);
-                        if (two) acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][1], bv[j & 1][q], acc[q][1], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < COB; ++i)
+                            if (i < nco) acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][i], bv[j & 1][q], acc[q][i], 0, 0, 0);
                     }
                 }
             }
@@ -198,13 +201,16 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const WgDev a
             const int kmid = (tc >> 2) << 1;
             for (int k = 0; k < tc; k += 2) {
                 if (k == kmid) store_next();
-                const float a0 = ap[k], a1 = ap[32 * WG_LDA + k];
+                float av1[COB];
+#pragma unroll
+                for (int i = 0; i < COB; ++i) av1[i] = (i < nco) ? ap[i * 32 * WG_LDA + k] : 0.f;
 #pragma unroll
                 for (int q = 0; q < WG_QPW; ++q) {
                     if (wave + WG_NW * q < ntaps) {       // (wave-uniform)
                         const float bvv = xT[boff[q] + k];
-                        acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bvv, acc[q][0], 0, 0, 0);
-                        if (two) acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bvv, acc[q][1], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < COB; ++i)
+                            if (i < nco) acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[i], bvv, acc[q][i], 0, 0, 0);
                     }
                 }
             }
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const WgDev a
         const int tap = wave + WG_NW * q;
         if (tap >= ntaps || ci >= p.Cin) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < COB; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -242,10 +248,13 @@ extern "C" int aid_conv2d_wgrad(const aid_conv2d_wgrad_params* p, void* stream) 
                 "aid_conv2d_wgrad: kernel sizes up to 5x3");
     WgDev a;
     a.p = *p;
-    a.co_tiles = aid_cdiv(p->Cout, WG_CO);
+    const int cob = (p->Cout % 64 != 0 && p->Cout % 96 == 0) ? 3 : 2;      // 96-channel tiles for C = 96 (no half-empty second tile)
+    a.co_tiles = aid_cdiv(p->Cout, 32 * cob);
     a.ci_tiles = aid_cdiv(p->Cin, 32);
     AID_REQUIRE((int64_t)p->B * p->S < 65536, "aid_conv2d_wgrad: too many (sample, split) pairs");
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)(a.co_tiles * a.ci_tiles), (unsigned)(p->B * p->S)), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)(a.co_tiles * a.ci_tiles), (unsigned)(p->B * p->S));
+    if (cob == 3) hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(WG_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, dim3(WG_THREADS), 0, (hipStream_t)stream, a);
     AID_CHECK_LAUNCH();
     return AID_OK;
 }

@@ -162,6 +162,12 @@ class WgradParams(C.Structure):
                 ("dilF", C.c_int), ("S", C.c_int), ("alpha", C.c_float)]
 
 
+class PackConvWeightParams(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("wpT", C.c_void_p), ("wpw", C.c_void_p), ("wpwT", C.c_void_p),
+                ("Cout", C.c_int), ("Cin", C.c_int), ("KH", C.c_int), ("KW", C.c_int),
+                ("Cin_pad", C.c_int), ("Cout_pad", C.c_int), ("Cin_padT", C.c_int), ("Cout_padT", C.c_int)]
+
+
 class WgradReduceParams(C.Structure):
     _fields_ = [("P", C.c_void_p), ("W", C.c_void_p), ("gate", C.c_void_p), ("gate_ld", C.c_int64),
                 ("in_scale", C.c_void_p), ("in_scale_ld", C.c_int64), ("dW", C.c_void_p), ("dgate", C.c_void_p), ("dgate_ld", C.c_int64),
@@ -206,7 +212,7 @@ class SumsqParams(C.Structure):
 
 AID_SUMSQ_BLOCKS = 512
 
-EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_stats", "aid_conv2d", "aid_conv2d_pack_dims", "aid_conv2d_stat_partials", "aid_resample",
+EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_stats", "aid_conv2d", "aid_conv2d_pack_dims", "aid_conv2d_stat_partials", "aid_pack_conv_weight", "aid_resample",
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
@@ -241,7 +247,7 @@ def lib():
             if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials"):
                 getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, name).restype = C.c_int
-        if L.aid_abi_version() != 4:
+        if L.aid_abi_version() != 5:
             raise AidError("ABI version mismatch")
         _lib = L
     return _lib

@@ -568,3 +568,65 @@ extern "C" int aid_sumsq(const aid_sumsq_params* p, void* stream) {
     AID_CHECK_LAUNCH();
     return AID_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// aid_pack_conv_weight: one launch writes every kernel-side layout of one conv weight [Cout,Cin,KH,KW]: the tap-major pack
+// wp[KH*KW][Cin_pad][Cout_pad], its input-gradient operator (taps flipped, channel roles swapped) wpT, and for 5x3 layers the F(4,3) packs
+// U = G w (fp64 arithmetic, rounded once) of both.  Replaces ~30 torch launches per layer after every optimiser step.
+__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const aid_pack_conv_weight_params p) {
+    const int K = p.KH * p.KW;
+    const int64_t n0 = (int64_t)K * p.Cin_pad * p.Cout_pad, n1 = p.wpT ? (int64_t)K * p.Cin_padT * p.Cout_padT : 0;
+    const int64_t n2 = p.wpw ? (int64_t)30 * p.Cin_pad * p.Cout_pad : 0, n3 = p.wpwT ? (int64_t)30 * p.Cin_padT * p.Cout_padT : 0;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n0 + n1 + n2 + n3) return;
+    int mode = 0;
+    if (i >= n0) { i -= n0; mode = 1; if (i >= n1) { i -= n1; mode = 2; if (i >= n2) { i -= n2; mode = 3; } } }
+    const bool tr = mode & 1;
+    const int cip = tr ? p.Cin_padT : p.Cin_pad, cop = tr ? p.Cout_padT : p.Cout_pad;
+    const int co = (int)(i % cop);                          // output channel of THIS operator (transposed: the layer's input channel)
+    const int ci = (int)((i / cop) % cip);
+    const int t = (int)(i / ((int64_t)cop * cip));
+    const int nci = tr ? p.Cout : p.Cin, nco = tr ? p.Cin : p.Cout;
+    float v = 0.f;
+    if (ci < nci && co < nco) {
+        auto W = [&](int kh, int kw) {                      // operator weight [co][ci][kh][kw]; transposed: w[ci][co][KH-1-kh][KW-1-kw]
+            const int o = tr ? ci : co, c = tr ? co : ci;
+            const int a = tr ? p.KH - 1 - kh : kh, b = tr ? p.KW - 1 - kw : kw;
+            return p.w[(((int64_t)o * p.Cin + c) * p.KH + a) * p.KW + b];
+        };
+        if (mode < 2) {
+            v = W(t / p.KW, t % p.KW);
+        } else {                                            // tap = xi * 5 + kh
+            const int xi = t / 5, kh = t - 5 * xi;
+            const double w0 = (double)W(kh, 0), w1 = (double)W(kh, 1), w2 = (double)W(kh, 2);
+            double u;
+            switch (xi) {
+                case 0: u = w0 / 4; break;
+                case 1: u = -(w0 + w1 + w2) / 6; break;
+                case 2: u = -(w0 - w1 + w2) / 6; break;
+                case 3: u = (w0 + 2 * w1 + 4 * w2) / 24; break;
+                case 4: u = (w0 - 2 * w1 + 4 * w2) / 24; break;
+                default: u = w2;
+            }
+            v = (float)u;
+        }
+    }
+    float* out = mode == 0 ? p.wp : (mode == 1 ? p.wpT : (mode == 2 ? p.wpw : p.wpwT));
+    out[i] = v;
+}
+
+extern "C" int aid_pack_conv_weight(const aid_pack_conv_weight_params* p, void* stream) {
+    AID_REQUIRE(p && p->w && p->wp, "aid_pack_conv_weight: null pointer");
+    AID_REQUIRE(p->Cin > 0 && p->Cout > 0 && p->KH >= 1 && p->KW >= 1, "aid_pack_conv_weight: bad shape");
+    int cip, cop, cipT, copT;
+    aid_conv2d_pack_dims(p->Cin, p->Cout, &cip, &cop);
+    aid_conv2d_pack_dims(p->Cout, p->Cin, &cipT, &copT);
+    AID_REQUIRE(p->Cin_pad == cip && p->Cout_pad == cop && (!p->wpT || (p->Cin_padT == cipT && p->Cout_padT == copT)), "aid_pack_conv_weight: padded dims != aid_conv2d_pack_dims()");
+    AID_REQUIRE((!p->wpw && !p->wpwT) || (p->KH == 5 && p->KW == 3), "aid_pack_conv_weight: the F(4,3) packs are for 5x3 layers");
+    AID_REQUIRE(!p->wpwT || p->wpT, "aid_pack_conv_weight: wpwT needs wpT's dims");
+    const int K = p->KH * p->KW;
+    const int64_t n = (int64_t)K * cip * cop + (p->wpT ? (int64_t)K * cipT * copT : 0) + (p->wpw ? (int64_t)30 * cip * cop : 0) + (p->wpwT ? (int64_t)30 * cipT * copT : 0);
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}

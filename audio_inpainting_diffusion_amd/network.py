@@ -638,15 +638,29 @@ class Unet_CQT_oct_with_attention(nn.Module):
                 self._packed[key] = t.clone()
                 self._states.clear()             # cached launch plans hold raw pointers into the replaced pack
 
+        def ensure(key, shape):
+            t = self._packed.get(key)
+            if t is None or tuple(t.shape) != tuple(shape) or t.device != dev:
+                t = self._packed[key] = torch.empty(*shape, device=dev, dtype=torch.float32)
+                self._states.clear()
+            return t
+
         sd = dict(self.named_parameters())
         for name, w in sd.items():
             leaf = name.rsplit(".", 1)[-1]
             if leaf == "weight" and w.dim() >= 3:                       # conv weights (2-D ones are Linears)
-                put(name, _lib.pack_conv_weight(w))
-                put(name + "#T", _lib.pack_conv_weight(w, transpose=True))
-                if w.dim() == 4 and tuple(w.shape[2:]) == (5, 3) and w.shape[0] >= 64 and w.shape[1] >= 64:
-                    put(name + "#W", _lib.pack_conv_weight_wino(w))                 # Winograd F(4,3) packs
-                    put(name + "#WT", _lib.pack_conv_weight_wino(w, transpose=True))
+                wd = w.detach()
+                co, ci = wd.shape[0], wd.shape[1]
+                kh, kw = (wd.shape[2], wd.shape[3]) if wd.dim() == 4 else (1, wd.shape[2])
+                wino = wd.dim() == 4 and (kh, kw) == (5, 3) and co >= 64 and ci >= 64       # Winograd F(4,3) packs
+                if wd.dtype != torch.float32 or not wd.is_contiguous():
+                    wd = wd.float().contiguous()
+                (cip, cop), (cipT, copT) = _lib.pack_dims(ci, co), _lib.pack_dims(co, ci)
+                bufs = [ensure(name, (kh * kw, cip, cop)), ensure(name + "#T", (kh * kw, cipT, copT)),
+                        ensure(name + "#W", (30, cip, cop)) if wino else None, ensure(name + "#WT", (30, cipT, copT)) if wino else None]
+                pp = _lib.PackConvWeightParams(wd.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr(), _lib.ptr(bufs[2]), _lib.ptr(bufs[3]),
+                                               co, ci, kh, kw, cip, cop, cipT, copT)
+                _lib.call("aid_pack_conv_weight", pp)       # all layouts of this weight in one launch (same values as _lib.pack_conv_weight*)
             elif leaf == "gamma":
                 put(name, w.detach().reshape(-1).float())
         # stacked modulation matrix: [affine2, gate2]? then per step [affine.k, gate.k], block after block

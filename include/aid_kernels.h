@@ -28,7 +28,7 @@ extern "C" {
 #define AID_E_BADARG (-1)   /* unsupported shape / null pointer / misaligned stride */
 #define AID_E_LAUNCH (-2)   /* hipLaunchKernel reported an error                    */
 
-#define AID_ABI_VERSION 4
+#define AID_ABI_VERSION 5
 int aid_abi_version(void);
 /* last HIP error string seen by a launcher in this process (never NULL) */
 const char* aid_last_error(void);
@@ -452,6 +452,19 @@ typedef struct {
     float alpha;
 } aid_conv2d_wgrad_params;
 int aid_conv2d_wgrad(const aid_conv2d_wgrad_params* p, void* stream);
+
+/* aid_pack_conv_weight: every kernel-side layout of one conv weight in one launch (replaces the torch pack ops of
+ * network.prepare() after each optimiser step; Conv2d weights of unet...py:79-88 in the state_dict's own layout [Cout,Cin,KH,KW]).
+ *   wp  [KH*KW][Cin_pad][Cout_pad]         wp[t][ci][co] = w[co][ci][kh][kw], t = kh*KW + kw, zero padded
+ *   wpT [KH*KW][Cin_padT][Cout_padT]       the input-gradient operator: taps flipped, channel roles swapped (pack dims of (Cout, Cin)); NULL: skip
+ *   wpw / wpwT [30][...]                   F(4,3) packs U = G w of both (5x3 only; fp64 arithmetic, rounded once); NULL: skip */
+typedef struct {
+    const float* w;
+    float* wp; float* wpT; float* wpw; float* wpwT;
+    int Cout, Cin, KH, KW;
+    int Cin_pad, Cout_pad, Cin_padT, Cout_padT;
+} aid_pack_conv_weight_params;
+int aid_pack_conv_weight(const aid_pack_conv_weight_params* p, void* stream);
 
 typedef struct {
     const float* P; const float* W;

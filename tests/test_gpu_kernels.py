@@ -633,3 +633,21 @@ def test_group_stats_from_conv_epilogue(L, case):
     assert rel_l2(out[0][0], out[1][0]) < 1e-6
     assert float((out[0][1][..., 0] - out[1][1][..., 0]).abs().max()) < 1e-6 * float(out[1][1][..., 0].abs().max() + 1)
     assert rel_l2(out[0][1][..., 1], out[1][1][..., 1]) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 5, 3), (96, 128, 5, 3), (2, 96, 5, 3), (256, 40, 1, 1), (192, 96, 1, 3)])
+def test_pack_conv_weight_kernel_matches_the_torch_packs(L, shape):
+    """aid_pack_conv_weight: the tap-major pack, its input-gradient operator and (5x3) both F(4,3) packs in one launch, bit-identical to
+    _lib.pack_conv_weight / pack_conv_weight_wino."""
+    co, ci, kh, kw = shape
+    w = _rand(co, ci, kh, kw, seed=97).to(DEV)
+    wino = (kh, kw) == (5, 3) and co >= 64 and ci >= 64
+    (cip, cop), (cipT, copT) = L.pack_dims(ci, co), L.pack_dims(co, ci)
+    outs = [torch.full((kh * kw, cip, cop), float("nan"), device=DEV), torch.full((kh * kw, cipT, copT), float("nan"), device=DEV),
+            torch.full((30, cip, cop), float("nan"), device=DEV) if wino else None, torch.full((30, cipT, copT), float("nan"), device=DEV) if wino else None]
+    p = L.PackConvWeightParams(w.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), L.ptr(outs[2]), L.ptr(outs[3]), co, ci, kh, kw, cip, cop, cipT, copT)
+    L.call("aid_pack_conv_weight", p)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], L.pack_conv_weight(w)) and torch.equal(outs[1], L.pack_conv_weight(w, transpose=True))
+    if wino:
+        assert torch.equal(outs[2], L.pack_conv_weight_wino(w)) and torch.equal(outs[3], L.pack_conv_weight_wino(w, transpose=True))

@@ -172,7 +172,7 @@ def main():
     dev = torch.device("cuda", local)
     T, gap_def, B_def = {"maestro22k": (36, 300.0, 8), "librispeech16k": (70, 50.0, 16), "musicnet44k": (128, 1500.0, 4)}[a.workload]
     gap_ms = a.gap_ms or gap_def
-    assert a.warmup + a.steps <= T - 1, "timed steps must be Heun steps (the last step of the schedule is Euler)"
+    assert a.warmup >= 0 and a.steps >= 1
     args = make_args(a.workload, audio_len=184184, T=T, gap_ms=gap_ms, xi=a.xi)
     L, B = args.exp.audio_len, (a.batch or B_def)
 
@@ -204,9 +204,22 @@ def main():
         mask = mask_from_args(args, generator=torch.Generator().manual_seed(99))     # tester_inpainting.py:231-254
         smp.setup_inpainting((y * mask).to(dev), mask)
 
+    # Every timed step is a Heun step (2 evaluations; the last step of a schedule is Euler): positions 0 .. T-4 of the schedule are walked,
+    # and when --warmup + --steps exceed them the sampler starts the next batch's trajectory (smp.begin) inside the run, as a job over many
+    # batches of segments does.  Two positions stay in reserve for the single-stream roofline pass.
+    span = T - 3
     state = smp.begin((B, L), dev)
+
+    def do_step(i):
+        nonlocal state
+        j = i % span
+        if j == 0 and i > 0:
+            state = smp.begin((B, L), dev)
+        smp.step(state, j)
+        return j
+
     for i in range(a.warmup):
-        smp.step(state, i)
+        do_step(i)
     n_split = net._n_split(B)
     timing = []
     graphs = bool(net.use_graphs and B <= net.GRAPH_MAX_B and n_split == 1)     # small batches replay a captured HIP graph
@@ -217,8 +230,9 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     t0 = time.perf_counter()
+    jlast = 0
     for i in range(a.warmup, a.warmup + a.steps):
-        smp.step(state, i)
+        jlast = do_step(i)
     torch.cuda.synchronize()
     D.barrier()
     wall = time.perf_counter() - t0
@@ -232,16 +246,16 @@ def main():
         # launch's start-to-end time in the timed region is not the kernel's speed.  Kernel speeds are measured right after
         # it: the SAME sampler continues for one warm-up and one measured Heun step with the network forced onto one stream.
         roofline_pass = ("separate single-stream pass of eager launches: 1 warm-up + 1 measured Heun step (steps %d, %d of the same run) right after "
-                         "the timed region, %s" % (a.warmup + a.steps, a.warmup + a.steps + 1,
+                         "the timed region, %s" % (jlast + 1, jlast + 2,
                                                     "which replays a captured HIP graph per evaluation" if graphs else "whose %d sub-batch streams overlap kernels" % n_split))
-        assert a.warmup + a.steps + 2 <= T - 1
+        assert jlast + 2 <= T - 2
         net.split_streams = 1
-        smp.step(state, a.warmup + a.steps)
+        smp.step(state, jlast + 1)
         for pl in net.timed_plans(B, a.xi > 0):
             pl.timing = timing
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        smp.step(state, a.warmup + a.steps + 1)
+        smp.step(state, jlast + 2)
         torch.cuda.synchronize()
         wall_serial = time.perf_counter() - t1
         for pl in net.timed_plans(B, a.xi > 0):
@@ -274,7 +288,8 @@ def main():
             "config": {"workload": {"maestro22k": "BASELINE.json configs[1]: batch %d x 22.05 kHz MAESTRO-shape segments (L=184184) per GPU, %g ms gap, ",
                                     "librispeech16k": "BASELINE.json configs[3]: batch %d x 16 kHz LibriSpeech-shape segments (L=184184) per GPU, 4 gaps of %g ms, ",
                                     "musicnet44k": "BASELINE.json configs[4]: batch %d x 44.1 kHz segments (L=184184) per GPU, 8-octave network, %g ms gap, "}[a.workload] % (B, gap_ms)
-                                   + "T=%d EDM schedule, Heun steps %d..%d" % (T, a.warmup, a.warmup + a.steps - 1)
+                                   + "T=%d EDM schedule, Heun steps %d..%d%s" % (T, a.warmup, a.warmup + a.steps - 1,
+                                                                                  "" if a.warmup + a.steps <= T - 3 else " (positions wrap at %d: the next batch's trajectory starts inside the run)" % (T - 3))
                                    + ("; STFT-domain mask (spectrogram inpainting)" if a.task == "spectrogram" else ""),
                        "branch": "xi=%g (%s)" % (a.xi, "reconstruction guidance: forward + input-VJP" if a.xi > 0 else "replacement / data-consistency: forward only"),
                        "segments_per_gpu": B, "evals_per_step": 2,

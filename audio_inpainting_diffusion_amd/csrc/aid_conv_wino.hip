@@ -677,7 +677,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
 struct ConvWinoRDev {
     aid_conv2d_params p;
     const float* zero;
-    int nchunks, quads, ttiles, ny, per_xcd, ntiles, rgroups, tpw;   // tpw: consecutive tiles per workgroup; per_xcd counts workgroups
+    int nchunks, quads, ttiles, ny, per_xcd, ntiles, rgroups;
     int m_base, m_stride;      // Cout tile `by` starts at m_base + by * m_stride
     int dot_all, dot_base;     // 96-channel layers (two launches): every launch writes all eight groups of its own partial slots
 };
@@ -710,7 +710,6 @@ __global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDe
     __shared__ __attribute__((aligned(16))) float sbuf0[BUFSZ];
     __shared__ __attribute__((aligned(16))) float sbuf1[BUFSZ];
     __shared__ __attribute__((aligned(16))) float sbuf2[NBUF == 3 ? BUFSZ : 4];
-    __shared__ float redbuf[NW * 16];                    // per-tile partial sums of the dot / statistics options
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -718,28 +717,24 @@ __global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDe
     const int wm = wave / WGN, wn = wave % WGN;
     const int half = lane >> 5;
 
-    // XCD-aware logical tiles (see conv53_wino4v_kernel); order: Cout tile fastest, then t tile, quad, residue-class group, sample.
-    // A workgroup walks a.tpw CONSECUTIVE tiles: the first two chunks of the next tile are requested before the epilogue of the finished
-    // one, so a tile's prologue (descriptor set-up, first-chunk latency) runs under the previous tile's epilogue traffic.
-    const int Lt0 = ((blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3)) * a.tpw;
-    if (Lt0 >= a.ntiles) return;
-    const int ntl = min(a.tpw, a.ntiles - Lt0);
-    const int nrow = p.F / p.dilF;                       // rows of one residue class
-    int tile_t, q, rg, b, res, t0, m0, j0;               // the tile being staged / multiplied
-    const float* psrc[PPW];
-    int pstride[PPW], plds[PPW];
-    auto setup_tile = [&](int Lt) {
+    // XCD-aware logical tile (see conv53_wino4v_kernel); order: Cout tile fastest, then t tile, quad, residue-class group, sample
+    const int Lt = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+    if (Lt >= a.ntiles) return;
     int rest = Lt;
     const int by = rest % a.ny; rest /= a.ny;
-    tile_t = rest % a.ttiles; rest /= a.ttiles;
-    q = rest % a.quads; rest /= a.quads;
-    rg = rest % a.rgroups;
-    b = rest / a.rgroups;
-    res = rg * NC;                                       // first residue class of this tile
-    t0 = tile_t * TT;
-    m0 = a.m_base + by * a.m_stride;
-    j0 = q * RA;                                         // first sub-lattice row of this tile
+    const int tile_t = rest % a.ttiles; rest /= a.ttiles;
+    const int q = rest % a.quads; rest /= a.quads;
+    const int rg = rest % a.rgroups;
+    const int b = rest / a.rgroups;
+    const int res = rg * NC;                             // first residue class of this tile
+    const int t0 = tile_t * TT;
+    const int m0 = a.m_base + by * a.m_stride;
+    const int nrow = p.F / p.dilF;                       // rows of one residue class
+    const int j0 = q * RA;                               // first sub-lattice row of this tile
+
     // ---- DMA piece descriptors ---------------------------------------------------------------------------------------------
+    const float* psrc[PPW];
+    int pstride[PPW], plds[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int pc = wave + i * NW;
@@ -766,8 +761,6 @@ __global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDe
             }
         }
     }
-    };
-    setup_tile(Lt0);
     // ---- operand addresses: lane's group g of this wave's 32 -> output row j = g / GPR, group tau = g % GPR -------------------------
     const int g = wn * 32 + (lane & 31);
     const int rl = g / GPR, tau = g % GPR;               // row of the tile: class rl / RA, sub-lattice row rl % RA
@@ -776,6 +769,10 @@ __global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDe
     const int vA = XSZ + half * WROW + wm * 32 + (lane & 31);
 
     f32x16 acc[NXI];
+#pragma unroll
+    for (int x = 0; x < NXI; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
     const int mine = (wave + (PPW - 1) * NW < NP) ? PPW : PPW - 1;
     auto issue_piece = [&](auto ic, int ch, float* buf) {
@@ -795,6 +792,8 @@ __global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDe
 
     issue_all(0, sbuf0);
     if (NBUF == 3 && a.nchunks > 1) issue_all(1, sbuf1);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
 
     auto chunk = [&](auto curc, int ch) {
         constexpr int cur = decltype(curc)::value;
@@ -830,13 +829,6 @@ __global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDe
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    for (int it = 0; it < ntl; ++it) {
-#pragma unroll
-    for (int x = 0; x < NXI; ++x)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
-    __builtin_amdgcn_s_waitcnt(0);                       // this tile's first chunk(s) (and the previous tile's stores)
-    __syncthreads();
     if (NBUF == 3) {
         for (int ch = 0; ch < a.nchunks; ch += 3) {
             chunk(std::integral_constant<int, 0>{}, ch);
@@ -850,15 +842,6 @@ __global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDe
         }
     }
 
-    // ---- the finished tile's coordinates; then the next tile's descriptors and first chunks (all LDS buffers are free after the K loop's
-    //      last barrier), so that they are in flight during the epilogue below ------------------------------------------------------------
-    const int e_b = b, e_res = res, e_rg = rg, e_q = q, e_tile_t = tile_t, e_t0 = t0, e_m0 = m0, e_j0 = j0;
-    if (it + 1 < ntl) {
-        setup_tile(Lt0 + it + 1);
-        issue_all(0, sbuf0);
-        if (NBUF == 3 && a.nchunks > 1) issue_all(1, sbuf1);
-    }
-    [&](const int b, const int res, const int rg, const int q, const int tile_t, const int t0, const int m0, const int j0) {
     // ---- epilogue (as conv53_wino4v_kernel; this lane's output row: sub-lattice row j0 + jl) -----------------------------------------
     float dsum[4] = {0.f, 0.f, 0.f, 0.f};                // <y, aux> (dot_ws) or sum y (stat_ws) per block of 4 rows
     float qsum[4] = {0.f, 0.f, 0.f, 0.f};                // sum y^2 (stat_ws)
@@ -916,7 +899,7 @@ __global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDe
             for (int off = 16; off >= 1; off >>= 1) { v += __shfl_xor(v, off, 32); if (st) w += __shfl_xor(w, off, 32); }
             dsum[qq] = v; qsum[qq] = w;
         }
-        float* red = redbuf;
+        float* red = sbuf0;
         if ((lane & 31) == 0) {
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) { red[(wave * 2 + half) * 4 + qq] = dsum[qq]; red[NW * 8 + (wave * 2 + half) * 4 + qq] = qsum[qq]; }
@@ -941,8 +924,6 @@ __global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDe
             }
         }
     }
-    }(e_b, e_res, e_rg, e_q, e_tile_t, e_t0, e_m0, e_j0);
-    }   // tiles of this workgroup
 }
 
 template <int MT, int NTT, int WGM, int WGN, int RMAX, int KC, int MINW = 1>
@@ -1069,9 +1050,7 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
         a.dot_base = dot_base;
         dot_base += a.rgroups * g.quads * g.ttiles;
         a.ntiles = p->B * a.rgroups * g.quads * g.ttiles * a.ny;
-        { static int tpw_env = -1; if (tpw_env < 0) { const char* e = getenv("AID_W4R_TPW"); tpw_env = e ? atoi(e) : 0; }
-          a.tpw = tpw_env > 0 ? tpw_env : (a.ntiles >= 1024 ? 2 : 1); }
-        a.per_xcd = ((a.ntiles + a.tpw - 1) / a.tpw + 7) / 8;
+        a.per_xcd = (a.ntiles + 7) / 8;
         const dim3 grid((unsigned)(8 * a.per_xcd));
 #define AID_W4R(TTv, NCv, WGMv) hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv>), grid, dim3(256), 0, st, a)
         switch ((l * 128 + g.TT) * 16 + g.NC) {

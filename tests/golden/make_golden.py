@@ -45,6 +45,10 @@ def _setup_imports():
     os.makedirs(os.path.join(stub, "cqt_nsgt_pytorch"))
     with open(os.path.join(stub, "cqt_nsgt_pytorch", "__init__.py"), "w") as f:
         f.write("from oracle.nsgt_cqt import OracleCQT as CQT_nsgt\n")
+    # import-only stand-ins for the logging / audio packages training/trainer.py pulls in at import time (none is called by train_step / update_ema)
+    for mod in ("librosa", "wandb", "omegaconf", "soundfile", "plotly", "plotly/express", "plotly/graph_objects"):
+        os.makedirs(os.path.join(stub, mod), exist_ok=True)
+        open(os.path.join(stub, mod, "__init__.py"), "w").close()
     for p in (stub, REF, ROOT):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -140,6 +144,73 @@ def gen_unet_small(out):
                  shapes=np.array([repr(tuple(v.shape)) for v in net.state_dict().values()]))
         np.savez_compressed(os.path.join(out, f"unet_small_{tag}.npz"), **d)
         print(f"unet_small_{tag}.npz  y rms {float(y.pow(2).mean().sqrt()):.4g}  x rms {float(x.pow(2).mean().sqrt()):.4g}")
+
+
+def gen_training(out):
+    """Three iterations of the reference's own Trainer.train_step + update_ema (training/trainer.py:253-304) with its EDM.loss_fn
+    (diff_params/edm.py:166-193) and setup_optimizer's Adam (utils/setup.py:55-58) on the small reference network 'a' (its CQT = the oracle
+    CQT, as in every U-Net fixture): per-iteration loss, sigma, and the network / EMA parameters after the last iteration."""
+    import copy
+    import diff_params.edm as E
+    import networks.unet_cqt_oct_with_projattention_adaLN_2 as R
+    import training.trainer as TR
+    from audio_inpainting_diffusion_amd.config import small_args
+    from audio_inpainting_diffusion_amd.init import seeded_normal
+    kw = dict(num_octs=4, bins_per_oct=8, Ns=(8, 8, 16, 16), num_dils=(1, 2, 2, 3), attention=(0, 0, 1, 1, 1), audio_len=4096, fs=22050, emb_dim=32)
+    args = small_args(**kw)
+    hp = dict(lr=2e-3, lr_rampup_it=2, use_grad_clip=True, max_grad_norm=1.0, ema_rate=0.9, ema_rampup=8, batch=2, num_accumulation_rounds=1)
+    for k, v in hp.items():
+        setattr(args.exp, k, v)
+    args.exp.optimizer = dict(beta1=0.9, beta2=0.999, eps=1e-8)
+    args.logging = dict(log=False)
+    net = R.Unet_CQT_oct_with_attention(args, torch.device("cpu"))
+    _seed_module(net, 100 + ord("a"))
+    tr = TR.Trainer.__new__(TR.Trainer)
+    tr.args, tr.network, tr.ema, tr.it = args, net, copy.deepcopy(net), 0
+    tr.diff_params = E.EDM(args)
+    tr.optimizer = torch.optim.Adam(net.parameters(), lr=args.exp.lr, betas=(0.9, 0.999), eps=1e-8)        # = utils/setup.py::setup_optimizer
+    B, L = hp["batch"], kw["audio_len"]
+    d = dict(cfg=np.array(repr(kw)), hp=np.array(repr(hp)), seed=np.array(100 + ord("a")), n_it=np.array(3))
+    losses = []
+    for it in range(3):
+        audio = torch.from_numpy(seeded_normal(41, it, B * L)).reshape(B, L) * 0.063
+        tr.get_batch = lambda a_=audio: a_
+        torch.manual_seed(500 + it)                      # loss_fn draws sigma (torch.rand) and the noise (torch.randn) from the global CPU generator
+        tr.train_step()
+        tr.update_ema()
+        tr.it += 1
+        torch.manual_seed(500 + it)
+        with torch.no_grad():                            # the sigma that iteration drew (first draw after the seed)
+            d[f"sigma.{it}"] = tr.diff_params.sample_ptrain_safe(B).numpy()
+        d[f"lr.{it}"] = np.array(tr.optimizer.param_groups[0]["lr"])
+    # the loss of each iteration, recomputed from the recorded print is fragile: re-run the three iterations' losses deterministically instead
+    net2 = R.Unet_CQT_oct_with_attention(args, torch.device("cpu"))
+    _seed_module(net2, 100 + ord("a"))
+    tr2 = TR.Trainer.__new__(TR.Trainer)
+    tr2.args, tr2.network, tr2.ema, tr2.it = args, net2, copy.deepcopy(net2), 0
+    tr2.diff_params = tr.diff_params
+    tr2.optimizer = torch.optim.Adam(net2.parameters(), lr=args.exp.lr, betas=(0.9, 0.999), eps=1e-8)
+    for it in range(3):
+        audio = torch.from_numpy(seeded_normal(41, it, B * L)).reshape(B, L) * 0.063
+        torch.manual_seed(500 + it)
+        with torch.no_grad():
+            err, sg = tr2.diff_params.loss_fn(net2, audio)
+        losses.append(float(err.mean()))
+        tr2.get_batch = lambda a_=audio: a_
+        torch.manual_seed(500 + it)
+        tr2.train_step()
+        tr2.update_ema()
+        tr2.it += 1
+    d["loss"] = np.array(losses)
+    sd, esd, sd2 = net.state_dict(), tr.ema.state_dict(), net2.state_dict()
+    assert all(torch.equal(sd[k], sd2[k]) for k in sd), "the reference loop is not deterministic"
+    for k in sd:
+        if k.endswith("RFF_freq") or k.endswith("kernel") or not sd[k].dtype.is_floating_point:
+            continue
+        d["p." + k] = sd[k].numpy()
+        d["ema." + k] = esd[k].numpy()
+    np.savez_compressed(os.path.join(out, "train_small.npz"), **d)
+    print("train_small.npz: losses", losses, "lr", [float(d[f"lr.{i}"]) for i in range(3)])
 
 
 def gen_edm(out):
@@ -310,7 +381,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     _setup_imports()
     torch.set_grad_enabled(True)
-    todo = a.only.split(",") if a.only else ["ops", "unet", "edm", "sampler", "spectral", "rid", "dc"] + (["full"] if a.full else [])
+    todo = a.only.split(",") if a.only else ["ops", "unet", "edm", "sampler", "spectral", "rid", "dc", "training"] + (["full"] if a.full else [])
     if "ops" in todo: gen_ops(HERE)
     if "unet" in todo: gen_unet_small(HERE)
     if "edm" in todo: gen_edm(HERE)
@@ -318,4 +389,5 @@ if __name__ == "__main__":
     if "spectral" in todo: gen_spectral(HERE)
     if "rid" in todo: gen_rid(HERE)
     if "dc" in todo: gen_dc(HERE)
+    if "training" in todo: gen_training(HERE)
     if "full" in todo: gen_full(HERE)

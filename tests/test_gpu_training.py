@@ -233,3 +233,36 @@ def test_reference_style_training_step_runs_unchanged():
     y = net(x, torch.tensor([[0.1]], device=DEV))
     gx = torch.autograd.grad(y.sum(), x)[0]
     assert torch.isfinite(gx).all() and all(p.grad is None or True for p in net.parameters())
+
+
+def test_three_iterations_vs_reference_trainer_golden():
+    """tests/golden/train_small.npz: three iterations of the REFERENCE's Trainer.train_step + update_ema (its EDM.loss_fn, setup_optimizer's
+    Adam, lr ramp-up, clipping, EMA) on the small network -- our all-HIP Trainer with the same hyper-parameters, segments, sigma and noise."""
+    from audio_inpainting_diffusion_amd.config import small_args
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    from audio_inpainting_diffusion_amd.training import Trainer
+    z = np.load(os.path.join(GOLDEN, "train_small.npz"))
+    kw, hp = ast.literal_eval(str(z["cfg"])), ast.literal_eval(str(z["hp"]))
+    args = small_args(**kw)
+    net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(DEV)), int(z["seed"]), gate_scale=10.0, affine_scale=10.0)
+    edm = EDM(args)
+    tr = Trainer(net, edm, lr=hp["lr"], lr_rampup_it=hp["lr_rampup_it"], use_grad_clip=hp["use_grad_clip"], max_grad_norm=hp["max_grad_norm"],
+                 ema_rate=hp["ema_rate"], ema_rampup=hp["ema_rampup"], batch=hp["batch"])
+    B, Ls = hp["batch"], kw["audio_len"]
+    for it in range(int(z["n_it"])):
+        audio = torch.from_numpy(seeded_normal(41, it, B * Ls)).reshape(B, Ls) * 0.063
+        torch.manual_seed(500 + it)                          # the reference's draws: sigma = f(torch.rand(B)), then noise = torch.randn(B, L) * sigma
+        sigma = edm.sample_ptrain_safe(B).unsqueeze(-1)
+        assert np.array_equal(sigma.reshape(-1).numpy(), z[f"sigma.{it}"])
+        noise = torch.randn(B, Ls) * sigma
+        loss = float(tr.train_step(audio.to(DEV), sigma, noise.to(DEV)))
+        assert abs(loss - float(z["loss"][it])) < 1e-4 * abs(float(z["loss"][it])), (it, loss, float(z["loss"][it]))
+    sd, ema = net.state_dict(), tr.ema_state_dict()
+    keys = [k[2:] for k in z.files if k.startswith("p.")]
+    num = math.sqrt(sum(float((sd[k].cpu() - torch.from_numpy(z["p." + k])).norm()) ** 2 for k in keys))
+    den = math.sqrt(sum(float(np.linalg.norm(z["p." + k])) ** 2 for k in keys))
+    nume = math.sqrt(sum(float((ema[k].cpu() - torch.from_numpy(z["ema." + k])).norm()) ** 2 for k in keys))
+    print(f"after 3 iterations vs the reference trainer: parameters rel-L2 = {num / den:.2e}, EMA rel-L2 = {nume / den:.2e}")
+    assert num / den < 1e-4 and nume / den < 1e-4

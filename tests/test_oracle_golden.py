@@ -180,3 +180,60 @@ def test_sampler_rid_debug_buffers():
     for name, r in zip(("out", "denoised", "grads", "grad_update", "pocs", "xt", "xt2", "t"), res):
         assert tuple(r.shape) == z[name].shape, name
         assert rel_l2(r, z[name]) < 1e-5, name
+
+
+def test_training_iterations_vs_reference_trainer():
+    """tests/golden/train_small.npz holds three iterations of the REFERENCE's Trainer.train_step + update_ema (training/trainer.py:253-304, its
+    EDM.loss_fn and setup_optimizer's Adam).  The same loop over the oracle network with our EDM restatement (sample_ptrain_safe, loss_fn) and
+    the reference's update rules restated here: sigma bit-identical, losses, parameters and EMA to fp32 op-order noise."""
+    from audio_inpainting_diffusion_amd.config import small_args
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
+    z = np.load(os.path.join(GOLDEN, "train_small.npz"))
+    kw, hp = ast.literal_eval(str(z["cfg"])), ast.literal_eval(str(z["hp"]))
+    args = small_args(**kw)
+    edm = EDM(args)
+    cqt = OracleCQT(kw["num_octs"], kw["bins_per_oct"], "oct", ("kaiser", 1), kw["fs"], kw["audio_len"])
+    orc = OU.OracleUnet(kw["num_octs"], kw["bins_per_oct"], cqt)
+    proto = _reference_shaped_state_dict(args, int(z["seed"]))
+    orc.load_state_dict(proto)
+    keys = list(orc.sd.keys())
+    params = [torch.nn.Parameter(orc.sd[k].clone()) for k in keys]
+    trainable = [p for k, p in zip(keys, params) if ("p." + k) in z.files]
+    opt = torch.optim.Adam(trainable, lr=hp["lr"], betas=(0.9, 0.999), eps=1e-8)
+    ema = {k: orc.sd[k].clone() for k in keys}
+    B, L = hp["batch"], kw["audio_len"]
+    for it in range(int(z["n_it"])):
+        audio = torch.from_numpy(seeded_normal(41, it, B * L)).reshape(B, L) * 0.063
+        orc.sd = {k: p for k, p in zip(keys, params)}
+        torch.manual_seed(500 + it)
+        opt.zero_grad()
+        err2, sigma = edm.loss_fn(orc, audio)
+        assert np.array_equal(sigma.reshape(-1).numpy(), z[f"sigma.{it}"])
+        loss = err2.mean()
+        assert abs(float(loss) - float(z["loss"][it])) < 2e-6 * abs(float(z["loss"][it]))
+        loss.backward()
+        if it <= hp["lr_rampup_it"]:
+            for g in opt.param_groups:
+                g["lr"] = hp["lr"] * min(it / max(hp["lr_rampup_it"], 1e-8), 1)
+        assert abs(opt.param_groups[0]["lr"] - float(z[f"lr.{it}"])) < 1e-12
+        torch.nn.utils.clip_grad_norm_(trainable, hp["max_grad_norm"])
+        opt.step()
+        t = it * hp["batch"]
+        s = float(np.clip(t / hp["ema_rampup"], 0.0, hp["ema_rate"])) if t < hp["ema_rampup"] else hp["ema_rate"]
+        with torch.no_grad():
+            for k, p in zip(keys, params):
+                if ("p." + k) in z.files:
+                    ema[k].copy_(ema[k] * s + p * (1 - s))
+    for k, p in zip(keys, params):
+        if ("p." + k) in z.files:
+            assert rel_l2(p.detach(), z["p." + k]) < 2e-5, k
+            assert rel_l2(ema[k], z["ema." + k]) < 2e-5, k
+
+
+def _reference_shaped_state_dict(args, seed):
+    """the seeded weights every U-Net fixture uses (make_golden.py::_seed_module): built on the parameter container of our module on the CPU"""
+    from audio_inpainting_diffusion_amd.init import seeded_init_
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    net = Unet_CQT_oct_with_attention(args, torch.device("cpu"))
+    return seeded_init_(net, seed, gate_scale=10.0, affine_scale=10.0).state_dict()

@@ -204,11 +204,19 @@ def gen_training(out):
     d["loss"] = np.array(losses)
     sd, esd, sd2 = net.state_dict(), tr.ema.state_dict(), net2.state_dict()
     assert all(torch.equal(sd[k], sd2[k]) for k in sd), "the reference loop is not deterministic"
-    for k in sd:
-        if k.endswith("RFF_freq") or k.endswith("kernel") or not sd[k].dtype.is_floating_point:
-            continue
-        d["p." + k] = sd[k].numpy()
-        d["ema." + k] = esd[k].numpy()
+    # Every trained tensor is pinned by four seeded random projections + its squared norm (fp64): <delta, probe> ~ N(0, |delta|^2), so the
+    # projections of a wrong tensor differ by about its error norm; tensors of <= 4096 elements are stored whole as well.  (The full set is 5 MB.)
+    from audio_inpainting_diffusion_amd.init import seeded_normal as _sn
+    names = [k for k in sd if not (k.endswith("RFF_freq") or k.endswith("kernel") or not sd[k].dtype.is_floating_point)]
+    d["names"] = np.array(names)
+    for i, k in enumerate(names):
+        n = sd[k].numel()
+        probes = np.stack([_sn(9000 + j, i, n) for j in range(4)]).astype(np.float64)
+        for tag, t in (("p", sd[k]), ("ema", esd[k])):
+            v = t.double().reshape(-1).numpy()
+            d[f"proj.{tag}.{k}"] = np.concatenate([probes @ v, [float(v @ v)]])
+            if n <= 4096:
+                d[f"{tag}.{k}"] = t.numpy()
     np.savez_compressed(os.path.join(out, "train_small.npz"), **d)
     print("train_small.npz: losses", losses, "lr", [float(d[f"lr.{i}"]) for i in range(3)])
 

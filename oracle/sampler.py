@@ -73,6 +73,14 @@ class OracleSampler:
     def get_score(self, x, t_i):
         B = x.shape[0]
         sig = t_i.reshape(1, 1).expand(B, 1)
+        if self.y is None:                                  # unconditional sampling (:115-125): denoise, DC/Nyquist projector, no projection
+            with torch.no_grad():
+                x_hat = self.edm.denoiser(x, self.model, sig)
+                if self.filter_hpf:
+                    x_hat = self.model.CQTransform.apply_hpf_DC(x_hat)
+            if self.trace is not None:
+                self.trace.append(x_hat.detach().clone())
+            return (x_hat - x) / t_i ** 2
         if self.xi > 0:
             x = x.detach().requires_grad_()
             x_hat = self.edm.denoiser(x, self.model, sig)
@@ -107,6 +115,12 @@ class OracleSampler:
         return torch.cat([torch.randn([1, shape[1]], generator=g) for g in gens], dim=0)
 
     # -- the loop (:178-262) -----------------------------------------------------------------------
+    def predict_unconditional(self, shape, seeds: Optional[List[int]] = None, record: bool = False):
+        """(:155-162) y = None, degradation = None"""
+        self.y = self.degradation = None
+        self._shape = tuple(shape)
+        return self._predict(seeds, record)
+
     def predict_inpainting(self, y_masked, mask, seeds: Optional[List[int]] = None, record: bool = False, rid: bool = False):
         self._want_rid = rid
         self.y, self.mask = y_masked, mask
@@ -128,7 +142,7 @@ class OracleSampler:
     def _predict(self, seeds, record):
         y_masked = self.y
         self.trace = [] if record else None
-        shape = y_masked.shape
+        shape = y_masked.shape if y_masked is not None else self._shape
         rid = getattr(self, "_want_rid", False)
         self._want_rid = False
         if rid:
@@ -162,7 +176,7 @@ class OracleSampler:
                 x = x + h * d
             if rid:
                 R["xt2"][i] = x
-        if self.data_consistency_end:                                                       # (:252)
+        if self.data_consistency_end and self.y is not None:                                # (:252)
             x = self.project(x)
         if rid:                                                                             # (:260)
             return x.detach(), R["denoised"], R["grads"], R["grad_update"], R["pocs"], R["xt"], R["xt2"], t

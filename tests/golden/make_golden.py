@@ -283,6 +283,25 @@ def gen_sampler(out):
     np.savez_compressed(os.path.join(out, "sampler_toy.npz"), **d)
 
 
+def gen_uncond(out):
+    """predict_unconditional (edm_sampler_inpainting.py:155-162, :115-125) on the toy denoiser: B = 1 and B = 2, with and without the DC/Nyquist projector."""
+    import diff_params.edm as E
+    import testing.edm_sampler_inpainting as S
+    from audio_inpainting_diffusion_amd.config import make_args
+    L, T = 2048, 5
+    d = {"L": np.array(L), "T": np.array(T)}
+    net = _ToyNet(L)
+    for tag, B, hpf, seed in (("u_b1", 1, True, 3), ("u_b2", 2, True, 4), ("u_b2_nohpf", 2, False, 5)):
+        args = make_args(audio_len=L, T=T, xi=0.25)
+        args.tester.filter_out_cqt_DC_Nyq = hpf
+        smp = S.Sampler(model=net, diff_params=E.EDM(args), args=args, rid=False)
+        torch.manual_seed(seed)
+        x = smp.predict_unconditional((B, L), torch.device("cpu"))
+        d[f"{tag}.out"], d[f"{tag}.meta"] = x.numpy(), np.array([B, int(hpf), seed], dtype=np.float64)
+        print("uncond", tag, "out rms", float(x.pow(2).mean().sqrt()))
+    np.savez_compressed(os.path.join(out, "sampler_uncond.npz"), **d)
+
+
 def gen_dc(out):
     """data_consistency.type variants of the reference sampler (edm_sampler_inpainting.py:22-24, :100, :141-147, :252):
     'end' projects only after the loop on the guided branch, but the replacement branch (xi = 0) projects at EVERY
@@ -389,7 +408,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     _setup_imports()
     torch.set_grad_enabled(True)
-    todo = a.only.split(",") if a.only else ["ops", "unet", "edm", "sampler", "spectral", "rid", "dc", "training"] + (["full"] if a.full else [])
+    todo = a.only.split(",") if a.only else ["ops", "unet", "edm", "sampler", "spectral", "rid", "dc", "training", "uncond"] + (["full"] if a.full else [])
     if "ops" in todo: gen_ops(HERE)
     if "unet" in todo: gen_unet_small(HERE)
     if "edm" in todo: gen_edm(HERE)
@@ -398,4 +417,5 @@ if __name__ == "__main__":
     if "rid" in todo: gen_rid(HERE)
     if "dc" in todo: gen_dc(HERE)
     if "training" in todo: gen_training(HERE)
+    if "uncond" in todo: gen_uncond(HERE)
     if "full" in todo: gen_full(HERE)

@@ -135,26 +135,10 @@ def test_unconditional_sampling_vs_oracle():
     smp = Sampler(model=net, diff_params=EDM(args), args=args)
     smp.seeds, smp.trace = [3, 4], []
     out = smp.predict_unconditional((2, Ls), torch.device(DEV))
-    # oracle: same loop, y = None
-    orc, edm = _oracle_for(net, kw), OracleEDM()
-    gens = [torch.Generator().manual_seed(s) for s in (3, 4)]
-    rn = lambda: torch.cat([torch.randn([1, Ls], generator=g) for g in gens])
-    t = edm.create_schedule(3)
-    gamma = edm.get_gamma(t)
-    x = rn() * t[0]
-    den = lambda xx, s: orc.CQTransform.apply_hpf_DC(edm.denoiser(xx, orc, s.reshape(1, 1).expand(2, 1)))
-    with torch.no_grad():
-        for i in range(3):
-            t_hat = t[i] + gamma[i] * t[i]
-            x = x + ((t_hat ** 2 - t[i] ** 2) ** 0.5) * rn()
-            d = -t_hat * ((den(x, t_hat) - x) / t_hat ** 2)
-            h = t[i + 1] - t_hat
-            if t[i + 1] != 0:
-                xp = x + h * d
-                dp = -t[i + 1] * ((den(xp, t[i + 1]) - xp) / t[i + 1] ** 2)
-                x = x + h * (0.5 * d + 0.5 * dp)
-            else:
-                x = x + h * d
+    # oracle: OracleSampler.predict_unconditional, pinned to the reference by tests/golden/sampler_uncond.npz
+    from oracle.sampler import OracleSampler
+    osmp = OracleSampler(_oracle_for(net, kw), OracleEDM(), T=3, xi=0.0, audio_len=Ls)
+    x = osmp.predict_unconditional((2, Ls), seeds=[3, 4])
     e = rel_l2(out.cpu(), x)
     print(f"unconditional sampler (3 steps): rel-L2 vs oracle = {e:.3e}")
     assert e < 5e-4

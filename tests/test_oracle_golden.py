@@ -117,6 +117,18 @@ def test_sampler_trajectories(tag):
     assert rel_l2(out, z[tag + ".out"]) < 1e-5
 
 
+@pytest.mark.parametrize("tag", ["u_b1", "u_b2", "u_b2_nohpf"])
+def test_unconditional_sampling_matches_reference(tag):
+    """predict_unconditional (edm_sampler_inpainting.py:155-162): no observations, no projection, optional DC/Nyquist projector (:121-122)."""
+    z = np.load(os.path.join(GOLDEN, "sampler_uncond.npz"))
+    L, T = int(z["L"]), int(z["T"])
+    B, hpf, seed = z[tag + ".meta"]
+    s = OracleSampler(_Toy(L), OracleEDM(), T=T, xi=0.25, filter_out_cqt_DC_Nyq=bool(hpf), audio_len=L)
+    torch.manual_seed(int(seed))
+    out = s.predict_unconditional((int(B), L))
+    assert rel_l2(out, z[tag + ".out"]) < 1e-5
+
+
 @pytest.mark.parametrize("tag", ["g_end", "r_end", "g_always"])
 def test_sampler_data_consistency_types_match_reference(tag):
     """data_consistency.type 'end' vs 'always' (edm_sampler_inpainting.py:22-24): the guided branch projects per

@@ -159,7 +159,11 @@ class StftParams(C.Structure):
 class WgradParams(C.Structure):
     _fields_ = [("gy", View), ("x", View), ("P", C.c_void_p),
                 ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("F", C.c_int), ("T", C.c_int), ("KH", C.c_int), ("KW", C.c_int),
-                ("dilF", C.c_int), ("S", C.c_int), ("alpha", C.c_float)]
+                ("dilF", C.c_int), ("S", C.c_int), ("alpha", C.c_float), ("wino", C.c_int)]
+
+
+class WinoGyParams(C.Structure):
+    _fields_ = [("gy", View), ("out", View), ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int)]
 
 
 class PackConvWeightParams(C.Structure):
@@ -171,7 +175,8 @@ class PackConvWeightParams(C.Structure):
 class WgradReduceParams(C.Structure):
     _fields_ = [("P", C.c_void_p), ("W", C.c_void_p), ("gate", C.c_void_p), ("gate_ld", C.c_int64),
                 ("in_scale", C.c_void_p), ("in_scale_ld", C.c_int64), ("dW", C.c_void_p), ("dgate", C.c_void_p), ("dgate_ld", C.c_int64),
-                ("B", C.c_int), ("S", C.c_int), ("Cout", C.c_int), ("Cin", C.c_int), ("K", C.c_int), ("accumulate", C.c_int)]
+                ("B", C.c_int), ("S", C.c_int), ("Cout", C.c_int), ("Cin", C.c_int), ("K", C.c_int), ("accumulate", C.c_int),
+                ("wino", C.c_int), ("Uw", C.c_void_p), ("Cin_pad", C.c_int), ("Cout_pad", C.c_int)]
 
 
 class ChannelDotParams(C.Structure):
@@ -212,7 +217,7 @@ class SumsqParams(C.Structure):
 
 AID_SUMSQ_BLOCKS = 512
 
-EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_stats", "aid_conv2d", "aid_conv2d_pack_dims", "aid_conv2d_stat_partials", "aid_pack_conv_weight", "aid_resample",
+EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_stats", "aid_conv2d", "aid_conv2d_pack_dims", "aid_conv2d_stat_partials", "aid_pack_conv_weight", "aid_wino_gy", "aid_resample",
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
@@ -247,7 +252,7 @@ def lib():
             if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials"):
                 getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, name).restype = C.c_int
-        if L.aid_abi_version() != 5:
+        if L.aid_abi_version() != 6:
             raise AidError("ABI version mismatch")
         _lib = L
     return _lib

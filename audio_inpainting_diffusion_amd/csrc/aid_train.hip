@@ -197,6 +197,17 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const WgDev a
                     }
                 }
             }
+        } else if (ntaps == 1) {
+            // 1x1 layers: one tap, so the eight waves split the chunk's positions instead (k-steps wave, wave + 8, ...) and their accumulators
+            // are added in wave order after the last step
+            store_next();
+            const int b0 = ((n % NS) * 32 + l32) * WG_LDB + 1 + half;      // tap 0 for every wave (boff[] is per-wave taps)
+            for (int k = 2 * wave; k < tc; k += 2 * WG_NW) {
+                const float bvv = xT[b0 + k];
+#pragma unroll
+                for (int i = 0; i < COB; ++i)
+                    if (i < nco) acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[i * 32 * WG_LDA + k], bvv, acc[0][i], 0, 0, 0);
+            }
         } else {
             const int kmid = (tc >> 2) << 1;
             for (int k = 0; k < tc; k += 2) {
@@ -223,6 +234,24 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const WgDev a
         cur ^= 1;
         n = n2; res = res2; c = c2;
     }
+    if (ntaps == 1) {                                       // fixed-order sum of the eight waves' tiles through LDS (the staging arrays are free now)
+        float* red = xT;                                    // [wave][16][64] floats = 32 KB per output-channel block
+#pragma unroll
+        for (int i = 0; i < COB; ++i) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[0][i][r];
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = red[r * 64 + lane];
+                    for (int w = 1; w < WG_NW; ++w) v += red[(w * 16 + r) * 64 + lane];
+                    acc[0][i][r] = v;
+                }
+            }
+        }
+    }
     // ---- write the partials P[(b*S+s)][co][tap][ci] (ci fastest: every store instruction writes two full 128-byte lines) ---------------
     float* P = p.P + ((int64_t)(b * p.S + s) * ntaps) * p.Cout * p.Cin;
     const int ci = ci0 + l32;
@@ -240,6 +269,200 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const WgDev a
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Winograd F(4,3) form of the weight gradient (5x3 layers): with y = A^T[(G w) . (B^T d)] per group of four outputs,
+//   dL/dU[co,ci,kh,xi] = sum_{b,f,g} (A gy)[co,f,g,xi] * (B^T d)[ci,f+(kh-2)dil,g,xi],      dL/dw = G^T dL/dU   (aid_wgrad_reduce),
+// i.e. 6 products per 4 positions and tap row instead of 12: half the MFMAs of the direct form.  Both operands arrive in the Winograd
+// domain [.,.,F,6,T/4] (gy: aid_wino_gy, d: aid_scale_act(wino=1), so no halo samples); a step is one output row x 16 groups; the 30
+// (xi,kh) pairs of a layer are spread over the 8 waves (pairs wave, wave+8, wave+16, wave+24); staging, ring and step sequence as in
+// conv_wgrad_kernel.
+#define WW_G 16                  // groups (of 4 samples) per staged chunk
+#define WW_ROW (6 * WW_G + 1)    // one channel's [xi][g] block in LDS, padded to an odd length (conflict-free transposed fragment reads)
+#define WW_QPW 4                 // pairs per wave
+__global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_wino_kernel(const WgDev a) {
+    constexpr int COB = 2, WG_CO = 64, KH = 5, NS = KH + 1, NPAIR = 30;
+    const aid_conv2d_wgrad_params& p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = (blockIdx.x % a.co_tiles) * WG_CO;
+    const int ci0 = (blockIdx.x / a.co_tiles) * 32;
+    const int b = blockIdx.y / p.S, s = blockIdx.y - b * p.S;
+    const int nco = min(COB, (p.Cout - co0 + 31) / 32);
+    const int G = p.T >> 2;                               // groups per row
+
+    __shared__ float gyT0[WG_CO * WW_ROW + 8];
+    __shared__ float gyT1[WG_CO * WW_ROW + 8];
+    __shared__ float xT[NS * 32 * WW_ROW + 8];
+
+    f32x16 acc[WW_QPW][COB];
+#pragma unroll
+    for (int q = 0; q < WW_QPW; ++q)
+#pragma unroll
+        for (int i = 0; i < COB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][i][r] = 0.f;
+    int pkh[WW_QPW], pxi[WW_QPW];                         // pair = xi * 5 + kh (the Winograd pack's tap order)
+#pragma unroll
+    for (int q = 0; q < WW_QPW; ++q) { const int pr = min(wave + WG_NW * q, NPAIR - 1); pxi[q] = pr / KH; pkh[q] = pr - pxi[q] * KH; }
+
+    // staging shares: gy 64 channels x 6 planes x 4 float4 = 1536 float4 -> 3 per thread; one input row 32 x 24 = 768 float4 -> threads < 256 take 2
+    auto gy_src = [&](int e, int f, int g0) {             // e: float4 index inside the tile, [co][xi][4]
+        const int co = co0 + e / 24, r = e % 24, xi = r >> 2, q4 = r & 3;
+        const int g = g0 + 4 * q4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (co < p.Cout && g < G) v = *reinterpret_cast<const float4*>(p.gy.p + (int64_t)b * p.gy.sB + (int64_t)co * p.gy.sC + (int64_t)f * p.gy.sF + (int64_t)xi * G + g);
+        return v;
+    };
+    auto x_src = [&](int e, int fi, int g0) {
+        const int ci = ci0 + e / 24, r = e % 24, xi = r >> 2, q4 = r & 3;
+        const int g = g0 + 4 * q4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ci < p.Cin && fi >= 0 && fi < p.F && g < G) v = *reinterpret_cast<const float4*>(p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + (int64_t)xi * G + g);
+        return v;
+    };
+    auto lds_put = [&](float* base, int e, const float4& v) {  // [ch][xi][g16] with the odd channel pitch
+        const int ch = e / 24, r = e % 24;
+        float* d = base + ch * WW_ROW + (r >> 2) * WW_G + 4 * (r & 3);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    };
+    auto load_gy = [&](int f, int g0, float4 (&g)[3]) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) g[i] = gy_src(tid + WG_THREADS * i, f, g0);
+    };
+    auto store_gy = [&](float* gyT, const float4 (&g)[3]) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) lds_put(gyT, tid + WG_THREADS * i, g[i]);
+    };
+    auto load_row = [&](int fi, int g0, float4 (&x)[2]) {
+        x[0] = x_src(tid, fi, g0);
+        x[1] = (tid < 768 - WG_THREADS) ? x_src(tid + WG_THREADS, fi, g0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_row = [&](int slot, const float4 (&x)[2]) {
+        lds_put(xT + slot * 32 * WW_ROW, tid, x[0]);
+        if (tid < 768 - WG_THREADS) lds_put(xT + slot * 32 * WW_ROW, tid + WG_THREADS, x[1]);
+    };
+
+    const int dil = p.dilF;
+    const int nct = (G + WW_G - 1) / WW_G;
+    const int gc = (G < WW_G) ? ((G + 1) & ~1) : WW_G;         // groups walked per chunk (T = 32: 8)
+    const int qd = p.F / dil, rem = p.F - qd * dil;
+    const int64_t total = (int64_t)nct * p.F;
+    const int g_lo = (int)((total * s) / p.S), g_hi = (int)((total * (s + 1)) / p.S);
+    int c = g_lo / p.F, res, n;
+    {
+        const int r = g_lo - c * p.F;
+        if (r < rem * (qd + 1)) { res = r / (qd + 1); n = r - res * (qd + 1); }
+        else { const int r2 = r - rem * (qd + 1); res = rem + r2 / qd; n = r2 - (res - rem) * qd; }
+    }
+    float4 pg[3], px[2];
+    auto stage_chain_start = [&](int f, int g0, int n0) {
+        for (int kh = 0; kh < KH; ++kh) {
+            load_row(f + (kh - 2) * dil, g0, px);
+            store_row((n0 + kh) % NS, px);
+        }
+    };
+    if (g_lo < g_hi) {
+        load_gy(res + n * dil, c * WW_G, pg);
+        store_gy(gyT0, pg);
+        stage_chain_start(res + n * dil, c * WW_G, n);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int g = g_lo; g < g_hi; ++g) {
+        int n2 = n + 1, res2 = res, c2 = c;
+        if (n2 >= qd + (res < rem ? 1 : 0)) { n2 = 0; ++res2; if (res2 >= dil || res2 >= p.F) { res2 = 0; ++c2; } }
+        const bool have = g + 1 < g_hi;
+        const bool chain = n2 != 0;
+        const int f2 = res2 + n2 * dil;
+        if (have) {
+            load_gy(f2, c2 * WW_G, pg);
+            if (chain) load_row(f2 + (KH - 1 - 2) * dil, c2 * WW_G, px);
+        }
+        const float* gyT = cur ? gyT1 : gyT0;
+        float* gyN = cur ? gyT0 : gyT1;
+        // fragment bases: A = (A gy)[co = l32 (+32 i)][xi][g = 2 k + half], B = V[slot n + kh][ci = l32][xi][g = 2 k + half]
+        int aoff[WW_QPW], boff[WW_QPW];
+#pragma unroll
+        for (int q = 0; q < WW_QPW; ++q) {
+            aoff[q] = l32 * WW_ROW + pxi[q] * WW_G + half;
+            boff[q] = (((n + pkh[q]) % NS) * 32 + l32) * WW_ROW + pxi[q] * WW_G + half;
+        }
+        const int kmid = (gc >> 2) << 1;
+        for (int k = 0; k < gc; k += 2) {
+            if (k == kmid && have) {
+                store_gy(gyN, pg);
+                if (chain) store_row((n2 + KH - 1) % NS, px);
+            }
+            float av[WW_QPW][COB], bv[WW_QPW];
+#pragma unroll
+            for (int q = 0; q < WW_QPW; ++q) {
+                bv[q] = xT[boff[q] + k];
+#pragma unroll
+                for (int i = 0; i < COB; ++i) av[q][i] = (i < nco) ? gyT[aoff[q] + i * 32 * WW_ROW + k] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < WW_QPW; ++q)
+#pragma unroll
+                for (int i = 0; i < COB; ++i)
+                    if (i < nco) acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][i], bv[q], acc[q][i], 0, 0, 0);
+        }
+        __syncthreads();
+        if (have && !chain) {
+            stage_chain_start(f2, c2 * WW_G, n2);
+            __syncthreads();
+        }
+        cur ^= 1;
+        n = n2; res = res2; c = c2;
+    }
+    // ---- partials P[(b*S+s)][co][pair (30)][ci] -------------------------------------------------------------------------------------
+    float* P = p.P + ((int64_t)(b * p.S + s) * NPAIR) * p.Cout * p.Cin;
+    const int ci = ci0 + l32;
+#pragma unroll
+    for (int q = 0; q < WW_QPW; ++q) {
+        const int pr = wave + WG_NW * q;
+        if (pr >= NPAIR || ci >= p.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < COB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < p.Cout) P[((int64_t)co * NPAIR + pr) * p.Cin + ci] = p.alpha * acc[q][i][r];
+            }
+    }
+}
+
+// (A gy) per group of four samples: [B,C,F,T] -> [B,C,F,6,T/4]   (A = transpose of the F(4,3) output transform; no neighbour samples)
+__global__ __launch_bounds__(256) void wino_gy_kernel(const aid_wino_gy_params p) {
+    const int G = p.T >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)p.B * p.C * p.F * G) return;
+    const int g = (int)(i % G);
+    const int64_t row = i / G;
+    const int f = (int)(row % p.F);
+    const int64_t bc = row / p.F;
+    const int c = (int)(bc % p.C), b = (int)(bc / p.C);
+    const float4 v = *reinterpret_cast<const float4*>(p.gy.p + (int64_t)b * p.gy.sB + (int64_t)c * p.gy.sC + (int64_t)f * p.gy.sF + 4 * g);
+    float* o = p.out.p + (int64_t)b * p.out.sB + (int64_t)c * p.out.sC + (int64_t)f * p.out.sF + g;
+    const float s02 = v.x + v.z, s13 = v.y + v.w, s04 = v.x + 4.f * v.z, s28 = 2.f * v.y + 8.f * v.w;
+    o[0] = v.x;
+    o[G] = s02 + s13;
+    o[2 * G] = s02 - s13;
+    o[3 * G] = s04 + s28;
+    o[4 * G] = s04 - s28;
+    o[5 * G] = v.w;
+}
+
+extern "C" int aid_wino_gy(const aid_wino_gy_params* p, void* stream) {
+    AID_REQUIRE(p && p->gy.p && p->out.p, "aid_wino_gy: null pointer");
+    AID_REQUIRE(p->B > 0 && p->C > 0 && p->F > 0 && p->T > 0 && (p->T % 4) == 0, "aid_wino_gy: T % 4 == 0");
+    AID_REQUIRE(((p->gy.sB | p->gy.sC | p->gy.sF) & 3) == 0 && (((uintptr_t)p->gy.p) & 15) == 0, "aid_wino_gy: gy must be float4-addressable");
+    AID_REQUIRE(p->out.sF >= 6 * (p->T / 4), "aid_wino_gy: out rows are [6][T/4]");
+    const int64_t n = (int64_t)p->B * p->C * p->F * (p->T / 4);
+    hipLaunchKernelGGL(wino_gy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}
+
 extern "C" int aid_conv2d_wgrad(const aid_conv2d_wgrad_params* p, void* stream) {
     AID_REQUIRE(p && p->gy.p && p->x.p && p->P, "aid_conv2d_wgrad: null pointer");
     AID_REQUIRE(p->B > 0 && p->Cin > 0 && p->Cout > 0 && p->F > 0 && p->T > 0 && p->S >= 1 && p->S <= p->F, "aid_conv2d_wgrad: bad shape");
@@ -248,6 +471,18 @@ extern "C" int aid_conv2d_wgrad(const aid_conv2d_wgrad_params* p, void* stream) 
                 "aid_conv2d_wgrad: kernel sizes up to 5x3");
     WgDev a;
     a.p = *p;
+    if (p->wino) {
+        AID_REQUIRE(p->KH == 5 && p->KW == 3 && (p->T % 8) == 0 && p->dilF >= 1, "aid_conv2d_wgrad: the F(4,3) form is for 5x3 layers with T % 8 == 0");
+        AID_REQUIRE(p->gy.sF >= 6 * (p->T / 4) && p->x.sF >= 6 * (p->T / 4), "aid_conv2d_wgrad: wino operands have rows [6][T/4]");
+        AID_REQUIRE(((p->gy.sB | p->gy.sC | p->gy.sF | p->x.sB | p->x.sC | p->x.sF) & 3) == 0 && ((((uintptr_t)p->gy.p) | ((uintptr_t)p->x.p)) & 15) == 0 && (p->T % 16) == 0,
+                    "aid_conv2d_wgrad: wino operands must be float4-addressable (T % 16 == 0)");
+        a.co_tiles = aid_cdiv(p->Cout, 64);
+        a.ci_tiles = aid_cdiv(p->Cin, 32);
+        AID_REQUIRE((int64_t)p->B * p->S < 65536, "aid_conv2d_wgrad: too many (sample, split) pairs");
+        hipLaunchKernelGGL(conv_wgrad_wino_kernel, dim3((unsigned)(a.co_tiles * a.ci_tiles), (unsigned)(p->B * p->S)), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
+        AID_CHECK_LAUNCH();
+        return AID_OK;
+    }
     const int cob = (p->Cout % 64 != 0 && p->Cout % 96 == 0) ? 3 : 2;      // 96-channel tiles for C = 96 (no half-empty second tile)
     a.co_tiles = aid_cdiv(p->Cout, 32 * cob);
     a.ci_tiles = aid_cdiv(p->Cin, 32);
@@ -268,12 +503,38 @@ __global__ __launch_bounds__(256) void wgrad_reduce_w_kernel(const aid_wgrad_red
     const int tap = (int)((i / p.Cin) % p.K);
     const int co = (int)(i / ((int64_t)p.Cin * p.K));
     float accv = 0.f;
-    for (int b = 0; b < p.B; ++b) {                         // fixed order: deterministic
-        float sp = 0.f;
-        for (int s = 0; s < p.S; ++s) sp += p.P[((int64_t)(b * p.S + s)) * n + i];
-        const float g = p.gate ? p.gate[(int64_t)b * p.gate_ld + co] : 1.f;
-        const float sc = p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_ld + ci] : 1.f;
-        accv += g * sc * sp;
+    if (p.wino) {                                               // P: [co][xi*5+kh][ci] (30 taps); dW[kh][kw] = sum_xi G[xi][kw] dU[xi][kh]
+        // one thread per (co, kh, ci): the six xi values are read once and give all three kw (threads with tap % 3 != 0 have nothing to do)
+        const int kh = tap / 3;
+        if (tap - 3 * kh != 0) return;
+        const int64_t n30 = (int64_t)p.Cout * p.Cin * 30;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int b = 0; b < p.B; ++b) {
+            float u[6];
+#pragma unroll
+            for (int xi = 0; xi < 6; ++xi) {
+                float sp = 0.f;
+                for (int s = 0; s < p.S; ++s) sp += p.P[((int64_t)(b * p.S + s)) * n30 + ((int64_t)co * 30 + xi * 5 + kh) * p.Cin + ci];
+                u[xi] = sp;
+            }
+            const float g = (p.gate ? p.gate[(int64_t)b * p.gate_ld + co] : 1.f) * (p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_ld + ci] : 1.f);
+            a0 += g * (0.25f * u[0] - (u[1] + u[2]) * (1.f / 6) + (u[3] + u[4]) * (1.f / 24));
+            a1 += g * ((u[2] - u[1]) * (1.f / 6) + (u[3] - u[4]) * (1.f / 12));
+            a2 += g * (u[5] - (u[1] + u[2]) * (1.f / 6) + (u[3] + u[4]) * (1.f / 6));
+        }
+        const int64_t o = ((int64_t)co * p.Cin + ci) * p.K + 3 * kh;
+        p.dW[o] = (p.accumulate ? p.dW[o] : 0.f) + a0;
+        p.dW[o + 1] = (p.accumulate ? p.dW[o + 1] : 0.f) + a1;
+        p.dW[o + 2] = (p.accumulate ? p.dW[o + 2] : 0.f) + a2;
+        return;
+    } else {
+        for (int b = 0; b < p.B; ++b) {                         // fixed order: deterministic
+            float sp = 0.f;
+            for (int s = 0; s < p.S; ++s) sp += p.P[((int64_t)(b * p.S + s)) * n + i];
+            const float g = p.gate ? p.gate[(int64_t)b * p.gate_ld + co] : 1.f;
+            const float sc = p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_ld + ci] : 1.f;
+            accv += g * sc * sp;
+        }
     }
     const int64_t o = ((int64_t)co * p.Cin + ci) * p.K + tap;       // the parameter's layout [co][ci][tap]
     p.dW[o] = (p.accumulate ? p.dW[o] : 0.f) + accv;
@@ -288,6 +549,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_gate_kernel(const aid_wgrad_
     __shared__ double red[4];
     double accv = 0.0;
     const int cpc = WRG_CHUNK / p.K;                        // input channels per staged chunk
+    if (p.wino) {                                           // <W, G^T dU> = <G W, dU>: the U-domain partials against the layer's F(4,3) weight pack
+        const int64_t n30 = (int64_t)p.Cout * p.Cin * 30;
+        for (int j = tid; j < 30 * p.Cin; j += 256) {       // j = pair * Cin + ci (the partials' order)
+            const int pr = j / p.Cin, ci = j - pr * p.Cin;
+            float sp = 0.f;
+            for (int s = 0; s < p.S; ++s) sp += p.P[((int64_t)(b * p.S + s)) * n30 + (int64_t)co * 30 * p.Cin + j];
+            const float sc = p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_ld + ci] : 1.f;
+            accv += (double)(p.Uw[((int64_t)pr * p.Cin_pad + ci) * p.Cout_pad + co] * sc) * (double)sp;
+        }
+    } else
     for (int c0 = 0; c0 < p.Cin; c0 += cpc) {
         const int nc = min(cpc, p.Cin - c0);
         __syncthreads();
@@ -312,6 +583,7 @@ extern "C" int aid_wgrad_reduce(const aid_wgrad_reduce_params* p, void* stream) 
     AID_REQUIRE(p && p->P && p->dW, "aid_wgrad_reduce: null pointer");
     AID_REQUIRE(!p->dgate || p->W, "aid_wgrad_reduce: dgate needs the weights");
     AID_REQUIRE(p->K >= 1 && p->K <= WRG_CHUNK, "aid_wgrad_reduce: bad tap count");
+    AID_REQUIRE(!p->wino || (p->K == 15 && (!p->dgate || (p->Uw && p->Cin_pad >= p->Cin && p->Cout_pad >= p->Cout))), "aid_wgrad_reduce: wino needs K = 15 (5x3) and, for dgate, the F(4,3) weight pack");
     const int64_t n = (int64_t)p->Cout * p->Cin * p->K;
     hipLaunchKernelGGL(wgrad_reduce_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
     AID_CHECK_LAUNCH();

@@ -318,27 +318,47 @@ class _Builder:
         assert 0 <= off < self.mod.shape[1] and view.stride(0) == self.mod.stride(0)
         return self.dmod[:, off:off + view.shape[1]]
 
-    def _train_conv(self, x, gy, gd, wname, cin, cout, kh, kw, dil, in_scale, act, out_scale, alpha):
-        """Parameter-gradient ops of one conv (weight, gate vector, and the <dL/du * scale, x> sums its input scale needs)."""
+    def _train_conv(self, x, gy, gd, wname, cin, cout, kh, kw, dil, in_scale, act, out_scale, alpha, wpw=None):
+        """Parameter-gradient ops of one conv (weight, gate vector, and the <dL/du * scale, x> sums its input scale needs).
+        5x3 layers with their F(4,3) weight pack take the Winograd form of the weight gradient (half the MFMAs): both operands are
+        transformed first -- gy by aid_wino_gy, the conv input by the aid_scale_act(wino=1) pass that re-creates what the forward saw."""
         B, _, F, T = gy.shape
         K = kh * kw
+        wino = bool(self.net.wgrad_wino and (kh, kw) == (5, 3) and T % 16 == 0 and cin >= 32 and cout >= 32
+                    and (out_scale is None or (wpw is not None and wpw.shape[0] == 30)))
         xin, isc = x, in_scale
-        if act:                                           # the conv saw gelu(x * scale): recompute it (one pass) into scratch
-            xin = self._scratch(("hw",) + tuple(x.shape))
-            sp = _lib.ScaleActParams(_lib.view4(x), _lib.view4(xin), in_scale.data_ptr(), in_scale.stride(0), B, cin, F, T, 1, 0)
+        if wino:
+            G6 = 6 * (T // 4)
+            xin = self._scratch(("hww", B, cin, F, G6))
+            sp = _lib.ScaleActParams(_lib.view4(x), _lib.view4(xin), _lib.ptr(in_scale) if act else None,
+                                     in_scale.stride(0) if (act and in_scale is not None) else 0, B, cin, F, T, 1 if act else 0, 1)
             self.plan.add("aid_scale_act", sp, x, xin, in_scale)
-            isc = None
+            if act:
+                isc = None
+            gyw = self._scratch(("gyw", B, cout, F, G6))
+            self.plan.add("aid_wino_gy", _lib.WinoGyParams(_lib.view4(gy), _lib.view4(gyw), B, cout, F, T), gy, gyw)
+            gop = gyw
+        else:
+            gop = gy
+            if act:                                       # the conv saw gelu(x * scale): recompute it (one pass) into scratch
+                xin = self._scratch(("hw",) + tuple(x.shape))
+                sp = _lib.ScaleActParams(_lib.view4(x), _lib.view4(xin), in_scale.data_ptr(), in_scale.stride(0), B, cin, F, T, 1, 0)
+                self.plan.add("aid_scale_act", sp, x, xin, in_scale)
+                isc = None
         tiles = -(-cout // 64) * -(-cin // 32)
         S = max(1, min(F, 1024 // (tiles * B)))           # <= 1024 workgroups: at most four full rounds of one workgroup per CU
-        P = self._scratch(("P", B * S * cout * cin * K))
-        wp = _lib.WgradParams(_lib.view4(gy), _lib.view4(xin), P.data_ptr(), B, cin, cout, F, T, kh, kw, dil, S, alpha)
-        self.plan.add("aid_conv2d_wgrad", wp, gy, xin, P, flops=2 * B * F * T * cin * cout * K)
+        KP = 30 if wino else K                            # taps per (co, ci) in the partials (U domain: xi * 5 + kh)
+        P = self._scratch(("P", B * S * cout * cin * KP))
+        wp = _lib.WgradParams(_lib.view4(gop), _lib.view4(xin), P.data_ptr(), B, cin, cout, F, T, kh, kw, dil, S, alpha, int(wino))
+        self.plan.add("aid_conv2d_wgrad", wp, gop, xin, P, flops=2 * B * F * T * cin * cout * K)
         W = self.params[wname]
         dg = self.dmod_like(out_scale)
         rp = _lib.WgradReduceParams(P.data_ptr(), W.data_ptr(), _lib.ptr(out_scale), 0 if out_scale is None else out_scale.stride(0),
                                     _lib.ptr(isc), 0 if isc is None else isc.stride(0), self.pgrad[wname].data_ptr(), _lib.ptr(dg),
-                                    0 if dg is None else dg.stride(0), B, S, cout, cin, K, 1)
-        self.plan.add("aid_wgrad_reduce", rp, P, W, out_scale, isc, dg)
+                                    0 if dg is None else dg.stride(0), B, S, cout, cin, K, 1, int(wino),
+                                    _lib.ptr(wpw) if wino else None, wpw.shape[1] if (wino and wpw is not None) else 0,
+                                    wpw.shape[2] if (wino and wpw is not None) else 0)
+        self.plan.add("aid_wgrad_reduce", rp, P, W, out_scale, isc, dg, wpw)
         if in_scale is not None and gd is not None:       # gd = dL/d(x*scale) * scale  ->  S[b,c] = sum gd * x  (aid_scale_bwd divides by scale)
             Sb = self.buf(B, cin)
             cp = _lib.ChannelDotParams(_lib.view4(gd), _lib.view4(x), Sb.data_ptr(), Sb.stride(0), B, cin, F, T)
@@ -455,7 +475,7 @@ class _Builder:
                     dp = _lib.GroupDotParams(_lib.view4(gd), _lib.view4(x), B, cin, F, T, 8, self.stats_ws.data_ptr())
                     self.plan.add("aid_group_dot", dp, gd, x)
                 if self.train and wname is not None:
-                    self._train_conv(x, gy, gd, wname, cin, cout, kh, kw, dil, in_scale, act, out_scale, alpha)
+                    self._train_conv(x, gy, gd, wname, cin, cout, kh, kw, dil, in_scale, act, out_scale, alpha, wpw=wpw)
                 npar = _lib.NormBwdParams(_lib.view4(gd), _lib.view4(x), _lib.view4(gy if fused_res else None), _lib.view4(self.G(x)),
                                           B, cin, F, T, 8, norm_stats.data_ptr(), dws.data_ptr(), 1e-7,
                                           alpha * res_scale, 1 if self._gacc(x) else 0, nd)
@@ -471,7 +491,7 @@ class _Builder:
                                epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None)
                 if self.train and wname is not None:
                     assert in_scale is None, "a scaled conv input without its statistics buffer has no parameter-gradient path"
-                    self._train_conv(x, gy, None, wname, cin, cout, kh, kw, dil, None, act, out_scale, alpha)
+                    self._train_conv(x, gy, None, wname, cin, cout, kh, kw, dil, None, act, out_scale, alpha, wpw=wpw)
         self.bwd.append(bw)
 
 
@@ -975,6 +995,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
     # input / output buffers, later calls copy the inputs in and replay.  Sub-batch streams (B >= 4) stay eager.
     # ---------------------------------------------------------------------------------------------------
     use_graphs = True
+    wgrad_wino = True          # training: F(4,3) form of the 5x3 weight gradients (aid_conv2d_wgrad wino=1)
     fuse_norm_bwd_wino = True  # reverse sweep: aid_norm_bwd also writes the Winograd-domain, gated copy that the dgrad conv below stages
     epilogue_stats = True      # forward group statistics from the epilogue of the conv that produces the tensor (row-shared F(4,3) kernel)
     GRAPH_MAX_B = 3

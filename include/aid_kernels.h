@@ -28,7 +28,7 @@ extern "C" {
 #define AID_E_BADARG (-1)   /* unsupported shape / null pointer / misaligned stride */
 #define AID_E_LAUNCH (-2)   /* hipLaunchKernel reported an error                    */
 
-#define AID_ABI_VERSION 5
+#define AID_ABI_VERSION 6
 int aid_abi_version(void);
 /* last HIP error string seen by a launcher in this process (never NULL) */
 const char* aid_last_error(void);
@@ -450,8 +450,16 @@ typedef struct {
     int B, Cin, Cout, F, T, KH, KW, dilF;
     int S;
     float alpha;
+    int wino;                  /* 1 (5x3 only, T % 16 == 0): gy and x are Winograd-domain tensors [.,.,F,6,T/4] -- gy = (A gy) from aid_wino_gy, x = (B^T d) from
+                                  aid_scale_act(wino=1) -- and P holds the 30 U-domain taps (xi*5+kh): P[(b*S+s)][co][30][ci]; half the MFMAs of the direct form.
+                                  aid_wgrad_reduce(wino=1) applies G^T. */
 } aid_conv2d_wgrad_params;
 int aid_conv2d_wgrad(const aid_conv2d_wgrad_params* p, void* stream);
+
+/* aid_wino_gy: out[b,c,f,xi,g] = (A gy)[xi] of the four samples 4g..4g+3 (A = transpose of the F(4,3) output transform): the output-gradient operand of
+ * the Winograd-form weight gradient.  out rows [6][T/4]. */
+typedef struct { aid_view gy, out; int B, C, F, T; } aid_wino_gy_params;
+int aid_wino_gy(const aid_wino_gy_params* p, void* stream);
 
 /* aid_pack_conv_weight: every kernel-side layout of one conv weight in one launch (replaces the torch pack ops of
  * network.prepare() after each optimiser step; Conv2d weights of unet...py:79-88 in the state_dict's own layout [Cout,Cin,KH,KW]).
@@ -472,6 +480,9 @@ typedef struct {
     const float* in_scale; int64_t in_scale_ld;
     float* dW; float* dgate; int64_t dgate_ld;
     int B, S, Cout, Cin, K, accumulate;
+    int wino;                  /* 1: P holds 30 U-domain taps per (co, ci) (aid_conv2d_wgrad wino=1); K stays 15: dW = G^T dU */
+    const float* Uw;           /* wino + dgate: the layer's F(4,3) weight pack [30][Cin_pad][Cout_pad] (<W, G^T dU> = <G W, dU>) */
+    int Cin_pad, Cout_pad;
 } aid_wgrad_reduce_params;
 int aid_wgrad_reduce(const aid_wgrad_reduce_params* p, void* stream);
 

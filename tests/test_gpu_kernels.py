@@ -651,3 +651,52 @@ def test_pack_conv_weight_kernel_matches_the_torch_packs(L, shape):
     assert torch.equal(outs[0], L.pack_conv_weight(w)) and torch.equal(outs[1], L.pack_conv_weight(w, transpose=True))
     if wino:
         assert torch.equal(outs[2], L.pack_conv_weight_wino(w)) and torch.equal(outs[3], L.pack_conv_weight_wino(w, transpose=True))
+
+
+WGRAD_WINO_CASES = [
+    # B, Cin, Cout, F, T, dil, S
+    (2, 64, 64, 12, 64, 2, 1),
+    (2, 96, 96, 20, 128, 4, 3),          # half-empty second Cout tile, two chunks, splits cutting chains
+    (1, 40, 72, 9, 48, 4, 2),            # ragged channels, a 12-group chunk, F % dil != 0
+    (1, 128, 64, 28, 32, 8, 4),          # T = 32: 8 groups per chunk, several residue classes per split
+    (3, 32, 64, 6, 80, 16, 2),           # dilation larger than F
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_WINO_CASES)
+def test_conv2d_wgrad_winograd_form(L, case):
+    """aid_wino_gy + aid_scale_act(wino=1) -> aid_conv2d_wgrad(wino=1) -> aid_wgrad_reduce(wino=1): the F(4,3) form of the 5x3 weight gradient
+    (half the MFMAs) and the gate gradient recovered from its U-domain partials, against the fp64 definition."""
+    B, Cin, Cout, Fd, T, dil, S = case
+    gy, x = _rand(B, Cout, Fd, T, seed=110), _rand(B, Cin, Fd, T, seed=111)
+    w = _rand(Cout, Cin, 5, 3, seed=112, scale=1.0 / math.sqrt(Cin * 15))
+    gate, isc = _rand(B, Cout, seed=113), 1.0 + 0.3 * _rand(B, Cin, seed=114)
+    alpha = 0.75
+    xp = F.pad(x.double(), (1, 1, 2 * dil, 2 * dil))
+    dWb = torch.zeros(B, Cout, Cin, 5, 3, dtype=torch.float64)
+    for kh in range(5):
+        for kw in range(3):
+            dWb[:, :, :, kh, kw] = alpha * torch.einsum("boft,bift->boi", gy.double(), xp[:, :, kh * dil:kh * dil + Fd, kw:kw + T])
+    dW_ref = torch.einsum("bo,bi,boihw->oihw", gate.double(), isc.double(), dWb)
+    dg_ref = torch.einsum("oihw,bi,boihw->bo", w.double(), isc.double(), dWb)
+    gd, xd, wd = gy.to(DEV), x.to(DEV), w.to(DEV)
+    G = T // 4
+    gyw = torch.empty(B, Cout, Fd, 6 * G, device=DEV)
+    xw = torch.empty(B, Cin, Fd, 6 * G, device=DEV)
+    L.call("aid_wino_gy", L.WinoGyParams(L.view4(gd), L.view4(gyw), B, Cout, Fd, T))
+    L.call("aid_scale_act", L.ScaleActParams(L.view4(xd), L.view4(xw), None, 0, B, Cin, Fd, T, 0, 1))
+    P = torch.full((B * S * Cout * Cin * 30 + 16,), float("nan"), device=DEV)
+    L.call("aid_conv2d_wgrad", L.WgradParams(L.view4(gyw), L.view4(xw), P.data_ptr(), B, Cin, Cout, Fd, T, 5, 3, dil, S, alpha, 1))
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(P[B * S * Cout * Cin * 30:]).all()) and bool(torch.isfinite(P[:B * S * Cout * Cin * 30]).all())
+    wpw = L.pack_conv_weight_wino(wd)
+    gated, iscd = gate.to(DEV), isc.to(DEV)
+    dW = torch.zeros(Cout, Cin, 15, device=DEV)
+    dg = torch.empty(B, Cout, device=DEV)
+    rp = L.WgradReduceParams(P.data_ptr(), wd.data_ptr(), gated.data_ptr(), gated.stride(0), iscd.data_ptr(), iscd.stride(0), dW.data_ptr(), dg.data_ptr(),
+                             dg.stride(0), B, S, Cout, Cin, 15, 0, 1, wpw.data_ptr(), wpw.shape[1], wpw.shape[2])
+    L.call("aid_wgrad_reduce", rp)
+    torch.cuda.synchronize()
+    e1, e2 = rel_l2(dW.cpu().double().reshape(Cout, Cin, 5, 3), dW_ref), rel_l2(dg.cpu().double(), dg_ref)
+    print(f"F(4,3) weight gradient: dW rel-L2 {e1:.2e}, dgate rel-L2 {e2:.2e}")
+    assert e1 < 1e-5 and e2 < 1e-5

@@ -31,4 +31,24 @@ for C, F, T, dil in SHAPES:
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     fl = 2.0 * B * F * T * C * C * 15
-    print(f"wgrad C={C:3d} F={F:3d} T={T:4d} dil={dil:2d} S={S:3d}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:6.1f} TFLOP/s  {fl / ms / 1e9 / 157.3:.3f} of peak")
+    print(f"wgrad C={C:3d} F={F:3d} T={T:4d} dil={dil:2d} S={S:3d}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:6.1f} TFLOP/s  {fl / ms / 1e9 / 157.3:.3f} of peak", end="")
+    # F(4,3) form: operands in the Winograd domain (the two transform passes timed separately)
+    Gq = T // 4
+    gyw = torch.empty(B, C, F, 6 * Gq, device=dev)
+    xw = torch.empty(B, C, F, 6 * Gq, device=dev)
+    Pw = torch.empty(B * S * C * C * 30, device=dev)
+    gp = L.WinoGyParams(L.view4(gy), L.view4(gyw), B, C, F, T)
+    sp = L.ScaleActParams(L.view4(x), L.view4(xw), None, 0, B, C, F, T, 0, 1)
+    wp = L.WgradParams(L.view4(gyw), L.view4(xw), Pw.data_ptr(), B, C, C, F, T, 5, 3, dil, S, 1.0, 1)
+    out = []
+    for name, q in (("aid_wino_gy", gp), ("aid_scale_act", sp), ("aid_conv2d_wgrad", wp)):
+        for _ in range(2):
+            L.call(name, q)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            L.call(name, q)
+        e1.record()
+        torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) / n)
+    print(f"   | F(4,3): {out[2] * 1e3:8.1f} us ({fl / out[2] / 1e9:6.1f} algorithmic TFLOP/s) + gy transform {out[0] * 1e3:6.1f} us + x transform {out[1] * 1e3:6.1f} us")

@@ -217,7 +217,7 @@ class SumsqParams(C.Structure):
 
 AID_SUMSQ_BLOCKS = 512
 
-EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_stats", "aid_conv2d", "aid_conv2d_pack_dims", "aid_conv2d_stat_partials", "aid_pack_conv_weight", "aid_wino_gy", "aid_resample",
+EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_stats", "aid_conv2d", "aid_conv2d_pack_dims", "aid_conv2d_stat_partials", "aid_pack_conv_weight", "aid_wino_gy", "aid_conv2d_wgrad_tiles", "aid_resample",
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_row_norm", "aid_scale_act", "aid_fft_pass",

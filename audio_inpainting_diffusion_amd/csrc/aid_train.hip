@@ -270,6 +270,127 @@ __global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_kernel(const WgDev a
 }
 
 // ------------------------------------------------------------------------------------------------------
+// 1x1 layers: dW[co,ci] = sum over positions of gy[co,pos] x[ci,pos] -- a plain GEMM with K = positions.  One tap means nothing to spread over the
+// waves, so a workgroup owns a (32 COB) x (32 NCI) block of dW, every wave holds ALL its COB x NCI accumulator tiles and the eight waves split the
+// positions of a chunk (k-steps wave, wave + 8, ...); a fixed-order sum over the waves follows the last step.  Both operands are double-buffered
+// in LDS (transposed reads, odd pitch), the next step is prefetched into registers and stored half-way through the K loop.
+template <int COB, int NCI>
+__global__ __launch_bounds__(WG_THREADS, 2) void conv_wgrad_1x1_kernel(const WgDev a) {
+    constexpr int NCO = 32 * COB, NCX = 32 * NCI;
+    const aid_conv2d_wgrad_params& p = a.p;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = (blockIdx.x % a.co_tiles) * NCO;
+    const int ci0 = (blockIdx.x / a.co_tiles) * NCX;
+    const int b = blockIdx.y / p.S, s = blockIdx.y - b * p.S;
+    const int nco = min(COB, (p.Cout - co0 + 31) / 32), nci = min(NCI, (p.Cin - ci0 + 31) / 32);
+
+    __shared__ float gyT[2][NCO * WG_LDA];
+    __shared__ float xT[2][NCX * WG_LDA];
+    f32x16 acc[COB][NCI];
+#pragma unroll
+    for (int i = 0; i < COB; ++i)
+#pragma unroll
+        for (int j = 0; j < NCI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool vec = ((p.T & 3) == 0) && ((p.gy.sB | p.gy.sC | p.gy.sF | p.x.sB | p.x.sC | p.x.sF) & 3) == 0 &&
+                     ((((uintptr_t)p.gy.p) | ((uintptr_t)p.x.p)) & 15) == 0;
+    auto ld4 = [&](const float* base, bool ok, int t) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && t < p.T) {
+            const float* src = base + t;
+            if (vec && t + 3 < p.T) v = *reinterpret_cast<const float4*>(src);
+            else { v.x = src[0]; if (t + 1 < p.T) v.y = src[1]; if (t + 2 < p.T) v.z = src[2]; if (t + 3 < p.T) v.w = src[3]; }
+        }
+        return v;
+    };
+    const int q4 = tid & 15, srow = tid >> 4;             // float4 column, base row 0..31 (rows srow + 32 i)
+    auto load = [&](int f, int t0, float4 (&g)[COB], float4 (&x)[NCI]) {
+#pragma unroll
+        for (int i = 0; i < COB; ++i) {
+            const int co = co0 + srow + 32 * i;
+            g[i] = ld4(p.gy.p + (int64_t)b * p.gy.sB + (int64_t)co * p.gy.sC + (int64_t)f * p.gy.sF, co < p.Cout, t0 + 4 * q4);
+        }
+#pragma unroll
+        for (int j = 0; j < NCI; ++j) {
+            const int ci = ci0 + srow + 32 * j;
+            x[j] = ld4(p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)f * p.x.sF, ci < p.Cin, t0 + 4 * q4);
+        }
+    };
+    auto store = [&](int buf, const float4 (&g)[COB], const float4 (&x)[NCI]) {
+#pragma unroll
+        for (int i = 0; i < COB; ++i) {
+            float* d = gyT[buf] + (srow + 32 * i) * WG_LDA + 4 * q4;
+            d[0] = g[i].x; d[1] = g[i].y; d[2] = g[i].z; d[3] = g[i].w;
+        }
+#pragma unroll
+        for (int j = 0; j < NCI; ++j) {
+            float* d = xT[buf] + (srow + 32 * j) * WG_LDA + 4 * q4;
+            d[0] = x[j].x; d[1] = x[j].y; d[2] = x[j].z; d[3] = x[j].w;
+        }
+    };
+    // steps: (chunk of 64 positions, row), rows fastest; the S splits of a sample cut the sequence into equal contiguous parts
+    const int nct = (p.T + WG_TC - 1) / WG_TC;
+    const int tc = (p.T < WG_TC) ? ((p.T + 3) & ~3) : WG_TC;
+    const int64_t total = (int64_t)nct * p.F;
+    const int g_lo = (int)((total * s) / p.S), g_hi = (int)((total * (s + 1)) / p.S);
+    float4 pg[COB], px[NCI];
+    if (g_lo < g_hi) {
+        load(g_lo % p.F, (g_lo / p.F) * WG_TC, pg, px);
+        store(0, pg, px);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int g = g_lo; g < g_hi; ++g) {
+        const bool have = g + 1 < g_hi;
+        if (have) load((g + 1) % p.F, ((g + 1) / p.F) * WG_TC, pg, px);
+        const float* ap = gyT[cur] + l32 * WG_LDA + half;
+        const float* bp = xT[cur] + l32 * WG_LDA + half;
+        bool stored = !have;
+        for (int k = 2 * wave; k < tc; k += 2 * WG_NW) {
+            if (!stored && k >= (tc >> 1)) { store(cur ^ 1, pg, px); stored = true; }
+            float av[COB], bv[NCI];
+#pragma unroll
+            for (int i = 0; i < COB; ++i) av[i] = (i < nco) ? ap[i * 32 * WG_LDA + k] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NCI; ++j) bv[j] = (j < nci) ? bp[j * 32 * WG_LDA + k] : 0.f;
+#pragma unroll
+            for (int i = 0; i < COB; ++i)
+#pragma unroll
+                for (int j = 0; j < NCI; ++j)
+                    if (i < nco && j < nci) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (!stored) store(cur ^ 1, pg, px);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // fixed-order sum of the eight waves' tiles through LDS, then P[(b*S+s)][co][ci]
+    float* red = gyT[0];                                    // [wave][16][64] floats = 32 KB (NCO >= 64: 2 x 64 x 65 floats are there)
+    float* P = p.P + ((int64_t)(b * p.S + s) * p.Cout) * p.Cin;
+#pragma unroll
+    for (int i = 0; i < COB; ++i)
+#pragma unroll
+        for (int j = 0; j < NCI; ++j) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[i][j][r];
+            __syncthreads();
+            if (wave == 0) {
+                const int ci = ci0 + 32 * j + l32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = red[r * 64 + lane];
+                    for (int w = 1; w < WG_NW; ++w) v += red[(w * 16 + r) * 64 + lane];
+                    const int co = co0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (co < p.Cout && ci < p.Cin) P[(int64_t)co * p.Cin + ci] = p.alpha * v;
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Winograd F(4,3) form of the weight gradient (5x3 layers): with y = A^T[(G w) . (B^T d)] per group of four outputs,
 //   dL/dU[co,ci,kh,xi] = sum_{b,f,g} (A gy)[co,f,g,xi] * (B^T d)[ci,f+(kh-2)dil,g,xi],      dL/dw = G^T dL/dU   (aid_wgrad_reduce),
 // i.e. 6 products per 4 positions and tap row instead of 12: half the MFMAs of the direct form.  Both operands arrive in the Winograd
@@ -463,6 +584,14 @@ extern "C" int aid_wino_gy(const aid_wino_gy_params* p, void* stream) {
     return AID_OK;
 }
 
+// workgroups per (sample, split) that aid_conv2d_wgrad launches for a layer: the caller sizes S with it (about one workgroup per CU in total)
+extern "C" int aid_conv2d_wgrad_tiles(int Cin, int Cout, int KH, int KW, int wino) {
+    if (wino) return aid_cdiv(Cout, 64) * aid_cdiv(Cin, 32);
+    if (KH == 1 && KW == 1 && Cout >= 64 && Cin >= 64) return aid_cdiv(Cout, Cout >= 128 ? 128 : 64) * aid_cdiv(Cin, 64);
+    const int cob = (Cout % 64 != 0 && Cout % 96 == 0) ? 3 : 2;
+    return aid_cdiv(Cout, 32 * cob) * aid_cdiv(Cin, 32);
+}
+
 extern "C" int aid_conv2d_wgrad(const aid_conv2d_wgrad_params* p, void* stream) {
     AID_REQUIRE(p && p->gy.p && p->x.p && p->P, "aid_conv2d_wgrad: null pointer");
     AID_REQUIRE(p->B > 0 && p->Cin > 0 && p->Cout > 0 && p->F > 0 && p->T > 0 && p->S >= 1 && p->S <= p->F, "aid_conv2d_wgrad: bad shape");
@@ -480,6 +609,17 @@ extern "C" int aid_conv2d_wgrad(const aid_conv2d_wgrad_params* p, void* stream) 
         a.ci_tiles = aid_cdiv(p->Cin, 32);
         AID_REQUIRE((int64_t)p->B * p->S < 65536, "aid_conv2d_wgrad: too many (sample, split) pairs");
         hipLaunchKernelGGL(conv_wgrad_wino_kernel, dim3((unsigned)(a.co_tiles * a.ci_tiles), (unsigned)(p->B * p->S)), dim3(WG_THREADS), 0, (hipStream_t)stream, a);
+        AID_CHECK_LAUNCH();
+        return AID_OK;
+    }
+    if (p->KH == 1 && p->KW == 1 && p->Cout >= 64 && p->Cin >= 64) {           // 1x1: position-split GEMM blocks of 128 x 64 or 64 x 64
+        const bool big = p->Cout >= 128;
+        a.co_tiles = aid_cdiv(p->Cout, big ? 128 : 64);
+        a.ci_tiles = aid_cdiv(p->Cin, 64);
+        AID_REQUIRE((int64_t)p->B * p->S < 65536, "aid_conv2d_wgrad: too many (sample, split) pairs");
+        const dim3 grid1((unsigned)(a.co_tiles * a.ci_tiles), (unsigned)(p->B * p->S));
+        if (big) hipLaunchKernelGGL((conv_wgrad_1x1_kernel<4, 2>), grid1, dim3(WG_THREADS), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((conv_wgrad_1x1_kernel<2, 2>), grid1, dim3(WG_THREADS), 0, (hipStream_t)stream, a);
         AID_CHECK_LAUNCH();
         return AID_OK;
     }

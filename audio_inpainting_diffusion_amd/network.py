@@ -345,7 +345,7 @@ class _Builder:
                 sp = _lib.ScaleActParams(_lib.view4(x), _lib.view4(xin), in_scale.data_ptr(), in_scale.stride(0), B, cin, F, T, 1, 0)
                 self.plan.add("aid_scale_act", sp, x, xin, in_scale)
                 isc = None
-        tiles = -(-cout // 64) * -(-cin // 32)
+        tiles = int(_lib.lib().aid_conv2d_wgrad_tiles(cin, cout, kh, kw, int(wino)))
         S = max(1, min(F, 256 // (tiles * B)))            # about one workgroup per CU: every extra split is another partial to write and reduce
                                                           # (1024 / 768 / 512 / 256 workgroups: 250 / 238 / 227 / 221 ms per iteration at batch 4)
         KP = 30 if wino else K                            # taps per (co, ci) in the partials (U domain: xi * 5 + kh)

@@ -455,6 +455,8 @@ typedef struct {
                                   aid_wgrad_reduce(wino=1) applies G^T. */
 } aid_conv2d_wgrad_params;
 int aid_conv2d_wgrad(const aid_conv2d_wgrad_params* p, void* stream);
+/* workgroups per (sample, split) of that launch (tile shape differs between the direct, the F(4,3) and the 1x1 kernels): S is sized with it */
+int aid_conv2d_wgrad_tiles(int Cin, int Cout, int KH, int KW, int wino);
 
 /* aid_wino_gy: out[b,c,f,xi,g] = (A gy)[xi] of the four samples 4g..4g+3 (A = transpose of the F(4,3) output transform): the output-gradient operand of
  * the Winograd-form weight gradient.  out rows [6][T/4]. */

@@ -517,6 +517,9 @@ WGRAD_CASES = [
     (3, 96, 8, 7, 64, 1, 1, 1, 2),          # 1x1, few output channels
     (2, 2, 64, 8, 96, 5, 3, 2, 8),          # pyramid projection 2 -> C, S = F
     (1, 64, 64, 28, 32, 5, 3, 8, 4),        # deep-level shape: several residue classes per split
+    (2, 64, 192, 8, 128, 1, 1, 1, 3),       # 1x1, position-split 128 x 64 blocks (second Cout block half empty)
+    (1, 96, 64, 5, 50, 1, 1, 1, 2),         # 1x1, 64 x 64 blocks, ragged Cin block, T % 4 != 0
+    (2, 256, 128, 6, 64, 1, 1, 1, 1),       # 1x1, four Cin blocks
 ]
 
 

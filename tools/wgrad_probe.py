@@ -15,7 +15,7 @@ SHAPES = [  # C, F, T, dil
 for C, F, T, dil in SHAPES:
     gy = torch.randn(B, C, F, T, device=dev)
     x = torch.randn(B, C, F, T, device=dev)
-    tiles = -(-C // 64) * -(-C // 32)
+    tiles = int(L.lib().aid_conv2d_wgrad_tiles(C, C, 5, 3, 1))
     S = max(1, min(F, 256 // (tiles * B)))
     P = torch.empty(B * S * C * C * 15, device=dev)
     p = L.WgradParams(L.view4(gy), L.view4(x), P.data_ptr(), B, C, C, F, T, 5, 3, dil, S, 1.0)

@@ -684,8 +684,10 @@ struct ConvWinoRDev {
 
 // WGM = 2: 64 output channels x 256 positions; WGM = 1: 32 output channels x 512 positions (the remainder tile of 96-channel layers,
 // whose first 64 channels take the 64-wide tile: four waves per workgroup either way, one per SIMD)
-template <int TT, int NC, int WGM>
-__global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDev a) {
+// NB: LDS buffers asked for.  3 (default): two workgroups per CU; 2: 43 KB, THREE workgroups per CU -- measured +1..3 % on the short-K layers
+// (Cin <= 128: more of the tile is prologue / epilogue, which a third resident workgroup covers) and -0.5 % on Cin = 256 (profiles/r02_wino4r_probe.txt).
+template <int TT, int NC, int WGM, int NB = 3>
+__global__ __launch_bounds__(256, NB == 2 ? 3 : 2) void conv53_wino4r_kernel(const ConvWinoRDev a) {
     constexpr int KH = 5, NXI = 6, TAPS = NXI * KH, KC = 2;
     constexpr int NW = 4, WGN = NW / WGM;
     constexpr int M_BLK = 32 * WGM, N_BLK = 128 * WGN;
@@ -699,7 +701,7 @@ __global__ __launch_bounds__(256, 2) void conv53_wino4r_kernel(const ConvWinoRDe
     constexpr int WSZ_RAW = TAPS * KC * WROW;           // 64 channels: 3840 floats = 15 pieces; 32: 1920 -> 8 pieces (the last half used)
     constexpr int WSZ = ((WSZ_RAW + 255) / 256) * 256;
     constexpr int BUFSZ = XSZ + WSZ;
-    constexpr int NBUF = (3 * BUFSZ * 4 * 2 <= 160 * 1024) ? 3 : 2;    // three buffers while two workgroups still fit a CU (NBUF 2 vs 3 measured +-1 %)
+    constexpr int NBUF = (NB == 3 && 3 * BUFSZ * 4 * 2 <= 160 * 1024) ? 3 : 2;    // three buffers only while two workgroups still fit a CU
     constexpr int NXP = XSZ / 256, NWP = WSZ / 256, NP = NXP + NWP;
     constexpr int PPW = (NP + NW - 1) / NW;
     constexpr int NSTEP = KH;
@@ -1053,15 +1055,16 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
         a.per_xcd = (a.ntiles + 7) / 8;
         const dim3 grid((unsigned)(8 * a.per_xcd));
 #define AID_W4R(TTv, NCv, WGMv) hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv>), grid, dim3(256), 0, st, a)
+        const bool short_k = p->Cin <= 128;                  // three workgroups per CU (two LDS buffers) for the short-K layers
         switch ((l * 128 + g.TT) * 16 + g.NC) {
-            case 64 * 16 + 1: AID_W4R(64, 1, 2); break;
+            case 64 * 16 + 1: if (short_k) hipLaunchKernelGGL((conv53_wino4r_kernel<64, 1, 2, 2>), grid, dim3(256), 0, st, a); else AID_W4R(64, 1, 2); break;
             case 64 * 16 + 2: AID_W4R(64, 2, 2); break;
             case 64 * 16 + 4: AID_W4R(64, 4, 2); break;
             case 32 * 16 + 1: AID_W4R(32, 1, 2); break;
             case 32 * 16 + 2: AID_W4R(32, 2, 2); break;
             case 32 * 16 + 4: AID_W4R(32, 4, 2); break;
             case 32 * 16 + 8: AID_W4R(32, 8, 2); break;
-            case (128 + 64) * 16 + 1: AID_W4R(64, 1, 1); break;
+            case (128 + 64) * 16 + 1: if (short_k) hipLaunchKernelGGL((conv53_wino4r_kernel<64, 1, 1, 2>), grid, dim3(256), 0, st, a); else AID_W4R(64, 1, 1); break;
             case (128 + 64) * 16 + 2: AID_W4R(64, 2, 1); break;
             default: aid_set_error("aid_conv2d: row-shared tile shape not instantiated"); return AID_E_BADARG;
         }

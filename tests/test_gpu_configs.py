@@ -76,7 +76,7 @@ def test_config4_cfgB_batch4_guided_evaluation_vs_oracle_autograd():
 def test_config1_batch8_teacher_forced_heun_steps_vs_oracle():
     """BASELINE.json configs[1] at FULL size and batch 8, guided branch: two Heun steps (four denoiser evaluations) of the
     GPU sampler; every evaluation's projected x_hat is compared, teacher-forced (the oracle is fed the GPU trajectory's own
-    inputs), with the CPU oracle for one of the eight items per evaluation (two different items over the two steps).  Covers the sampler <-> network plumbing at the benchmarked
+    inputs), with the CPU oracle for one of the eight items at the first evaluation of each step (two different items).  Covers the sampler <-> network plumbing at the benchmarked
     batch size (per-item guidance norms, schedule scalars, projection) that single-evaluation tests do not."""
     from audio_inpainting_diffusion_amd.config import make_args
     from audio_inpainting_diffusion_amd.edm import EDM
@@ -107,8 +107,11 @@ def test_config1_batch8_teacher_forced_heun_steps_vs_oracle():
     osmp.mask = mask
     osmp.smask = smooth_mask_rows(mask, 50)
     for k, ((xin, t), xh) in enumerate(zip(smp.trace_in, smp.trace)):
-        items = [6] if k < 2 else [1]                    # (each oracle item-evaluation is ~30 s of CPU: one item per evaluation, item 6 for the
-        osmp.y = y[items]                                #  first Heun step, item 1 for the second -- they run in different sub-batch streams)
+        assert bool(torch.isfinite(xh).all())
+        if k in (1, 3):                                  # (each oracle item-evaluation is 30-45 s of CPU: the first evaluation of each Heun step is
+            continue                                     #  compared -- item 6 in step 0, item 1 in step 1, which run in different sub-batch streams;
+        items = [6] if k == 0 else [1]                   #  the second evaluations' inputs are already functions of the first ones' outputs)
+        osmp.y = y[items]
         osmp.trace = []
         osmp.get_score(xin[items].cpu(), torch.tensor(t, dtype=torch.float32))
         e = rel_l2(xh[items].cpu(), osmp.trace[0])

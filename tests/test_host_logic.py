@@ -343,3 +343,36 @@ def test_graft_entry_build_checks_the_header_abi_version():
     """__graft_entry__.build() is what the driver runs: it must compile, load the library and agree with the header's ABI version."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_header_compiles_as_c_and_struct_sizes_match_the_binding(tmp_path):
+    """include/aid_kernels.h is the C ABI: it must compile as plain C99, and every parameter struct must have the size the ctypes mirror in
+    _lib.py gives it (a drifted field list would shift every later field silently)."""
+    import ctypes
+    import shutil
+    import subprocess
+    from audio_inpainting_diffusion_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    pairs = {"aid_view": "View", "aid_group_stats_params": "GroupStatsParams", "aid_conv2d_params": "Conv2dParams", "aid_resample_params": "ResampleParams",
+             "aid_attention_params": "AttentionParams", "aid_embed_params": "EmbedParams", "aid_modulation_params": "ModulationParams",
+             "aid_cqt_tables": "CqtTables", "aid_cqt_params": "CqtParams", "aid_cqt_gather_params": "CqtGatherParams", "aid_fft_pass_params": "FftPassParams",
+             "aid_axpby_params": "AxpbyParams", "aid_score_step_params": "ScoreStepParams", "aid_group_dot_params": "GroupDotParams",
+             "aid_norm_bwd_params": "NormBwdParams", "aid_attention_bwd_params": "AttentionBwdParams", "aid_guidance_seed_params": "GuidanceSeedParams",
+             "aid_row_norm_params": "RowNormParams", "aid_resample_poly_params": "ResamplePolyParams", "aid_stft_params": "StftParams",
+             "aid_scale_act_params": "ScaleActParams", "aid_add2_params": "Add2Params", "aid_conv2d_wgrad_params": "WgradParams",
+             "aid_wino_gy_params": "WinoGyParams", "aid_pack_conv_weight_params": "PackConvWeightParams", "aid_wgrad_reduce_params": "WgradReduceParams",
+             "aid_channel_dot_params": "ChannelDotParams", "aid_scale_bwd_params": "ScaleBwdParams", "aid_modulation_bwd_params": "ModulationBwdParams",
+             "aid_embed_bwd_params": "EmbedBwdParams", "aid_adam_params": "AdamParams", "aid_ema_params": "EmaParams", "aid_sumsq_params": "SumsqParams"}
+    hdr = open(os.path.join(ROOT, "include", "aid_kernels.h")).read()
+    declared = set(re.findall(r"\}\s*(aid_\w+)\s*;", hdr))
+    assert declared == set(pairs), declared ^ set(pairs)
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "aid_kernels.h"\nint main(void) {\n' +
+                   "".join(f'    printf("{c} %zu\\n", sizeof({c}));\n' for c in pairs) + "    return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)]).decode().splitlines())
+    for c, py in pairs.items():
+        assert int(out[c]) == ctypes.sizeof(getattr(_lib, py)), (c, out[c], ctypes.sizeof(getattr(_lib, py)))

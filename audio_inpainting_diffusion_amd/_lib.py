@@ -89,14 +89,17 @@ class CqtGatherParams(C.Structure):
 
 class AxpbyParams(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("out", C.c_void_p), ("a", C.c_void_p), ("b", C.c_void_p),
-                ("B", C.c_int), ("L", C.c_int64)]
+                ("B", C.c_int), ("L", C.c_int64), ("a_host", C.c_float), ("b_host", C.c_float)]
+
+    def __init__(self, x, y, out, a, b, B, L, a_host=1.0, b_host=1.0):
+        super().__init__(x, y, out, a, b, B, L, a_host, b_host)
 
 
 class ScoreStepParams(C.Structure):
     _fields_ = [("x", C.c_void_p), ("xhat", C.c_void_p), ("yobs", C.c_void_p), ("smask", C.c_void_p),
                 ("smask_sB", C.c_int64), ("x0", C.c_void_p), ("d0", C.c_void_p), ("t", C.c_void_p), ("h", C.c_void_p),
                 ("xnext", C.c_void_p), ("dout", C.c_void_p), ("xh_out", C.c_void_p),
-                ("B", C.c_int), ("L", C.c_int64), ("mode", C.c_int)]
+                ("B", C.c_int), ("L", C.c_int64), ("mode", C.c_int), ("t_host", C.c_float), ("h_host", C.c_float)]
 
 
 class Add2Params(C.Structure):
@@ -134,7 +137,19 @@ class AttentionBwdParams(C.Structure):
 
 class GuidanceSeedParams(C.Structure):
     _fields_ = [("xhat", C.c_void_p), ("y", C.c_void_p), ("mask", C.c_void_p), ("mask_sB", C.c_int64),
-                ("g", C.c_void_p), ("norm", C.c_void_p), ("B", C.c_int), ("L", C.c_int64)]
+                ("g", C.c_void_p), ("norm", C.c_void_p), ("B", C.c_int), ("L", C.c_int64), ("norm_type", C.c_int), ("beta", C.c_float)]
+
+    def __init__(self, xhat, y, mask, mask_sB, g, norm, B, L, norm_type=2, beta=1.0):
+        super().__init__(xhat, y, mask, mask_sB, g, norm, B, L, norm_type, beta)
+
+
+class GuidanceStepParams(C.Structure):
+    _fields_ = [("xhat", C.c_void_p), ("g", C.c_void_p), ("out", C.c_void_p), ("step_out", C.c_void_p), ("s_out", C.c_void_p),
+                ("B", C.c_int), ("L", C.c_int64), ("coef", C.c_float), ("inv_sqrt_len", C.c_float), ("eps", C.c_float)]
+
+
+class SetRowsParams(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("ld", C.c_int64), ("B", C.c_int), ("n", C.c_int), ("v", C.c_float * 8)]
 
 
 class RowNormParams(C.Structure):
@@ -220,7 +235,7 @@ AID_SUMSQ_BLOCKS = 512
 EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_stats", "aid_conv2d", "aid_conv2d_pack_dims", "aid_conv2d_stat_partials", "aid_pack_conv_weight", "aid_wino_gy", "aid_conv2d_wgrad_tiles", "aid_resample",
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
-           "aid_time_attention_bwd", "aid_guidance_seed", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
+           "aid_time_attention_bwd", "aid_guidance_seed", "aid_guidance_step", "aid_set_rows", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
            "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials",
            "aid_conv2d_wgrad", "aid_wgrad_reduce", "aid_channel_dot", "aid_scale_bwd", "aid_modulation_bwd", "aid_embed_bwd",
            "aid_adam", "aid_ema", "aid_sumsq"]
@@ -252,7 +267,7 @@ def lib():
             if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials"):
                 getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, name).restype = C.c_int
-        if L.aid_abi_version() != 6:
+        if L.aid_abi_version() != 7:
             raise AidError("ABI version mismatch")
         _lib = L
     return _lib

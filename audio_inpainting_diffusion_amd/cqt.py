@@ -61,12 +61,15 @@ class CQTRules:
     window_sampling  "integer": w((j)/(M/2)) at integer offsets j about the centre (ours);
                      "half_sample_odd": odd-length windows sampled at j - 1/2 (a periodic window of odd length rolled by M//2)
     centre_rounding  "nearest" | "even" (round(b/2)*2, the sliCQ convention)
+    last_centre      "grid": the highest constant-Q band sits on its grid frequency (ours) | "midpoint": it is moved half-way between its lower
+                     neighbour and Nyquist AFTER the window lengths were taken from the grid (the NSGT toolbox's nsgfwin does this to its last band)
     """
     band0_len: str = "constq"
     last_len: str = "neighbours"
     nyq_len: str = "gap"
     window_sampling: str = "integer"
     centre_rounding: str = "nearest"
+    last_centre: str = "grid"
 
 
 RULES_DEFAULT = CQTRules()
@@ -75,6 +78,9 @@ RULE_PRESETS = {
     # our best recollection of the NSGT toolbox's sliCQ window rule (f/q for the first / last / Nyquist bands)
     "nsgt_f_over_q": CQTRules(band0_len="f_over_q", last_len="f_over_q", nyq_len="f_over_q"),
     "nsgt_f_over_q_periodic": CQTRules(band0_len="f_over_q", last_len="f_over_q", nyq_len="f_over_q", window_sampling="half_sample_odd"),
+    # nsgfwin as recalled by a reviewer: f/q for the first and last band, the Nyquist band spanning the gap, the last centre re-placed at the midpoint
+    "nsgt_midpoint": CQTRules(band0_len="f_over_q", last_len="f_over_q", nyq_len="gap", last_centre="midpoint"),
+    "nsgt_midpoint_periodic": CQTRules(band0_len="f_over_q", last_len="f_over_q", nyq_len="gap", last_centre="midpoint", window_sampling="half_sample_odd"),
 }
 
 
@@ -108,6 +114,11 @@ def frame_design(numocts: int, binsoct: int, fs: float, L: int, rules: CQTRules)
         raise ValueError(rules.last_len)
     Lg[K + 1] = {"gap": 2.0 * (nyq - b[K - 1]), "f_over_q": b[K - 1] / q}[rules.nyq_len]
     Lg = np.maximum(np.round(Lg).astype(np.int64), 4)
+    if rules.last_centre == "midpoint":
+        centre = centre.copy()
+        centre[K] = 0.5 * (centre[K - 1] + centre[K + 1])
+    elif rules.last_centre != "grid":
+        raise ValueError(rules.last_centre)
     if rules.centre_rounding == "nearest":
         rc = np.round(centre).astype(np.int64)
     elif rules.centre_rounding == "even":

@@ -3,7 +3,7 @@
 
 __global__ __launch_bounds__(256) void axpby_kernel(const aid_axpby_params p) {
     const int b = blockIdx.y;
-    const float a = p.a ? p.a[b] : 1.f, bb = p.b ? p.b[b] : 1.f;
+    const float a = p.a ? p.a[b] : p.a_host, bb = p.b ? p.b[b] : p.b_host;
     const int64_t base = (int64_t)b * p.L;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.L; i += (int64_t)gridDim.x * 256) {
         float v = a * p.x[base + i];
@@ -22,7 +22,7 @@ extern "C" int aid_axpby(const aid_axpby_params* p, void* stream) {
 
 __global__ __launch_bounds__(256) void score_step_kernel(const aid_score_step_params p) {
     const int b = blockIdx.y;
-    const float t = p.t[b], h = p.h[b];
+    const float t = p.t ? p.t[b] : p.t_host, h = p.h ? p.h[b] : p.h_host;
     const float inv_t = 1.0f / t;
     const int64_t base = (int64_t)b * p.L;
     const float* sm = p.smask ? p.smask + (int64_t)b * p.smask_sB : nullptr;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void score_step_kernel(const aid_score_step_pa
 }
 
 extern "C" int aid_score_step(const aid_score_step_params* p, void* stream) {
-    AID_REQUIRE(p && p->x && p->xhat && p->t && p->h && p->xnext, "aid_score_step: null pointer");
+    AID_REQUIRE(p && p->x && p->xhat && p->xnext, "aid_score_step: null pointer");
     AID_REQUIRE(p->mode == 0 || (p->x0 && p->d0), "aid_score_step: Heun combine needs x0 and d0");
     AID_REQUIRE(!p->smask || p->yobs, "aid_score_step: projection needs the observations");
     int gx = aid_cdiv(p->L, 256); if (gx > 1024) gx = 1024;
@@ -127,26 +127,74 @@ extern "C" int aid_row_norm(const aid_row_norm_params* p, void* stream) {
 
 __global__ __launch_bounds__(1024) void guidance_seed_kernel(const aid_guidance_seed_params p) {
     const int b = blockIdx.x;
-    const float* m = p.mask + (int64_t)b * p.mask_sB;
+    const float* m = p.mask ? p.mask + (int64_t)b * p.mask_sB : nullptr;
     const int64_t base = (int64_t)b * p.L;
+    const int kind = p.norm_type;                        // 2: || r ||_2, 1: || r ||_1, 3: sum smooth_l1(r; beta)   with r = y - mask*xhat
+    const float beta = p.beta;
     double s = 0.0;
     for (int64_t i = threadIdx.x; i < p.L; i += 1024) {
-        const double r = (double)p.y[base + i] - (double)(m[i] * p.xhat[base + i]);
-        s += r * r;
+        const float mi = m ? m[i] : 1.f;
+        const double r = (double)p.y[base + i] - (double)(mi * p.xhat[base + i]);
+        if (kind == 2) s += r * r;
+        else if (kind == 1) s += fabs(r);
+        else { const double ar = fabs(r); s += (ar < (double)beta) ? 0.5 * r * r / (double)beta : ar - 0.5 * (double)beta; }
     }
     s = block_sum_1024(s);
-    const float nrm = (float)sqrt(s);
+    const float nrm = kind == 2 ? (float)sqrt(s) : (float)s;
     if (threadIdx.x == 0) p.norm[b] = nrm;
     const float inv = nrm > 0.f ? 1.0f / nrm : 0.f;
     for (int64_t i = threadIdx.x; i < p.L; i += 1024) {
-        const float mi = m[i];
-        p.g[base + i] = -mi * (p.y[base + i] - mi * p.xhat[base + i]) * inv;
+        const float mi = m ? m[i] : 1.f;
+        const float r = p.y[base + i] - mi * p.xhat[base + i];
+        float d;                                         // d norm / d r
+        if (kind == 2) d = r * inv;
+        else if (kind == 1) d = (r > 0.f) ? 1.f : ((r < 0.f) ? -1.f : 0.f);
+        else d = (fabsf(r) < beta) ? r / beta : ((r > 0.f) ? 1.f : -1.f);
+        p.g[base + i] = -mi * d;
     }
 }
 
 extern "C" int aid_guidance_seed(const aid_guidance_seed_params* p, void* stream) {
-    AID_REQUIRE(p && p->xhat && p->y && p->mask && p->g && p->norm, "aid_guidance_seed: null pointer");
+    AID_REQUIRE(p && p->xhat && p->y && p->g && p->norm, "aid_guidance_seed: null pointer");
+    AID_REQUIRE(p->norm_type == 2 || p->norm_type == 1 || (p->norm_type == 3 && p->beta > 0.f), "aid_guidance_seed: norm_type is 2, 1 or 3 (smooth-L1, beta > 0)");
     hipLaunchKernelGGL(guidance_seed_kernel, dim3(p->B), dim3(1024), 0, (hipStream_t)stream, *p);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}
+
+// ---- guidance step: out = xhat - coef / (||g||_2 * inv_sqrt_len + eps) * g, per item (edm_sampler_inpainting.py:83-97) ----
+__global__ __launch_bounds__(1024) void guidance_step_kernel(const aid_guidance_step_params p) {
+    const int b = blockIdx.x;
+    const int64_t base = (int64_t)b * p.L;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < p.L; i += 1024) { const double v = p.g[base + i]; s += v * v; }
+    s = block_sum_1024(s);
+    const float normguide = (float)sqrt(s) * p.inv_sqrt_len;
+    const float sc = p.coef / (normguide + p.eps);
+    if (threadIdx.x == 0 && p.s_out) p.s_out[b] = sc;
+    for (int64_t i = threadIdx.x; i < p.L; i += 1024) {
+        const float u = sc * p.g[base + i];
+        if (p.step_out) p.step_out[base + i] = u;
+        p.out[base + i] = p.xhat[base + i] - u;
+    }
+}
+
+extern "C" int aid_guidance_step(const aid_guidance_step_params* p, void* stream) {
+    AID_REQUIRE(p && p->xhat && p->g && p->out, "aid_guidance_step: null pointer");
+    hipLaunchKernelGGL(guidance_step_kernel, dim3(p->B), dim3(1024), 0, (hipStream_t)stream, *p);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}
+
+// ---- host scalars -> device rows: out[i*ld + b] = v[i] for b < B (the EDM preconditioning scalars of one evaluation in ONE launch) ----
+__global__ void set_rows_kernel(const aid_set_rows_params p) {
+    const int i = blockIdx.x;
+    for (int b = threadIdx.x; b < p.B; b += blockDim.x) p.out[(int64_t)i * p.ld + b] = p.v[i];
+}
+
+extern "C" int aid_set_rows(const aid_set_rows_params* p, void* stream) {
+    AID_REQUIRE(p && p->out && p->n >= 1 && p->n <= 8 && p->B >= 1 && p->ld >= p->B, "aid_set_rows: 1..8 rows of B <= ld values");
+    hipLaunchKernelGGL(set_rows_kernel, dim3(p->n), dim3(64), 0, (hipStream_t)stream, *p);
     AID_CHECK_LAUNCH();
     return AID_OK;
 }

@@ -26,20 +26,27 @@ def cqt_is_pinned() -> bool:
     return bool(glob.glob(os.path.join(root, "tests", "golden", "cqt_ref_*.npz")))
 
 
-def load_checkpoint(net, state, key: str = "ema", cqt_pinned: Optional[bool] = None) -> Tuple[int, str]:
+class UnpinnedCQTError(RuntimeError):
+    pass
+
+
+def load_checkpoint(net, state, key: str = "ema", cqt_pinned: Optional[bool] = None, allow_unpinned_cqt: bool = False) -> Tuple[int, str]:
     """Returns (iteration stored in the checkpoint or 0, strategy used: 'strict' | 'non-strict' | 'shape-matched').
 
     Trained weights only mean something on the transform they were trained with.  The reference's CQT is the external
     package ``cqt_nsgt_pytorch``; ours follows the same call contract but its frame design is pinned to the package only
-    once the conformance fixtures exist.  Until then this function warns, loudly."""
+    once the conformance fixtures exist (one command: tools/pin_external.sh).  Until then this function
+    REFUSES (``UnpinnedCQTError``) unless the caller opts out with ``allow_unpinned_cqt=True``, which still warns."""
     import warnings
     if cqt_pinned is None:
         cqt_pinned = cqt_is_pinned()
     if not cqt_pinned and hasattr(net, "CQTransform") and hasattr(net.CQTransform, "plan"):
-        warnings.warn("loading trained weights into the MI355X network while its CQT is NOT pinned to cqt_nsgt_pytorch "
-                      f"(rules {net.CQTransform.plan.rules}): outputs are not comparable with the reference until "
-                      "tests/golden/make_cqt_golden.py has been run where the package is installed and "
-                      "tests/test_cqt_conformance.py passes", RuntimeWarning, stacklevel=2)
+        msg = ("loading trained weights into the MI355X network while its CQT is NOT pinned to cqt_nsgt_pytorch "
+               f"(rules {net.CQTransform.plan.rules}): outputs are not comparable with the reference until "
+               "tools/pin_external.sh (tests/golden/make_cqt_golden.py + tests/test_cqt_conformance.py) has been run where the package is installed")
+        if not allow_unpinned_cqt:
+            raise UnpinnedCQTError(msg + "; pass allow_unpinned_cqt=True to load anyway")
+        warnings.warn(msg, RuntimeWarning, stacklevel=2)
     if isinstance(state, (str, bytes)) or hasattr(state, "__fspath__"):
         state = torch.load(state, map_location="cpu")
     it = int(state["it"]) if "it" in state else 0

@@ -185,8 +185,15 @@ class _Plan:
     def run(self):
         stream = torch.cuda.current_stream().cuda_stream
         timing = self.timing
+        trace = getattr(self, "trace", None)   # set to a list to bracket EVERY launch with HIP events (tools/plan_trace.py)
         for fn, addr, name, flops in self.ops:
-            if timing is not None and flops > 0 and name == "aid_conv2d":
+            if trace is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(addr, stream)
+                e1.record()
+                trace.append((e0, e1, name, self._cur_descr(fn, addr), addr, _lib.lib().aid_last_kernel().decode() if name == "aid_conv2d" else ""))
+            elif timing is not None and flops > 0 and name == "aid_conv2d":
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = fn(addr, stream)
@@ -970,11 +977,17 @@ class Unet_CQT_oct_with_attention(nn.Module):
     def forward(self, inputs: torch.Tensor, sigma: torch.Tensor) -> torch.Tensor:
         """inputs[B,L] (time domain), sigma[B,1] (= c_noise) -> [B,L]     (unet...py:730-845)"""
         self._check_input(inputs)
-        if torch.is_grad_enabled() and inputs.requires_grad:
+        if torch.is_grad_enabled() and inputs.requires_grad and not (self.training and self.param_grads_in_train_mode):
             from .autograd import DenoiserFn   # input-VJP through the same kernels (guidance branch; the reference's tester leaves
-            return DenoiserFn.apply(inputs, sigma, self)          # the network in train() mode, so this case comes first)
+            if self.training and not getattr(self, "_warned_input_only", False) and any(p.requires_grad for p in self.parameters()):
+                import warnings                # the network in train() mode, so this case comes first -- and says so once)
+                self._warned_input_only = True
+                warnings.warn("Unet_CQT_oct_with_attention: train()-mode call with an input that requires grad -> input-VJP only (what the "
+                              "sampler's guidance needs); parameter gradients are NOT produced on this path. Set "
+                              "net.param_grads_in_train_mode = True to get both.", RuntimeWarning, stacklevel=2)
+            return DenoiserFn.apply(inputs, sigma, self)
         if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
-            from .autograd import TrainFn      # training: gradients w.r.t. the parameters through the same kernels
+            from .autograd import TrainFn      # training: gradients w.r.t. the parameters (and the input, if it asks) through the same kernels
             return TrainFn.apply(inputs, sigma, self, *self.parameters())
         return self._forward_impl(inputs, sigma)
 
@@ -996,6 +1009,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
     # input / output buffers, later calls copy the inputs in and replay.  Sub-batch streams (B >= 4) stay eager.
     # ---------------------------------------------------------------------------------------------------
     use_graphs = True
+    param_grads_in_train_mode = False   # True: a train()-mode call whose INPUT requires grad also yields parameter gradients (TrainFn) instead of
+                                        # the input-only VJP; off by default because the reference's tester samples with the network in train() mode
     wgrad_wino = True          # training: F(4,3) form of the 5x3 weight gradients (aid_conv2d_wgrad wino=1)
     fuse_norm_bwd_wino = True  # reverse sweep: aid_norm_bwd also writes the Winograd-domain, gated copy that the dgrad conv below stages
     epilogue_stats = True      # forward group statistics from the epilogue of the conv that produces the tensor (row-shared F(4,3) kernel)
@@ -1008,43 +1023,78 @@ class Unet_CQT_oct_with_attention(nn.Module):
         plans = [st["plan_body"]] + ([st["plan_bwd"]] if "plan_bwd" in st else [])
         return all(pl.timing is None for pl in plans)
 
-    def _graph_run(self, st, key, inputs, fn):
-        """inputs: dict name -> tensor copied into static buffers; fn(static inputs dict) -> tuple of output tensors.
+    def _graph_run(self, st, key, inputs, scalars, fn):
+        """inputs: dict name -> tensor copied into static buffers; scalars: (cnoise, cin, cskip, cout) as host floats or device [B]
+        tensors, written into a static [4, B] buffer outside the graph; fn(static dict) -> tuple of output tensors.
         Returns clones of the static outputs."""
         graphs = st.setdefault("graphs", {})
         ent = graphs.get(key)
+        B = st["B"]
+        dev = next(iter(inputs.values())).device
+        names = ("cnoise", "cin", "cskip", "cout")
         if ent is None:                                   # first call: eager (builds lazily created plans / tables)
             graphs[key] = {"seen": 1}
             while len(graphs) > self.GRAPH_MAX_PER_STATE:
                 graphs.pop(next(iter(graphs)))
-            return fn(inputs)
+            d = dict(inputs)
+            d.update(zip(names, self._scalar_rows(B, dev, *scalars)))
+            return fn(d)
+
+        def put_scalars(buf):
+            if all(isinstance(v, float) for v in scalars):
+                self._scalar_rows(B, dev, *scalars, out=buf)
+            else:
+                for i, v in enumerate(scalars):
+                    buf[i].copy_(v.reshape(-1))
         if "graph" not in ent:                            # second call: capture
             static = {k: v.clone() for k, v in inputs.items()}
+            sbuf = torch.empty(4, B, device=dev, dtype=torch.float32)
+            put_scalars(sbuf)
+            static.update(zip(names, (sbuf[0], sbuf[1], sbuf[2], sbuf[3])))
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 outs = fn(static)
-            ent.update(graph=g, static=static, outs=outs)
+            ent.update(graph=g, static=static, outs=outs, sbuf=sbuf)
         else:
             for k, v in inputs.items():
                 ent["static"][k].copy_(v)
+            put_scalars(ent["sbuf"])
         ent["graph"].replay()
         return tuple(o.clone() for o in ent["outs"])
+
+    def _scalar_rows(self, B, device, cnoise, cin, cskip, cout, out=None):
+        """The four per-evaluation EDM scalars as device [B] vectors.  Host floats (one noise level for the whole batch -- what the sampling
+        loop has) are broadcast by ONE aid_set_rows launch into a persistent [4, B] buffer; device tensors pass through."""
+        vals = (cnoise, cin, cskip, cout)
+        if all(isinstance(v, float) for v in vals):
+            buf = out
+            if buf is None:
+                cache = self.__dict__.setdefault("_scal_cache", {})
+                buf = cache.get((B, device))
+                if buf is None:
+                    buf = cache[(B, device)] = torch.empty(4, B, device=device, dtype=torch.float32)
+            sp = _lib.SetRowsParams(buf.data_ptr(), buf.stride(0), B, 4, (C.c_float * 8)(*vals, 0.0, 0.0, 0.0, 0.0))
+            _lib.call("aid_set_rows", sp)
+            return buf[0], buf[1], buf[2], buf[3]
+        return tuple(v.reshape(-1) for v in vals)
 
     @torch.no_grad()
     def denoise(self, x, cnoise, cin, cskip, cout, hpf: bool):
         """Fused EDM denoiser  D(x) = [hpf](cskip*x + cout*F(cin*x, cnoise))  (diff_params/edm.py:133-148 and,
-        with hpf=True, CQT.apply_hpf_DC of edm_sampler_inpainting.py:63).  cin/cskip/cout/cnoise: device [B]."""
+        with hpf=True, CQT.apply_hpf_DC of edm_sampler_inpainting.py:63).  cin/cskip/cout/cnoise: device [B] tensors, or four host
+        floats (one noise level for the batch)."""
         self._check_input(x)
         B, L = x.shape
         x = x.contiguous()
         if self._n_split(B) == 1:
             st = self._state(B)
             if self._graph_ok(B, st):
-                ins = dict(x=x, cnoise=cnoise.reshape(-1), cin=cin.reshape(-1), cskip=cskip.reshape(-1), cout=cout.reshape(-1))
-                return self._graph_run(st, ("fwd", bool(hpf)), ins,
+                return self._graph_run(st, ("fwd", bool(hpf)), dict(x=x), (cnoise, cin, cskip, cout),
                                        lambda t: (self._denoise_one(t["x"], t["cnoise"], t["cin"], t["cskip"], t["cout"], hpf, st),))[0]
+            cnoise, cin, cskip, cout = self._scalar_rows(B, x.device, cnoise, cin, cskip, cout)
             return self._denoise_one(x, cnoise, cin, cskip, cout, hpf, st)
+        cnoise, cin, cskip, cout = self._scalar_rows(B, x.device, cnoise, cin, cskip, cout)
         n, bounds, streams = self._split_plan(B)
         out = torch.empty(B, L, device=x.device, dtype=torch.float32)
         cur = torch.cuda.current_stream()
@@ -1100,11 +1150,17 @@ class Unet_CQT_oct_with_attention(nn.Module):
         return tr.irfft(S)
 
     @torch.no_grad()
-    def denoise_guided(self, x, cnoise, cin, cskip, cout, hpf: bool, y, mask, degradation=None):
+    def denoise_guided(self, x, cnoise, cin, cskip, cout, hpf: bool, y, mask, degradation=None, norm_type=2, beta=1.0):
         """Fused guided evaluation: x_hat = [hpf](cskip*x + cout*F(cin*x)) and
         rec_grads = d/dx || y - A(x_hat) ||_2 (per item, edm_sampler_inpainting.py:60-81), computed with the
         hand-written input-VJP instead of torch.autograd.  A = time-domain mask (default) or any linear operator
-        object with ``apply`` / ``adjoint`` (stft.SpectralMask).  Returns (x_hat, rec_grads, norm[B])."""
+        object with ``apply`` / ``adjoint`` (stft.SpectralMask).  norm_type: tester.posterior_sampling.norm -- 2, 1 or "smoothl1"
+        (beta = smoothl1_beta), all seeded analytically by aid_guidance_seed (:72-75).  cnoise .. cout: device [B] tensors or host floats.
+        Returns (x_hat, rec_grads, norm[B])."""
+        nt = {2: 2, 1: 1, "smoothl1": 3, 3: 3}.get(norm_type)
+        if nt is None:
+            raise _lib.AidError(f"denoise_guided: posterior_sampling.norm={norm_type!r} is not one of 2, 1, 'smoothl1'")
+        nk = (nt, float(beta))
         self._check_input(x)
         B, L = x.shape
         x = x.contiguous()
@@ -1113,11 +1169,12 @@ class Unet_CQT_oct_with_attention(nn.Module):
         if (degradation is not None and not getattr(degradation, "shared_mask", False)) or self._n_split(B) == 1:
             st = self._state(B)                                      # (per-item operator masks: one stream)
             if degradation is None and self._graph_ok(B, st):
-                ins = dict(x=x, cnoise=cnoise.reshape(-1), cin=cin.reshape(-1), cskip=cskip.reshape(-1), cout=cout.reshape(-1))
-                key = ("guided", bool(hpf), y.data_ptr(), mask.data_ptr(), tuple(mask.shape))       # y / mask are read in place
-                return self._graph_run(st, key, ins, lambda t: self._denoise_guided_one(
-                    t["x"], t["cnoise"], t["cin"], t["cskip"], t["cout"], hpf, y, mask, None, st))
-            return self._denoise_guided_one(x, cnoise, cin, cskip, cout, hpf, y, mask, degradation, st)
+                key = ("guided", bool(hpf), y.data_ptr(), mask.data_ptr(), tuple(mask.shape), nk)   # y / mask are read in place
+                return self._graph_run(st, key, dict(x=x), (cnoise, cin, cskip, cout), lambda t: self._denoise_guided_one(
+                    t["x"], t["cnoise"], t["cin"], t["cskip"], t["cout"], hpf, y, mask, None, st, nk=nk))
+            cnoise, cin, cskip, cout = self._scalar_rows(B, x.device, cnoise, cin, cskip, cout)
+            return self._denoise_guided_one(x, cnoise, cin, cskip, cout, hpf, y, mask, degradation, st, nk=nk)
+        cnoise, cin, cskip, cout = self._scalar_rows(B, x.device, cnoise, cin, cskip, cout)
         m = None if degradation is not None else (mask if mask.dim() == 2 else mask.reshape(1, -1))
         n, bounds, streams = self._split_plan(B)
         x_hat = torch.empty(B, L, device=x.device, dtype=torch.float32)
@@ -1130,12 +1187,12 @@ class Unet_CQT_oct_with_attention(nn.Module):
             with torch.cuda.stream(streams[i]):
                 self._denoise_guided_one(x[lo:hi], cnoise[lo:hi], cin[lo:hi], cskip[lo:hi], cout[lo:hi], hpf, y[lo:hi],
                                          None if m is None else (m[lo:hi] if m.shape[0] > 1 else m), degradation, self._state(hi - lo, i, (B, n)),
-                                         outs=(x_hat[lo:hi], grads[lo:hi], norm[lo:hi]))
+                                         outs=(x_hat[lo:hi], grads[lo:hi], norm[lo:hi]), nk=nk)
         for st_ in streams:
             cur.wait_stream(st_)
         return x_hat, grads, norm
 
-    def _denoise_guided_one(self, x, cnoise, cin, cskip, cout, hpf, y, mask, degradation, st, outs=None):
+    def _denoise_guided_one(self, x, cnoise, cin, cskip, cout, hpf, y, mask, degradation, st, outs=None, nk=(2, 1.0)):
         B, L = x.shape
         tr = self.CQTransform
         tab = tr._tables(x.device)
@@ -1151,12 +1208,11 @@ class Unet_CQT_oct_with_attention(nn.Module):
                 raise _lib.AidError("denoise_guided: mask must be a float32 GPU tensor [1|B, L] with unit inner stride "
                                     "(Sampler.setup_inpainting normalises it)")
             sp = _lib.GuidanceSeedParams(x_hat.data_ptr(), y.data_ptr(), m.data_ptr(), m.stride(0) if m.shape[0] > 1 else 0,
-                                         g.data_ptr(), norm.data_ptr(), B, L)
+                                         g.data_ptr(), norm.data_ptr(), B, L, nk[0], nk[1])
             _lib.call("aid_guidance_seed", sp)
-        else:                                    # g = -A^T (y - A x_hat) / ||y - A x_hat||
+        else:                                    # g = -A^T d norm(y - A x_hat) / d r   (no mask: the operator is the degradation)
             den = degradation.apply(x_hat)
-            ones = self._ones_row(L, x.device)
-            sp = _lib.GuidanceSeedParams(den.data_ptr(), y.data_ptr(), ones.data_ptr(), 0, g.data_ptr(), norm.data_ptr(), B, L)
+            sp = _lib.GuidanceSeedParams(den.data_ptr(), y.data_ptr(), None, 0, g.data_ptr(), norm.data_ptr(), B, L, nk[0], nk[1])
             _lib.call("aid_guidance_seed", sp)
             g = degradation.adjoint(g)
         Gh = tr.rfft(g)
@@ -1248,12 +1304,6 @@ class Unet_CQT_oct_with_attention(nn.Module):
             g = tr._hpf(g)
         self._train_backward(g)
         return loss, err * err
-
-    def _ones_row(self, L, device):
-        o = getattr(self, "_ones_cache", None)
-        if o is None or o.shape[1] != L or o.device != device:
-            o = self._ones_cache = torch.ones(1, L, device=device, dtype=torch.float32)
-        return o
 
     def flops_per_eval(self, B: int = 1) -> int:
         """Algorithmic conv/GEMM/attention FLOPs of one forward evaluation at batch B (2*MACs)."""

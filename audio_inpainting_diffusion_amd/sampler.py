@@ -72,84 +72,75 @@ class Sampler:
         dp.Schurn, dp.Stmin, dp.Stmax, dp.Snoise = tp.Schurn, tp.Stmin, tp.Stmax, tp.Snoise
 
     # ---------------------------------------------------------------------------------------------------
-    def _fast(self) -> bool:
-        return hasattr(self.model, "denoise")
+    def _check_model(self):
+        """The loop drives the model through the fused entry points ``denoise`` / ``denoise_guided`` of the MI355X network (network.py).
+        A foreign torch model has to be wrapped explicitly: ``Sampler(model=generic.GenericModelAdapter(model, diff_params), ...)``."""
+        if not (hasattr(self.model, "denoise") and hasattr(self.model, "denoise_guided")):
+            raise _lib.AidError("Sampler needs a model with the fused entry points denoise / denoise_guided (the MI355X network); wrap any other "
+                                "torch model in audio_inpainting_diffusion_amd.generic.GenericModelAdapter -- there is no implicit eager path")
 
-    def _randn(self, shape):
+    def _draw(self, shape, scale):
+        """scale * randn(shape) from the CPU generator(s) in the reference's order (:212, edm.py:94), drawn straight into one of two
+        pinned staging buffers (re-used alternately; an event guards the one still in flight) -> host tensor ready for an async copy."""
+        ring = self.__dict__.setdefault("_pin_ring", {"shape": None})
+        if ring["shape"] != tuple(shape):
+            ring.update(shape=tuple(shape), bufs=[torch.empty(shape, dtype=torch.float32).pin_memory() for _ in range(2)], ev=[None, None], k=0)
+        k = ring["k"] = ring["k"] ^ 1
+        if ring["ev"][k] is not None:
+            ring["ev"][k].synchronize()                   # the copy issued two draws ago (long finished; never blocks in steady state)
+        buf = ring["bufs"][k]
         if self.seeds is None:
-            n = torch.randn(shape)
+            torch.randn(shape, out=buf)
         else:
-            n = torch.cat([torch.randn([1, shape[1]], generator=g) for g in self._gens], dim=0)
-        return n
+            for b, g in enumerate(self._gens):
+                torch.randn([1, shape[1]], generator=g, out=buf[b:b + 1])
+        if float(scale) != 1.0:
+            buf.mul_(scale)
+        return buf, k
 
-    def _to_dev(self, cpu_tensor, device):
-        return cpu_tensor.pin_memory().to(device, non_blocking=True) if device.type == "cuda" else cpu_tensor.to(device)
-
-    def _vec(self, value, B, device):
-        """host scalar (0-d float32 tensor or float) -> device [B]"""
-        return torch.full((B,), float(value), dtype=torch.float32, device=device)
+    def _draw_to(self, shape, scale, device):
+        buf, k = self._draw(shape, scale)
+        out = buf.to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pin_ring["ev"][k] = ev
+        return out
 
     # ---- one denoiser evaluation -> projected x_hat --------------------------------------------------------
+    def _scalars(self, t_i):
+        """c_noise, c_in, c_skip, c_out of this evaluation as host floats, computed by diff_params in float32 torch arithmetic (edm.py:97-128)"""
+        dp = self.diff_params
+        s = t_i.reshape(1)
+        return float(dp.cnoise(s)), float(dp.cin(s)), float(dp.cskip(s)), float(dp.cout(s))
+
     def _denoise(self, x, t_i):
         """x_hat = D(x; t_i) [+ guidance step] ; data-consistency projection is applied by the caller's fused
         step kernel.  t_i: 0-d float32 CPU tensor."""
         B = x.shape[0]
-        dp = self.diff_params
         self.n_evals += B
         if self.trace_in is not None:
             self.trace_in.append((x.clone(), float(t_i)))
         if self.y is not None and self.xi > 0:
             return self._denoise_guided(x, t_i)
         hpf = bool(self.y is None and self.args.tester.filter_out_cqt_DC_Nyq)   # (:122-123) unconditional only
-        if self._fast():
-            s = t_i.reshape(1)
-            return self.model.denoise(x, self._vec(dp.cnoise(s), B, x.device), self._vec(dp.cin(s), B, x.device),
-                                      self._vec(dp.cskip(s), B, x.device), self._vec(dp.cout(s), B, x.device), hpf)
-        with torch.no_grad():
-            x_hat = dp.denoiser(x, self.model, t_i.reshape(1).to(x.device).unsqueeze(-1))
-            if hpf:
-                x_hat = self.model.CQTransform.apply_hpf_DC(x_hat)
-        return x_hat
+        return self.model.denoise(x, *self._scalars(t_i), hpf)
 
     def _denoise_guided(self, x, t_i):
-        """Reconstruction guidance (:57-105), per item.  With the MI355X network the gradient comes from its
-        hand-written input-VJP (network.denoise_guided); any other model goes through torch.autograd."""
-        dp = self.diff_params
+        """Reconstruction guidance (:57-105), per item: analytic seed of the chosen norm, the network's hand-written input-VJP,
+        then the normalised step x_hat - t*xi/(||g||/sqrt(L) + 1e-6) * g in one launch (aid_guidance_step)."""
         B, L = x.shape
-        nrm = self.args.tester.posterior_sampling.norm
+        ps = self.args.tester.posterior_sampling
         hpf = bool(self.args.tester.filter_out_cqt_DC_Nyq)
-        if self._fast() and hasattr(self.model, "denoise_guided") and nrm == 2:
-            s1 = t_i.reshape(1)
-            x_hat, rec_grads, _ = self.model.denoise_guided(
-                x, self._vec(dp.cnoise(s1), B, x.device), self._vec(dp.cin(s1), B, x.device), self._vec(dp.cskip(s1), B, x.device),
-                self._vec(dp.cout(s1), B, x.device), hpf, self.y, self.mask, self.spectral)
-            gn = torch.empty(B, device=x.device, dtype=torch.float32)
-            _lib.call("aid_row_norm", _lib.RowNormParams(rec_grads.data_ptr(), gn.data_ptr(), B, L))
-            normguide = gn / self.args.exp.audio_len ** 0.5                      # (:83) per item
-            s = -(float(t_i) * self.xi) / (normguide + 1e-6)                     # (:87), sign folded for the axpy
-            out = torch.empty_like(x_hat)
-            _lib.call("aid_axpby", _lib.AxpbyParams(x_hat.data_ptr(), rec_grads.data_ptr(), out.data_ptr(), None, s.data_ptr(), B, L))
-            if self.rid:                                                         # (:92-99: denoised estimate, s*rec_grads, updated estimate)
-                self._rid_last = (x_hat, -s[:, None] * rec_grads, out)
-            return out                                                           # x_hat - s*rec_grads (:97)
-        x = x.detach().requires_grad_()
-        sig = t_i.reshape(1, 1).to(x.device).expand(B, 1)
-        with torch.enable_grad():
-            x_hat = dp.denoiser(x, self.model, sig)
-            if hpf:
-                x_hat = self.model.CQTransform.apply_hpf_DC(x_hat)
-            den_rec = self.mask * x_hat if self.spectral is None else _SpectralFn.apply(x_hat, self.spectral)
-            if nrm == "smoothl1":
-                norm = torch.nn.functional.smooth_l1_loss(self.y, den_rec, reduction="none",
-                                                          beta=self.args.tester.posterior_sampling.smoothl1_beta).sum(dim=1)
-            else:
-                norm = torch.linalg.norm(self.y - den_rec, dim=1, ord=nrm)
-            rec_grads = torch.autograd.grad(outputs=norm.sum(), inputs=x)[0]
-        normguide = torch.linalg.norm(rec_grads, dim=1, keepdim=True) / self.args.exp.audio_len ** 0.5
-        s = float(t_i) * self.xi / (normguide + 1e-6)
-        out = (x_hat.detach() - s * rec_grads).detach()
-        if self.rid:
-            self._rid_last = (x_hat.detach(), s * rec_grads, out)
+        x_hat, rec_grads, _ = self.model.denoise_guided(x, *self._scalars(t_i), hpf, self.y, self.mask, self.spectral,
+                                                        norm_type=ps.norm, beta=float(getattr(ps, "smoothl1_beta", 1.0)))
+        out = torch.empty_like(x_hat)
+        upd = torch.empty_like(x_hat) if self.rid else None
+        inv = float(np.float32(1.0) / np.float32(self.args.exp.audio_len ** 0.5))
+        p = _lib.GuidanceStepParams(x_hat.data_ptr(), rec_grads.data_ptr(), out.data_ptr(), _lib.ptr(upd), None, B, L,
+                                    float(t_i) * self.xi, inv, 1e-6)                # (:83, :87, :97)
+        _lib.call("aid_guidance_step", p)
+        if self.rid:                                                                 # (:92-99: denoised estimate, s*rec_grads, updated estimate)
+            self._rid_last = (x_hat, upd, out)
         return out
 
     def _score_step(self, x, x_hat, t_i, h, mode, x0=None, d0=None):
@@ -166,13 +157,11 @@ class Sampler:
         if proj and self.spectral is not None:                     # y + x_hat - A(x_hat)   (:360)
             x_hat, proj = self.spectral.project(x_hat, self.y), False
         xh_out = torch.empty_like(x) if (self.trace is not None or self.rid) else None
-        tv, hv = self._vec(t_i, B, x.device), self._vec(h, B, x.device)   # keep alive until after the launch
         p = _lib.ScoreStepParams(x.data_ptr(), x_hat.data_ptr(), _lib.ptr(self.y) if proj else None,
                                  _lib.ptr(self.smask) if proj else None, (self.smask.stride(0) if self.smask.shape[0] > 1 else 0) if proj else 0,
-                                 _lib.ptr(x0), _lib.ptr(d0), tv.data_ptr(), hv.data_ptr(),
-                                 xnext.data_ptr(), _lib.ptr(dout), _lib.ptr(xh_out), B, L, mode)
+                                 _lib.ptr(x0), _lib.ptr(d0), None, None,
+                                 xnext.data_ptr(), _lib.ptr(dout), _lib.ptr(xh_out), B, L, mode, float(t_i), float(h))
         _lib.call("aid_score_step", p)
-        del tv, hv
         if self.trace is not None:
             self.trace.append(xh_out)
         self._rid_pocs = xh_out
@@ -189,11 +178,12 @@ class Sampler:
         device = torch.device(device)
         if device.type != "cuda":
             raise _lib.AidError("the MI355X sampler runs on the GPU only (no CPU fallback)")
+        self._check_model()
         dp = self.diff_params
         self._gens = None if self.seeds is None else [torch.Generator().manual_seed(int(s)) for s in self.seeds]
         t = dp.create_schedule(self.nb_steps)                 # host, float32
         gamma = dp.get_gamma(t)
-        x = self._to_dev(self._randn(shape) * t[0], device)   # prior (edm.py:94)
+        x = self._draw_to(shape, t[0], device)                # prior (edm.py:94)
         return dict(x=x, t=t, gamma=gamma, shape=tuple(shape), device=device)
 
     def step(self, state, i: int):
@@ -205,13 +195,11 @@ class Sampler:
             t_hat = t[i]
         else:
             t_hat = t[i] + gamma[i] * t[i]
-            eps = self._to_dev(self._randn(shape) * dp.Snoise, device)
+            eps = self._draw_to(shape, dp.Snoise, device)
             coef = (t_hat ** 2 - t[i] ** 2) ** (1 / 2)
             xn = torch.empty_like(x)
-            cv = self._vec(coef, B, device)
-            p = _lib.AxpbyParams(x.data_ptr(), eps.data_ptr(), xn.data_ptr(), None, cv.data_ptr(), B, L)
+            p = _lib.AxpbyParams(x.data_ptr(), eps.data_ptr(), xn.data_ptr(), None, None, B, L, 1.0, float(coef))
             _lib.call("aid_axpby", p)                      # x + sqrt(t_hat^2 - t_i^2) * eps   (:214)
-            del cv
             x = xn
         rid = state.get("rid")
         if rid is not None:
@@ -283,16 +271,3 @@ class Sampler:
         (:348-364): degradation = STFT-domain masking, projection y + x - A(x)."""
         self.setup_spectrogram_inpainting(y_masked, mask)
         return self.predict(self.y.shape, self.y.device)
-
-
-class _SpectralFn(torch.autograd.Function):
-    """A(x) with A^T as its backward -- only used when a foreign (non-MI355X) model is driven through torch.autograd."""
-
-    @staticmethod
-    def forward(ctx, x, op):
-        ctx.op = op
-        return op.apply(x.detach())
-
-    @staticmethod
-    def backward(ctx, g):
-        return ctx.op.adjoint(g.contiguous()), None

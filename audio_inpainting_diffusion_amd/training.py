@@ -70,10 +70,23 @@ class Trainer:
     def grads(self, B: int) -> torch.Tensor:
         return self.net.train_state(B)["gflat"]
 
+    def _rehome(self):
+        """The optimiser walks the flat parameter buffer.  If the parameters were re-homed since the constructor (``load_state_dict(assign=True)``,
+        ``.to()``, a dtype change), the plan builder has made a NEW flat buffer and gradients follow that one: adopt it, so that Adam / EMA keep
+        updating the live weights (moments and EMA keep their values when the layout is unchanged, otherwise the mismatch is an error)."""
+        live = flatten_parameters_(self.net)
+        if live.data_ptr() != self.flat.data_ptr():
+            if live.numel() != self.flat.numel() or live.device != self.flat.device:
+                raise _lib.AidError("Trainer: the network's flat parameter buffer changed size or device after the Trainer was built")
+            self.flat = live
+
     def optimizer_step(self, B: int):
         """lr ramp-up (trainer.py:270-274), clip_grad_norm_ (:277-278), Adam.step (:281)."""
+        self._rehome()
         g = self.grads(B)
         n = g.numel()
+        if n != self.flat.numel():
+            raise _lib.AidError("Trainer: gradient buffer and parameter buffer have different layouts")
         lr = self.lr * min(self.it / max(self.lr_rampup_it, 1e-8), 1) if self.it <= self.lr_rampup_it else self.lr
         _lib.call("aid_sumsq", _lib.SumsqParams(g.data_ptr(), self.ws.data_ptr(), self.gstat.data_ptr(), n,
                                                 self.max_grad_norm if self.use_grad_clip else 0.0))
@@ -84,9 +97,9 @@ class Trainer:
                                               1.0 - self.beta1 ** t, math.sqrt(1.0 - self.beta2 ** t)))
         self.net._packed_ver = None          # parameters changed behind torch's version counters: refresh the kernel-side packs
 
-    def update_ema(self):
-        """trainer.py:288-304"""
-        t = self.it * self.batch
+    def update_ema(self, batch: Optional[int] = None):
+        """trainer.py:288-304 (t = it * batch_size: the batch actually trained on, ``batch`` of the constructor when not given)"""
+        t = self.it * (self.batch if batch is None else int(batch))
         rate = float(min(max(t / self.ema_rampup, 0.0), self.ema_rate)) if t < self.ema_rampup else self.ema_rate
         _lib.call("aid_ema", _lib.EmaParams(self.ema.data_ptr(), self.flat.data_ptr(), self.flat.numel(), rate))
 
@@ -94,17 +107,78 @@ class Trainer:
         """One iteration (num_accumulation_rounds = 1): returns the loss (device scalar)."""
         loss, _, _ = self.loss_and_grads(audio, sigma, noise)
         self.optimizer_step(audio.shape[0])
-        self.update_ema()                     # (training_loop: train_step, update_ema, then it += 1; trainer.py:366-368)
+        self.update_ema(audio.shape[0])       # (training_loop: train_step, update_ema, then it += 1; trainer.py:366-368)
         self.it += 1
         return loss
 
+    def _layout(self):
+        """(name, offset, shape) of every fp32 parameter, then every fp32 buffer, in the flat buffers' order (dist.flatten_parameters_)"""
+        items = [(k, v) for k, v in self.net.named_parameters() if v.dtype == torch.float32] + \
+                [(k, v) for k, v in self.net.named_buffers() if v.dtype == torch.float32]
+        out, off = [], 0
+        for k, v in items:
+            out.append((k, off, tuple(v.shape)))
+            off += v.numel()
+        assert off == self.flat.numel()
+        return out
+
+    def _views(self, flat):
+        return {k: flat[off:off + int(torch.Size(shape).numel())].view(shape) for k, off, shape in self._layout()}
+
     def ema_state_dict(self):
         """state_dict-shaped view of the EMA buffer (what the reference checkpoints as 'ema')."""
-        out, off = {}, 0
-        sd = self.net.state_dict()
-        names = [k for k, v in self.net.named_parameters() if v.dtype == torch.float32] + [k for k, v in self.net.named_buffers() if v.dtype == torch.float32]
-        for k in names:
-            n = sd[k].numel()
-            out[k] = self.ema[off:off + n].view(sd[k].shape)
-            off += n
-        return out
+        return self._views(self.ema)
+
+    # ---- checkpoints in the reference's shape (training/trainer.py:186-199: {'it', 'network', 'optimizer', 'ema', 'args'}) -----------------
+    def state_dict(self, args=None):
+        """'optimizer' is what ``torch.optim.Adam(network.parameters(), ...).state_dict()`` of the reference (utils/setup.py:55-58) would hold:
+        per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` indexed by position in ``network.parameters()`` (trainable parameters only), and
+        one param group -- so a run on this Trainer resumes under the reference's trainer and vice versa."""
+        m, v = self._views(self.m), self._views(self.v)
+        params = list(self.net.named_parameters())
+        state = {}
+        if self.steps > 0:
+            for i, (k, p) in enumerate(params):
+                if p.requires_grad:
+                    state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": m[k].clone(), "exp_avg_sq": v[k].clone()}
+        group = {"lr": self.lr, "betas": (self.beta1, self.beta2), "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(params)))}
+        return {"it": self.it, "network": {k: t.detach().clone() for k, t in self.net.state_dict().items()},
+                "optimizer": {"state": state, "param_groups": [group]},
+                "ema": {k: t.clone() for k, t in self.ema_state_dict().items()}, "args": args}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd, strict: bool = True):
+        """Restore a checkpoint of the reference's shape: weights and EMA in place (the flat views stay intact), Adam moments and step count
+        from 'optimizer' (so bias correction and the lr ramp-up continue instead of restarting), ``it``."""
+        self._rehome()
+        self.net.load_state_dict(sd["network"], strict=strict)
+        self.net._packed_ver = None
+        ema = self._views(self.ema)
+        for k, t in sd.get("ema", {}).items():
+            if k in ema:
+                ema[k].copy_(t.to(ema[k].device, torch.float32))
+            elif strict:
+                raise KeyError(f"unexpected key {k!r} in checkpoint['ema']")
+        opt = sd.get("optimizer")
+        if opt is not None:
+            m, v = self._views(self.m), self._views(self.v)
+            self.m.zero_()
+            self.v.zero_()
+            params = list(self.net.named_parameters())
+            steps = 0
+            for i, st in opt.get("state", {}).items():
+                k = params[int(i)][0]
+                m[k].copy_(st["exp_avg"].to(m[k].device, torch.float32))
+                v[k].copy_(st["exp_avg_sq"].to(v[k].device, torch.float32))
+                steps = max(steps, int(round(float(st["step"]))))
+            self.steps = steps
+            g = (opt.get("param_groups") or [{}])[0]
+            if "betas" in g:
+                self.beta1, self.beta2 = float(g["betas"][0]), float(g["betas"][1])
+            self.eps = float(g.get("eps", self.eps))
+        self.it = int(sd.get("it", self.it))
+        return True
+
+    def save_checkpoint(self, path: str, args=None):
+        torch.save(self.state_dict(args), path)

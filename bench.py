@@ -20,18 +20,20 @@ segments; the only collective is the start-up weight broadcast (not timed).
 Default branch: xi=0.25 = reconstruction guidance, the reference tester's shipped setting: every evaluation is a
 forward pass PLUS the input-VJP through the whole denoiser (--xi 0 times the forward-only replacement branch).
 
-roofline (fp32 MFMA, peak 157.3 TFLOP/s): every aid_conv2d launch inside the timed region (forward and VJP plans) is
+roofline (fp32 MFMA, peak 157.3 TFLOP/s): every aid_conv2d launch of a single-stream pass (forward and VJP plans) is
 bracketed by HIP events on the launch stream and attributed to the device kernel it dispatched to (aid_last_kernel).
-The line reports the DOMINANT kernel (most GPU time; conv53_wino4v_kernel, the 5x3 layers in Winograd F(4,3) form):
-    achieved = MFMA FLOPs that kernel ISSUES per launch / its average launch duration
+The line reports the DOMINANT kernel BY ITS ROCPROF NAME (most GPU time: conv53_wino4r_kernel, the 5x3 layers in Winograd
+F(4,3) form), over ALL its template instances / tile kinds (`families` keeps the sub-family table):
+    achieved = MFMA FLOPs that kernel ISSUES / its launch time, summed over every launch of >= 3 Heun steps
                (F(4,3) issues 6 products per 4 outputs x 3 taps = half the direct-form FLOPs; 1x1 / direct kernels issue all)
     frac     = achieved / 157.3
     algorithmic_tflops = direct-convolution FLOPs (2*B*F*T*Cin*Cout*KH*KW) / the same time -- may exceed the peak
-`families` holds the same three numbers, launch count, average duration and algorithmic bytes for every conv kernel
-family; `all_conv` the aggregate.  traffic (HBM bytes per launch from PMC counters) cannot be measured from inside
-this process: it is null here and the PMC passes of this same command are committed under profiles/ (`traffic_from_profile`).
-cpu_baseline: the CPU oracle (torch-CPU restatement of the reference path, oracle/) timed on this host's cores
-for the same network and branch at B=1 (rank 0, N=1 only): one warm-up evaluation, then three timed evaluations.
+    step_executed_frac = MFMA FLOPs issued by ALL conv / GEMM launches of a step / the step's wall time in the TIMED region / 157.3
+`kernels` aggregates every conv kernel by name, `families` by name + tile kind, `all_conv` over all of them.  traffic (HBM bytes
+per launch from PMC counters) cannot be measured from inside this process: it is null here and the PMC passes of this same command
+are committed under profiles/ (`traffic_from_profile`).
+cpu_baseline: the CPU oracle (torch-CPU restatement of the reference path, oracle/) timed on this host's cores for the same
+network and branch at B=1 (rank 0, N=1 only): one warm-up evaluation OF THE SAME BRANCH, then three timed evaluations; value = 1 / median.
 """
 import argparse
 import json
@@ -75,10 +77,8 @@ def cpu_baseline(net, args, guided: bool, spectral: bool = False, n_timed: int =
     mask = torch.ones(1, L)
     mask[:, L // 2 - 3307: L // 2 + 3308] = 0
     s = torch.full((1, 1), 0.5)
-    with torch.no_grad():
-        edm.denoiser(x, orc, s)                      # warm-up
     times = []
-    for _ in range(n_timed):
+    for it in range(n_timed + 1):                    # the first pass (same branch: autograd / oneDNN warm-up) is not counted
         t0 = time.time()
         if guided:
             xr = x.clone().requires_grad_()
@@ -94,21 +94,24 @@ def cpu_baseline(net, args, guided: bool, spectral: bool = False, n_timed: int =
         else:
             with torch.no_grad():
                 edm.denoiser(x, orc, s)
-        times.append(time.time() - t0)
-    dt = sum(times) / len(times)
+        if it > 0:
+            times.append(time.time() - t0)
+    dt = sorted(times)[len(times) // 2]
     what = "guided (xi=0.25: forward with graph + input-VJP by torch.autograd)" if guided else "forward-only (xi=0)"
     return {"value": round(1.0 / dt, 4), "unit": "denoiser evaluations per second", "cores": cores, "kind": "port",
             "cpu_model": cpu_model(), "seconds_per_evaluation": [round(t, 2) for t in times],
-            "sample": f"B=1 full-size {args.exp.exp_name} network, {what}: 1 warm-up forward + {n_timed} timed evaluations "
-                      f"(mean {dt:.2f} s, min {min(times):.2f} s), torch {torch.__version__} CPU fp32, {cores} threads"}
+            "median_s": round(dt, 2), "min_s": round(min(times), 2),
+            "sample": f"B=1 full-size {args.exp.exp_name} network, {what}: 1 warm-up evaluation of the same branch + {n_timed} timed evaluations "
+                      f"(median {dt:.2f} s, min {min(times):.2f} s; value = 1 / median), torch {torch.__version__} CPU fp32, {cores} threads"}
 
 
-def family_table(timing):
-    """timing: (event0, event1, algorithmic_flops, description, algorithmic_bytes, kernel_name) per conv launch."""
+def family_table(timing, by_kernel=False):
+    """timing: (event0, event1, algorithmic_flops, description, algorithmic_bytes, kernel_name) per conv launch.
+    by_kernel: aggregate by the device kernel's name (what rocprofv3 lists) instead of name + tile kind."""
     fam = {}
     for e0, e1, fl, _d, nb, kn in timing:
-        base = kn.split("(")[0]
-        r = fam.setdefault(kn, dict(launches=0, ms=0.0, alg=0.0, exe=0.0, bytes=0.0))
+        base = kn.split("(")[0].split("+")[0]
+        r = fam.setdefault(base if by_kernel else kn, dict(launches=0, ms=0.0, alg=0.0, exe=0.0, bytes=0.0))
         r["launches"] += 1
         r["ms"] += e0.elapsed_time(e1)
         r["alg"] += fl
@@ -164,6 +167,8 @@ def main():
     from audio_inpainting_diffusion_amd.sampler import Sampler
 
     rank, local, world = D.init_distributed()
+    if world > 1:                                      # N ranks share the host: keep each rank's CPU noise generation on its share of the cores
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     shared = int(os.environ.get("AID_SHARED_GPU", "0"))        # set by launch_ranks when ranks have to share GPUs
@@ -207,7 +212,8 @@ def main():
     # Every timed step is a Heun step (2 evaluations; the last step of a schedule is Euler): positions 0 .. T-4 of the schedule are walked,
     # and when --warmup + --steps exceed them the sampler starts the next batch's trajectory (smp.begin) inside the run, as a job over many
     # batches of segments does.  Two positions stay in reserve for the single-stream roofline pass.
-    span = T - 3
+    ROOF_STEPS = 3                                     # Heun steps of the single-stream roofline pass (after one warm-up step)
+    span = T - 2 - (ROOF_STEPS + 1)
     state = smp.begin((B, L), dev)
 
     def do_step(i):
@@ -223,10 +229,6 @@ def main():
     n_split = net._n_split(B)
     timing = []
     graphs = bool(net.use_graphs and B <= net.GRAPH_MAX_B and n_split == 1)     # small batches replay a captured HIP graph
-    separate = n_split > 1 or graphs                   # per-launch HIP events cannot be taken inside the product schedule
-    if not separate:                                   # one stream, eager launches: per-launch HIP events inside the timed region
-        for pl in net.timed_plans(B, a.xi > 0):
-            pl.timing = timing
     torch.cuda.synchronize()
     D.barrier()
     t0 = time.perf_counter()
@@ -236,33 +238,30 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     wall = time.perf_counter() - t0
-    for pl in net.timed_plans(B, a.xi > 0):
-        pl.timing = None
     wall = D.max_over_ranks(wall, dev)
     assert torch.isfinite(state["x"]).all()
-    roofline_pass = "per-launch HIP events inside the timed region (single stream)"
-    if separate:
-        # The product schedule runs %d sub-batches on concurrent HIP streams: kernels of different sub-batches overlap, so a
-        # launch's start-to-end time in the timed region is not the kernel's speed.  Kernel speeds are measured right after
-        # it: the SAME sampler continues for one warm-up and one measured Heun step with the network forced onto one stream.
-        roofline_pass = ("separate single-stream pass of eager launches: 1 warm-up + 1 measured Heun step (steps %d, %d of the same run) right after "
-                         "the timed region, %s" % (jlast + 1, jlast + 2,
-                                                    "which replays a captured HIP graph per evaluation" if graphs else "whose %d sub-batch streams overlap kernels" % n_split))
-        assert jlast + 2 <= T - 2
-        net.split_streams = 1
-        smp.step(state, jlast + 1)
-        for pl in net.timed_plans(B, a.xi > 0):
-            pl.timing = timing
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        smp.step(state, jlast + 2)
-        torch.cuda.synchronize()
-        wall_serial = time.perf_counter() - t1
-        for pl in net.timed_plans(B, a.xi > 0):
-            pl.timing = None
-        net.split_streams = a.streams or None
-    else:
-        wall_serial = wall / a.steps
+    # Kernel speeds are measured right after the timed region: the SAME sampler continues for one warm-up and ROOF_STEPS measured
+    # Heun steps with the network forced onto one stream and eager launches (the product schedule overlaps kernels of different
+    # sub-batches on concurrent HIP streams, or replays a captured HIP graph: a launch's start-to-end time there is not the kernel's speed).
+    roofline_pass = ("separate single-stream pass of eager launches: 1 warm-up + %d measured Heun steps (steps %d..%d of the same run) right after "
+                     "the timed region, %s" % (ROOF_STEPS, jlast + 2, jlast + 1 + ROOF_STEPS,
+                                                "which replays a captured HIP graph per evaluation" if graphs else
+                                                ("whose %d sub-batch streams overlap kernels" % n_split if n_split > 1 else "which runs the same single-stream schedule")))
+    assert jlast + 1 + ROOF_STEPS <= T - 2
+    net.split_streams, use_graphs = 1, net.use_graphs
+    net.use_graphs = False
+    smp.step(state, jlast + 1)
+    for pl in net.timed_plans(B, a.xi > 0):
+        pl.timing = timing
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for k in range(ROOF_STEPS):
+        smp.step(state, jlast + 2 + k)
+    torch.cuda.synchronize()
+    wall_serial = (time.perf_counter() - t1) / ROOF_STEPS
+    for pl in net.timed_plans(B, a.xi > 0):
+        pl.timing = None
+    net.split_streams, net.use_graphs = (a.streams or None), use_graphs
 
     if a.conv_table and rank == 0:
         agg = {}
@@ -275,8 +274,9 @@ def main():
     evals = world * B * 2 * a.steps
     if rank == 0:
         fams = family_table(timing)
-        dom_name = next(iter(fams)) if fams else None
-        dom = fams.get(dom_name, {})
+        kerns = family_table(timing, by_kernel=True)
+        dom_name = next(iter(kerns)) if kerns else None
+        dom = kerns.get(dom_name, {})
         conv_ms = sum(v["time_ms"] for v in fams.values())
         alg = sum(t[2] for t in timing)
         exe = sum(t[2] * (0.5 if t[5].split("(")[0] in WINO_KERNELS else 1.0) for t in timing)
@@ -298,17 +298,22 @@ def main():
                                       % (world, nbytes / 1e6, t_bcast, (torch.distributed.get_backend() if world > 1 else "single process")),
                        "sub_batch_streams": n_split, "hip_graph_replay": graphs, "functional_shared_gpu": bool(shared)},
             "roofline": {"bound": "mfma", "kernel": dom_name, "measured_in": roofline_pass,
-                         "definition": "achieved = MFMA FLOPs the dominant kernel issues per launch / its average launch duration (HIP events in the timed region); "
-                                       "Winograd F(4,3) issues half of the direct-form FLOPs; algorithmic_tflops = direct-form FLOPs / the same time",
+                         "definition": "achieved = MFMA FLOPs issued by ALL launches of the dominant kernel (by device-kernel name, every template instance / tile kind) "
+                                       "/ their summed duration (HIP events around each launch); Winograd F(4,3) issues half of the direct-form FLOPs; "
+                                       "algorithmic_tflops = direct-form FLOPs / the same time; step_executed_frac = issued MFMA FLOPs of all conv / GEMM launches "
+                                       "of one step / ms_per_step of the timed region / peak",
+                         "step_executed_frac": round(exe / ROOF_STEPS / (wall / a.steps) / 1e12 / PEAK_F32_MFMA, 4),
+                         "step_executed_tflops": round(exe / ROOF_STEPS / (wall / a.steps) / 1e12, 2),
+                         "non_winograd_conv_time_fraction_single_stream": round(1.0 - dom.get("time_ms", 0.0) / ROOF_STEPS / (1e3 * wall_serial), 3),
                          "achieved": dom.get("executed_mfma_tflops"), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s", "frac": dom.get("frac_of_fp32_mfma_peak"),
                          "algorithmic_tflops": dom.get("algorithmic_tflops"), "launches": dom.get("launches"), "avg_launch_us": dom.get("avg_launch_us"),
                          "algorithmic_gflop_per_launch": dom.get("algorithmic_gflop_per_launch"),
                          "traffic": None, "traffic_from_profile": _profile_traffic(),
                          "share_of_conv_time": round(dom.get("time_ms", 0.0) / max(conv_ms, 1e-9), 3),
                          "all_conv": {"launches": len(timing), "executed_mfma_tflops": round(exe / sec / 1e12, 2), "frac_of_fp32_mfma_peak": round(exe / sec / 1e12 / PEAK_F32_MFMA, 4),
-                                      "algorithmic_tflops": round(alg / sec / 1e12, 2), "conv_time_fraction_of_wall": round(sec / (wall_serial if separate else wall), 3),
+                                      "algorithmic_tflops": round(alg / sec / 1e12, 2), "conv_time_fraction_of_wall": round(sec / (ROOF_STEPS * wall_serial), 3),
                                       "single_stream_ms_per_step": round(1e3 * wall_serial, 2)},
-                         "families": fams},
+                         "kernels": kerns, "families": fams},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(net, args, guided=a.xi > 0, spectral=a.task == "spectrogram")
@@ -321,7 +326,7 @@ def main():
 
 def _profile_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of this command (profiles/), or null."""
-    for name in ("r02_conv_traffic.json", "r01_conv_traffic.json"):
+    for name in ("r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json"):
         tr = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tr):
             try:

@@ -28,7 +28,7 @@ extern "C" {
 #define AID_E_BADARG (-1)   /* unsupported shape / null pointer / misaligned stride */
 #define AID_E_LAUNCH (-2)   /* hipLaunchKernel reported an error                    */
 
-#define AID_ABI_VERSION 6
+#define AID_ABI_VERSION 7
 int aid_abi_version(void);
 /* last HIP error string seen by a launcher in this process (never NULL) */
 const char* aid_last_error(void);
@@ -282,17 +282,19 @@ int aid_fft_pass(const aid_fft_pass_params* p, void* stream);
  * ------------------------------------------------------------------------------------------------- */
 typedef struct {
     const float* x; const float* y; float* out;
-    const float* a; const float* b;   /* per-sample [B] */
+    const float* a; const float* b;   /* per-sample [B]; NULL: the host scalar a_host / b_host for every sample */
     int B; int64_t L;
+    float a_host, b_host;
 } aid_axpby_params;
 int aid_axpby(const aid_axpby_params* p, void* stream);
 
 typedef struct {
     const float* x; const float* xhat; const float* yobs; const float* smask; int64_t smask_sB;
     const float* x0; const float* d0;
-    const float* t; const float* h;   /* per-sample [B] */
+    const float* t; const float* h;   /* per-sample [B]; NULL: the host scalars t_host / h_host (one schedule for the batch) */
     float* xnext; float* dout; float* xh_out;
     int B; int64_t L; int mode;
+    float t_host, h_host;
 } aid_score_step_params;
 int aid_score_step(const aid_score_step_params* p, void* stream);
 
@@ -342,11 +344,28 @@ typedef struct {
 int aid_time_attention_bwd(const aid_attention_bwd_params* p, void* stream);
 
 typedef struct {
-    const float* xhat; const float* y; const float* mask; int64_t mask_sB;
+    const float* xhat; const float* y; const float* mask; int64_t mask_sB;   /* mask NULL: all ones (operator degradations) */
     float* g; float* norm;        /* g [B,L], norm [B] */
     int B; int64_t L;
+    int norm_type;                /* tester.posterior_sampling.norm (:72-75): 2 = L2, 1 = L1, 3 = "smoothl1" (summed over the item) */
+    float beta;                   /* smoothl1_beta (norm_type 3) */
 } aid_guidance_seed_params;
 int aid_guidance_seed(const aid_guidance_seed_params* p, void* stream);
+
+/* aid_guidance_step : the guidance update of one evaluation in one launch (:83-97), per item:
+ *       normguide = ||g[b]||_2 * inv_sqrt_len ;  s = coef / (normguide + eps) ;  out = xhat - s*g
+ *   coef = t_i * xi (host), inv_sqrt_len = 1/sqrt(audio_len), eps = 1e-6; optional s_out [B] and step_out = s*g [B,L] (rid buffers). */
+typedef struct {
+    const float* xhat; const float* g; float* out; float* step_out; float* s_out;
+    int B; int64_t L;
+    float coef, inv_sqrt_len, eps;
+} aid_guidance_step_params;
+int aid_guidance_step(const aid_guidance_step_params* p, void* stream);
+
+/* aid_set_rows : out[i*ld + b] = v[i], i < n <= 8, b < B -- the per-evaluation EDM scalars (c_noise, c_in, c_skip, c_out: edm.py:97-128,
+ *   computed on the host in the reference's float32 arithmetic) broadcast to the [B] vectors the fused kernels read, in one launch. */
+typedef struct { float* out; int64_t ld; int B, n; float v[8]; } aid_set_rows_params;
+int aid_set_rows(const aid_set_rows_params* p, void* stream);
 
 typedef struct { const float* x; float* out; int B; int64_t L; } aid_row_norm_params;
 int aid_row_norm(const aid_row_norm_params* p, void* stream);

@@ -63,7 +63,7 @@ def _hann_centered(M: int, half_sample_odd: bool = False) -> np.ndarray:
 # (audio_inpainting_diffusion_amd/cqt.py documents every value); tests/test_cqt_conformance.py selects between them
 # from a fixture dumped from the real package (tests/golden/make_cqt_golden.py) when one is available.
 DEFAULT_RULES = dict(band0_len="constq", last_len="neighbours", nyq_len="gap",
-                     window_sampling="integer", centre_rounding="nearest")
+                     window_sampling="integer", centre_rounding="nearest", last_centre="grid")
 
 
 class OracleCQT:
@@ -112,6 +112,10 @@ class OracleCQT:
             M[K + 1] = int(np.round(2.0 * (nyq - b[K - 1])))
         M = np.maximum(M, 4)
         self.Lg = M.copy()  # window lengths (support in DFT bins)
+        if R["last_centre"] == "midpoint":      # the highest constant-Q band moves half-way between its lower neighbour and Nyquist
+            centre[K] = (centre[K - 1] + centre[K + 1]) / 2.0
+        else:
+            assert R["last_centre"] == "grid"
         if R["centre_rounding"] == "even":
             self.rc = (np.round(centre / 2.0) * 2).astype(np.int64)
         else:

@@ -55,9 +55,10 @@ def spectral_mask_apply(x: torch.Tensor, mask: torch.Tensor, n_fft=1024, hop=256
 
 class OracleSampler:
     def __init__(self, model, edm, T=35, order=2, xi=0.25, norm=2, data_consistency=True, smooth=True,
-                 hann_size=50, filter_out_cqt_DC_Nyq=True, audio_len=None, dc_type="always"):
+                 hann_size=50, filter_out_cqt_DC_Nyq=True, audio_len=None, dc_type="always", smoothl1_beta=1.0):
         self.model, self.edm = model, edm
         self.nb_steps, self.order, self.xi, self.norm = T, order, xi, norm
+        self.smoothl1_beta = smoothl1_beta              # tester.posterior_sampling.smoothl1_beta (norm == "smoothl1", :72-73)
         # (:22-24) data_consistency.use and type == "always" | "end"
         self.data_consistency = bool(data_consistency) and dc_type == "always"
         self.data_consistency_end = bool(data_consistency) and dc_type == "end"
@@ -86,7 +87,10 @@ class OracleSampler:
             x_hat = self.edm.denoiser(x, self.model, sig)
             if self.filter_hpf:
                 x_hat = self.model.CQTransform.apply_hpf_DC(x_hat)
-            norm = torch.linalg.norm(self.y - self.degradation(x_hat), dim=1, ord=self.norm)   # [B]  (:65,:75)
+            if self.norm == "smoothl1":                                                     # (:72-73; 'sum' over the item)
+                norm = torch.nn.functional.smooth_l1_loss(self.y, self.degradation(x_hat), reduction="none", beta=self.smoothl1_beta).sum(dim=1)
+            else:
+                norm = torch.linalg.norm(self.y - self.degradation(x_hat), dim=1, ord=self.norm)   # [B]  (:65,:75)
             g = torch.autograd.grad(norm.sum(), x)[0]                                       # per-item grads
             L = self.audio_len if self.audio_len is not None else x.shape[-1]
             normguide = torch.linalg.norm(g, dim=1, keepdim=True) / L ** 0.5                # (:83) per item

@@ -302,6 +302,33 @@ def gen_uncond(out):
     np.savez_compressed(os.path.join(out, "sampler_uncond.npz"), **d)
 
 
+def gen_norms(out):
+    """tester.posterior_sampling.norm variants of the reference's guidance (edm_sampler_inpainting.py:72-75): 1 (L1) and "smoothl1"
+    (reduction 'sum', smoothl1_beta), B = 1, on the toy denoiser."""
+    import diff_params.edm as E
+    import testing.edm_sampler_inpainting as S
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.init import seeded_normal
+    L, T = 2048, 5
+    d = {"L": np.array(L), "T": np.array(T)}
+    net = _ToyNet(L)
+    for tag, norm, beta, seed in (("l1", 1, 1.0, 0), ("sl1_small", "smoothl1", 0.01, 1), ("sl1_large", "smoothl1", 0.2, 2)):
+        args = make_args(audio_len=L, T=T, xi=0.25)
+        args.tester.posterior_sampling.norm = norm
+        args.tester.posterior_sampling.smoothl1_beta = beta
+        args.tester.data_consistency.hann_size = 20
+        smp = S.Sampler(model=net, diff_params=E.EDM(args), args=args, rid=False)
+        y = torch.from_numpy(seeded_normal(6, seed, L)).reshape(1, L) * 0.063
+        mask = torch.ones(1, L)
+        mask[:, 700:1000] = 0
+        torch.manual_seed(seed)
+        x = smp.predict_inpainting(y * mask, mask)
+        d[f"{tag}.y"], d[f"{tag}.mask"], d[f"{tag}.out"] = (y * mask).numpy(), mask.numpy(), x.numpy()
+        d[f"{tag}.meta"] = np.array([1.0 if norm == 1 else 3.0, beta, seed], dtype=np.float64)
+        print("norms", tag, "out rms", float(x.pow(2).mean().sqrt()))
+    np.savez_compressed(os.path.join(out, "sampler_norms.npz"), **d)
+
+
 def gen_dc(out):
     """data_consistency.type variants of the reference sampler (edm_sampler_inpainting.py:22-24, :100, :141-147, :252):
     'end' projects only after the loop on the guided branch, but the replacement branch (xi = 0) projects at EVERY
@@ -408,7 +435,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     _setup_imports()
     torch.set_grad_enabled(True)
-    todo = a.only.split(",") if a.only else ["ops", "unet", "edm", "sampler", "spectral", "rid", "dc", "training", "uncond"] + (["full"] if a.full else [])
+    todo = a.only.split(",") if a.only else ["ops", "unet", "edm", "sampler", "spectral", "rid", "dc", "training", "uncond", "norms"] + (["full"] if a.full else [])
     if "ops" in todo: gen_ops(HERE)
     if "unet" in todo: gen_unet_small(HERE)
     if "edm" in todo: gen_edm(HERE)
@@ -418,4 +445,5 @@ if __name__ == "__main__":
     if "dc" in todo: gen_dc(HERE)
     if "training" in todo: gen_training(HERE)
     if "uncond" in todo: gen_uncond(HERE)
+    if "norms" in todo: gen_norms(HERE)
     if "full" in todo: gen_full(HERE)

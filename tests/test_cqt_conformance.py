@@ -29,7 +29,7 @@ def _presets():
     return {k: dataclasses.asdict(v) for k, v in RULE_PRESETS.items()}
 
 
-@pytest.mark.parametrize("preset", ["default", "nsgt_f_over_q", "nsgt_f_over_q_periodic"])
+@pytest.mark.parametrize("preset", ["default", "nsgt_f_over_q", "nsgt_f_over_q_periodic", "nsgt_midpoint", "nsgt_midpoint_periodic"])
 def test_every_rule_preset_is_a_frame_in_the_oracle(preset):
     from oracle.nsgt_cqt import OracleCQT
     L, fs = 16384, 22050
@@ -41,13 +41,17 @@ def test_every_rule_preset_is_a_frame_in_the_oracle(preset):
     assert rel_l2(q.bwd(c)[:, 0], q.apply_hpf_DC(x)) < 1e-10
 
 
-@pytest.mark.parametrize("preset", ["default", "nsgt_f_over_q", "nsgt_f_over_q_periodic"])
+@pytest.mark.parametrize("preset", ["default", "nsgt_f_over_q", "nsgt_f_over_q_periodic", "nsgt_midpoint", "nsgt_midpoint_periodic"])
 @pytest.mark.parametrize("cfg", [(7, 64, 22050, 184184), (8, 64, 44100, 368368), (3, 8, 22050, 2048)])
 def test_plan_matches_oracle_design_for_every_supported_preset(preset, cfg):
     from audio_inpainting_diffusion_amd.cqt import CQTPlan
     from oracle.nsgt_cqt import OracleCQT
     no, bpo, fs, L = cfg
-    P = CQTPlan(no, bpo, fs, L, ("kaiser", 1.0), rules=preset)
+    try:
+        P = CQTPlan(no, bpo, fs, L, ("kaiser", 1.0), rules=preset)
+    except NotImplementedError as e:         # (the midpoint presets push the last band's window across Nyquist on some grids: oracle only)
+        assert "midpoint" in preset, e
+        pytest.skip(f"{preset}: {e}")
     O = OracleCQT(no, bpo, "oct", ("kaiser", 1), fs, L, rules=_presets()[preset])
     K = no * bpo
     assert P.T_oct == O.size_per_oct
@@ -170,7 +174,7 @@ def test_hip_cqt_reproduces_the_real_package(path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("preset", ["nsgt_f_over_q", "nsgt_f_over_q_periodic"])
+@pytest.mark.parametrize("preset", ["nsgt_f_over_q", "nsgt_f_over_q_periodic", "nsgt_midpoint"])
 @pytest.mark.parametrize("cfg", [(4, 8, 16000, 4096), (7, 64, 22050, 184184)])
 def test_hip_cqt_under_alternative_rules_vs_oracle(preset, cfg):
     """The non-default rule sets run through the same HIP kernels (only the host tables change)."""
@@ -178,7 +182,11 @@ def test_hip_cqt_under_alternative_rules_vs_oracle(preset, cfg):
     from oracle.nsgt_cqt import OracleCQT
     no, bpo, fs, Ls = cfg
     orc = OracleCQT(no, bpo, "oct", ("kaiser", 1), fs, Ls, rules=_presets()[preset])
-    tr = CQTransform(no, bpo, "oct", ("kaiser", 1.0), fs, Ls, device="cuda", rules=preset)
+    try:
+        tr = CQTransform(no, bpo, "oct", ("kaiser", 1.0), fs, Ls, device="cuda", rules=preset)
+    except NotImplementedError as e:
+        assert "midpoint" in preset, e
+        pytest.skip(f"{preset}: {e}")
     x = torch.randn(2, Ls, generator=torch.Generator().manual_seed(60)) * 0.063
     for a, b in zip(tr.fwd(x[:, None].cuda()), orc.fwd(x[:, None])):
         assert rel_l2(torch.view_as_real(a.cpu()), torch.view_as_real(b)) < 1e-5

@@ -251,3 +251,73 @@ def test_hip_graph_replay_equals_eager_launches(B):
         smp.seeds = list(range(40, 40 + B))
         res[mode] = smp.predict_inpainting(yd, md)
     assert torch.equal(res[False], res[True])
+
+
+def _full_step(net, args, y, mask, seeds, dev):
+    """prior draw + ONE guided Heun step (churn, two evaluations with the input-VJP, projection, Heun combine) -> x after the step"""
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.sampler import Sampler
+    smp = Sampler(model=net, diff_params=EDM(args), args=args)
+    smp.seeds = seeds
+    smp.setup_inpainting((y * mask).to(dev), mask.to(dev))
+    st = smp.begin(tuple(y.shape), torch.device(dev))
+    smp.step(st, 0)
+    return st["x"]
+
+
+def _full_setup(dev, seed):
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
+    from audio_inpainting_diffusion_amd.masks import mask_from_args
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    args = make_args("maestro22k", audio_len=184184, T=36, gap_ms=300.0, xi=0.25)
+    net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(dev)), seed, gate_scale=10.0, affine_scale=10.0)
+    L = args.exp.audio_len
+    y = torch.stack([torch.from_numpy(seeded_normal(41, g, L)) for g in range(4)]) * 0.063
+    return net, args, y, mask_from_args(args, generator=torch.Generator().manual_seed(99))
+
+
+def _worker_full(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      AID_DIST_BACKEND="gloo")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from audio_inpainting_diffusion_amd import dist as D
+    r, _, w = D.init_distributed()
+    torch.cuda.set_device(0)
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
+    net, args, y, mask = _full_setup("cuda:0", seed=rank)         # rank 1 starts from DIFFERENT weights: the one broadcast must fix that
+    nbytes = D.broadcast_parameters(net, src=0)
+    lo, hi = D.shard_range(4, r, w)
+    out = _full_step(net, args, y[lo:hi], mask, D.item_seeds(700, lo, hi), "cuda:0")
+    allout = D.gather_outputs(out, 4)
+    D.barrier()
+    q.put((rank, nbytes, (lo, hi), allout.cpu().numpy()))
+    torch.distributed.destroy_process_group()
+
+
+def test_full_size_two_ranks_on_one_gpu_equal_one_process():
+    """BASELINE configs[2] at its real shapes on ONE GPU: the full-size 22.05 kHz network (186 M parameters, L = 184184), 2 ranks sharing
+    cuda:0 with 2 segments each (collectives on gloo), ONE 745 MB weight broadcast, one guided Heun step (two evaluations with the
+    hand-written input-VJP), output gather == the single-process batch-4 run (which itself runs as 2 sub-batch streams)."""
+    from audio_inpainting_diffusion_amd import dist as D
+    net, args, y, mask = _full_setup(DEV, seed=0)
+    ref = _full_step(net, args, y, mask, D.item_seeds(700, 0, 4), DEV).cpu()
+    del net
+    torch.cuda.empty_cache()
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_full, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=1200) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert [r[2] for r in res] == [(0, 2), (2, 4)]
+    for rank, nbytes, _, allout in res:
+        e = rel_l2(allout, ref)
+        print(f"full size, rank {rank}: gathered 2x2 segments vs single-process B=4 after one guided Heun step: rel-L2 = {e:.2e} ({nbytes / 1e6:.0f} MB broadcast)")
+        assert allout.shape == tuple(ref.shape) and nbytes > 700e6 and e < 1e-6
+    assert np.array_equal(res[0][3], res[1][3])

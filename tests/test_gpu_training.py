@@ -264,3 +264,77 @@ def test_three_iterations_vs_reference_trainer_golden():
     ee = projected_rel_error(z, "ema", tr.ema_state_dict())
     print(f"after 3 iterations vs the reference trainer: parameters rel-L2 (projected) = {ep:.2e}, EMA = {ee:.2e}")
     assert ep < 1e-4 and ee < 1e-4
+
+
+def test_trainer_checkpoint_roundtrip_in_the_reference_shape(tmp_path):
+    """Trainer.state_dict() has the reference checkpoint's shape (training/trainer.py:186-199): its 'optimizer' entry loads into the
+    torch.optim.Adam that the reference's setup_optimizer builds (utils/setup.py:55-58) and a state_dict of THAT optimiser loads back;
+    resuming from a saved checkpoint continues bit-identically (Adam moments, step count -> bias correction, lr ramp-up, EMA, it)."""
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.training import Trainer
+    net, orc, z, kw, args = _setup("a")
+    edm = EDM(args)
+    kwt = dict(lr=2e-3, lr_rampup_it=5, max_grad_norm=1.0, ema_rate=0.9, ema_rampup=8, batch=2)
+    tr = Trainer(net, edm, **kwt)
+    B, Ls = 2, kw["audio_len"]
+    g0 = torch.Generator().manual_seed(11)
+    data = []
+    for _ in range(4):
+        audio = torch.randn(B, Ls, generator=g0) * 0.063
+        sigma = torch.rand(B, 1, generator=g0) * 0.5 + 0.05
+        data.append((audio.to(DEV), sigma, (torch.randn(B, Ls, generator=g0) * sigma).to(DEV)))
+    for d in data[:2]:
+        tr.train_step(*d)
+    ck = tr.state_dict(args="cfg")
+    assert set(ck) == {"it", "network", "optimizer", "ema", "args"} and ck["it"] == 2
+    assert list(ck["network"]) == list(net.state_dict()) and list(ck["ema"]) == list(net.state_dict())
+    # the reference's optimiser accepts it, and what it saves comes back
+    ref_opt = torch.optim.Adam(net.parameters(), lr=2e-3, betas=(0.9, 0.999), eps=1e-8)
+    ref_opt.load_state_dict(ck["optimizer"])
+    names = [k for k, _ in net.named_parameters()]
+    i_w = names.index("downs.0.2.H.0.weight")
+    st = ref_opt.state[list(net.parameters())[i_w]]
+    assert float(st["step"]) == 2.0 and torch.equal(st["exp_avg"], ck["optimizer"]["state"][i_w]["exp_avg"])
+    assert names.index("embedding.RFF_freq") not in ck["optimizer"]["state"]          # frozen parameter: no Adam state, like torch
+    path = str(tmp_path / "ck.pt")
+    tr.save_checkpoint(path, args="cfg")
+    # continue the original run
+    ref_losses = [float(tr.train_step(*d)) for d in data[2:]]
+    ref_params = {k: v.clone() for k, v in net.state_dict().items()}
+    ref_ema = {k: v.clone() for k, v in tr.ema_state_dict().items()}
+    # a fresh network + trainer resumed from the file
+    net2, *_ = _setup("a")
+    tr2 = Trainer(net2, edm, **kwt)
+    assert tr2.load_state_dict(torch.load(path, map_location=DEV, weights_only=False))
+    assert tr2.it == 2 and tr2.steps == 2
+    losses = [float(tr2.train_step(*d)) for d in data[2:]]
+    assert losses == ref_losses
+    for k, v in net2.state_dict().items():
+        assert torch.equal(v, ref_params[k]), k
+    for k, v in tr2.ema_state_dict().items():
+        assert torch.equal(v, ref_ema[k]), k
+    # a checkpoint whose optimiser state was written by torch.optim.Adam itself (the reference trainer's) restores the same moments
+    ck2 = dict(ck, optimizer=ref_opt.state_dict())
+    tr3 = Trainer(_setup("a")[0], edm, **kwt)
+    tr3.load_state_dict(ck2)
+    m_ck = torch.cat([ck["optimizer"]["state"][i]["exp_avg"].reshape(-1) for i in sorted(ck["optimizer"]["state"])])
+    m_3 = torch.cat([tr3._views(tr3.m)[names[i]].reshape(-1) for i in sorted(ck["optimizer"]["state"])])
+    assert tr3.steps == 2 and torch.equal(m_3, m_ck)
+
+
+def test_trainer_follows_rehomed_parameters():
+    """If the parameters are re-homed after the Trainer was built (here: a fresh flat buffer), optimiser and EMA must keep updating the LIVE weights."""
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.training import Trainer
+    net, orc, z, kw, args = _setup("a")
+    tr = Trainer(net, EDM(args), lr=2e-3, lr_rampup_it=0, batch=2)
+    for p in list(net.parameters()) + list(net.buffers()):      # what load_state_dict(assign=True) / .to() do: new storage per tensor
+        p.data = p.data.clone()
+    net._aid_flat = None
+    B, Ls = 2, kw["audio_len"]
+    audio = torch.randn(B, Ls, generator=torch.Generator().manual_seed(1)) * 0.063
+    before = net.state_dict()["downs.0.2.H.0.weight"].clone()
+    tr.it = 1
+    tr.train_step(audio.to(DEV))
+    after = net.state_dict()["downs.0.2.H.0.weight"]
+    assert float((after - before).abs().max()) > 0, "the optimiser step did not reach the live parameters"

@@ -33,7 +33,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in aid_kernels.h but not exported"
     lib.aid_abi_version.restype = ctypes.c_int
-    assert lib.aid_abi_version() == int(re.search(r"#define AID_ABI_VERSION (\d+)", hdr).group(1)) == 6
+    assert lib.aid_abi_version() == int(re.search(r"#define AID_ABI_VERSION (\d+)", hdr).group(1)) == 7
     from audio_inpainting_diffusion_amd import _lib
     assert set(_lib.EXPORTS) == declared
     a, b = _lib.pack_dims(2, 96)
@@ -289,25 +289,28 @@ def test_checkpoint_loading_strategies_and_long_file_window():
     src = seeded_init_(Unet_CQT_oct_with_attention(small_args(), torch.device("cpu")), 1)
     sd = {k: v.clone() for k, v in src.state_dict().items()}
     dst = Unet_CQT_oct_with_attention(small_args(), torch.device("cpu"))
-    with pytest.warns(RuntimeWarning, match="NOT pinned to cqt_nsgt_pytorch"):      # trained weights on an unpinned CQT: loud
-        assert load_checkpoint(dst, {"it": 750000, "ema": sd}, cqt_pinned=False) == (750000, "strict")
+    from audio_inpainting_diffusion_amd.harness import UnpinnedCQTError
+    with pytest.raises(UnpinnedCQTError, match="NOT pinned to cqt_nsgt_pytorch"):    # trained weights on an unpinned CQT: refused by default
+        load_checkpoint(dst, {"it": 750000, "ema": sd}, cqt_pinned=False)
+    with pytest.warns(RuntimeWarning, match="NOT pinned to cqt_nsgt_pytorch"):      # ... and loud when the caller opts out
+        assert load_checkpoint(dst, {"it": 750000, "ema": sd}, cqt_pinned=False, allow_unpinned_cqt=True) == (750000, "strict")
     assert all(torch.equal(a, b) for a, b in zip(dst.state_dict().values(), sd.values()))
     k0 = next(k for k in sd if k.endswith("H.0.weight"))
     extra = dict(sd, **{"not.a.parameter": torch.zeros(3)})
     del extra[k0]
     dst = Unet_CQT_oct_with_attention(small_args(), torch.device("cpu"))
-    assert load_checkpoint(dst, {"ema": extra}) == (0, "non-strict")
+    assert load_checkpoint(dst, {"ema": extra}, allow_unpinned_cqt=True) == (0, "non-strict")
     bad = dict(sd)
     bad[k0] = torch.zeros(1, 2, 3)                                   # wrong shape: only the third strategy survives
     dst = Unet_CQT_oct_with_attention(small_args(), torch.device("cpu"))
     before = dst.state_dict()[k0].clone()
-    assert load_checkpoint(dst, {"ema": bad})[1] == "shape-matched"
+    assert load_checkpoint(dst, {"ema": bad}, allow_unpinned_cqt=True)[1] == "shape-matched"
     assert torch.equal(dst.state_dict()[k0], before)
     k1 = next(k for k in sd if k.endswith("H.1.weight"))
     assert torch.equal(dst.state_dict()[k1], sd[k1])
-    assert load_checkpoint(dst, {"ema": {"nothing": torch.zeros(1)}})[1] == "non-strict"      # (as the reference: attempt 2 accepts it)
+    assert load_checkpoint(dst, {"ema": {"nothing": torch.zeros(1)}}, allow_unpinned_cqt=True)[1] == "non-strict"      # (as the reference: attempt 2 accepts it)
     with pytest.raises(ValueError):
-        load_checkpoint(dst, {"ema": {k0: torch.zeros(1, 2, 3)}})                            # nothing matches by name AND shape
+        load_checkpoint(dst, {"ema": {k0: torch.zeros(1, 2, 3)}}, allow_unpinned_cqt=True)                            # nothing matches by name AND shape
     # 6 s file at 22.05 kHz, 1.5 s gap, 184184-sample model window
     assert centre_gap_window(132300 * 2, 184184, 33075) == (132300 - 16537, 132300 - 92092)
     with pytest.raises(ValueError):
@@ -360,7 +363,7 @@ def test_header_compiles_as_c_and_struct_sizes_match_the_binding(tmp_path):
              "aid_cqt_tables": "CqtTables", "aid_cqt_params": "CqtParams", "aid_cqt_gather_params": "CqtGatherParams", "aid_fft_pass_params": "FftPassParams",
              "aid_axpby_params": "AxpbyParams", "aid_score_step_params": "ScoreStepParams", "aid_group_dot_params": "GroupDotParams",
              "aid_norm_bwd_params": "NormBwdParams", "aid_attention_bwd_params": "AttentionBwdParams", "aid_guidance_seed_params": "GuidanceSeedParams",
-             "aid_row_norm_params": "RowNormParams", "aid_resample_poly_params": "ResamplePolyParams", "aid_stft_params": "StftParams",
+             "aid_row_norm_params": "RowNormParams", "aid_guidance_step_params": "GuidanceStepParams", "aid_set_rows_params": "SetRowsParams", "aid_resample_poly_params": "ResamplePolyParams", "aid_stft_params": "StftParams",
              "aid_scale_act_params": "ScaleActParams", "aid_add2_params": "Add2Params", "aid_conv2d_wgrad_params": "WgradParams",
              "aid_wino_gy_params": "WinoGyParams", "aid_pack_conv_weight_params": "PackConvWeightParams", "aid_wgrad_reduce_params": "WgradReduceParams",
              "aid_channel_dot_params": "ChannelDotParams", "aid_scale_bwd_params": "ScaleBwdParams", "aid_modulation_bwd_params": "ModulationBwdParams",

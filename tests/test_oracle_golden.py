@@ -142,6 +142,18 @@ def test_sampler_data_consistency_types_match_reference(tag):
     assert rel_l2(out, z[tag + ".out"]) < 1e-5
 
 
+@pytest.mark.parametrize("tag", ["l1", "sl1_small", "sl1_large"])
+def test_sampler_guidance_norm_variants_match_reference(tag):
+    """tester.posterior_sampling.norm = 1 and "smoothl1" (edm_sampler_inpainting.py:72-75)."""
+    z = np.load(os.path.join(GOLDEN, "sampler_norms.npz"))
+    L, T = int(z["L"]), int(z["T"])
+    kind, beta, seed = z[tag + ".meta"]
+    s = OracleSampler(_Toy(L), OracleEDM(), T=T, xi=0.25, hann_size=20, audio_len=L, norm=1 if kind == 1 else "smoothl1", smoothl1_beta=float(beta))
+    torch.manual_seed(int(seed))
+    out = s.predict_inpainting(torch.from_numpy(z[tag + ".y"]), torch.from_numpy(z[tag + ".mask"]))
+    assert rel_l2(out, z[tag + ".out"]) < 1e-5
+
+
 def test_replacement_branch_without_projection_raises_like_the_reference():
     L = 2048
     s = OracleSampler(_Toy(L), OracleEDM(), T=2, xi=0.0, data_consistency=False, audio_len=L)

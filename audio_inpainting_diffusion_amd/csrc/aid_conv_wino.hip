@@ -686,18 +686,17 @@ struct ConvWinoRDev {
 // whose first 64 channels take the 64-wide tile: four waves per workgroup either way, one per SIMD)
 // NB: LDS buffers asked for.  3 (default): two workgroups per CU; 2: 43 KB, THREE workgroups per CU -- measured +1..3 % on the short-K layers
 // (Cin <= 128: more of the tile is prologue / epilogue, which a third resident workgroup covers) and -0.5 % on Cin = 256 (profiles/r02_wino4r_probe.txt).
-// Weights are staged as the RAW 15 taps (kh*3+kw) of the plain pack and the Winograd transform U = G w (6 values from 3) is applied in
-// registers when the A fragments are formed: 9 VALU per k-step next to 6 MFMAs of 64 cycles each, half the weight bytes through the
-// direct-to-LDS path (7.5 KB instead of 15 KB per chunk: 14 pieces instead of 21) and 3 instead of 6 A-operand LDS reads per k-step.
 // x region layout per input channel: slots are interleaved in units of IL = 32 / GPR rows -- [slot / IL][xi][slot % IL][GPR groups] -- so that
 // the IL adjacent rows one half-wave ds_read_b32 touches (lanes of a half-wave own 32 consecutive groups = IL rows) fall on 32 distinct
 // banks for every kh (with the plain [slot][xi][GPR] order rows are 6*GPR floats = 0 mod 32 banks apart: every B read was 2-way conflicted,
-// a third of the kernel's LDS cycles, profiles/r02_wino_pmc.txt).  Classes with CSLOT % IL != 0 (NC >= 4) keep the plain order.
-// NB: LDS buffers (3: loads run two chunks ahead; 2: one); WPC: workgroups per CU the register budget is bounded for; NWV: waves per
-// workgroup (4; 2 = the 64 x 128 half tile for launches that would leave CUs without a workgroup).
-template <int TT, int NC, int WGM, int NB = 3, int WPC = 2, int NWV = 4, int RAW = 1, int ILV = 1>
+// a third of the kernel's LDS cycles, profiles/r02_wino_pmc.txt; now 0, profiles/r03_wino4r_staging_pmc.txt).  Classes with CSLOT % IL != 0
+// (NC >= 4) keep the plain order.  Measured with it (round 3, profiles/r03_wino4r_staging_ab.txt): staging the RAW 15 taps and forming U = G w
+// in registers (half the weight bytes, 14 instead of 21 direct-to-LDS pieces per chunk, 3 instead of 6 A reads per k-step, 2x the VALU) and the
+// conflict-free layout change the kernel time by less than 0.5 % in either direction: it is bound by the matrix pipe (84 % busy at K = 256)
+// and by the prologue / epilogue of a tile, not by LDS or staging any more.  The interleave stays (no conflicts, no cost); raw-tap staging does not.
+template <int TT, int NC, int WGM, int NB = 3, int WPC = 2, int NWV = 4>
 __global__ __launch_bounds__(64 * NWV, (WPC * NWV + 3) / 4) void conv53_wino4r_kernel(const ConvWinoRDev a) {
-    constexpr int KH = 5, KW = 3, NXI = 6, TAPS = RAW ? KH * KW : NXI * KH, KC = 2;
+    constexpr int KH = 5, NXI = 6, TAPS = NXI * KH, KC = 2;
     constexpr int NW = NWV, WGN = NW / WGM;
     constexpr int M_BLK = 32 * WGM, N_BLK = 128 * WGN;
     constexpr int GPR = TT / 4;                         // groups of 4 outputs per row
@@ -705,11 +704,11 @@ __global__ __launch_bounds__(64 * NWV, (WPC * NWV + 3) / 4) void conv53_wino4r_k
     constexpr int CSLOT = RA + KH - 1;                  // staged input rows per channel and class
     constexpr int NSLOT = NC * CSLOT;
     constexpr int ILR = 32 / GPR;                       // rows read by one half-wave
-    constexpr int IL = (ILV && CSLOT % ILR == 0 && RA % ILR == 0) ? ILR : 1;   // slot interleave unit (1: plain order)
+    constexpr int IL = (CSLOT % ILR == 0 && RA % ILR == 0) ? ILR : 1;   // slot interleave unit (1: plain order)
     constexpr int XCI = NSLOT * NXI * GPR;              // floats per input channel in the x region
     constexpr int XSZ = ((KC * XCI + 255) / 256) * 256;
     constexpr int WROW = M_BLK;
-    constexpr int WSZ_RAW = TAPS * KC * WROW;           // 64 channels: 1920 floats = 7.5 pieces; 32: 960 -> 3.75 pieces
+    constexpr int WSZ_RAW = TAPS * KC * WROW;           // 64 channels: 3840 floats = 15 pieces; 32: 1920 -> 8 pieces (the last half used)
     constexpr int WSZ = ((WSZ_RAW + 255) / 256) * 256;
     constexpr int BUFSZ = XSZ + WSZ;
     constexpr int NBUF = (NB == 3 && 3 * BUFSZ * 4 * WPC <= 160 * 1024) ? 3 : 2;  // three buffers only while WPC workgroups still fit a CU
@@ -770,7 +769,7 @@ __global__ __launch_bounds__(64 * NWV, (WPC * NWV + 3) / 4) void conv53_wino4r_k
             const int tap = row / KC, ci = row % KC;
             plds[i] = XSZ + (pc - NXP) * 256;
             if (e < WSZ_RAW) {
-                psrc[i] = (RAW ? p.wp : p.wp_wino) + ((int64_t)tap * p.Cin_pad + ci) * p.Cout_pad + m0 + col;
+                psrc[i] = p.wp_wino + ((int64_t)tap * p.Cin_pad + ci) * p.Cout_pad + m0 + col;
                 pstride[i] = KC * p.Cout_pad;
             }
         }
@@ -820,13 +819,12 @@ __global__ __launch_bounds__(64 * NWV, (WPC * NWV + 3) / 4) void conv53_wino4r_k
         float* Nx = NBUF == 3 ? (cur == 0 ? sbuf2 : (cur == 1 ? sbuf0 : sbuf1)) : (cur == 0 ? sbuf1 : sbuf0);
         const int ahead = NBUF - 1;
         const bool more = (ch + ahead) < a.nchunks;
-        constexpr int NAW = RAW ? KW : NXI;
-        float bv[2][NXI], aw[2][NAW];
+        float bv[2][NXI], av[2][NXI];
         auto load_step = [&](int kh, int buf) {
 #pragma unroll
             for (int x = 0; x < NXI; ++x) bv[buf][x] = Bf[vBk[kh] + x * (IL * GPR)];
 #pragma unroll
-            for (int k = 0; k < NAW; ++k) aw[buf][k] = Bf[vA + ((RAW ? (kh * KW + k) : (k * KH + kh)) * KC) * WROW];
+            for (int x = 0; x < NXI; ++x) av[buf][x] = Bf[vA + ((x * KH + kh) * KC) * WROW];
         };
         load_step(0, 0);
         aid_static_for<NSTEP>([&](auto sc) {
@@ -834,20 +832,9 @@ __global__ __launch_bounds__(64 * NWV, (WPC * NWV + 3) / 4) void conv53_wino4r_k
             if (more) issue_step(sc, ch + ahead, Nx);
             if (s + 1 < NSTEP) load_step(s + 1, (s + 1) & 1);
             constexpr int bq = s & 1;
-            // U = G w:  w0/4, -(w0+w1+w2)/6, -(w0-w1+w2)/6, (w0+2w1+4w2)/24, (w0-2w1+4w2)/24, w2
-            if constexpr (RAW) {
-                const float w0 = aw[bq][0], w1 = aw[bq][1], w2 = aw[bq][2];
-                const float s02 = w0 + w2, t04 = fmaf(4.f, w2, w0);
-                const float av[NXI] = {0.25f * w0, (s02 + w1) * (-1.f / 6.f), (s02 - w1) * (-1.f / 6.f),
-                                       fmaf(2.f, w1, t04) * (1.f / 24.f), fmaf(-2.f, w1, t04) * (1.f / 24.f), w2};
 #pragma unroll
-                for (int x = 0; x < NXI; ++x)
-                    acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bv[bq][x], acc[x], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int x = 0; x < NXI; ++x)
-                    acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[bq][x], bv[bq][x], acc[x], 0, 0, 0);
-            }
+            for (int x = 0; x < NXI; ++x)
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[bq][x], bv[bq][x], acc[x], 0, 0, 0);
         });
         asm volatile("" ::: "memory");
         if (NBUF == 3 && more) {
@@ -1082,21 +1069,10 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
         a.ntiles = p->B * a.rgroups * g.quads * g.ttiles * a.ny;
         a.per_xcd = (a.ntiles + 7) / 8;
         const dim3 grid((unsigned)(8 * a.per_xcd));
-        static int mode = -1, raw = 1, ilv = 1;              // EXPERIMENT (to be removed): AID_W4R_MODE / AID_W4R_RAW / AID_W4R_IL
-        if (mode < 0) {
-            const char* e = getenv("AID_W4R_MODE"); mode = e ? atoi(e) : 0;
-            e = getenv("AID_W4R_RAW"); raw = e ? atoi(e) : 1;
-            e = getenv("AID_W4R_IL"); ilv = e ? atoi(e) : 1;
-        }
         const bool short_k = p->Cin <= 128;                  // three workgroups per CU (two LDS buffers) for the short-K layers
-        const int v = mode == 0 ? (short_k ? 1 : 0) : (mode == 1 ? 2 : (mode == 2 ? 0 : 1));   // 0: (3 buffers, 2 / CU), 1: (2, 3), 2: (3, 3)
-#define AID_W4R_V(TTv, NCv, WGMv, R, I) do { \
-            if (v == 0) hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv, 3, 2, 4, R, I>), grid, dim3(256), 0, st, a); \
-            else if (v == 1) hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv, 2, 3, 4, R, I>), grid, dim3(256), 0, st, a); \
-            else hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv, 3, 3, 4, R, I>), grid, dim3(256), 0, st, a); } while (0)
 #define AID_W4R(TTv, NCv, WGMv) do { \
-            if (raw && ilv) AID_W4R_V(TTv, NCv, WGMv, 1, 1); else if (raw) AID_W4R_V(TTv, NCv, WGMv, 1, 0); \
-            else if (ilv) AID_W4R_V(TTv, NCv, WGMv, 0, 1); else AID_W4R_V(TTv, NCv, WGMv, 0, 0); } while (0)
+            if (short_k) hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv, 2, 3>), grid, dim3(256), 0, st, a); \
+            else hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv, 3, 2>), grid, dim3(256), 0, st, a); } while (0)
         switch ((l * 128 + g.TT) * 16 + g.NC) {
             case 64 * 16 + 1: AID_W4R(64, 1, 2); break;
             case 64 * 16 + 2: AID_W4R(64, 2, 2); break;
@@ -1110,7 +1086,6 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
             default: aid_set_error("aid_conv2d: row-shared tile shape not instantiated"); return AID_E_BADARG;
         }
 #undef AID_W4R
-#undef AID_W4R_V
         AID_CHECK_LAUNCH();
     }
     aid_note_kernel(m96 ? "conv53_wino4r_kernel(64+32)" : (plan[0].NC == 1 ? "conv53_wino4r_kernel" : "conv53_wino4r_kernel(multi-class)"));

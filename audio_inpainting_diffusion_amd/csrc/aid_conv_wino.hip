@@ -682,6 +682,9 @@ struct ConvWinoRDev {
     int dot_all, dot_base;     // 96-channel layers (two launches): every launch writes all eight groups of its own partial slots
 };
 
+// Tried for small grids (round 3, profiles/r03_half_tile_probe.txt): two-wave workgroups on half the positions (64 x 128 / 32 x 256 tiles, twice
+// the workgroups, four per CU) when a launch has fewer than 300 ... 1100 full tiles -- B = 1: 24.7 -> 29.4 ... 30.2 ms of 5x3 time per guided
+// evaluation, B = 2 / 3 neutral to -12 %: the weight slice every tile re-stages is amortised over half the MFMAs.  Not kept.
 // WGM = 2: 64 output channels x 256 positions; WGM = 1: 32 output channels x 512 positions (the remainder tile of 96-channel layers,
 // whose first 64 channels take the 64-wide tile: four waves per workgroup either way, one per SIMD)
 // NB: LDS buffers asked for.  3 (default): two workgroups per CU; 2: 43 KB, THREE workgroups per CU -- measured +1..3 % on the short-K layers

@@ -153,57 +153,7 @@ class _ResBlock(nn.Module):
 # =========================================================================================================
 # Launch plan
 # =========================================================================================================
-class _Plan:
-    """Flat list of (C function, params struct) pairs executed in order on the current stream."""
-
-    def __init__(self):
-        self.ops = []          # (fn, addr, name, flops)
-        self.keep = []         # structs + tensors referenced by raw pointers
-        self.flops = 0
-        self.timing = None     # set to a list to bracket every conv launch with HIP events (bench.py roofline)
-
-    def add(self, name, params, *tensors, flops=0, nbytes=0):
-        fn = getattr(_lib.lib(), name)
-        self.ops.append((fn, C.addressof(params), name, flops))
-        self.opbytes = getattr(self, "opbytes", {})
-        self.opbytes[C.addressof(params)] = nbytes
-        self.descr = getattr(self, "descr", [])
-        if name == "aid_conv2d":
-            q = params
-            self.descr.append("conv %dx%d d%-3d Cin%-4d Cout%-4d F%-3d T%-4d act%d epi%d" % (q.KH, q.KW, q.dilF, q.Cin, q.Cout, q.F, q.T, q.act, q.epi))
-        else:
-            self.descr.append(name)
-        self.keep.append(params)
-        self.keep.extend(t for t in tensors if t is not None)
-        self.flops += flops
-
-    def _cur_descr(self, fn, addr):
-        if not hasattr(self, "_dmap"):
-            self._dmap = {o[1]: d for o, d in zip(self.ops, self.descr)}
-        return self._dmap.get(addr, "?")
-
-    def run(self):
-        stream = torch.cuda.current_stream().cuda_stream
-        timing = self.timing
-        trace = getattr(self, "trace", None)   # set to a list to bracket EVERY launch with HIP events (tools/plan_trace.py)
-        for fn, addr, name, flops in self.ops:
-            if trace is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                rc = fn(addr, stream)
-                e1.record()
-                trace.append((e0, e1, name, self._cur_descr(fn, addr), addr, _lib.lib().aid_last_kernel().decode() if name == "aid_conv2d" else ""))
-            elif timing is not None and flops > 0 and name == "aid_conv2d":
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                rc = fn(addr, stream)
-                e1.record()
-                timing.append((e0, e1, flops, self._cur_descr(fn, addr), self.opbytes.get(addr, 0),
-                               _lib.lib().aid_last_kernel().decode()))
-            else:
-                rc = fn(addr, stream)
-            if rc != 0:
-                raise _lib.AidError(f"{name} failed rc={rc}: {_lib.lib().aid_last_error().decode()}")
+from .plan import Plan as _Plan   # flat launch list + read / write sets + two-lane schedule (plan.py)
 
 
 class _Builder:
@@ -216,8 +166,10 @@ class _Builder:
         self.params = None         # name -> parameter tensor (its own layout)
         self.plan = _Plan()
         self.nbytes = 0
-        self.stats_ws = torch.empty(B * 8 * _lib.AID_STATS_SPLIT * 2, device=device, dtype=torch.float64)
-        self.bwd = []          # closures emitting the VJP ops of each forward op (run in reverse by finish_backward)
+        self.lane = 0          # lane of the ops emitted next (plan.py): 0 = trunk, 1 = init blocks / pyramid / out blocks
+        self.use_lanes = not self.train and bool(getattr(net, "plan_lanes", True))
+        self._stats_ws = {}    # lane -> scratch of the two-stage group reductions (lanes run concurrently: one each)
+        self.bwd = []          # (lane, closure emitting the VJP ops of a forward op); run in reverse by finish_backward
         self._stat_src = {}    # view key of a forward conv output -> (its params struct, partials per (b, group)): see stats()
         self._nb_src = {}      # (reverse sweep) view key of a gradient tensor -> (the aid_norm_bwd params that wrote it last, op index, end address)
         self._g_last = {}      # (reverse sweep) Winograd-domain gradient scratch data_ptr -> index of the last op that used it
@@ -250,11 +202,38 @@ class _Builder:
         return True
 
     def _scratch(self, shape):
-        key = tuple(shape)
+        key = (self.lane,) + tuple(shape)                 # one set of scratch tensors per lane (they run concurrently)
         t = self.scratch.get(key)
         if t is None:
-            t = self.scratch[key] = self.buf(*[d for d in key if not isinstance(d, str)])
+            t = self.scratch[key] = self.buf(*[d for d in tuple(shape) if not isinstance(d, str)])
         return t
+
+    @property
+    def stats_ws(self):
+        t = self._stats_ws.get(self.lane)
+        if t is None:
+            t = self._stats_ws[self.lane] = torch.empty(self.B * 8 * _lib.AID_STATS_SPLIT * 2, device=self.device, dtype=torch.float64)
+            self.nbytes += t.numel() * 8
+        return t
+
+    def on_lane(self, lane):
+        """context manager: ops (and the backward closures registered meanwhile) go to ``lane``"""
+        bd = self
+
+        class _L:
+            def __enter__(self_):
+                self_.prev, bd.lane = bd.lane, (lane if bd.use_lanes else 0)
+
+            def __exit__(self_, *a):
+                bd.lane = self_.prev
+        return _L()
+
+    def _add(self, name, params, *tensors, **kw):
+        self.plan.lane = self.lane
+        return self.plan.add(name, params, *tensors, **kw)
+
+    def _reg_bwd(self, fn):
+        self.bwd.append((self.lane, fn))
 
     def finish_backward(self):
         """Emit the reverse sweep (input-VJP) into ``self.bplan``."""
@@ -263,8 +242,10 @@ class _Builder:
         self._stat_src.clear()
         self._nb_src.clear()
         self._g_last.clear()
-        for emit in reversed(self.bwd):
+        for lane, emit in reversed(self.bwd):
+            self.lane = lane
             emit()
+        self.lane = 0
         self._in_bwd = False
         self.bplan, self.plan = self.plan, fwd_plan
         return self.bplan
@@ -301,10 +282,11 @@ class _Builder:
             ws = torch.empty(B * 8 * ws_n * 2, device=self.device, dtype=torch.float64)
             self.nbytes += ws.numel() * 8
             cp.stat_ws, cp.stat_n = ws.data_ptr(), ws_n
+            src[3].also_writes(ws)                         # (the conv's epilogue now writes the partials this op folds)
         p = _lib.GroupStatsParams(_lib.view4(x), B, Cc, F, T, 8, gamma.data_ptr(), _lib.ptr(mod),
                                   0 if mod is None else mod.stride(0), 1e-7, scale.data_ptr(), _lib.ptr(stats),
                                   ws.data_ptr(), ws_n)
-        self.plan.add("aid_group_stats", p, x, gamma, mod, scale, stats, ws)
+        self._add("aid_group_stats", p, x, gamma, mod, scale, stats, ws, writes=(scale, stats) + (() if src is not None else (ws,)))
         if self.train and gname is not None:
             def bw():                                   # gradient of scale = gamma (1 + affine) / (std + eps) w.r.t. gamma and the affine vector
                 S = self.S_of.pop(scale.data_ptr(), None)
@@ -314,8 +296,8 @@ class _Builder:
                 sp = _lib.ScaleBwdParams(S.data_ptr(), S.stride(0), scale.data_ptr(), scale.stride(0), gamma.data_ptr(), _lib.ptr(mod),
                                          0 if mod is None else mod.stride(0), stats.data_ptr(), self.pgrad[gname].data_ptr(),
                                          _lib.ptr(dm), 0 if dm is None else dm.stride(0), B, Cc, 8, 1)
-                self.plan.add("aid_scale_bwd", sp, S, scale, gamma, mod, stats, dm)
-            self.bwd.append(bw)
+                self._add("aid_scale_bwd", sp, S, scale, gamma, mod, stats, dm, writes=(self.pgrad[gname], dm))
+            self._reg_bwd(bw)
 
     def dmod_like(self, view):
         """the slice of the modulation-gradient buffer that corresponds to a slice ``view`` of the modulation buffer"""
@@ -339,18 +321,18 @@ class _Builder:
             xin = self._scratch(("hww", B, cin, F, G6))
             sp = _lib.ScaleActParams(_lib.view4(x), _lib.view4(xin), _lib.ptr(in_scale) if act else None,
                                      in_scale.stride(0) if (act and in_scale is not None) else 0, B, cin, F, T, 1 if act else 0, 1)
-            self.plan.add("aid_scale_act", sp, x, xin, in_scale)
+            self._add("aid_scale_act", sp, x, xin, in_scale, writes=(xin,))
             if act:
                 isc = None
             gyw = self._scratch(("gyw", B, cout, F, G6))
-            self.plan.add("aid_wino_gy", _lib.WinoGyParams(_lib.view4(gy), _lib.view4(gyw), B, cout, F, T), gy, gyw)
+            self._add("aid_wino_gy", _lib.WinoGyParams(_lib.view4(gy), _lib.view4(gyw), B, cout, F, T), gy, gyw, writes=(gyw,))
             gop = gyw
         else:
             gop = gy
             if act:                                       # the conv saw gelu(x * scale): recompute it (one pass) into scratch
                 xin = self._scratch(("hw",) + tuple(x.shape))
                 sp = _lib.ScaleActParams(_lib.view4(x), _lib.view4(xin), in_scale.data_ptr(), in_scale.stride(0), B, cin, F, T, 1, 0)
-                self.plan.add("aid_scale_act", sp, x, xin, in_scale)
+                self._add("aid_scale_act", sp, x, xin, in_scale, writes=(xin,))
                 isc = None
         tiles = int(_lib.lib().aid_conv2d_wgrad_tiles(cin, cout, kh, kw, int(wino)))
         S = max(1, min(F, 256 // (tiles * B)))            # about one workgroup per CU: every extra split is another partial to write and reduce
@@ -358,7 +340,7 @@ class _Builder:
         KP = 30 if wino else K                            # taps per (co, ci) in the partials (U domain: xi * 5 + kh)
         P = self._scratch(("P", B * S * cout * cin * KP))
         wp = _lib.WgradParams(_lib.view4(gop), _lib.view4(xin), P.data_ptr(), B, cin, cout, F, T, kh, kw, dil, S, alpha, int(wino))
-        self.plan.add("aid_conv2d_wgrad", wp, gop, xin, P, flops=2 * B * F * T * cin * cout * K)
+        self._add("aid_conv2d_wgrad", wp, gop, xin, P, flops=2 * B * F * T * cin * cout * K, writes=(P,))
         W = self.params[wname]
         dg = self.dmod_like(out_scale)
         rp = _lib.WgradReduceParams(P.data_ptr(), W.data_ptr(), _lib.ptr(out_scale), 0 if out_scale is None else out_scale.stride(0),
@@ -366,11 +348,11 @@ class _Builder:
                                     0 if dg is None else dg.stride(0), B, S, cout, cin, K, 1, int(wino),
                                     _lib.ptr(wpw) if wino else None, wpw.shape[1] if (wino and wpw is not None) else 0,
                                     wpw.shape[2] if (wino and wpw is not None) else 0)
-        self.plan.add("aid_wgrad_reduce", rp, P, W, out_scale, isc, dg, wpw)
+        self._add("aid_wgrad_reduce", rp, P, W, out_scale, isc, dg, wpw, writes=(self.pgrad[wname], dg))
         if in_scale is not None and gd is not None:       # gd = dL/d(x*scale) * scale  ->  S[b,c] = sum gd * x  (aid_scale_bwd divides by scale)
             Sb = self.buf(B, cin)
             cp = _lib.ChannelDotParams(_lib.view4(gd), _lib.view4(x), Sb.data_ptr(), Sb.stride(0), B, cin, F, T)
-            self.plan.add("aid_channel_dot", cp, gd, x, Sb)
+            self._add("aid_channel_dot", cp, gd, x, Sb, writes=(Sb,))
             self.S_of[in_scale.data_ptr()] = Sb
 
     def _conv_raw(self, x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha, epi=0,
@@ -400,20 +382,22 @@ class _Builder:
         assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] == 30 and wpw.shape[1:] == wp.shape[1:]))
         # algorithmic HBM bytes: x once, residual / aux once, y once, weights once
         nb = 4 * (B * F * T * (cin + cout * (1 + (res is not None) + (aux is not None))) + cin * cout * kh * kw)
-        self.plan.add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, ws, flops=2 * B * F * T * cin * cout * kh * kw,
-                      nbytes=nb)
+        dws = None if dot is None else dot[0]
+        op = self._add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, ws, dws, flops=2 * B * F * T * cin * cout * kh * kw,
+                       nbytes=nb, writes=(y, ws, dws))
         self._wrote(y)
         if not self._in_bwd and x_wino and epi == 0 and dot is None and self.net.epilogue_stats:
             n = int(_lib.lib().aid_conv2d_stat_partials(B, cin, cout, F, T, dil, 1))
             if n:                                         # a later stats(y) may ask this conv's epilogue for the partial sums
                 hi = y.data_ptr() + 4 * (1 + sum((m - 1) * st for m, st in zip(y.shape, y.stride())))
-                self._stat_src[self._vkey(y)] = (p, n, hi)
+                self._stat_src[self._vkey(y)] = (p, n, hi, op)
 
     def _dot_ws(self, n):
         """scratch for the per-tile <gd, x> partials written by the conv epilogue: [B*8, n] doubles + B*8 floats (coef)"""
-        t = self.scratch.get(("dot", n))
+        key = (self.lane, "dot", n)
+        t = self.scratch.get(key)
         if t is None:
-            t = self.scratch[("dot", n)] = torch.zeros(self.B * 8 * (n + 1), device=self.device, dtype=torch.float64)
+            t = self.scratch[key] = torch.zeros(self.B * 8 * (n + 1), device=self.device, dtype=torch.float64)
             self.nbytes += t.numel() * 8
         return t
 
@@ -434,7 +418,7 @@ class _Builder:
             hbuf = self._scratch(("h",) + hshape)
             sp = _lib.ScaleActParams(_lib.view4(x), _lib.view4(hbuf), in_scale.data_ptr(), in_scale.stride(0), x.shape[0], cin,
                                      x.shape[2], x.shape[3], 1, int(xw))
-            self.plan.add("aid_scale_act", sp, x, hbuf, in_scale)
+            self._add("aid_scale_act", sp, x, hbuf, in_scale, writes=(hbuf,))
             self._conv_raw(hbuf, y, wp, cin, cout, kh, kw, dil, None, 0, out_scale, res, res_scale, alpha, wpw=wpw, x_wino=xw)
         else:
             self._conv_raw(x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha)
@@ -459,14 +443,15 @@ class _Builder:
                 gshape = (gy.shape[0], cout, gy.shape[2], 6 * (gy.shape[3] // 4)) if gw else tuple(gy.shape)
                 gin = self._scratch(("g",) + gshape)
                 nb = self._nb_src.pop(self._vkey(gy), None) if (gw and self.net.fuse_norm_bwd_wino) else None
-                if nb is not None and nb[1] > self._g_last.get(gin.data_ptr(), -1):
+                if nb is not None and nb[1] > self._g_last.get(gin.data_ptr(), -1) and nb[3].lane == self.lane:
                     # gy was written last by an aid_norm_bwd and nothing used this scratch since: that pass also writes gin
                     nb[0].wout, nb[0].wscale, nb[0].wscale_ld = _lib.view4(gin), out_scale.data_ptr(), out_scale.stride(0)
                     self.plan.keep.extend((gin, out_scale))
+                    nb[3].also_writes(gin)
                 else:
                     sp = _lib.ScaleActParams(_lib.view4(gy), _lib.view4(gin), out_scale.data_ptr(), out_scale.stride(0), gy.shape[0],
                                              cout, gy.shape[2], gy.shape[3], 0, int(gw))
-                    self.plan.add("aid_scale_act", sp, gy, gin, out_scale)
+                    self._add("aid_scale_act", sp, gy, gin, out_scale, writes=(gin,))
                 self._g_last[gin.data_ptr()] = len(self.plan.ops)      # (the dgrad conv below reads it)
                 gsc = None
             if norm_stats is not None:
@@ -481,18 +466,18 @@ class _Builder:
                                dot=(dws, nd) if nd else None)
                 if not nd:
                     dp = _lib.GroupDotParams(_lib.view4(gd), _lib.view4(x), B, cin, F, T, 8, self.stats_ws.data_ptr())
-                    self.plan.add("aid_group_dot", dp, gd, x)
+                    self._add("aid_group_dot", dp, gd, x, self.stats_ws, writes=(self.stats_ws,))
                 if self.train and wname is not None:
                     self._train_conv(x, gy, gd, wname, cin, cout, kh, kw, dil, in_scale, act, out_scale, alpha, wpw=wpw)
                 npar = _lib.NormBwdParams(_lib.view4(gd), _lib.view4(x), _lib.view4(gy if fused_res else None), _lib.view4(self.G(x)),
                                           B, cin, F, T, 8, norm_stats.data_ptr(), dws.data_ptr(), 1e-7,
                                           alpha * res_scale, 1 if self._gacc(x) else 0, nd)
-                self.plan.add("aid_norm_bwd", npar, gd, x, gy, norm_stats)
                 gxv = self.G(x)
+                nop = self._add("aid_norm_bwd", npar, gd, x, gy, norm_stats, dws, gxv, writes=(gxv,))
                 self._wrote(gxv)
                 if npar.accumulate == 0 and x.shape[3] % 16 == 0:
                     hi = gxv.data_ptr() + 4 * (1 + sum((m - 1) * st for m, st in zip(gxv.shape, gxv.stride())))
-                    self._nb_src[self._vkey(gxv)] = (npar, len(self.plan.ops) - 1, hi)
+                    self._nb_src[self._vkey(gxv)] = (npar, len(self.plan.ops) - 1, hi, nop)
             else:
                 gx = self.G(x)
                 self._conv_raw(gin, gx, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, gx if self._gacc(x) else None, 1.0 / alpha, alpha,
@@ -500,14 +485,14 @@ class _Builder:
                 if self.train and wname is not None:
                     assert in_scale is None, "a scaled conv input without its statistics buffer has no parameter-gradient path"
                     self._train_conv(x, gy, None, wname, cin, cout, kh, kw, dil, None, act, out_scale, alpha, wpw=wpw)
-        self.bwd.append(bw)
+        self._reg_bwd(bw)
 
 
     def add2_raw(self, u, v, y, a, b):
         """y = a*u + b*v   (v may be None: y = a*u)"""
         B, Cc, F, T = u.shape
         p = _lib.Add2Params(_lib.view4(u), _lib.view4(v), _lib.view4(y), B, Cc, F, T, a, b)
-        self.plan.add("aid_add2", p, u, v, y)
+        self._add("aid_add2", p, u, v, y, writes=(y,))
         self._wrote(y)
 
     def add2(self, u, v, y, a, b):
@@ -520,7 +505,7 @@ class _Builder:
                     self.add2_raw(gt, gy, gt, 1.0, c)
                 else:
                     self.add2_raw(gy, None, gt, c, 0.0)
-        self.bwd.append(bw)
+        self._reg_bwd(bw)
 
     def copy(self, u, y):
         """y = u (strided views), with its VJP"""
@@ -532,24 +517,24 @@ class _Builder:
                 self.add2_raw(gu, gy, gu, 1.0, 1.0)
             else:
                 self.add2_raw(gy, None, gu, 1.0, 0.0)
-        self.bwd.append(bw)
+        self._reg_bwd(bw)
 
     def _resample_raw(self, x, y, up, adjoint=0, accumulate=0):
         B, Cc, F, T = x.shape
         p = _lib.ResampleParams(_lib.view4(x), _lib.view4(y), B, Cc, F, T, int(up), int(adjoint), int(accumulate))
-        self.plan.add("aid_resample", p, x, y)
+        self._add("aid_resample", p, x, y, writes=(y,))
         self._wrote(y)
 
     def resample(self, x, y, up):
         self._resample_raw(x, y, up)
-        self.bwd.append(lambda: self._resample_raw(self.G(y), self.G(x), up, adjoint=1, accumulate=1 if self._gacc(x) else 0))
+        self._reg_bwd(lambda: self._resample_raw(self.G(y), self.G(x), up, adjoint=1, accumulate=1 if self._gacc(x) else 0))
 
     def attention(self, qk, v, out, heads, F, T, bias=None):
         B = v.shape[0]
         probs = self.buf(B, heads, T, T)
         scale = float(F) ** -0.5
         p = _lib.AttentionParams(qk.data_ptr(), v.data_ptr(), out.data_ptr(), probs.data_ptr(), B, heads, F, T, scale, _lib.ptr(bias))
-        self.plan.add("aid_time_attention", p, qk, v, out, probs, bias, flops=4 * B * heads * T * T * F)
+        self._add("aid_time_attention", p, qk, v, out, probs, bias, flops=4 * B * heads * T * T * F, writes=(out, probs))
         self._wrote(out)
 
         def bw():
@@ -559,10 +544,10 @@ class _Builder:
             dsws = self._scratch(("ds", B, heads, T, T))
             bp = _lib.AttentionBwdParams(qk.data_ptr(), v.data_ptr(), probs.data_ptr(), go.data_ptr(), gq.data_ptr(), gv.data_ptr(),
                                          B, heads, F, T, scale, 1 if self._gacc(v) else 0, dsws.data_ptr())
-            self.plan.add("aid_time_attention_bwd", bp, qk, v, probs, go, gq, gv, dsws, flops=10 * B * heads * T * T * F)
+            self._add("aid_time_attention_bwd", bp, qk, v, probs, go, gq, gv, dsws, flops=10 * B * heads * T * T * F, writes=(gq, gv, dsws))
             self._wrote(gq)
             self._wrote(gv)
-        self.bwd.append(bw)
+        self._reg_bwd(bw)
 
 
 # =========================================================================================================
@@ -859,19 +844,22 @@ class Unet_CQT_oct_with_attention(nn.Module):
         Xb = [bd.buf(B, Ns[i] if i == 0 else Ns[i - 1], Fl[i], Tl[i]) for i in range(n)]   # cat(C2, X) along F (:770)
         # -- encoder (:747-795) ---------------------------------------------------------------------------------
         pyr_prev = None
+        # Lane 1 (plan.py): the per-octave init blocks, the pyramid path and the out blocks -- few-channel, latency-bound launches that depend on
+        # the trunk only where they join it.  With plan.lanes = 2 they run on a second stream next to the trunk's 5x3 convolutions.
         for i in range(n):
             Cin = octs_in[n - 1 - i]
-            self._emit_resblock(bd, st, f"downs.{i}.0.", self.downs[i][0], Cin if cin_full is None else cin_full[n - 1 - i],
-                                Xb[i][:, :, :bpo, :])
-            if cin_full is not None and i == n - 1:          # the deepest octave is also the first rows of the pyramid input (:773)
-                bd.copy(Cin, pyrL[:, :, :bpo, :])
-            if i < n - 1:
-                pyr = pyrL[:, :, bpo:, :] if i == n - 2 else bd.buf(B, 2, Fl[i], Tl[i] // 2)
-                bd.resample(Cin, pyr[:, :, :bpo, :], up=0)
-                if i > 0:
-                    bd.resample(pyr_prev, pyr[:, :, bpo:, :], up=0)
-            else:
-                pyr = pyrL
+            with bd.on_lane(1):
+                self._emit_resblock(bd, st, f"downs.{i}.0.", self.downs[i][0], Cin if cin_full is None else cin_full[n - 1 - i],
+                                    Xb[i][:, :, :bpo, :])
+                if cin_full is not None and i == n - 1:          # the deepest octave is also the first rows of the pyramid input (:773)
+                    bd.copy(Cin, pyrL[:, :, :bpo, :])
+                if i < n - 1:
+                    pyr = pyrL[:, :, bpo:, :] if i == n - 2 else bd.buf(B, 2, Fl[i], Tl[i] // 2)
+                    bd.resample(Cin, pyr[:, :, :bpo, :], up=0)
+                    if i > 0:
+                        bd.resample(pyr_prev, pyr[:, :, bpo:, :], up=0)
+                else:
+                    pyr = pyrL
             hs = D[i][:, Ns[i]:, :, :]
             self._emit_resblock(bd, st, f"downs.{i}.2.", self.downs[i][2], Xb[i], hs)
             wpyr, wpyrT = W[f"downs.{i}.1.weight"], W[f"downs.{i}.1.weight#T"]
@@ -891,7 +879,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
             self._emit_resblock(bd, st, f"middle.{m}.1.", self.middle[m][1], Xcur, tgt)
             Xcur = tgt
         Xout = bd.buf(B, 2, Fl[n - 1], Tl[n - 1])
-        self._emit_resblock(bd, st, f"middle.{nm - 1}.0.", self.middle[nm - 1][0], Xcur, Xout)
+        with bd.on_lane(1):
+            self._emit_resblock(bd, st, f"middle.{nm - 1}.0.", self.middle[nm - 1][0], Xcur, Xout)
         # -- decoder (:807-839) -------------------------------------------------------------------------------------
         octs_out = [None] * n
         for i in range(n):
@@ -899,14 +888,17 @@ class Unet_CQT_oct_with_attention(nn.Module):
             dim_out = Ns[j - 1] if j > 0 else Ns[0]
             R = bd.buf(B, dim_out, Fl[j], Tl[j])
             self._emit_resblock(bd, st, f"ups.{i}.1.", self.ups[i][1], D[j], R)
+            if j > 0:                                    # (trunk first: in the reverse sweep the out block then contributes to dL/dR before the
+                bd.resample(R[:, :, bpo:, :], D[j - 1][:, :Ns[j - 1], :, :], up=1)       # trunk does, and lane 1 never waits for the trunk there)
             Xo = bd.buf(B, 2, Fl[j], Tl[j])
-            self._emit_resblock(bd, st, f"ups.{i}.0.", self.ups[i][0], R, Xo, prev_out=Xout)
-            octs_out[i] = Xo[:, :, :bpo, :]
-            if j > 0:
-                bd.resample(R[:, :, bpo:, :], D[j - 1][:, :Ns[j - 1], :, :], up=1)
-                Xout = bd.buf(B, 2, Fl[j - 1], Tl[j - 1])
-                bd.resample(Xo[:, :, bpo:, :], Xout, up=1)
+            with bd.on_lane(1):
+                self._emit_resblock(bd, st, f"ups.{i}.0.", self.ups[i][0], R, Xo, prev_out=Xout)
+                octs_out[i] = Xo[:, :, :bpo, :]
+                if j > 0:
+                    Xout = bd.buf(B, 2, Fl[j - 1], Tl[j - 1])
+                    bd.resample(Xo[:, :, bpo:, :], Xout, up=1)
         st["octs_out"] = octs_out
+        bd.plan.lanes = self._plan_lanes(B)
         st["plan_body"] = bd.plan
         st["nbytes"] = bd.nbytes
         st["flops"] = bd.plan.flops
@@ -1009,6 +1001,9 @@ class Unet_CQT_oct_with_attention(nn.Module):
     # input / output buffers, later calls copy the inputs in and replay.  Sub-batch streams (B >= 4) stay eager.
     # ---------------------------------------------------------------------------------------------------
     use_graphs = True
+    plan_lanes = True          # tag the init blocks / pyramid / out blocks as lane 1 of the launch plans (plan.py)
+    lanes_max_batch = 3        # ... and run the two lanes on two streams for batches up to this size (larger batches already fill the GPU, and
+                               # run as sub-batch streams)
     param_grads_in_train_mode = False   # True: a train()-mode call whose INPUT requires grad also yields parameter gradients (TrainFn) instead of
                                         # the input-only VJP; off by default because the reference's tester samples with the network in train() mode
     wgrad_wino = True          # training: F(4,3) form of the 5x3 weight gradients (aid_conv2d_wgrad wino=1)
@@ -1016,6 +1011,9 @@ class Unet_CQT_oct_with_attention(nn.Module):
     epilogue_stats = True      # forward group statistics from the epilogue of the conv that produces the tensor (row-shared F(4,3) kernel)
     GRAPH_MAX_B = 3
     GRAPH_MAX_PER_STATE = 4
+
+    def _plan_lanes(self, B: int) -> int:
+        return 2 if (self.plan_lanes and B <= self.lanes_max_batch) else 1
 
     def _graph_ok(self, B, st):
         if not (self.use_graphs and B <= self.GRAPH_MAX_B and self._n_split(B) == 1):
@@ -1121,6 +1119,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
         if "plan_bwd" not in st:
             bd = st["builder"]
             st["plan_bwd"] = bd.finish_backward()
+            st["plan_bwd"].lanes = self._plan_lanes(st["B"])
             st["gin"] = [bd.G(t) for t in st["octs_in"]]
             st["gout"] = [bd.G(t) for t in st["octs_out"]]
             st["gzero"] = [g for k, g in bd.gmap.items() if bd.gstate.get(k) != "full"]

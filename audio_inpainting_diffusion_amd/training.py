@@ -126,8 +126,9 @@ class Trainer:
         return {k: flat[off:off + int(torch.Size(shape).numel())].view(shape) for k, off, shape in self._layout()}
 
     def ema_state_dict(self):
-        """state_dict-shaped view of the EMA buffer (what the reference checkpoints as 'ema')."""
-        return self._views(self.ema)
+        """state_dict-shaped view of the EMA buffer (what the reference checkpoints as 'ema'), in the module's own key order."""
+        v = self._views(self.ema)
+        return {k: v[k] for k in self.net.state_dict() if k in v}
 
     # ---- checkpoints in the reference's shape (training/trainer.py:186-199: {'it', 'network', 'optimizer', 'ema', 'args'}) -----------------
     def state_dict(self, args=None):

@@ -54,8 +54,9 @@ def shape_of(k):
 
 cat = collections.OrderedDict()
 rows = []
+lane_us = {}
 for nm in ("fwd", "bwd"):
-    for (a0, a1, name, descr, addr, kn) in tr[nm]:
+    for (a0, a1, name, descr, addr, kn, lane) in tr[nm]:
         us = 1e3 * a0.elapsed_time(a1)
         k = structs.get(addr)
         sh = shape_of(k) if (k is not None and name != "aid_conv2d") else ""
@@ -79,11 +80,13 @@ for nm in ("fwd", "bwd"):
         elif extra and name in ("aid_norm_bwd", "aid_scale_act"):
             key += " " + ("wino" if "wino" in extra else "plain")
         r = cat.setdefault(key, [0, 0.0]); r[0] += 1; r[1] += us
-        rows.append((nm, name, descr if name == "aid_conv2d" else sh + " " + extra, kn, us))
+        rows.append((nm + str(lane), name, descr if name == "aid_conv2d" else sh + " " + extra, kn, us))
+        lane_us[lane] = lane_us.get(lane, 0.0) + us
 if "--list" in sys.argv:
     for nm, name, d, kn, us in rows:
         print("%s %-22s %-62s %-34s %8.1f us" % (nm, name.replace("aid_", ""), d, kn, us))
 s = sum(v[1] for v in cat.values())
 print("batch %d %s: guided evaluation %.2f ms wall (single stream, events around every launch), sum of launches %.2f ms, %d launches" % (B, wl, total, s / 1e3, len(rows)))
+print("  time by lane: " + ", ".join("lane %d %.2f ms" % (l, u / 1e3) for l, u in sorted(lane_us.items())))
 for k, (n, us) in sorted(cat.items(), key=lambda kv: -kv[1][1]):
     print("  %-44s n=%4d  %9.2f ms  %5.1f%%" % (k, n, us / 1e3, 100 * us / s))

@@ -147,6 +147,8 @@ def main():
                                                               "configs[3] sweeps 25 / 50 / 100, conf/tester/inpainting_tester_shortgaps.yaml:74-75)")
     ap.add_argument("--streams", type=int, default=0, help="sub-batch HIP streams per evaluation (default: automatic, network._n_split; 1 = plain single-stream schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true", help="A/B: eager launches instead of HIP-graph replay at small batches")
+    ap.add_argument("--no-lanes", action="store_true", help="A/B: single-stream launch plans at small batches (plan.py lanes off)")
     ap.add_argument("--no-fused-norm-bwd", action="store_true", help="A/B: separate gate / Winograd-transform pre-pass before every dgrad conv")
     ap.add_argument("--no-epilogue-stats", action="store_true", help="A/B: group statistics by their own read pass instead of the conv epilogue")
     ap.add_argument("--conv-table", action="store_true", help="print per-shape conv kernel times (stderr)")
@@ -188,6 +190,10 @@ def main():
         net.fuse_norm_bwd_wino = False
     if a.streams:
         net.split_streams = a.streams
+    if a.no_graphs:
+        net.use_graphs = False
+    if a.no_lanes:
+        net.lanes_max_batch = 0
     if rank == 0:
         seeded_init_(net, 0)                       # reference-scale gates (1e-7), like a fresh reference network
     D.barrier()

@@ -45,7 +45,8 @@ class Conv2dParams(C.Structure):
                 ("act", C.c_int), ("epi", C.c_int),
                 ("alpha", C.c_float), ("res_scale", C.c_float), ("wp_wino", C.c_void_p), ("wino_taps", C.c_int),
                 ("x_wino", C.c_int), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
-                ("dot_ws", C.c_void_p), ("dot_n", C.c_int), ("stat_ws", C.c_void_p), ("stat_n", C.c_int)]
+                ("dot_ws", C.c_void_p), ("dot_n", C.c_int), ("stat_ws", C.c_void_p), ("stat_n", C.c_int),
+                ("x2", View), ("Cin1", C.c_int)]
 
 
 class ResampleParams(C.Structure):
@@ -236,7 +237,7 @@ EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_st
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_guidance_step", "aid_set_rows", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
-           "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials",
+           "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported",
            "aid_conv2d_wgrad", "aid_wgrad_reduce", "aid_channel_dot", "aid_scale_bwd", "aid_modulation_bwd", "aid_embed_bwd",
            "aid_adam", "aid_ema", "aid_sumsq"]
 
@@ -263,8 +264,15 @@ def lib():
         L.aid_conv2d_wino_input_supported.restype = C.c_int
         L.aid_conv2d_dot_partials.argtypes = [C.c_int] * 7
         L.aid_conv2d_dot_partials.restype = C.c_int
+        L.aid_conv2d_x2_supported.argtypes = [C.c_int] * 5
+        L.aid_conv2d_x2_supported.restype = C.c_int
+        L.aid_conv2d_stat_partials.argtypes = [C.c_int] * 7
+        L.aid_conv2d_stat_partials.restype = C.c_int
+        L.aid_conv2d_wgrad_tiles.argtypes = [C.c_int] * 5
+        L.aid_conv2d_wgrad_tiles.restype = C.c_int
         for name in EXPORTS[3:]:
-            if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials"):
+            if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported",
+                            "aid_conv2d_stat_partials", "aid_conv2d_wgrad_tiles"):
                 getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, name).restype = C.c_int
         if L.aid_abi_version() != 7:

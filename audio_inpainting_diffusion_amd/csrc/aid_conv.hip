@@ -490,6 +490,13 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     AID_REQUIRE(p->epi == 0 || (p->epi == 1 && p->aux.p && p->aux_scale), "aid_conv2d: epi=1 needs aux + aux_scale");
     AID_REQUIRE((int64_t)p->B * p->in_scale_ld < (1LL << 31), "aid_conv2d: in_scale too large");
     AID_REQUIRE(!p->x_wino || (p->KH == 5 && p->KW == 3 && p->wp_wino), "aid_conv2d: x_wino is a 5x3 Winograd-path input layout");
+    if (p->x2.p) {
+        AID_REQUIRE(p->KH == 1 && p->KW == 1 && !p->in_scale && p->act == 0 && p->Cin1 > 0 && p->Cin1 < p->Cin && (p->Cin1 % 16) == 0 && ((p->Cin - p->Cin1) % 16) == 0,
+                    "aid_conv2d: x2 is an option of plain 1x1 convolutions with both K segments multiples of 16");
+        const int r = aid_conv1x1_dma_try(p, st);
+        if (r == 0) aid_set_error("aid_conv2d: x2 given but the layer is not eligible for the direct-to-LDS 1x1 kernel");
+        return r == 1 ? AID_OK : (r < 0 ? r : AID_E_BADARG);
+    }
     if (p->stat_ws) {
         AID_REQUIRE(!p->dot_ws && p->epi == 0 && p->x_wino, "aid_conv2d: stat_ws is an option of the forward epilogue on Winograd-domain input");
         AID_REQUIRE(p->stat_n > 0 && p->stat_n == aid_conv2d_stat_partials(p->B, p->Cin, p->Cout, p->F, p->T, p->dilF, p->x_wino), "aid_conv2d: stat_n != aid_conv2d_stat_partials()");

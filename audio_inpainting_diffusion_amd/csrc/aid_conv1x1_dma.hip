@@ -22,6 +22,7 @@ struct C11Dev {
     const float* zero;
     int tt_log2, rows_log2, tiles_t, nrows, nchunks;
     int nx, ny, per_xcd;
+    int nch1;                  // chunks served by p.x (all of them unless p.x2 is given: then chunks >= nch1 read channels of p.x2)
 };
 
 __device__ float4 g_aid_zero_page_c11[16];
@@ -84,11 +85,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv11_dma_kernel(const 
 
     // ---- DMA piece descriptors ---------------------------------------------------------------------------------------
     const float* psrc[PPW];
-    int pstride[PPW], plds[PPW];
+    const float* psrc2[PPW];                             // second K segment (p.x2): same piece, channels of the other tensor
+    int pstride[PPW], pstride2[PPW], plds[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int pc = wave + i * NW;
         psrc[i] = a.zero; pstride[i] = 0; plds[i] = -1;
+        psrc2[i] = a.zero; pstride2[i] = 0;
         if (pc < NXP) {
             const int ci = pc / (N_BLK / 256), sub = pc % (N_BLK / 256);
             const int n = sub * 256 + 4 * lane;
@@ -99,6 +102,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv11_dma_kernel(const 
             if (b >= 0 && t0 + tt < p.T) {
                 psrc[i] = p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)f * p.x.sF + t0 + tt;
                 pstride[i] = (int)(KC * p.x.sC);
+                if (p.x2.p) {
+                    psrc2[i] = p.x2.p + (int64_t)b * p.x2.sB + (int64_t)ci * p.x2.sC + (int64_t)f * p.x2.sF + t0 + tt;
+                    pstride2[i] = (int)(KC * p.x2.sC);
+                }
             }
         } else if (pc < NP) {
             const int wp_ = pc - NXP;
@@ -108,6 +115,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv11_dma_kernel(const 
             if (col < M_BLK) {
                 psrc[i] = p.wp + (int64_t)ci * p.Cout_pad + m0 + col;
                 pstride[i] = KC * p.Cout_pad;
+                psrc2[i] = psrc[i] + (int64_t)a.nch1 * pstride[i];       // (weights: one stacked pack, K continues)
+                pstride2[i] = pstride[i];
             }
         }
     }
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv11_dma_kernel(const 
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             if (plds[i] >= 0) {
-                const float* src = psrc[i] + (int64_t)ch * pstride[i];
+                const float* src = ch < a.nch1 ? psrc[i] + (int64_t)ch * pstride[i] : psrc2[i] + (int64_t)(ch - a.nch1) * pstride2[i];
                 GLDS16C(src, buf + plds[i]);
             }
         }
@@ -248,6 +257,7 @@ static int launch_c11(const aid_conv2d_params* p, hipStream_t st) {
     a.tiles_t = aid_cdiv(p->T, TT);
     a.nrows = p->B * p->F;
     a.nchunks = aid_cdiv(p->Cin, KC);
+    a.nch1 = p->x2.p ? p->Cin1 / KC : a.nchunks;
     a.nx = aid_cdiv(a.nrows, ROWS) * a.tiles_t;
     a.ny = p->Cout_pad / M_BLK;
     a.per_xcd = (a.nx * a.ny + 7) / 8;
@@ -255,6 +265,17 @@ static int launch_c11(const aid_conv2d_params* p, hipStream_t st) {
     AID_CHECK_LAUNCH();
     aid_note_kernel("conv11_dma_kernel");
     return AID_OK;
+}
+
+// shapes on which the two-tensor K axis (x2 / Cin1) is available: what aid_conv1x1_dma_try accepts below, minus the pointer alignment checks
+extern "C" int aid_conv2d_x2_supported(int Cin, int Cin1, int Cout, int F, int T) {
+    int cip, cop;
+    aid_conv2d_pack_dims(Cin, Cout, &cip, &cop);
+    if (F <= 1 || Cin < 32 || (Cin % 16) || Cout < 32 || Cin1 <= 0 || Cin1 >= Cin || (Cin1 % 16)) return 0;
+    if ((T % 4) || aid_pow2ceil(T) < 8) return 0;
+    int TT = aid_pow2ceil(T); if (TT > 256) TT = 256;
+    if (256 / TT > 16) return 0;
+    return (cop % 128 == 0 || cop % 64 == 0 || cop % 96 == 0) ? 1 : 0;
 }
 
 // returns 1 if this kernel took the launch, 0 if not eligible, <0 on error
@@ -265,6 +286,7 @@ int aid_conv1x1_dma_try(const aid_conv2d_params* p, hipStream_t st) {
     auto al = [](const aid_view& v, int q) { return (v.sB % q) == 0 && (v.sC % q) == 0 && (v.sF % q) == 0 && (((uintptr_t)v.p) & (4 * q - 1)) == 0; };
     if (!al(p->x, 4) || !al(p->y, 2) || (p->res.p && !al(p->res, 2)) || (p->aux.p && !al(p->aux, 2))) return 0;
     if ((int64_t)4 * 16 * p->x.sC >= (1LL << 31)) return 0;
+    if (p->x2.p && (!al(p->x2, 4) || (int64_t)4 * 16 * p->x2.sC >= (1LL << 31) || (p->Cin1 % 16) || p->in_scale)) return 0;
     // a tile (256 positions) must stay inside one sample when a per-(b,ci) scale is applied to the weights
     int TT = aid_pow2ceil(p->T); if (TT > 256) TT = 256;
     const int ROWS = 256 / TT;

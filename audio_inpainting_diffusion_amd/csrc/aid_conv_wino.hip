@@ -1072,12 +1072,11 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
         a.ntiles = p->B * a.rgroups * g.quads * g.ttiles * a.ny;
         a.per_xcd = (a.ntiles + 7) / 8;
         const dim3 grid((unsigned)(8 * a.per_xcd));
-        static int shortk_max = -1;                          // EXPERIMENT (to be removed): AID_W4R_SHORTK = largest Cin that takes the 3-workgroup variant
-        if (shortk_max < 0) { const char* e = getenv("AID_W4R_SHORTK"); shortk_max = e ? atoi(e) : 128; }
-        const bool short_k = p->Cin <= shortk_max;           // three workgroups per CU (two LDS buffers) for the short-K layers
+        const bool short_k = p->Cin <= 128;                  // three workgroups per CU (two LDS buffers) for the short-K layers (re-measured in round 3 with
+                                                             // sub-batch streams: Cin <= 128 / 64 / never = 42.33 / 42.08 / 42.17 evaluations/s)
 #define AID_W4R(TTv, NCv, WGMv) do { \
-            if (short_k) hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv, 2, 3>), grid, dim3(256), 0, st, a); \
-            else hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv, 3, 2>), grid, dim3(256), 0, st, a); } while (0)
+            if constexpr (TTv == 64 && NCv <= 2) { if (short_k) { hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv, 2, 3>), grid, dim3(256), 0, st, a); break; } } \
+            hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv, 3, 2>), grid, dim3(256), 0, st, a); } while (0)
         switch ((l * 128 + g.TT) * 16 + g.NC) {
             case 64 * 16 + 1: AID_W4R(64, 1, 2); break;
             case 64 * 16 + 2: AID_W4R(64, 2, 2); break;

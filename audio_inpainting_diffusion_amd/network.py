@@ -356,9 +356,9 @@ class _Builder:
             self.S_of[in_scale.data_ptr()] = Sb
 
     def _conv_raw(self, x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha, epi=0,
-                  aux=None, aux_scale=None, wpw=None, x_wino=False, dot=None):
+                  aux=None, aux_scale=None, wpw=None, x_wino=False, dot=None, x2=None):
         B, _, F, T = y.shape
-        assert x.shape[1] == cin and y.shape[1] == cout and x.shape[0] == B and x.shape[2] == F
+        assert x.shape[1] + (0 if x2 is None else x2.shape[1]) == cin and y.shape[1] == cout and x.shape[0] == B and x.shape[2] == F
         assert x.shape[3] == (6 * (T // 4) if x_wino else T)
         p = _lib.Conv2dParams()
         p.x, p.y, p.res, p.aux = _lib.view4(x), _lib.view4(y), _lib.view4(res), _lib.view4(aux)
@@ -375,6 +375,8 @@ class _Builder:
         p.x_wino = int(x_wino)
         if dot is not None:                              # (buffer, partials per (b, group)): <y, aux> folded into the epilogue
             p.dot_ws, p.dot_n = dot[0].data_ptr(), dot[1]
+        if x2 is not None:                               # K axis in two tensors (aid_kernels.h: x2 / Cin1)
+            p.x2, p.Cin1 = _lib.view4(x2), x.shape[1]
         ws = None
         if F == 1 and kh == 1 and epi == 0:              # qk projections: few columns, long K -> split-K scratch (aid_kernels.h)
             ws = self._scratch(("ws", 8 * B * cout * T))
@@ -383,7 +385,7 @@ class _Builder:
         # algorithmic HBM bytes: x once, residual / aux once, y once, weights once
         nb = 4 * (B * F * T * (cin + cout * (1 + (res is not None) + (aux is not None))) + cin * cout * kh * kw)
         dws = None if dot is None else dot[0]
-        op = self._add("aid_conv2d", p, x, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, ws, dws, flops=2 * B * F * T * cin * cout * kh * kw,
+        op = self._add("aid_conv2d", p, x, x2, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, ws, dws, flops=2 * B * F * T * cin * cout * kh * kw,
                        nbytes=nb, writes=(y, ws, dws))
         self._wrote(y)
         if not self._in_bwd and x_wino and epi == 0 and dot is None and self.net.epilogue_stats:
@@ -487,6 +489,25 @@ class _Builder:
                     self._train_conv(x, gy, None, wname, cin, cout, kh, kw, dil, None, act, out_scale, alpha, wpw=wpw)
         self._reg_bwd(bw)
 
+
+    def pair_dgrad(self, xin, x0, yout, wpair, n, cout):
+        """Register the MERGED input gradient of a ResnetBlock's proj_in (xin -> x0) and res_conv (xin -> yout) at the place of proj_in
+        (so that it runs after the block's steps in the reverse sweep): dL/dxin (+)= [W_pi^T ; alpha W_rc^T] . [dL/dx0 ; dL/dyout] as ONE 1x1
+        conv whose K axis lives in two tensors, instead of two read-modify-write passes over dL/dxin."""
+        def bw():
+            g1, g2, gx = self.G(x0), self.G(yout), self.G(xin)
+            self._conv_raw(g1, gx, wpair, 2 * n, cout, 1, 1, 1, None, 0, None, gx if self._gacc(xin) else None, 1.0, 1.0, x2=g2)
+        self._reg_bwd(bw)
+
+    def res_grad(self, res, y, c):
+        """Register dL/dres (+)= c * dL/dy (the residual input of a conv whose own input gradient is taken elsewhere)."""
+        def bw():
+            gy, gr = self.G(y), self.G(res)
+            if self._gacc(res):
+                self.add2_raw(gr, gy, gr, 1.0, c)
+            else:
+                self.add2_raw(gy, None, gr, c, 0.0)
+        self._reg_bwd(bw)
 
     def add2_raw(self, u, v, y, a, b):
         """y = a*u + b*v   (v may be None: y = a*u)"""
@@ -676,6 +697,17 @@ class Unet_CQT_oct_with_attention(nn.Module):
                 _lib.call("aid_pack_conv_weight", pp)       # all layouts of this weight in one launch (same values as _lib.pack_conv_weight*)
             elif leaf == "gamma":
                 put(name, w.detach().reshape(-1).float())
+        # ResnetBlocks that project their input twice (proj_in and res_conv on the same tensor): one stacked pack [W_pi^T ; W_rc^T / sqrt2] for the
+        # merged input gradient (aid_conv2d x2 / Cin1); K segments must be multiples of 16 and start at row N of the pack
+        for pfx, blk in self._resblocks():
+            if hasattr(blk, "proj_in") and hasattr(blk, "res_conv") and blk.proj_place == "before" and blk.N % 16 == 0 and blk.dim >= 32 and blk.dim % 16 == 0:
+                n = blk.N
+                a, b = self._packed[pfx + "proj_in.weight#T"], self._packed[pfx + "res_conv.weight#T"]
+                cip, cop = _lib.pack_dims(2 * n, blk.dim)
+                assert a.shape[2] == cop and b.shape[2] == cop
+                t = torch.zeros(1, cip, cop, device=dev, dtype=torch.float32)
+                t[:, :n], t[:, n:2 * n] = a[:, :n], b[:, :n] * RSQRT2
+                put(pfx + "#pairT", t)
         # stacked modulation matrix: [affine2, gate2]? then per step [affine.k, gate.k], block after block
         rows, biases, layout, off = [], [], {}, 0
         for pfx, blk in self._resblocks():
@@ -724,9 +756,15 @@ class Unet_CQT_oct_with_attention(nn.Module):
         B, _, F, T = xin.shape
         N, W = blk.N, self._packed
         x = xin
+        pair = ((pfx + "#pairT") in W and not bd.train and self.merge_pair_dgrad
+                and bool(_lib.lib().aid_conv2d_x2_supported(2 * N, N, blk.dim, F, T)))
         if hasattr(blk, "proj_in"):
             x = bd.buf(B, N, F, T)
-            bd.conv(xin, x, W[pfx + "proj_in.weight"], blk.dim, N, wpT=W[pfx + "proj_in.weight#T"], wname=pfx + "proj_in.weight")
+            if pair:                                     # forward as always; the input gradients of proj_in and res_conv are taken together
+                bd.conv(xin, x, W[pfx + "proj_in.weight"], blk.dim, N)
+                bd.pair_dgrad(xin, x, yout, W[pfx + "#pairT"], N, blk.dim)
+            else:
+                bd.conv(xin, x, W[pfx + "proj_in.weight"], blk.dim, N, wpT=W[pfx + "proj_in.weight#T"], wname=pfx + "proj_in.weight")
         if blk.has_attn:
             H = blk.heads
             assert F == blk.fdim, "attention block built for a different number of frequency rows"
@@ -766,13 +804,16 @@ class Unet_CQT_oct_with_attention(nn.Module):
                 bd.conv(xin, t1, W[pfx + "res_conv.weight"], blk.dim, blk.dim_out, wpT=W[pfx + "res_conv.weight#T"], wname=pfx + "res_conv.weight")
                 a2 = RSQRT2
             bd.conv(x, yout, W[pfx + "proj_out.weight"], N, blk.dim_out, res=t1, alpha=a2, wpT=W[pfx + "proj_out.weight#T"], wname=pfx + "proj_out.weight")
+        elif hasattr(blk, "res_conv") and pair:
+            bd.conv(xin, yout, W[pfx + "res_conv.weight"], blk.dim, blk.dim_out, res=x, alpha=RSQRT2)
+            bd.res_grad(x, yout, RSQRT2)
         elif hasattr(blk, "res_conv"):
             bd.conv(xin, yout, W[pfx + "res_conv.weight"], blk.dim, blk.dim_out, res=x, alpha=RSQRT2,
                     wpT=W[pfx + "res_conv.weight#T"], wname=pfx + "res_conv.weight")
         else:
             bd.add2(x, xin, yout, RSQRT2, RSQRT2)
 
-    def _build_state(self, B: int, train: bool = False):
+    def _build_state(self, B: int, train: bool = False, lanes: bool = True):
         self.prepare()
         dev = next(self.parameters()).device
         n, bpo, Ns = self.num_octs, self.bins_per_oct, self.Ns
@@ -898,7 +939,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
                     Xout = bd.buf(B, 2, Fl[j - 1], Tl[j - 1])
                     bd.resample(Xo[:, :, bpo:, :], Xout, up=1)
         st["octs_out"] = octs_out
-        bd.plan.lanes = self._plan_lanes(B)
+        st["lanes"] = bd.plan.lanes = self._plan_lanes(B) if lanes else 1
         st["plan_body"] = bd.plan
         st["nbytes"] = bd.nbytes
         st["flops"] = bd.plan.flops
@@ -921,7 +962,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
         self._states[group] = grp                                       # (re)insert as most recently used
         st = grp.get((B, slot))
         if st is None:
-            st = grp[(B, slot)] = self._build_state(B, train=(group[1] == "train"))
+            st = grp[(B, slot)] = self._build_state(B, train=(group[1] == "train"), lanes=(group[1] == 1))   # (sub-batches already share the GPU)
         return st
 
     # ---------------------------------------------------------------------------------------------------
@@ -1001,9 +1042,10 @@ class Unet_CQT_oct_with_attention(nn.Module):
     # input / output buffers, later calls copy the inputs in and replay.  Sub-batch streams (B >= 4) stay eager.
     # ---------------------------------------------------------------------------------------------------
     use_graphs = True
+    merge_pair_dgrad = True    # reverse sweep: input gradients of a block's proj_in and res_conv as ONE 1x1 conv over a K axis in two tensors
     plan_lanes = True          # tag the init blocks / pyramid / out blocks as lane 1 of the launch plans (plan.py)
-    lanes_max_batch = 3        # ... and run the two lanes on two streams for batches up to this size (larger batches already fill the GPU, and
-                               # run as sub-batch streams)
+    lanes_max_batch = 3        # ... and run the two lanes on two streams for whole batches up to this size.  Larger batches fill the GPU and run as
+                               # sub-batch streams; a second lane INSIDE each sub-batch stream measured -19 % at batch 8 (six streams competing)
     param_grads_in_train_mode = False   # True: a train()-mode call whose INPUT requires grad also yields parameter gradients (TrainFn) instead of
                                         # the input-only VJP; off by default because the reference's tester samples with the network in train() mode
     wgrad_wino = True          # training: F(4,3) form of the 5x3 weight gradients (aid_conv2d_wgrad wino=1)
@@ -1119,7 +1161,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
         if "plan_bwd" not in st:
             bd = st["builder"]
             st["plan_bwd"] = bd.finish_backward()
-            st["plan_bwd"].lanes = self._plan_lanes(st["B"])
+            st["plan_bwd"].lanes = st["lanes"]
             st["gin"] = [bd.G(t) for t in st["octs_in"]]
             st["gout"] = [bd.G(t) for t in st["octs_out"]]
             st["gzero"] = [g for k, g in bd.gmap.items() if bd.gstate.get(k) != "full"]

@@ -120,8 +120,14 @@ typedef struct {
                                  also reduces (sum y, sum y^2) per (sample, channel group of Cout/8) over its tile:
                                  stat_ws[((b*8 + g) * stat_n + tile) * 2 + {0,1}] -- the read pass of the NEXT layer's aid_group_stats folded into
                                  the conv that produces its input (aid_group_stats ws_n = stat_n).  stat_n must equal aid_conv2d_stat_partials(...). */
+    aid_view x2; int Cin1;       /* optional (1x1 only, no prologue): input channels [Cin1, Cin) are read from x2 (channel c of x2 = input channel
+                                 Cin1 + c); Cin1 and Cin - Cin1 multiples of 16.  One GEMM over a K axis that lives in two tensors: the input
+                                 gradients of a ResnetBlock's proj_in and res_conv (unet...py:414-415, :488-491), which both flow into dL/d(block
+                                 input), as ONE launch on the stacked transposed weights instead of two read-modify-write passes over it. */
 } aid_conv2d_params;
 int aid_conv2d(const aid_conv2d_params* p, void* stream);
+/* 1 when aid_conv2d accepts the x2 / Cin1 option (K axis in two tensors) for this 1x1 shape */
+int aid_conv2d_x2_supported(int Cin, int Cin1, int Cout, int F, int T);
 /* non-zero when a 5x3 layer of this shape can take Winograd-domain input (x_wino = 1) */
 int aid_conv2d_wino_input_supported(int Cin, int Cout, int T);
 /* number of per-tile partial dots per (sample, group) the F(4,3) epilogue writes for this shape; 0 = not supported */

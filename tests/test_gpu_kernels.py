@@ -703,3 +703,37 @@ def test_conv2d_wgrad_winograd_form(L, case):
     e1, e2 = rel_l2(dW.cpu().double().reshape(Cout, Cin, 5, 3), dW_ref), rel_l2(dg.cpu().double(), dg_ref)
     print(f"F(4,3) weight gradient: dW rel-L2 {e1:.2e}, dgate rel-L2 {e2:.2e}")
     assert e1 < 1e-5 and e2 < 1e-5
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 192, 16, 64, True), (1, 96, 96, 256, 8, 256, False), (3, 128, 128, 64, 9, 32, True), (2, 16, 48, 96, 12, 16, False)])
+def test_conv1x1_with_the_k_axis_in_two_tensors(L, case):
+    """aid_conv2d x2 / Cin1: y = alpha * (res + W[:, :Cin1] x + W[:, Cin1:] x2) -- the merged input gradient of a ResnetBlock's proj_in and
+    res_conv (unet...py:414-415, :488-491) -- against F.conv2d on the concatenated input (fp64 reference)."""
+    B, c1, c2, cout, Fd, T, acc = case
+    assert L.lib().aid_conv2d_x2_supported(c1 + c2, c1, cout, Fd, T)
+    g = torch.Generator().manual_seed(7)
+    big = torch.randn(B, c1 + 8, Fd, T, generator=g)                     # x is a channel slice of a wider buffer: strided view
+    x1, x2 = big[:, 4:4 + c1], torch.randn(B, c2, Fd, T, generator=g)
+    w = torch.randn(cout, c1 + c2, 1, 1, generator=g) / math.sqrt(c1 + c2)
+    res = torch.randn(B, cout, Fd, T, generator=g)
+    ref = F.conv2d(torch.cat([x1, x2], 1).double(), w.double())
+    if acc:
+        ref = ref + res.double()
+    bigd = big.to(DEV)
+    x1d, x2d, yd = bigd[:, 4:4 + c1], x2.to(DEV), res.to(DEV).clone()
+    wp = L.pack_conv_weight(w.to(DEV))
+    p = L.Conv2dParams()
+    p.x, p.x2, p.Cin1, p.y, p.res, p.aux = L.view4(x1d), L.view4(x2d), c1, L.view4(yd), L.view4(yd if acc else None), L.view4(None)
+    p.wp = wp.data_ptr()
+    p.B, p.Cin, p.Cout, p.F, p.T = B, c1 + c2, cout, Fd, T
+    p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
+    p.KH, p.KW, p.dilF, p.act, p.epi = 1, 1, 1, 0, 0
+    p.alpha, p.res_scale = 1.0, 1.0
+    L.call("aid_conv2d", p)
+    assert L.lib().aid_last_kernel().decode() == "conv11_dma_kernel"
+    e = rel_l2(yd.cpu(), ref)
+    assert e < 1e-5, e
+    # unsupported shapes are refused loudly, not routed elsewhere
+    p.Cin1 = c1 + 1
+    with pytest.raises(L.AidError):
+        L.call("aid_conv2d", p)

@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="sub-batch HIP streams per evaluation (default: automatic, network._n_split; 1 = plain single-stream schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="A/B: eager launches instead of HIP-graph replay at small batches")
+    ap.add_argument("--no-pair-merge", action="store_true", help="A/B: separate input-gradient convs for proj_in and res_conv")
     ap.add_argument("--no-lanes", action="store_true", help="A/B: single-stream launch plans at small batches (plan.py lanes off)")
     ap.add_argument("--no-fused-norm-bwd", action="store_true", help="A/B: separate gate / Winograd-transform pre-pass before every dgrad conv")
     ap.add_argument("--no-epilogue-stats", action="store_true", help="A/B: group statistics by their own read pass instead of the conv epilogue")
@@ -192,6 +193,8 @@ def main():
         net.split_streams = a.streams
     if a.no_graphs:
         net.use_graphs = False
+    if a.no_pair_merge:
+        net.merge_pair_dgrad = False
     if a.no_lanes:
         net.lanes_max_batch = 0
     if rank == 0:

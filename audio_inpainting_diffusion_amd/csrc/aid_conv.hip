@@ -379,6 +379,13 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const aid_conv2
     *reinterpret_cast<float4*>(p.y.p + (int64_t)b * p.y.sB + (int64_t)m * p.y.sC + (int64_t)f * p.y.sF + t) = o;
 }
 
+int aid_conv_splitk_reduce(const aid_conv2d_params* p, const float* ws, int splits, hipStream_t st) {
+    const int64_t total = (int64_t)p->B * p->Cout * ((int64_t)p->F * p->T / 4);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *p, ws, splits);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------
 static int pick_mblk(int Cout) {
     if (Cout <= 32) return 32;

@@ -23,6 +23,8 @@ struct C11Dev {
     int tt_log2, rows_log2, tiles_t, nrows, nchunks;
     int nx, ny, per_xcd;
     int nch1;                  // chunks served by p.x (all of them unless p.x2 is given: then chunks >= nch1 read channels of p.x2)
+    int splits, cps;           // split-K (grid-starved GEMMs: the qk projections, N = B*T columns only): blockIdx.y walks `splits` ranges of
+    float* ws;                 // `cps` chunks; raw partial sums go to ws[z][B][Cout][F][T], reduced in a fixed order by aid_conv_splitk_reduce
 };
 
 __device__ float4 g_aid_zero_page_c11[16];
@@ -155,15 +157,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv11_dma_kernel(const 
         }
     };
 
-    issue_dma(0, sbuf0);
-    load_scales(0, 0);
+    const int ch_lo = blockIdx.y * a.cps;                            // this workgroup's K range (the whole K unless split)
+    const int ch_hi = min(a.nchunks, ch_lo + a.cps);
+    issue_dma(ch_lo, sbuf0);
+    load_scales(ch_lo, 0);
     __syncthreads();
 
     auto chunk = [&](auto curc, int ch) {
         constexpr int cur = decltype(curc)::value;
         const float* Bf = cur ? sbuf1 : sbuf0;
         float* Nx = cur ? sbuf0 : sbuf1;
-        const bool more = (ch + 1) < a.nchunks;
+        const bool more = (ch + 1) < ch_hi;
         if (more) { issue_dma(ch + 1, Nx); load_scales(ch + 1, cur ^ 1); }
         float2 bv[2];
         float av[2][MT];
@@ -186,9 +190,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv11_dma_kernel(const 
         }
         __syncthreads();
     };
-    for (int ch = 0; ch < a.nchunks; ch += 2) {
+    for (int ch = ch_lo; ch < ch_hi; ch += 2) {
         chunk(std::integral_constant<int, 0>{}, ch);
-        if (ch + 1 < a.nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
+        if (ch + 1 < ch_hi) chunk(std::integral_constant<int, 1>{}, ch + 1);
     }
 
     // ---- epilogue: two consecutive positions per lane and output channel ---------------------------------------------
@@ -198,6 +202,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv11_dma_kernel(const 
     const int f = rowinfo[2 * rr + 1];
     const int t = t0 + tt;
     if (b < 0 || t >= p.T) return;                                   // T % 2 == 0: both samples in range together
+    if (a.splits > 1) {                                              // split-K: raw partial sums (float2 per output channel)
+        const int64_t ft = (int64_t)p.F * p.T;
+        float* wsb = a.ws + (((int64_t)blockIdx.y * p.B + b) * p.Cout) * ft + (int64_t)f * p.T + t;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int mbase = m0 + (wm * MT + i) * 32 + 4 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                if (m < p.Cout) *reinterpret_cast<float2*>(wsb + (int64_t)m * ft) = make_float2(acc[i][0][r], acc[i][1][r]);
+            }
+        }
+        return;
+    }
     const int64_t ybase = (int64_t)b * p.y.sB + (int64_t)f * p.y.sF + t;
     const int64_t rbase = p.res.p ? ((int64_t)b * p.res.sB + (int64_t)f * p.res.sF + t) : 0;
     const int64_t abase = p.aux.p ? ((int64_t)b * p.aux.sB + (int64_t)f * p.aux.sF + t) : 0;
@@ -235,8 +253,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv11_dma_kernel(const 
     }
 }
 
+int aid_conv_splitk_reduce(const aid_conv2d_params* p, const float* ws, int splits, hipStream_t st);      // aid_conv.hip
+
 template <int MT, int WGM, int WGN, int RMAX, int KC, int MINW>
-static int launch_c11(const aid_conv2d_params* p, hipStream_t st) {
+static int launch_c11(const aid_conv2d_params* p, hipStream_t st, int splits = 1) {
     constexpr int M_BLK = 32 * MT * WGM;
     constexpr int N_BLK = 64 * WGN;
     static const float* zero = nullptr;
@@ -261,9 +281,14 @@ static int launch_c11(const aid_conv2d_params* p, hipStream_t st) {
     a.nx = aid_cdiv(a.nrows, ROWS) * a.tiles_t;
     a.ny = p->Cout_pad / M_BLK;
     a.per_xcd = (a.nx * a.ny + 7) / 8;
-    hipLaunchKernelGGL((conv11_dma_kernel<MT, WGM, WGN, RMAX, KC, MINW>), dim3((unsigned)(8 * a.per_xcd)), dim3(64 * WGM * WGN), 0, st, a);
+    a.cps = aid_cdiv(a.nchunks, splits);
+    a.cps += a.cps & 1;                                  // (even: the two LDS buffers alternate from the first chunk of every range)
+    a.splits = aid_cdiv(a.nchunks, a.cps);
+    a.ws = (float*)p->ws;
+    hipLaunchKernelGGL((conv11_dma_kernel<MT, WGM, WGN, RMAX, KC, MINW>), dim3((unsigned)(8 * a.per_xcd), (unsigned)a.splits), dim3(64 * WGM * WGN), 0, st, a);
     AID_CHECK_LAUNCH();
-    aid_note_kernel("conv11_dma_kernel");
+    aid_note_kernel(a.splits > 1 ? "conv11_dma_kernel+splitk" : "conv11_dma_kernel");
+    if (a.splits > 1) return aid_conv_splitk_reduce(p, (const float*)p->ws, a.splits, st);
     return AID_OK;
 }
 
@@ -281,7 +306,9 @@ extern "C" int aid_conv2d_x2_supported(int Cin, int Cin1, int Cout, int F, int T
 // returns 1 if this kernel took the launch, 0 if not eligible, <0 on error
 int aid_conv1x1_dma_try(const aid_conv2d_params* p, hipStream_t st) {
     if (!(p->KH == 1 && p->KW == 1) || p->act != 0) return 0;
-    if (p->F == 1 || p->Cin < 32 || (p->Cin % 16) || p->Cout < 32) return 0;      // (K is walked in whole 16-channel chunks: no ragged tail)
+    if (p->Cin < 32 || (p->Cin % 16) || p->Cout < 32) return 0;      // (K is walked in whole 16-channel chunks: no ragged tail)
+    const bool gemm = p->F == 1;                                     // the qk projections: a plain GEMM with N = B*T columns
+    if (gemm && (p->epi != 0 || p->in_scale || p->x2.p || (p->Cout_pad % 128) || p->Cin < 256)) return 0;
     if ((p->T % 4) || aid_pow2ceil(p->T) < 8) return 0;
     auto al = [](const aid_view& v, int q) { return (v.sB % q) == 0 && (v.sC % q) == 0 && (v.sF % q) == 0 && (((uintptr_t)v.p) & (4 * q - 1)) == 0; };
     if (!al(p->x, 4) || !al(p->y, 2) || (p->res.p && !al(p->res, 2)) || (p->aux.p && !al(p->aux, 2))) return 0;
@@ -293,6 +320,18 @@ int aid_conv1x1_dma_try(const aid_conv2d_params* p, hipStream_t st) {
     if (ROWS > 16) return 0;
     if (p->in_scale && (p->F % ROWS)) return 0;
     int rc;
+    if (gemm) {
+        // grid-starved: split K over up to 8 workgroups per tile when the scratch is there (deterministic fixed-order reduction)
+        const int64_t tiles = (int64_t)aid_cdiv(p->B, ROWS) * aid_cdiv(p->T, TT) * (p->Cout_pad / 128);
+        int S = (int)((640 + tiles - 1) / tiles);
+        if (S > 8) S = 8;
+        if (S > p->Cin / 64) S = p->Cin / 64;
+        auto al4 = [](const aid_view& v) { return (v.sB % 4) == 0 && (v.sC % 4) == 0 && (v.sF % 4) == 0 && (((uintptr_t)v.p) & 15) == 0; };
+        if (S > 1 && !(p->ws && (int64_t)S * p->B * p->Cout * p->F * p->T * 4 <= p->ws_bytes && al4(p->y) && (!p->res.p || al4(p->res)))) S = 1;
+        rc = launch_c11<2, 2, 4, 16, 16, 4>(p, st, S);
+        if (rc == 1000) return 0;
+        return rc == AID_OK ? 1 : rc;
+    }
     if (p->Cout_pad % 128 == 0)      rc = launch_c11<2, 2, 4, 16, 16, 4>(p, st);      // 128 x 256, 8 waves, 2 workgroups / CU
     else if (p->Cout_pad % 64 == 0)  rc = launch_c11<1, 2, 4, 16, 16, 4>(p, st);      //  64 x 256
     else if (p->Cout_pad % 96 == 0)  rc = launch_c11<3, 1, 4, 16, 16, 2>(p, st);      //  96 x 256, 4 waves

@@ -89,6 +89,10 @@ CONV_CASES = [
     (3, 40, 40, 9, 12, 5, 3, 2, True, True),         # ragged: T not a power of two, odd row count
     # few-channel layers -> VALU streaming kernels (aid_conv_small.hip)
     (2, 96, 2, 12, 64, 5, 3, 4, False, True),        # pyramid-projection input gradient C -> 2
+    (2, 96, 2, 12, 64, 5, 3, 1, False, True),        # ... at dilation 1: sliding-row kernel (4 rows per lane, channels split over the waves)
+    (1, 256, 2, 8, 32, 5, 3, 1, False, True),        # deep level: 8 lanes per row, 8 row groups per wave
+    (3, 64, 2, 20, 512, 5, 3, 1, False, False),      # two t-tiles per row, no residual
+    (2, 40, 2, 4, 8, 5, 3, 1, False, True),          # F = R: every input row of the halo is out of range
     (2, 2, 96, 12, 64, 5, 3, 8, False, True),        # pyramid projection 2 -> C, dilation > F/2
     (2, 64, 2, 10, 32, 1, 1, 1, True, True),         # out-block projection with prologue scale
     (2, 96, 8, 6, 16, 1, 1, 1, True, False),         # attention proj_in

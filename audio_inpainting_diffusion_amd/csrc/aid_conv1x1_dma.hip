@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+int aid_conv_splitk_reduce(const aid_conv2d_params* p, const float* ws, int splits, hipStream_t st);      // aid_conv.hip
 
 struct C11Dev {
     aid_conv2d_params p;
@@ -253,8 +254,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv11_dma_kernel(const 
     }
 }
 
-int aid_conv_splitk_reduce(const aid_conv2d_params* p, const float* ws, int splits, hipStream_t st);      // aid_conv.hip
-
 template <int MT, int WGM, int WGN, int RMAX, int KC, int MINW>
 static int launch_c11(const aid_conv2d_params* p, hipStream_t st, int splits = 1) {
     constexpr int M_BLK = 32 * MT * WGM;
@@ -292,6 +291,65 @@ static int launch_c11(const aid_conv2d_params* p, hipStream_t st, int splits = 1
     return AID_OK;
 }
 
+// ---- skinny GEMM: the qk projections when N = B*T <= 128 columns (the reference's testers run B = 1) -------------------------------------
+// y[M, N] = W^T x with K, M in the thousands and N of 32 ... 128: the weights (52 ... 103 MB per layer) are read once and nothing else matters.
+// The tiled kernels stage one 8-KB weight chunk per workgroup at a time: 0.7 TB/s (latency-bound: Little's law wants ~48 KB in flight per CU).
+// Here a wave owns 32 output rows x all N columns of one K range and loads BOTH operands straight from global memory into the MFMA fragments
+// (weights: 2 x 128 contiguous bytes per load, x: L2-resident), U = 8 k-pairs unrolled = 16 independent loads in flight per wave, no LDS, no
+// barriers; K is split over blockIdx.y and the partial sums go through the same fixed-order reduction as the other split-K paths.
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const aid_conv2d_params p, float* __restrict__ ws, int kps) {
+    constexpr int U = 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = (blockIdx.x * 4 + wave) * 32;
+    if (m0 >= p.Cout_pad) return;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int k0 = blockIdx.y * kps, k1 = min(p.Cin, k0 + kps);
+    const float* wp = p.wp + m0 + l31;
+    const float* xq[NT];
+    bool ok[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = j * 32 + l31;
+        const int b = n / p.T, t = n - b * p.T;
+        ok[j] = b < p.B;
+        xq[j] = p.x.p + (ok[j] ? ((int64_t)b * p.x.sB + t) : 0);
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int kk = k0; kk < k1; kk += 2 * U) {
+        float a[U], bv[U][NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = kk + 2 * u + half;
+            const bool kin = k < k1;
+            a[u] = kin ? wp[(int64_t)k * p.Cout_pad] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[u][j] = (kin && ok[j]) ? xq[j][(int64_t)k * p.x.sC] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u][j], acc[j], 0, 0, 0);
+    }
+    const int64_t ft = p.T;                                         // F = 1
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = j * 32 + l31;
+        const int b = n / p.T, t = n - b * p.T;
+        if (b >= p.B) continue;
+        float* wsb = ws + (((int64_t)blockIdx.y * p.B + b) * p.Cout) * ft + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + 4 * half + (r & 3) + 8 * (r >> 2);
+            if (m < p.Cout) wsb[(int64_t)m * ft] = acc[j][r];
+        }
+    }
+}
+
 // shapes on which the two-tensor K axis (x2 / Cin1) is available: what aid_conv1x1_dma_try accepts below, minus the pointer alignment checks
 extern "C" int aid_conv2d_x2_supported(int Cin, int Cin1, int Cout, int F, int T) {
     int cip, cop;
@@ -320,6 +378,30 @@ int aid_conv1x1_dma_try(const aid_conv2d_params* p, hipStream_t st) {
     if (ROWS > 16) return 0;
     if (p->in_scale && (p->F % ROWS)) return 0;
     int rc;
+    if (gemm && p->B * p->T <= 128 && (p->T % 4) == 0 && (p->Cin % 2) == 0 && p->ws) {
+        // skinny GEMM: a wave per 32 rows and K range; enough K ranges for ~2000 waves, as the scratch allows (16 at most)
+        const int nt = aid_cdiv(p->B * p->T, 32);
+        const int rowtiles = p->Cout_pad / 32;
+        int S = aid_cdiv(2048, rowtiles);
+        if (S > 16) S = 16;
+        while (S > 1 && (int64_t)S * p->B * p->Cout * p->T * 4 > p->ws_bytes) --S;
+        int kps = aid_cdiv(p->Cin, S); kps += kps & 1;
+        S = aid_cdiv(p->Cin, kps);
+        auto al4 = [](const aid_view& v) { return (v.sB % 4) == 0 && (v.sC % 4) == 0 && (v.sF % 4) == 0 && (((uintptr_t)v.p) & 15) == 0; };
+        if ((int64_t)S * p->B * p->Cout * p->T * 4 <= p->ws_bytes && al4(p->y) && (!p->res.p || al4(p->res))) {
+            const dim3 grid((unsigned)aid_cdiv(rowtiles, 4), (unsigned)S);
+            switch (nt) {
+                case 1: hipLaunchKernelGGL(gemm_skinny_kernel<1>, grid, dim3(256), 0, st, *p, (float*)p->ws, kps); break;
+                case 2: hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, dim3(256), 0, st, *p, (float*)p->ws, kps); break;
+                case 3: hipLaunchKernelGGL(gemm_skinny_kernel<3>, grid, dim3(256), 0, st, *p, (float*)p->ws, kps); break;
+                default: hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, dim3(256), 0, st, *p, (float*)p->ws, kps); break;
+            }
+            AID_CHECK_LAUNCH();
+            aid_note_kernel("gemm_skinny_kernel+splitk");
+            rc = aid_conv_splitk_reduce(p, (const float*)p->ws, S, st);
+            return rc == AID_OK ? 1 : rc;
+        }
+    }
     if (gemm) {
         // grid-starved: split K over up to 8 workgroups per tile when the scratch is there (deterministic fixed-order reduction)
         const int64_t tiles = (int64_t)aid_cdiv(p->B, ROWS) * aid_cdiv(p->T, TT) * (p->Cout_pad / 128);

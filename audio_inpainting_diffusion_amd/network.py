@@ -379,7 +379,7 @@ class _Builder:
             p.x2, p.Cin1 = _lib.view4(x2), x.shape[1]
         ws = None
         if F == 1 and kh == 1 and epi == 0:              # qk projections: few columns, long K -> split-K scratch (aid_kernels.h)
-            ws = self._scratch(("ws", 8 * B * cout * T))
+            ws = self._scratch(("ws", 16 * B * cout * T))
             p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
         assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] == 30 and wpw.shape[1:] == wp.shape[1:]))
         # algorithmic HBM bytes: x once, residual / aux once, y once, weights once

@@ -86,6 +86,10 @@ CONV_CASES = [
     (2, 96, 192, 1, 8, 1, 1, 1, False, False),       # qk GEMM, F = 1
     (1, 320, 640, 1, 128, 1, 1, 1, False, False),    # qk GEMM, larger K (split-K through the scratch buffer)
     (2, 1024, 512, 1, 64, 1, 1, 1, False, True),     # qk-sized GEMM with gate + residual epilogue after the split-K reduction
+    (1, 2560, 5120, 1, 128, 1, 1, 1, False, False),  # the reference's batch: N = 128 columns -> skinny GEMM (4 column tiles per wave, K split 13 ways)
+    (1, 512, 1024, 1, 32, 1, 1, 1, False, True),     # N = 32: one column tile per wave, epilogue through the reduction
+    (3, 256, 640, 1, 36, 1, 1, 1, False, True),      # N = 108: ragged last column tile (columns >= B*T masked), T not a power of two
+    (4, 768, 384, 1, 64, 1, 1, 1, False, False),     # N = 256 > 128: direct-to-LDS tiles + split-K
     (3, 40, 40, 9, 12, 5, 3, 2, True, True),         # ragged: T not a power of two, odd row count
     # few-channel layers -> VALU streaming kernels (aid_conv_small.hip)
     (2, 96, 2, 12, 64, 5, 3, 4, False, True),        # pyramid-projection input gradient C -> 2
@@ -152,7 +156,7 @@ def test_conv2d(L, case, wino):
     p.KH, p.KW, p.dilF, p.act, p.epi = KH, KW, dil, act, 0
     p.alpha, p.res_scale = alpha, res_scale
     if Fd == 1:                                          # scratch for the split-K path (NULL -> single pass, also valid)
-        ws = torch.empty(8 * B * Cout * T, device=DEV)
+        ws = torch.empty(16 * B * Cout * T, device=DEV)
         p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
     wpw = None
     if wino:
@@ -465,7 +469,7 @@ def test_conv2d_dispatch_fuzz(L):
             p.wp_wino, p.wino_taps = wpw.data_ptr(), 30
         ws = None
         if Fd == 1 and not k53:
-            ws = torch.empty(8 * B * Cout * T, device=DEV)
+            ws = torch.empty(16 * B * Cout * T, device=DEV)
             p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
         P = 0
         dws = None

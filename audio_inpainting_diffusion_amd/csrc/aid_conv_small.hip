@@ -11,7 +11,7 @@
 #include "aid_common.h"
 #include <stdlib.h>
 
-struct CsDev { aid_conv2d_params p; int lpr_log2, nrows, tiles; };
+struct CsDev { aid_conv2d_params p; int lpr_log2, nrows, tiles, co_per_y; };   // co_per_y: output channels walked by one blockIdx.y slice (small-Cin kernel)
 
 template <int KH, int KW>
 __device__ __forceinline__ void load_patch(const aid_conv2d_params& p, const float* xr, int f, int t4, float (&v)[KH][4 + (KW > 1 ? 2 : 0)]) {
@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const CsDev a) {
     }
     const int64_t ybase = (int64_t)b * p.y.sB + (int64_t)f * p.y.sF + t4;
     const int64_t rbase = p.res.p ? ((int64_t)b * p.res.sB + (int64_t)f * p.res.sF + t4) : 0;
-    for (int co = 0; co < p.Cout; ++co) {
+    const int co_lo = blockIdx.y * a.co_per_y, co_hi = min(p.Cout, co_lo + a.co_per_y);
+    for (int co = co_lo; co < co_hi; ++co) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci)
@@ -250,7 +251,7 @@ static int launch_cout2_rows(const aid_conv2d_params* p, hipStream_t st) {
 }
 
 template <typename K>
-static int launch_cs(K kern, const aid_conv2d_params* p, hipStream_t st) {
+static int launch_cs(K kern, const aid_conv2d_params* p, hipStream_t st, bool split_cout = false) {
     CsDev a;
     a.p = *p;
     int lpr = aid_pow2ceil(p->T / 4);
@@ -259,7 +260,14 @@ static int launch_cs(K kern, const aid_conv2d_params* p, hipStream_t st) {
     a.nrows = p->B * p->F;
     a.tiles = aid_cdiv(p->T / 4, lpr);
     const int rpb = 256 / lpr;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(aid_cdiv(a.nrows, rpb) * a.tiles)), dim3(256), 0, st, a);
+    const int gx = aid_cdiv(a.nrows, rpb) * a.tiles;
+    // small-Cin kernel at small batches: a handful of workgroups would each walk all output channels (17 us for 4 MB at B = 1) -- slice Cout over
+    // blockIdx.y until ~512 workgroups exist (every slice reloads the few-channel input patch: negligible)
+    int ny = 1;
+    if (split_cout && gx < 512) { ny = aid_cdiv(512, gx); if (ny > p->Cout / 8) ny = p->Cout / 8; if (ny < 1) ny = 1; }
+    a.co_per_y = aid_cdiv(p->Cout, ny);
+    ny = aid_cdiv(p->Cout, a.co_per_y);
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ny), dim3(256), 0, st, a);
     AID_CHECK_LAUNCH();
     aid_note_kernel("conv_small_kernel");
     return AID_OK;
@@ -281,7 +289,7 @@ int aid_conv_small_try(const aid_conv2d_params* p, hipStream_t st) {
     }
     // one thread walks the whole "other" channel dimension: ahead of the MFMA kernels on the wide, shallow levels (C <= 96, many
     // positions: 1.3-1.8x), behind them where C >= 128 and a level has too few positions to hide the serial walk
-    if (p->Cin > 96 || p->Cout > 96) return 0;
+    if (p->Cin > 96 || (p->Cout > 96 && p->Cin > 8)) return 0;      // (few input channels: any Cout -- the walk over Cout is sliced over blockIdx.y)
     const bool k11 = p->KH == 1 && p->KW == 1, k53 = p->KH == 5 && p->KW == 3;
     if (!k11 && !k53) return 0;
     auto al4 = [](const aid_view& v) { return (v.sB % 4) == 0 && (v.sC % 4) == 0 && (v.sF % 4) == 0 && (((uintptr_t)v.p) & 15) == 0; };
@@ -292,8 +300,8 @@ int aid_conv_small_try(const aid_conv2d_params* p, hipStream_t st) {
         else if (p->Cout <= 2) rc = launch_cs(conv_small_cout_kernel<5, 3, 2>, p, st);
         else return 0;
     } else if (p->Cin <= 8 && p->Cout >= 8) {
-        if (k11)            rc = p->Cin <= 2 ? launch_cs(conv_small_cin_kernel<1, 1, 2>, p, st) : launch_cs(conv_small_cin_kernel<1, 1, 8>, p, st);
-        else if (p->Cin <= 2) rc = launch_cs(conv_small_cin_kernel<5, 3, 2>, p, st);
+        if (k11)            rc = p->Cin <= 2 ? launch_cs(conv_small_cin_kernel<1, 1, 2>, p, st, true) : launch_cs(conv_small_cin_kernel<1, 1, 8>, p, st, true);
+        else if (p->Cin <= 2) rc = launch_cs(conv_small_cin_kernel<5, 3, 2>, p, st, true);
         else return 0;
     } else return 0;
     return rc == AID_OK ? 1 : rc;

@@ -940,6 +940,10 @@ class Unet_CQT_oct_with_attention(nn.Module):
                     bd.resample(Xo[:, :, bpo:, :], Xout, up=1)
         st["octs_out"] = octs_out
         st["lanes"] = bd.plan.lanes = self._plan_lanes(B) if lanes else 1
+        if st["lanes"] > 1:                              # ONE side stream for every two-lane plan of this network (they never run concurrently)
+            if getattr(self, "_lane_stream", None) is None:
+                self._lane_stream = torch.cuda.Stream(device=dev)
+            bd.plan.side_stream = self._lane_stream
         st["plan_body"] = bd.plan
         st["nbytes"] = bd.nbytes
         st["flops"] = bd.plan.flops
@@ -984,7 +988,9 @@ class Unet_CQT_oct_with_attention(nn.Module):
         n = self._n_split(B)
         bounds = [(i * B) // n for i in range(n + 1)]
         if getattr(self, "_side_streams", None) is None or len(self._side_streams) < n:
-            self._side_streams = [torch.cuda.Stream() for _ in range(n)]
+            import os
+            pr = [int(v) for v in os.environ.get("AID_STREAM_PRIO", "").split(",") if v.strip()]     # EXPERIMENT (to be removed)
+            self._side_streams = [torch.cuda.Stream(priority=(pr[i] if i < len(pr) else 0)) for i in range(n)]
         return n, bounds, self._side_streams[:n]
 
     def states_of(self, B: int):
@@ -1162,6 +1168,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
             bd = st["builder"]
             st["plan_bwd"] = bd.finish_backward()
             st["plan_bwd"].lanes = st["lanes"]
+            st["plan_bwd"].side_stream = st["plan_body"].side_stream
             st["gin"] = [bd.G(t) for t in st["octs_in"]]
             st["gout"] = [bd.G(t) for t in st["octs_out"]]
             st["gzero"] = [g for k, g in bd.gmap.items() if bd.gstate.get(k) != "full"]

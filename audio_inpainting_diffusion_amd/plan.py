@@ -81,7 +81,7 @@ class Plan:
         self.timing = None         # set to a list to bracket every conv launch with HIP events (bench.py roofline)
         self.trace = None          # set to a list to bracket EVERY launch with HIP events (tools/plan_trace.py)
         self._sched = None
-        self._streams = None
+        self.side_stream = None    # stream of lane 1 (the owner may share one between plans that never run at the same time)
 
     # ---- construction ------------------------------------------------------------------------------------------------------
     def add(self, name, params, *tensors, flops=0, nbytes=0, writes: Sequence[torch.Tensor] = ()):
@@ -215,9 +215,9 @@ class Plan:
                     self._fail(op, rc)
             return
         waits, record, _ = self.schedule()
-        if self._streams is None or self._streams[0].device != cur.device:
-            self._streams = [torch.cuda.Stream(device=cur.device)]
-        side = self._streams[0]
+        if self.side_stream is None or self.side_stream.device != cur.device:
+            self.side_stream = torch.cuda.Stream(device=cur.device)
+        side = self.side_stream
         side.wait_stream(cur)
         streams = (cur, side)
         handles = (cur.cuda_stream, side.cuda_stream)

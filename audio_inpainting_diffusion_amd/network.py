@@ -988,9 +988,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
         n = self._n_split(B)
         bounds = [(i * B) // n for i in range(n + 1)]
         if getattr(self, "_side_streams", None) is None or len(self._side_streams) < n:
-            import os
-            pr = [int(v) for v in os.environ.get("AID_STREAM_PRIO", "").split(",") if v.strip()]     # EXPERIMENT (to be removed)
-            self._side_streams = [torch.cuda.Stream(priority=(pr[i] if i < len(pr) else 0)) for i in range(n)]
+            # (equal priorities: raising one or two of the three sub-batch streams measured 43.7 -> 41.6 ... 42.7 evaluations/s)
+            self._side_streams = [torch.cuda.Stream() for _ in range(n)]
         return n, bounds, self._side_streams[:n]
 
     def states_of(self, B: int):

@@ -508,6 +508,12 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
         AID_REQUIRE(!p->dot_ws && p->epi == 0 && p->x_wino, "aid_conv2d: stat_ws is an option of the forward epilogue on Winograd-domain input");
         AID_REQUIRE(p->stat_n > 0 && p->stat_n == aid_conv2d_stat_partials(p->B, p->Cin, p->Cout, p->F, p->T, p->dilF, p->x_wino), "aid_conv2d: stat_n != aid_conv2d_stat_partials()");
     }
+    if (p->dot_ws && p->KH == 1 && p->KW == 1) {                     // <y, aux> partials from the direct-to-LDS 1x1 kernel's dGELU epilogue
+        AID_REQUIRE(p->epi == 1 && !p->res.p, "aid_conv2d: dot_ws on a 1x1 layer is an option of the dGELU epilogue without residual");
+        const int r = aid_conv1x1_dma_try(p, st);
+        if (r == 0) aid_set_error("aid_conv2d: dot_ws given but the 1x1 layer is not eligible (aid_conv2d_dot_partials_1x1)");
+        return r == 1 ? AID_OK : (r < 0 ? r : AID_E_BADARG);
+    }
     if (p->dot_ws) {
         AID_REQUIRE(p->KH == 5 && p->KW == 3 && p->wp_wino && p->wino_taps == 30 && p->epi == 1 && !p->res.p,
                     "aid_conv2d: dot_ws is an option of the F(4,3) dGELU epilogue");

@@ -202,8 +202,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv11_dma_kernel(const 
     const int b = rowinfo[2 * rr];
     const int f = rowinfo[2 * rr + 1];
     const int t = t0 + tt;
-    if (b < 0 || t >= p.T) return;                                   // T % 2 == 0: both samples in range together
-    if (a.splits > 1) {                                              // split-K: raw partial sums (float2 per output channel)
+    const bool live = !(b < 0 || t >= p.T);                          // T % 2 == 0: both samples in range together
+    if (!live && !p.dot_ws) return;
+    if (live && a.splits > 1) {                                      // split-K: raw partial sums (float2 per output channel)
         const int64_t ft = (int64_t)p.F * p.T;
         float* wsb = a.ws + (((int64_t)blockIdx.y * p.B + b) * p.Cout) * ft + (int64_t)f * p.T + t;
 #pragma unroll
@@ -215,13 +216,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv11_dma_kernel(const 
                 if (m < p.Cout) *reinterpret_cast<float2*>(wsb + (int64_t)m * ft) = make_float2(acc[i][0][r], acc[i][1][r]);
             }
         }
-        return;
     }
+    if (a.splits > 1) return;
     const int64_t ybase = (int64_t)b * p.y.sB + (int64_t)f * p.y.sF + t;
     const int64_t rbase = p.res.p ? ((int64_t)b * p.res.sB + (int64_t)f * p.res.sF + t) : 0;
     const int64_t abase = p.aux.p ? ((int64_t)b * p.aux.sB + (int64_t)f * p.aux.sF + t) : 0;
+    float dsum[MT][4];                                               // <y, aux> per block of 4 rows (dot_ws)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dsum[i][q] = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
+        if (!live) break;
         const int mbase = m0 + (wm * MT + i) * 32 + 4 * half;
 #pragma unroll
         for (int r0 = 0; r0 < 16; r0 += 4) {             // gather 4 rows, then compute + store (res may alias y)
@@ -248,14 +255,50 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv11_dma_kernel(const 
                 if (p.epi == 1) { y0 *= aid_dgelu(uv[q].x * as[q]); y1 *= aid_dgelu(uv[q].y * as[q]); }
                 y0 += p.res_scale * rv[q].x;
                 y1 += p.res_scale * rv[q].y;
-                *reinterpret_cast<float2*>(p.y.p + ybase + (int64_t)m * p.y.sC) = make_float2(p.alpha * y0, p.alpha * y1);
+                y0 *= p.alpha; y1 *= p.alpha;
+                *reinterpret_cast<float2*>(p.y.p + ybase + (int64_t)m * p.y.sC) = make_float2(y0, y1);
+                if (p.dot_ws) dsum[i][r0 >> 2] += y0 * uv[q].x + y1 * uv[q].y;
             }
+        }
+    }
+    if (p.dot_ws) {                                                  // per (sample, channel group): one partial per position tile (as conv53_wino4r_kernel)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = live ? dsum[i][q] : 0.f;
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 32);
+                dsum[i][q] = v;
+            }
+        float* red = sbuf0;                                          // (every wave is past the last chunk's barrier)
+        if ((lane & 31) == 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[((wave * 2 + half) * MT + i) * 4 + q] = dsum[i][q];
+        }
+        __syncthreads();
+        const int cpg = p.Cout >> 3;                                 // channels per group (8 groups); M_BLK % cpg == 0 and cpg % 4 == 0 (host-checked)
+        const int grp = m0 / cpg + tid;
+        if (tid < M_BLK / cpg && grp < 8) {
+            float sacc = 0.f;
+            for (int w = 0; w < NW; ++w)                             // fixed order: deterministic
+                for (int h = 0; h < 2; ++h)
+                    for (int i = 0; i < MT; ++i)
+                        for (int q = 0; q < 4; ++q) {
+                            const int mrow = m0 + ((w / WGN) * MT + i) * 32 + 4 * h + 8 * q;
+                            if (mrow < p.Cout && mrow / cpg == grp) sacc += red[((w * 2 + h) * MT + i) * 4 + q];
+                        }
+            const int bt = rowinfo[0];
+            const int ptile = ((row0 - bt * p.F) >> a.rows_log2) * a.tiles_t + tile_t;
+            p.dot_ws[((int64_t)bt * 8 + grp) * p.dot_n + ptile] = (double)sacc;
         }
     }
 }
 
 template <int MT, int WGM, int WGN, int RMAX, int KC, int MINW>
-static int launch_c11(const aid_conv2d_params* p, hipStream_t st, int splits = 1) {
+static int launch_c11(const aid_conv2d_params* p, hipStream_t st, int splits = 1, int kps = 0) {      // splits > 1: the partition of gemm_k_partition
     constexpr int M_BLK = 32 * MT * WGM;
     constexpr int N_BLK = 64 * WGN;
     static const float* zero = nullptr;
@@ -280,8 +323,7 @@ static int launch_c11(const aid_conv2d_params* p, hipStream_t st, int splits = 1
     a.nx = aid_cdiv(a.nrows, ROWS) * a.tiles_t;
     a.ny = p->Cout_pad / M_BLK;
     a.per_xcd = (a.nx * a.ny + 7) / 8;
-    a.cps = aid_cdiv(a.nchunks, splits);
-    a.cps += a.cps & 1;                                  // (even: the two LDS buffers alternate from the first chunk of every range)
+    a.cps = splits > 1 ? kps / KC : a.nchunks;
     a.splits = aid_cdiv(a.nchunks, a.cps);
     a.ws = (float*)p->ws;
     hipLaunchKernelGGL((conv11_dma_kernel<MT, WGM, WGN, RMAX, KC, MINW>), dim3((unsigned)(8 * a.per_xcd), (unsigned)a.splits), dim3(64 * WGM * WGN), 0, st, a);
@@ -350,6 +392,32 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const aid_conv2d_param
     }
 }
 
+// partials per (sample, group) of the <y, aux> option on this kernel (epi = 1 on a 1x1 layer): position tiles per sample; 0 = not available
+extern "C" int aid_conv2d_dot_partials_1x1(int B, int Cin, int Cout, int F, int T) {
+    int cip, cop;
+    aid_conv2d_pack_dims(Cin, Cout, &cip, &cop);
+    if (F <= 1 || Cin < 32 || (Cin % 16) || Cout < 32 || (Cout % 8) || (T % 4) || aid_pow2ceil(T) < 8) return 0;
+    const int mblk = (cop % 128 == 0) ? 128 : ((cop % 64 == 0) ? 64 : ((cop % 96 == 0) ? 96 : 0));
+    const int cpg = Cout / 8;
+    if (!mblk || (cpg % 4) || (mblk % cpg)) return 0;
+    int TT = aid_pow2ceil(T); if (TT > 256) TT = 256;
+    const int ROWS = 256 / TT;
+    if (ROWS > 16 || (F % ROWS)) return 0;
+    return (F / ROWS) * aid_cdiv(T, TT);
+}
+
+// K partition of the qk GEMMs: a function of K ALONE -- the skinny kernel (N <= 128) and the tiled kernel (any N) then add the same k-pairs in
+// the same order into the same number of partial planes, so a segment's result does not depend on the batch it is evaluated in.
+static void gemm_k_partition(int Cin, int* S, int* kps) {
+    int s = 8;
+    if (s > Cin / 64) s = Cin / 64;
+    if (s < 1) s = 1;
+    int cps = aid_cdiv(aid_cdiv(Cin, 16), s);          // 16-channel chunks per range, even (two LDS buffers alternate from the first chunk)
+    cps += cps & 1;
+    *kps = cps * 16;
+    *S = aid_cdiv(Cin, *kps);
+}
+
 // shapes on which the two-tensor K axis (x2 / Cin1) is available: what aid_conv1x1_dma_try accepts below, minus the pointer alignment checks
 extern "C" int aid_conv2d_x2_supported(int Cin, int Cin1, int Cout, int F, int T) {
     int cip, cop;
@@ -377,16 +445,14 @@ int aid_conv1x1_dma_try(const aid_conv2d_params* p, hipStream_t st) {
     const int ROWS = 256 / TT;
     if (ROWS > 16) return 0;
     if (p->in_scale && (p->F % ROWS)) return 0;
+    if (p->dot_ws && (p->epi != 1 || p->dot_n != aid_conv2d_dot_partials_1x1(p->B, p->Cin, p->Cout, p->F, p->T) || p->dot_n <= 0 || p->x2.p)) return 0;
     int rc;
     if (gemm && p->B * p->T <= 128 && (p->T % 4) == 0 && (p->Cin % 2) == 0 && p->ws) {
         // skinny GEMM: a wave per 32 rows and K range; enough K ranges for ~2000 waves, as the scratch allows (16 at most)
         const int nt = aid_cdiv(p->B * p->T, 32);
         const int rowtiles = p->Cout_pad / 32;
-        int S = aid_cdiv(2048, rowtiles);
-        if (S > 16) S = 16;
-        while (S > 1 && (int64_t)S * p->B * p->Cout * p->T * 4 > p->ws_bytes) --S;
-        int kps = aid_cdiv(p->Cin, S); kps += kps & 1;
-        S = aid_cdiv(p->Cin, kps);
+        int S, kps;
+        gemm_k_partition(p->Cin, &S, &kps);
         auto al4 = [](const aid_view& v) { return (v.sB % 4) == 0 && (v.sC % 4) == 0 && (v.sF % 4) == 0 && (((uintptr_t)v.p) & 15) == 0; };
         if ((int64_t)S * p->B * p->Cout * p->T * 4 <= p->ws_bytes && al4(p->y) && (!p->res.p || al4(p->res))) {
             const dim3 grid((unsigned)aid_cdiv(rowtiles, 4), (unsigned)S);
@@ -403,14 +469,12 @@ int aid_conv1x1_dma_try(const aid_conv2d_params* p, hipStream_t st) {
         }
     }
     if (gemm) {
-        // grid-starved: split K over up to 8 workgroups per tile when the scratch is there (deterministic fixed-order reduction)
-        const int64_t tiles = (int64_t)aid_cdiv(p->B, ROWS) * aid_cdiv(p->T, TT) * (p->Cout_pad / 128);
-        int S = (int)((640 + tiles - 1) / tiles);
-        if (S > 8) S = 8;
-        if (S > p->Cin / 64) S = p->Cin / 64;
+        // grid-starved: split K over several workgroups per tile when the scratch is there (deterministic fixed-order reduction)
+        int S, kps;
+        gemm_k_partition(p->Cin, &S, &kps);
         auto al4 = [](const aid_view& v) { return (v.sB % 4) == 0 && (v.sC % 4) == 0 && (v.sF % 4) == 0 && (((uintptr_t)v.p) & 15) == 0; };
         if (S > 1 && !(p->ws && (int64_t)S * p->B * p->Cout * p->F * p->T * 4 <= p->ws_bytes && al4(p->y) && (!p->res.p || al4(p->res)))) S = 1;
-        rc = launch_c11<2, 2, 4, 16, 16, 4>(p, st, S);
+        rc = launch_c11<2, 2, 4, 16, 16, 4>(p, st, S, kps);
         if (rc == 1000) return 0;
         return rc == AID_OK ? 1 : rc;
     }

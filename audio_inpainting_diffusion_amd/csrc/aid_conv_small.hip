@@ -279,9 +279,10 @@ int aid_conv_small_try(const aid_conv2d_params* p, hipStream_t st) {
     {   // C -> 2, 5x3, dilation 1 (any C >= 8): sliding-row kernel
         auto al4 = [](const aid_view& v) { return (v.sB % 4) == 0 && (v.sC % 4) == 0 && (v.sF % 4) == 0 && (((uintptr_t)v.p) & 15) == 0; };
         int lpr = aid_pow2ceil(p->T / 4); if (lpr > 64) lpr = 64;
-        const int64_t wgs = (int64_t)aid_cdiv(p->B * (p->F / 4), 64 / lpr) * aid_cdiv(p->T / 4, lpr);
-        // (deep levels at small batches: a dozen workgroups walking 64 channels per wave lose to the MFMA kernel: 244 vs 150 us at B = 1, C = 256)
-        if (p->KH == 5 && p->KW == 3 && p->dilF == 1 && p->Cout <= 2 && p->Cin >= 8 && !p->in_scale && (p->F % 4) == 0 && !(p->Cin > 128 && wgs < 104) &&
+        const int64_t wgs1 = (int64_t)aid_cdiv(p->F / 4, 64 / lpr) * aid_cdiv(p->T / 4, lpr);      // workgroups PER SAMPLE: the choice must not depend on the
+        // batch (item b of a batch has to come out bit-identical however the batch is cut).  Deep levels: a dozen workgroups per sample walking 64
+        // channels per wave lose to the MFMA kernel (244 vs 150 us at B = 1, C = 256; level at B = 8)
+        if (p->KH == 5 && p->KW == 3 && p->dilF == 1 && p->Cout <= 2 && p->Cin >= 8 && !p->in_scale && (p->F % 4) == 0 && !(p->Cin > 128 && wgs1 < 16) &&
             al4(p->x) && al4(p->y) && (!p->res.p || al4(p->res))) {
             const int rc = launch_cout2_rows(p, st);
             return rc == AID_OK ? 1 : rc;

@@ -379,7 +379,7 @@ class _Builder:
             p.x2, p.Cin1 = _lib.view4(x2), x.shape[1]
         ws = None
         if F == 1 and kh == 1 and epi == 0:              # qk projections: few columns, long K -> split-K scratch (aid_kernels.h)
-            ws = self._scratch(("ws", 16 * B * cout * T))
+            ws = self._scratch(("ws", 8 * B * cout * T))
             p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
         assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] == 30 and wpw.shape[1:] == wp.shape[1:]))
         # algorithmic HBM bytes: x once, residual / aux once, y once, weights once
@@ -462,6 +462,8 @@ class _Builder:
                 nd = 0
                 if act and kh == 5 and gsc is None and wpwT is not None and wpwT.shape[0] == 30:
                     nd = int(_lib.lib().aid_conv2d_dot_partials(B, cout, cin, F, T, dil, int(gw)))
+                elif act and kh == 1 and kw == 1 and self.net.fuse_dot_1x1:        # 1x1 steps (init / out blocks): the direct-to-LDS kernel's epilogue
+                    nd = int(_lib.lib().aid_conv2d_dot_partials_1x1(B, cout, cin, F, T))
                 dws = self._dot_ws(nd) if nd else self.stats_ws
                 self._conv_raw(gin, gd, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, None, 1.0, alpha,
                                epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None, wpw=wpwT, x_wino=gw,
@@ -1047,6 +1049,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
     # input / output buffers, later calls copy the inputs in and replay.  Sub-batch streams (B >= 4) stay eager.
     # ---------------------------------------------------------------------------------------------------
     use_graphs = True
+    fuse_dot_1x1 = True        # reverse sweep: <gd, x> partials of the 1x1 steps from the dgrad conv's epilogue instead of an aid_group_dot pass
     merge_pair_dgrad = True    # reverse sweep: input gradients of a block's proj_in and res_conv as ONE 1x1 conv over a K axis in two tensors
     plan_lanes = True          # tag the init blocks / pyramid / out blocks as lane 1 of the launch plans (plan.py)
     lanes_max_batch = 3        # ... and run the two lanes on two streams for whole batches up to this size.  Larger batches fill the GPU and run as

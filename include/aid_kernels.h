@@ -112,7 +112,7 @@ typedef struct {
                                  B*T columns only, K of several thousand) split K over up to 8 workgroups per tile; partial sums
                                  go to ws[S][B][Cout][F][T] and a second kernel reduces them in a FIXED order (deterministic) and
                                  applies the epilogue.  NULL / too small: single-pass kernel. */
-    double* dot_ws; int dot_n;   /* optional (input-VJP, epi = 1 on the F(4,3) path only): the epilogue also reduces <y, aux> per
+    double* dot_ws; int dot_n;   /* optional (input-VJP, epi = 1 on the F(4,3) path or on a 1x1 layer, see aid_conv2d_dot_partials_1x1): the epilogue also reduces <y, aux> per
                                  (sample, channel group of Cout/8) over its tile and writes one partial per tile,
                                  dot_ws[(b*8 + g) * dot_n + tile_in_sample] -- the aid_group_dot pass over the dgrad output
                                  folded into the conv that produces it.  dot_n must equal aid_conv2d_dot_partials(...). */
@@ -126,6 +126,8 @@ typedef struct {
                                  input), as ONE launch on the stacked transposed weights instead of two read-modify-write passes over it. */
 } aid_conv2d_params;
 int aid_conv2d(const aid_conv2d_params* p, void* stream);
+/* partials per (sample, group) when dot_ws is asked of a 1x1 layer (epi = 1, no residual; direct-to-LDS kernel); 0: not available */
+int aid_conv2d_dot_partials_1x1(int B, int Cin, int Cout, int F, int T);
 /* 1 when aid_conv2d accepts the x2 / Cin1 option (K axis in two tensors) for this 1x1 shape */
 int aid_conv2d_x2_supported(int Cin, int Cin1, int Cout, int F, int T);
 /* non-zero when a 5x3 layer of this shape can take Winograd-domain input (x_wino = 1) */

@@ -86,7 +86,7 @@ CONV_CASES = [
     (2, 96, 192, 1, 8, 1, 1, 1, False, False),       # qk GEMM, F = 1
     (1, 320, 640, 1, 128, 1, 1, 1, False, False),    # qk GEMM, larger K (split-K through the scratch buffer)
     (2, 1024, 512, 1, 64, 1, 1, 1, False, True),     # qk-sized GEMM with gate + residual epilogue after the split-K reduction
-    (1, 2560, 5120, 1, 128, 1, 1, 1, False, False),  # the reference's batch: N = 128 columns -> skinny GEMM (4 column tiles per wave, K split 13 ways)
+    (1, 2560, 5120, 1, 128, 1, 1, 1, False, False),  # the reference's batch: N = 128 columns -> skinny GEMM (4 column tiles per wave, K split 8 ways)
     (1, 512, 1024, 1, 32, 1, 1, 1, False, True),     # N = 32: one column tile per wave, epilogue through the reduction
     (3, 256, 640, 1, 36, 1, 1, 1, False, True),      # N = 108: ragged last column tile (columns >= B*T masked), T not a power of two
     (4, 768, 384, 1, 64, 1, 1, 1, False, False),     # N = 256 > 128: direct-to-LDS tiles + split-K
@@ -156,7 +156,7 @@ def test_conv2d(L, case, wino):
     p.KH, p.KW, p.dilF, p.act, p.epi = KH, KW, dil, act, 0
     p.alpha, p.res_scale = alpha, res_scale
     if Fd == 1:                                          # scratch for the split-K path (NULL -> single pass, also valid)
-        ws = torch.empty(16 * B * Cout * T, device=DEV)
+        ws = torch.empty(8 * B * Cout * T, device=DEV)
         p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
     wpw = None
     if wino:
@@ -745,3 +745,29 @@ def test_conv1x1_with_the_k_axis_in_two_tensors(L, case):
     p.Cin1 = c1 + 1
     with pytest.raises(L.AidError):
         L.call("aid_conv2d", p)
+
+
+def test_qk_gemm_is_bit_identical_across_batch_sizes(L):
+    """The qk projections take the skinny GEMM when N = B*T <= 128 and direct-to-LDS tiles above; both split K by the same batch-independent
+    partition and add the same k-pairs in the same order, so a segment's result does not depend on the batch it is evaluated in."""
+    Cin, Cout, T = 2560, 5120, 64
+    w = _rand(Cout, Cin, 1, 1, seed=71, scale=1.0 / math.sqrt(Cin)).to(DEV)
+    wp = L.pack_conv_weight(w)
+    x8 = _rand(8, Cin, 1, T, seed=72).to(DEV)
+    outs = {}
+    for B in (1, 2, 8):
+        xb = x8[:B].contiguous()
+        y = torch.empty(B, Cout, 1, T, device=DEV)
+        ws = torch.empty(8 * B * Cout * T, device=DEV)
+        p = L.Conv2dParams()
+        p.x, p.y, p.res, p.aux = L.view4(xb), L.view4(y), L.view4(None), L.view4(None)
+        p.wp = wp.data_ptr()
+        p.B, p.Cin, p.Cout, p.F, p.T = B, Cin, Cout, 1, T
+        p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
+        p.KH, p.KW, p.dilF, p.act, p.epi = 1, 1, 1, 0, 0
+        p.alpha, p.res_scale = 1.0, 1.0
+        p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        L.call("aid_conv2d", p)
+        outs[B] = (y, L.lib().aid_last_kernel().decode())
+    assert outs[1][1].startswith("gemm_skinny") and outs[2][1].startswith("gemm_skinny") and outs[8][1].startswith("conv11_dma")
+    assert torch.equal(outs[1][0], outs[8][0][:1]) and torch.equal(outs[2][0], outs[8][0][:2])

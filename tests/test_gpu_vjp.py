@@ -243,6 +243,48 @@ def test_conv_epilogue_dot_partials(L, case):
     assert float((got - want).abs().max()) < 1e-5 * float((yc.abs() * aux.double().abs()).reshape(B, 8, -1).sum(-1).max())
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 16, 256, True), (1, 96, 96, 8, 128, False), (3, 128, 128, 64, 32, True), (2, 256, 256, 16, 64, True), (1, 64, 192, 4, 512, False)])
+def test_conv1x1_epilogue_dot_partials(L, case):
+    """The same <y, aux> partials from the direct-to-LDS 1x1 kernel (dgrad of the 1x1 ResnetBlock steps of the init / out blocks, with the gate
+    as per-(b,ci) prologue scale): y and the per-(sample, group) sums against fp64 torch."""
+    B, Cin, Cout, Fd, T, gate = case
+    P = L.lib().aid_conv2d_dot_partials_1x1(B, Cin, Cout, Fd, T)
+    assert P > 0
+    g = _rand(B, Cin, Fd, T, seed=50)
+    w = _rand(Cout, Cin, 1, 1, seed=51, scale=1.0 / math.sqrt(Cin))
+    aux = _rand(B, Cout, Fd, T, seed=52)
+    asc = 1.0 + 0.3 * _rand(B, Cout, seed=53)
+    isc = (1.0 + 0.5 * _rand(B, Cin, seed=54)) if gate else None
+    gd, wd, auxd, ascd = g.to(DEV), w.to(DEV), aux.to(DEV), asc.to(DEV)
+    iscd = None if isc is None else isc.to(DEV)
+    wp = L.pack_conv_weight(wd)
+    y = torch.empty(B, Cout, Fd, T, device=DEV)
+    ws = torch.full((B * 8 * (P + 1),), float("nan"), device=DEV, dtype=torch.float64)
+    p = L.Conv2dParams()
+    p.x, p.y, p.res, p.aux = L.view4(gd), L.view4(y), L.view4(None), L.view4(auxd)
+    p.wp = wp.data_ptr()
+    p.in_scale, p.in_scale_ld = L.ptr(iscd), (0 if iscd is None else iscd.stride(0))
+    p.out_scale, p.out_scale_ld = ascd.data_ptr(), ascd.stride(0)
+    p.aux_scale, p.aux_scale_ld = ascd.data_ptr(), ascd.stride(0)
+    p.B, p.Cin, p.Cout, p.F, p.T = B, Cin, Cout, Fd, T
+    p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
+    p.KH, p.KW, p.dilF, p.act, p.epi = 1, 1, 1, 0, 1
+    p.alpha, p.res_scale = 0.7, 1.0
+    p.dot_ws, p.dot_n = ws.data_ptr(), P
+    L.call("aid_conv2d", p)
+    assert L.lib().aid_last_kernel().decode() == "conv11_dma_kernel"
+    yc = y.cpu().double()
+    u = aux.double() * asc.double()[:, :, None, None]
+    dg = 0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
+    gin = g.double() if isc is None else g.double() * isc.double()[:, :, None, None]
+    ref = 0.7 * F.conv2d(gin, w.double()) * asc.double()[:, :, None, None] * dg
+    assert rel_l2(yc, ref) < 1e-5
+    got = ws[:B * 8 * P].cpu().reshape(B, 8, P).sum(-1)
+    want = (yc * aux.double()).reshape(B, 8, Cout // 8, Fd, T).sum((2, 3, 4))
+    assert torch.isfinite(got).all()
+    assert float((got - want).abs().max()) < 1e-5 * float((yc.abs() * aux.double().abs()).reshape(B, 8, -1).sum(-1).max())
+
+
 def test_sampler_rid_debug_buffers_vs_oracle():
     """Sampler(rid=True).predict_inpainting returns the reference's 8-tuple (edm_sampler_inpainting.py:185-191, :260)."""
     from audio_inpainting_diffusion_amd.edm import EDM

@@ -243,7 +243,7 @@ def test_conv_epilogue_dot_partials(L, case):
     assert float((got - want).abs().max()) < 1e-5 * float((yc.abs() * aux.double().abs()).reshape(B, 8, -1).sum(-1).max())
 
 
-@pytest.mark.parametrize("case", [(2, 64, 64, 16, 256, True), (1, 96, 96, 8, 128, False), (3, 128, 128, 64, 32, True), (2, 256, 256, 16, 64, True), (1, 64, 192, 4, 512, False)])
+@pytest.mark.parametrize("case", [(2, 64, 64, 16, 256, True), (1, 96, 96, 8, 128, False), (3, 128, 128, 64, 32, True), (2, 256, 256, 16, 64, True), (1, 64, 128, 4, 512, False)])
 def test_conv1x1_epilogue_dot_partials(L, case):
     """The same <y, aux> partials from the direct-to-LDS 1x1 kernel (dgrad of the 1x1 ResnetBlock steps of the init / out blocks, with the gate
     as per-(b,ci) prologue scale): y and the per-(sample, group) sums against fp64 torch."""

@@ -1297,6 +1297,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
                                  g["embedding.MLP.1.weight"].data_ptr(), g["embedding.MLP.1.bias"].data_ptr(),
                                  g["embedding.MLP.2.weight"].data_ptr(), g["embedding.MLP.2.bias"].data_ptr(), 0)
         pl.add("aid_embed_bwd", ep)
+        st["embed_bwd_params"] = ep
         st["plan_tail"] = pl
         return pl
 
@@ -1311,30 +1312,40 @@ class Unet_CQT_oct_with_attention(nn.Module):
         return self.CQTransform.irfft(self.CQTransform.synthesis_spectrum(st["octs_out"]))
 
     @torch.no_grad()
-    def _train_backward(self, g_out, need_input=False):
-        """g_out[B,L] = d loss / d network output of the LAST _train_forward -> fills the flat gradient buffer; returns
-        (d loss / d inputs or None, [gradient view per parameter, in self.parameters() order])."""
+    def _train_backward(self, g_out, need_input=False, accumulate=False):
+        """g_out[B,L] = d loss / d network output of the LAST _train_forward -> fills the flat gradient buffer (accumulate: adds to what an
+        earlier accumulation round left there, trainer.py:259-266); returns (d loss / d inputs or None, [gradient view per parameter, in
+        self.parameters() order])."""
         B = g_out.shape[0]
         st = self.train_state(B)
         tr = self.CQTransform
         tab = tr._tables(g_out.device)
         Gh = tr.rfft(g_out.detach().float().contiguous())
-        st["gflat"].zero_()
+        if not accumulate:
+            st["gflat"].zero_()
         st["dmod"].zero_()
         self._body_vjp(st, tr.spectrum_scale(Gh, tab["w_over_L"]))
-        self._tail_plan(st).run()
+        tail = self._tail_plan(st)
+        st["embed_bwd_params"].accumulate = 1 if accumulate else 0
+        tail.run()
         gp = st["builder"].pgrad
         for key, (off, n) in self._mod_layout.items():               # stacked [sum N, E] rows -> the Linears' own gradient tensors
-            gp[key + ".weight"].copy_(st["dWm"][off:off + n])
-            gp[key + ".bias"].copy_(st["dbm"][off:off + n])
+            if accumulate:
+                gp[key + ".weight"].add_(st["dWm"][off:off + n])
+                gp[key + ".bias"].add_(st["dbm"][off:off + n])
+            else:
+                gp[key + ".weight"].copy_(st["dWm"][off:off + n])
+                gp[key + ".bias"].copy_(st["dbm"][off:off + n])
         gin = tr.irfft(tr.analysis_adjoint(st["gin"])) if need_input else None
         return gin, [gp[k] if p.requires_grad else None for k, p in self.named_parameters()]
 
     @torch.no_grad()
-    def loss_and_grads(self, inputs: torch.Tensor, cnoise: torch.Tensor, target: torch.Tensor, hpf_error: bool = False):
-        """error = net(inputs, cnoise) - target  [-> apply_hpf_DC(error) if hpf_error, edm.py:180-187];  loss = mean(error**2)
-        (trainer.py:262-263).  Fills the flat gradient buffer of the training state (``train_state(B)['gflat']``, laid out like
-        the flat parameter buffer) with d loss / d parameter, all through HIP kernels.  Returns (loss [device scalar], error**2)."""
+    def loss_and_grads(self, inputs: torch.Tensor, cnoise: torch.Tensor, target: torch.Tensor, hpf_error: bool = False, fir=None,
+                       accumulate: bool = False):
+        """error = net(inputs, cnoise) - target  [-> apply_hpf_DC(error) if hpf_error, edm.py:180-187] [-> fir.apply(error): the A-weighting
+        filter, edm.py:189-190];  loss = mean(error**2) (trainer.py:262-263).  Fills (accumulate: adds to) the flat gradient buffer of the
+        training state (``train_state(B)['gflat']``, laid out like the flat parameter buffer) with d loss / d parameter, all through HIP
+        kernels.  Returns (loss [device scalar], error**2)."""
         B, L = inputs.shape
         tr = self.CQTransform
         est = self._train_forward(inputs, cnoise)
@@ -1343,6 +1354,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
         _lib.call("aid_axpby", _lib.AxpbyParams(est.data_ptr(), target.contiguous().float().data_ptr(), err.data_ptr(), None, minus1.data_ptr(), B, L))
         if hpf_error:
             err = tr._hpf(err)
+        if fir is not None:
+            err = fir.apply(err)
         rn = torch.empty(B, device=est.device, dtype=torch.float32)
         _lib.call("aid_row_norm", _lib.RowNormParams(err.data_ptr(), rn.data_ptr(), B, L))
         loss = (rn * rn).sum() / (B * L)
@@ -1350,9 +1363,11 @@ class Unet_CQT_oct_with_attention(nn.Module):
         g = torch.empty_like(err)
         coef = torch.full((B,), 2.0 / (B * L), device=est.device)
         _lib.call("aid_axpby", _lib.AxpbyParams(err.data_ptr(), None, g.data_ptr(), coef.data_ptr(), None, B, L))
+        if fir is not None:
+            g = fir.adjoint(g)
         if hpf_error:
             g = tr._hpf(g)
-        self._train_backward(g)
+        self._train_backward(g, accumulate=accumulate)
         return loss, err * err
 
     def flops_per_eval(self, B: int = 1) -> int:

@@ -38,16 +38,61 @@ def prepare_train_preconditioning(edm, x: torch.Tensor, sigma: torch.Tensor, noi
     return cin * (x + noise), target, cnoise
 
 
+def a_weighting_taps(fs: float, ntaps: int = 101):
+    """The A-weighting FIR of the reference's perceptual error filter (utils/training_utils.py:94-120, after auraloss): analog IEC/CD 1672 filter ->
+    bilinear transform -> 512-point magnitude response -> least-squares FIR fit; float32 taps."""
+    import numpy as np
+    import scipy.signal
+    if ntaps % 2 == 0:
+        raise ValueError(f"ntaps must be odd (ntaps={ntaps}).")
+    f1, f2, f3, f4, A1000 = 20.598997, 107.65265, 737.86223, 12194.217, 1.9997
+    nums = [(2 * np.pi * f4) ** 2 * (10 ** (A1000 / 20)), 0, 0, 0, 0]
+    dens = np.polymul([1, 4 * np.pi * f4, (2 * np.pi * f4) ** 2], [1, 4 * np.pi * f1, (2 * np.pi * f1) ** 2])
+    dens = np.polymul(np.polymul(dens, [1, 2 * np.pi * f3]), [1, 2 * np.pi * f2])
+    b, a = scipy.signal.bilinear(nums, dens, fs=fs)
+    w_iir, h_iir = scipy.signal.freqz(b, a, worN=512, fs=fs)
+    return scipy.signal.firls(ntaps, w_iir, abs(h_iir), fs=fs).astype("float32")
+
+
+class FirFilter:
+    """y = conv1d(x, taps, padding=ntaps//2) on [B, L] GPU rows (FIRFilter.forward, utils/training_utils.py:122-137) and its adjoint, both through
+    aid_resample_poly at ratio 1:1 (one phase of 2*width + 1 taps)."""
+
+    def __init__(self, taps, device):
+        t = torch.as_tensor(taps, dtype=torch.float32).reshape(-1)
+        if t.numel() % 2 == 0:
+            raise ValueError("odd number of taps expected")
+        self.width = t.numel() // 2
+        self.k = t.to(device).contiguous()
+        self.kT = t.flip(0).to(device).contiguous()
+
+    def _run(self, x, k):
+        x = x.contiguous().float()
+        B, L = x.shape
+        y = torch.empty_like(x)
+        p = _lib.ResamplePolyParams(x.data_ptr(), y.data_ptr(), k.data_ptr(), x.stride(0), y.stride(0), L, L, B, 1, 1, self.width, k.numel())
+        _lib.call("aid_resample_poly", p)
+        return y
+
+    def apply(self, x):
+        return self._run(x, self.k)
+
+    def adjoint(self, g):
+        return self._run(g, self.kT)
+
+
 class Trainer:
     """The per-iteration part of the reference ``Trainer`` (optimizer conf/exp/*.yaml:12-19,62-69)."""
 
     def __init__(self, net, edm, lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, lr_rampup_it=10000, use_grad_clip=True, max_grad_norm=1.0,
-                 ema_rate=0.9999, ema_rampup=10000, batch=4, use_cqt_DC_correction=False):
+                 ema_rate=0.9999, ema_rampup=10000, batch=4, use_cqt_DC_correction=False, aweighting_taps=None):
         self.net, self.edm = net, edm
         self.lr, self.beta1, self.beta2, self.eps = float(lr), float(beta1), float(beta2), float(eps)
         self.lr_rampup_it, self.use_grad_clip, self.max_grad_norm = lr_rampup_it, bool(use_grad_clip), float(max_grad_norm)
         self.ema_rate, self.ema_rampup, self.batch = float(ema_rate), ema_rampup, int(batch)
         self.hpf_error = bool(use_cqt_DC_correction)
+        # diff_params.aweighting.use_aweighting (edm.py:33-34, :189-190): pass a_weighting_taps(fs, ntaps); None = off (the shipped default)
+        self.fir = None if aweighting_taps is None else FirFilter(aweighting_taps, next(net.parameters()).device)
         self.flat = flatten_parameters_(net)
         self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
         self.ema = self.flat.clone()                                   # EMA of every parameter, same flat layout (trainer.py:66-68 deepcopy)
@@ -57,14 +102,15 @@ class Trainer:
         self.steps = 0
 
     # -----------------------------------------------------------------------------------------------------------------------
-    def loss_and_grads(self, audio: torch.Tensor, sigma: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None):
-        """EDM.loss_fn (edm.py:166-193) + loss.backward(): returns (loss, error**2, sigma); gradients land in the state's flat buffer."""
+    def loss_and_grads(self, audio: torch.Tensor, sigma: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, accumulate: bool = False):
+        """EDM.loss_fn (edm.py:166-193) + loss.backward(): returns (loss, error**2, sigma); gradients land in (accumulate: are added to) the
+        state's flat buffer."""
         B = audio.shape[0]
         if sigma is None:
             sigma = sample_ptrain_safe(self.edm, B)
         sigma = sigma.reshape(B, 1).to(audio.device)
         inp, target, cnoise = prepare_train_preconditioning(self.edm, audio, sigma, noise)
-        loss, err2 = self.net.loss_and_grads(inp, cnoise, target, hpf_error=self.hpf_error)
+        loss, err2 = self.net.loss_and_grads(inp, cnoise, target, hpf_error=self.hpf_error, fir=self.fir, accumulate=accumulate)
         return loss, err2, sigma
 
     def grads(self, B: int) -> torch.Tensor:
@@ -103,9 +149,18 @@ class Trainer:
         rate = float(min(max(t / self.ema_rampup, 0.0), self.ema_rate)) if t < self.ema_rampup else self.ema_rate
         _lib.call("aid_ema", _lib.EmaParams(self.ema.data_ptr(), self.flat.data_ptr(), self.flat.numel(), rate))
 
-    def train_step(self, audio: torch.Tensor, sigma=None, noise=None):
-        """One iteration (num_accumulation_rounds = 1): returns the loss (device scalar)."""
-        loss, _, _ = self.loss_and_grads(audio, sigma, noise)
+    def train_step(self, audio, sigma=None, noise=None):
+        """One iteration: returns the loss (device scalar) of the last accumulation round.  ``audio`` is one batch [B, L], or a list of batches =
+        the reference's ``num_accumulation_rounds`` (trainer.py:259-266: one loss.backward() per round into the same gradients, unnormalised);
+        ``sigma`` / ``noise`` then are lists too (or None)."""
+        rounds = list(audio) if isinstance(audio, (list, tuple)) else [audio]
+        sg = list(sigma) if isinstance(sigma, (list, tuple)) else [sigma] * len(rounds)
+        nz = list(noise) if isinstance(noise, (list, tuple)) else [noise] * len(rounds)
+        if len({a.shape[0] for a in rounds}) != 1:
+            raise ValueError("accumulation rounds must share one batch size (they share one launch-plan state)")
+        for r, a in enumerate(rounds):
+            loss, _, _ = self.loss_and_grads(a, sg[r], nz[r], accumulate=r > 0)
+        audio = rounds[0]
         self.optimizer_step(audio.shape[0])
         self.update_ema(audio.shape[0])       # (training_loop: train_step, update_ema, then it += 1; trainer.py:366-368)
         self.it += 1

@@ -329,6 +329,22 @@ def gen_norms(out):
     np.savez_compressed(os.path.join(out, "sampler_norms.npz"), **d)
 
 
+def gen_aweighting(out):
+    """The A-weighting error filter of the reference's loss (utils/training_utils.py:55-137 FIRFilter("aw"), used at diff_params/edm.py:33-34, :189-190):
+    taps for the three shipped sampling rates and the filter applied to a seeded signal."""
+    import utils.training_utils as TU
+    from audio_inpainting_diffusion_amd.init import seeded_normal
+    d = {}
+    x = torch.from_numpy(seeded_normal(8, 0, 2 * 4096)).reshape(2, 4096)
+    d["x"] = x.numpy()
+    for fs in (22050, 44100, 16000):
+        f = TU.FIRFilter(filter_type="aw", fs=fs, ntaps=101)
+        d[f"taps{fs}"] = f.fir.weight.data.reshape(-1).numpy()
+        d[f"y{fs}"] = f(x).numpy()
+    np.savez_compressed(os.path.join(out, "aweighting.npz"), **d)
+    print("aweighting taps centre", d["taps22050"][50])
+
+
 def gen_dc(out):
     """data_consistency.type variants of the reference sampler (edm_sampler_inpainting.py:22-24, :100, :141-147, :252):
     'end' projects only after the loop on the guided branch, but the replacement branch (xi = 0) projects at EVERY
@@ -435,7 +451,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     _setup_imports()
     torch.set_grad_enabled(True)
-    todo = a.only.split(",") if a.only else ["ops", "unet", "edm", "sampler", "spectral", "rid", "dc", "training", "uncond", "norms"] + (["full"] if a.full else [])
+    todo = a.only.split(",") if a.only else ["ops", "unet", "edm", "sampler", "spectral", "rid", "dc", "training", "uncond", "norms", "aweighting"] + (["full"] if a.full else [])
     if "ops" in todo: gen_ops(HERE)
     if "unet" in todo: gen_unet_small(HERE)
     if "edm" in todo: gen_edm(HERE)
@@ -446,4 +462,5 @@ if __name__ == "__main__":
     if "training" in todo: gen_training(HERE)
     if "uncond" in todo: gen_uncond(HERE)
     if "norms" in todo: gen_norms(HERE)
+    if "aweighting" in todo: gen_aweighting(HERE)
     if "full" in todo: gen_full(HERE)

@@ -338,3 +338,46 @@ def test_trainer_follows_rehomed_parameters():
     tr.train_step(audio.to(DEV))
     after = net.state_dict()["downs.0.2.H.0.weight"]
     assert float((after - before).abs().max()) > 0, "the optimiser step did not reach the live parameters"
+
+
+def test_accumulation_rounds_and_a_weighted_loss_vs_oracle_loop():
+    """trainer.py:259-266 with num_accumulation_rounds = 2 (two loss.backward() into the same gradients) and the A-weighted, DC-corrected error of
+    edm.py:180-190 (FirFilter = the reference's FIRFilter("aw"), golden-pinned taps): loss, parameters and EMA after two iterations vs the same loop in
+    torch autograd over the CPU oracle."""
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.training import Trainer, a_weighting_taps, prepare_train_preconditioning
+    net, orc, z, kw, args = _setup("a")
+    edm = EDM(args)
+    taps = a_weighting_taps(kw["fs"], 101)
+    tr = Trainer(net, edm, lr=2e-3, lr_rampup_it=0, max_grad_norm=1.0, ema_rate=0.9, ema_rampup=8, batch=2, use_cqt_DC_correction=True, aweighting_taps=taps)
+    B, Ls = 2, kw["audio_len"]
+    g0 = torch.Generator().manual_seed(21)
+    keys = list(orc.sd.keys())
+    params = [torch.nn.Parameter(orc.sd[k].clone()) for k in keys]
+    trainable = [p for k, p in zip(keys, params) if not (k.endswith("RFF_freq") or k.endswith("kernel"))]
+    opt = torch.optim.Adam(trainable, lr=2e-3, betas=(0.9, 0.999), eps=1e-8)
+    wt = torch.from_numpy(taps).view(1, 1, -1)
+    for it in range(2):
+        rounds = []
+        for _ in range(2):
+            audio = torch.randn(B, Ls, generator=g0) * 0.063
+            sigma = torch.rand(B, 1, generator=g0) * 0.5 + 0.05
+            rounds.append((audio, sigma, torch.randn(B, Ls, generator=g0) * sigma))
+        loss = float(tr.train_step([a.to(DEV) for a, _, _ in rounds], [s for _, s, _ in rounds], [n.to(DEV) for _, _, n in rounds]))
+        orc.sd = {k: p for k, p in zip(keys, params)}
+        opt.zero_grad()
+        for audio, sigma, noise in rounds:
+            inp, target, cnoise = prepare_train_preconditioning(edm, audio, sigma, noise)
+            err = orc.CQTransform.apply_hpf_DC(orc(inp, cnoise) - target)
+            err = torch.nn.functional.conv1d(err.unsqueeze(1), wt, padding=50).squeeze(1)
+            ref_loss = (err ** 2).mean()
+            ref_loss.backward()
+        torch.nn.utils.clip_grad_norm_(trainable, 1.0)
+        opt.step()
+        print(f"iteration {it}: loss of the last round {loss:.6f} vs oracle {float(ref_loss):.6f}")
+        assert abs(loss - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
+    sd = net.state_dict()
+    num = math.sqrt(sum(float((sd[k].cpu() - params[i].detach()).norm()) ** 2 for i, k in enumerate(keys)))
+    den = math.sqrt(sum(float(params[i].detach().norm()) ** 2 for i in range(len(keys))))
+    print(f"parameters after 2 iterations x 2 rounds, A-weighted loss: rel-L2 vs oracle loop = {num / den:.2e}")
+    assert num / den < 1e-4

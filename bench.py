@@ -147,6 +147,7 @@ def main():
                                                               "configs[3] sweeps 25 / 50 / 100, conf/tester/inpainting_tester_shortgaps.yaml:74-75)")
     ap.add_argument("--streams", type=int, default=0, help="sub-batch HIP streams per evaluation (default: automatic, network._n_split; 1 = plain single-stream schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roof-steps", type=int, default=3, help="Heun steps of the single-stream roofline pass after the timed region (>= 1; 3 by default)")
     ap.add_argument("--no-graphs", action="store_true", help="A/B: eager launches instead of HIP-graph replay at small batches")
     ap.add_argument("--no-pair-merge", action="store_true", help="A/B: separate input-gradient convs for proj_in and res_conv")
     ap.add_argument("--no-lanes", action="store_true", help="A/B: single-stream launch plans at small batches (plan.py lanes off)")
@@ -221,7 +222,7 @@ def main():
     # Every timed step is a Heun step (2 evaluations; the last step of a schedule is Euler): positions 0 .. T-4 of the schedule are walked,
     # and when --warmup + --steps exceed them the sampler starts the next batch's trajectory (smp.begin) inside the run, as a job over many
     # batches of segments does.  Two positions stay in reserve for the single-stream roofline pass.
-    ROOF_STEPS = 3                                     # Heun steps of the single-stream roofline pass (after one warm-up step)
+    ROOF_STEPS = max(1, a.roof_steps)                  # Heun steps of the single-stream roofline pass (after one warm-up step)
     span = T - 2 - (ROOF_STEPS + 1)
     state = smp.begin((B, L), dev)
 

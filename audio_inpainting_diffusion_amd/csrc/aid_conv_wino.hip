@@ -1019,7 +1019,7 @@ static int launch_wino4v(const aid_conv2d_params* p, hipStream_t st) {
 // npos: positions per tile (256 for the 64-channel tile, 512 for the 32-channel remainder tile of 96-channel layers).
 static int wino4r_tile(const aid_conv2d_params* p, int npos, int max_nc, int* TTo, int* NCo, int* quads, int* ttiles) {
     if (p->dilF < 1 || (p->F % p->dilF)) return 0;
-    const int TT = p->T >= 64 ? 64 : 32;
+    const int TT = p->T >= 64 ? 64 : (p->T >= 32 ? 32 : 16);      // (T = 16: the deepest level of the 8-octave 44.1 kHz network at L = 184184)
     if (p->T % TT) return 0;
     const int nrow = p->F / p->dilF;
     for (int NC = 1; NC * TT <= 256 && NC <= max_nc; NC *= 2) {
@@ -1085,6 +1085,10 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
             case 32 * 16 + 2: AID_W4R(32, 2, 2); break;
             case 32 * 16 + 4: AID_W4R(32, 4, 2); break;
             case 32 * 16 + 8: AID_W4R(32, 8, 2); break;
+            case 16 * 16 + 1: AID_W4R(16, 1, 2); break;
+            case 16 * 16 + 2: AID_W4R(16, 2, 2); break;
+            case 16 * 16 + 4: AID_W4R(16, 4, 2); break;
+            case 16 * 16 + 8: AID_W4R(16, 8, 2); break;
             case (128 + 64) * 16 + 1: AID_W4R(64, 1, 1); break;
             case (128 + 64) * 16 + 2: AID_W4R(64, 2, 1); break;
             default: aid_set_error("aid_conv2d: row-shared tile shape not instantiated"); return AID_E_BADARG;
@@ -1108,10 +1112,23 @@ static int wino_tile_n(int B, int Cout_pad, int F, int T) {
 static bool wino_v_shape_ok(int Cin, int Cout, int T) {
     int cip, cop;
     aid_conv2d_pack_dims(Cin, Cout, &cip, &cop);
-    return (Cin % 4) == 0 && Cout >= 64 && ((cop % 64) == 0 || (cop % 96) == 0) && (T % 16) == 0 && T >= 32;
+    return (Cin % 4) == 0 && Cout >= 64 && ((cop % 64) == 0 || (cop % 96) == 0) && (T % 16) == 0 && T >= 16;
 }
 
-extern "C" int aid_conv2d_wino_input_supported(int Cin, int Cout, int T) { return wino_v_shape_ok(Cin, Cout, T) ? 1 : 0; }
+extern "C" int aid_conv2d_wino_input_supported(int Cin, int Cout, int T) { return (wino_v_shape_ok(Cin, Cout, T) && T >= 32) ? 1 : 0; }
+
+// Geometry-aware form of aid_conv2d_wino_input_supported: T = 16 layers have only the row-shared kernel (the 512-position tiles of the fallback
+// kernels would span 32 rows), so there the answer also depends on F and the dilation.
+extern "C" int aid_conv2d_wino_input_ok(int B, int Cin, int Cout, int F, int T, int dilF) {
+    if (!wino_v_shape_ok(Cin, Cout, T)) return 0;
+    if (T >= 32) return 1;
+    int cip, cop;
+    aid_conv2d_pack_dims(Cin, Cout, &cip, &cop);
+    aid_conv2d_params q{};
+    q.B = B; q.Cin = Cin; q.Cout = Cout; q.F = F; q.T = T; q.dilF = dilF; q.Cout_pad = cop;
+    Wino4rPlan plan[2];
+    return wino4r_geometry(&q, plan) == 1 ? 1 : 0;
+}
 
 // partials per (sample, group) of the forward (sum, sum of squares) option: the row-shared kernel only
 extern "C" int aid_conv2d_stat_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino) {

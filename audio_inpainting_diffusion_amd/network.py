@@ -403,11 +403,11 @@ class _Builder:
             self.nbytes += t.numel() * 8
         return t
 
-    def _wino_input(self, cin, cout, T, wp, wpw):
+    def _wino_input(self, cin, cout, T, wp, wpw, F=0, dil=1):
         """True when the pre-pass should write the F(4,3) input transform (aid_scale_act wino=1 -> aid_conv2d x_wino=1):
         every 5x3 layer with Cin % 4 == 0, a 64- or 96-multiple Cout pack and T % 16 == 0, T >= 32 (the library answers)."""
         return (wpw is not None and wpw.shape[0] == 30
-                and bool(_lib.lib().aid_conv2d_wino_input_supported(cin, cout, T)))
+                and bool(_lib.lib().aid_conv2d_wino_input_ok(self.B, cin, cout, F, T, dil)))
 
     def conv(self, x, y, wp, cin, cout, kh=1, kw=1, dil=1, in_scale=None, act=0, out_scale=None, res=None,
              res_scale=1.0, alpha=1.0, wpT=None, norm_stats=None, wpw=None, wpwT=None, res_nograd=False, wname=None):
@@ -415,7 +415,7 @@ class _Builder:
         ``in_scale`` was produced by ``stats`` from this same ``x`` (the scale then depends on x)."""
         if act and kh > 1:
             # evaluate norm*mod -> GELU once per element into a scratch tensor; the conv stages plain copies
-            xw = self._wino_input(cin, cout, x.shape[3], wp, wpw)
+            xw = self._wino_input(cin, cout, x.shape[3], wp, wpw, x.shape[2], dil)
             hshape = (x.shape[0], cin, x.shape[2], 6 * (x.shape[3] // 4)) if xw else tuple(x.shape)
             hbuf = self._scratch(("h",) + hshape)
             sp = _lib.ScaleActParams(_lib.view4(x), _lib.view4(hbuf), in_scale.data_ptr(), in_scale.stride(0), x.shape[0], cin,
@@ -441,7 +441,7 @@ class _Builder:
             if kh > 1 and out_scale is not None:
                 # 5x3 dgrad: apply the gate in a copy pass so the conv input needs no in-kernel prologue
                 # (keeps it on the direct-to-LDS kernel)
-                gw = norm_stats is not None and self._wino_input(cout, cin, gy.shape[3], wpT, wpwT)
+                gw = norm_stats is not None and self._wino_input(cout, cin, gy.shape[3], wpT, wpwT, gy.shape[2], dil)
                 gshape = (gy.shape[0], cout, gy.shape[2], 6 * (gy.shape[3] // 4)) if gw else tuple(gy.shape)
                 gin = self._scratch(("g",) + gshape)
                 nb = self._nb_src.pop(self._vkey(gy), None) if (gw and self.net.fuse_norm_bwd_wino) else None

@@ -132,6 +132,8 @@ int aid_conv2d_dot_partials_1x1(int B, int Cin, int Cout, int F, int T);
 int aid_conv2d_x2_supported(int Cin, int Cin1, int Cout, int F, int T);
 /* non-zero when a 5x3 layer of this shape can take Winograd-domain input (x_wino = 1) */
 int aid_conv2d_wino_input_supported(int Cin, int Cout, int T);
+/* the same question with the layer's geometry: T = 16 layers are served only when the row-shared tiles fit F and the dilation */
+int aid_conv2d_wino_input_ok(int B, int Cin, int Cout, int F, int T, int dilF);
 /* number of per-tile partial dots per (sample, group) the F(4,3) epilogue writes for this shape; 0 = not supported */
 int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino);
 /* number of per-tile (sum, sum of squares) partials per (sample, group) for stat_ws; 0 = the kernel that takes this shape does not write them */

@@ -185,6 +185,11 @@ WINO_V_CASES = [
     (1, 64, 64, 40, 64, 4, 1, False),        # <64, 2>: 10 rows per class
     (2, 64, 64, 20, 128, 4, 0, True),        # <64, 4>: 5 rows per class, two t tiles
     (1, 256, 256, 448, 32, 16, 1, True),     # the deepest level of the shipped network (28 rows per class)
+    # T = 16 (deepest level of the 8-octave 44.1 kHz network at L = 184184): <16, NC> tiles, 16 / NC rows per class
+    (2, 256, 256, 64, 16, 1, 1, True),       # <16, 1>
+    (1, 64, 128, 64, 16, 8, 0, True),        # <16, 2>: 8 rows per class
+    (2, 128, 64, 32, 16, 8, 1, False),       # <16, 4>: 4 rows per class
+    (1, 64, 64, 32, 16, 16, 1, True),        # <16, 8>: 2 rows per class
     # 96 output channels: 64-channel tiles + 32-channel x 512-position remainder tiles (two launches)
     (1, 96, 96, 32, 256, 2, 1, True),
     (2, 64, 96, 48, 64, 2, 0, False),        # remainder tile over two residue classes <64, 2, 1>
@@ -197,7 +202,8 @@ WINO_V_CASES = [
 def test_conv2d_winograd_domain_input(L, case):
     """aid_scale_act(wino=1) -> aid_conv2d(x_wino=1): the input transform of F(4,3) done by the producer pass."""
     B, Cin, Cout, Fd, T, dil, act, epi = case
-    assert L.lib().aid_conv2d_wino_input_supported(Cin, Cout, T)
+    assert L.lib().aid_conv2d_wino_input_ok(B, Cin, Cout, Fd, T, dil)
+    assert bool(L.lib().aid_conv2d_wino_input_supported(Cin, Cout, T)) == (T >= 32)      # (the geometry-free form only vouches for T >= 32)
     x = _rand(B, Cin, Fd, T, seed=30)
     w = _rand(Cout, Cin, 5, 3, seed=31, scale=1.0 / math.sqrt(Cin * 15))
     in_scale = 1.0 + 0.5 * _rand(B, Cin, seed=32)

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 shape="$1"; V=$2
 for pass in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM"; do
   rm -rf gpurun_out/pmc_tmp
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d gpurun_out/pmc_tmp -o p -- env PROBE_V=$V PROBE_WINO=30 python tools/conv_probe.py $shape 5 -1 > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d gpurun_out/pmc_tmp -o p -- env PROBE_V=$V PROBE_WINO=30 python tools/conv_probe.py $shape 5 -1 > /dev/null 2>&1
   python - <<PY
 import csv,glob,collections
 f=glob.glob("gpurun_out/pmc_tmp/*counter_collection.csv")[0]

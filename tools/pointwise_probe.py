@@ -57,10 +57,13 @@ for (C, F, T) in [(64, 64, 2048), (96, 128, 1024), (96, 192, 512), (128, 256, 25
     cases.append(("add2 (copy)", "aid_add2", L.Add2Params(L.view4(x), L.view4(None), L.view4(out), B, C, F, T, 0.7, 0.0), 8 * n))
     cases.append(("resample down", "aid_resample", L.ResampleParams(L.view4(x), L.view4(half), B, C, F, T, 0, 0, 0), 6 * n))
     cases.append(("resample up", "aid_resample", L.ResampleParams(L.view4(half), L.view4(out), B, C, F, T // 2, 1, 0, 0), 6 * n))
-    cases.append(("resample down adjoint (+=)", "aid_resample", L.ResampleParams(L.view4(half), L.view4(out), B, C, F, T, 0, 1, 1), 10 * n))
-    cases.append(("resample up adjoint", "aid_resample", L.ResampleParams(L.view4(out), L.view4(half), B, C, F, T // 2, 1, 1, 0), 6 * n))
+    # (aid_kernels.h: T = length of the tensor passed as x; for adjoint = 1 that is the incoming gradient)
+    cases.append(("resample down adjoint (+=)", "aid_resample", L.ResampleParams(L.view4(half), L.view4(out), B, C, F, T // 2, 0, 1, 1), 10 * n))
+    cases.append(("resample up adjoint", "aid_resample", L.ResampleParams(L.view4(out), L.view4(half), B, C, F, T, 1, 1, 0), 6 * n))
     line = []
     for label, fn, params, nbytes in cases:
+        if os.environ.get("PW_VERBOSE"):
+            print("C%d F%d T%d %s" % (C, F, T, label), file=sys.stderr, flush=True)
         ms = timeit(lambda: L.call(fn, params))
         rows.append(dict(kernel=label, C=C, F=F, T=T, bytes=nbytes))
         if not manifest:

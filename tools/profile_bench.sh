@@ -6,7 +6,7 @@ tag=${1:-r02}
 for mode in streams3 streams1; do
   extra=""; [ $mode = streams1 ] && extra="--streams 1"
   rm -rf gpurun_out/prof_tmp
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_tmp -o p -- python bench.py --steps 3 --warmup 1 --roof-steps 1 --no-cpu-baseline $extra > gpurun_out/${tag}_bench_${mode}_under_rocprof.json 2> gpurun_out/${tag}_bench_${mode}_under_rocprof.err
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_tmp -o p -- python bench.py --steps 3 --warmup 1 --roof-steps 1 --no-cpu-baseline $extra > gpurun_out/${tag}_bench_${mode}_under_rocprof.json 2> gpurun_out/${tag}_bench_${mode}_under_rocprof.err
   f=$(find gpurun_out/prof_tmp -name "*kernel_stats.csv" | head -1)
   cp "$f" gpurun_out/${tag}_bench_${mode}_kernel_stats.csv
   python - <<PY

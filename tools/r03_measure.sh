@@ -33,7 +33,7 @@ prof)
 pmc)
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $O/pmc_$c
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python bench.py --steps 1 --warmup 0 --roof-steps 1 --no-cpu-baseline --streams 1 > /dev/null 2>&1
+    timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python bench.py --steps 1 --warmup 0 --roof-steps 1 --no-cpu-baseline --streams 1 > /dev/null 2>&1
   done
   python tools/conv_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/r03_conv_traffic.json > /dev/null
   rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE

@@ -674,12 +674,25 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
 // slot j + kh.  Requires F % dilF == 0 (rows of a residue class: F/dilF).
 // Large dilations leave few rows per residue class (F/dilF = 28, 14, 7 on the deepest level): there a tile takes RA rows of each of NC
 // ADJACENT residue classes (NC x RA x TT = 256 positions, NC (RA + 4) staged rows), so that RA divides the class without padding rows.
+#define AID_W4R_SPLIT_MAX_TILES 512
+#define AID_W4R_SPLIT_FLAG_BYTES AID_CONV2D_SPLIT_FLAG_BYTES
+static_assert(AID_W4R_SPLIT_MAX_TILES * 2 * 4 <= AID_CONV2D_SPLIT_FLAG_BYTES, "flag region");
+static inline int64_t aid_w4r_split_bytes(int64_t ntiles) { return AID_W4R_SPLIT_FLAG_BYTES + ntiles * (int64_t)(96 * 256 * 4); }
+
+struct W4rGeo {                // one tile family of a launch
+    int quads, ttiles, ny, per_xcd, ntiles, rgroups;
+    int m_base, m_stride;      // Cout tile `by` starts at m_base + by * m_stride
+    int dot_base;              // first per-sample partial slot of this family
+};
 struct ConvWinoRDev {
     aid_conv2d_params p;
     const float* zero;
-    int nchunks, quads, ttiles, ny, per_xcd, ntiles, rgroups;
-    int m_base, m_stride;      // Cout tile `by` starts at m_base + by * m_stride
-    int dot_all, dot_base;     // 96-channel layers (two launches): every launch writes all eight groups of its own partial slots
+    int nchunks;               // chunks of 2 input channels PER SPLIT
+    int dot_all;               // 96-channel layers (two tile families): every tile writes all eight groups of its own partial slots
+    int splits;                // 1, or 2: the K axis of a tile is shared by two workgroups (see the kernel)
+    float* part;               // splits == 2: [tile][96][256] Winograd-domain partial accumulators of the workgroup that finishes first
+    unsigned* flags;           // splits == 2: [tile][2] (arrival counter, partial published); zero before and after every launch
+    W4rGeo g[2];               // [1]: the 32-channel remainder tiles of a 96-channel layer (pair instances)
 };
 
 // Tried for small grids (round 3, profiles/r03_half_tile_probe.txt): two-wave workgroups on half the positions (64 x 128 / 32 x 256 tiles, twice
@@ -697,34 +710,47 @@ struct ConvWinoRDev {
 // in registers (half the weight bytes, 14 instead of 21 direct-to-LDS pieces per chunk, 3 instead of 6 A reads per k-step, 2x the VALU) and the
 // conflict-free layout change the kernel time by less than 0.5 % in either direction: it is bound by the matrix pipe (84 % busy at K = 256)
 // and by the prologue / epilogue of a tile, not by LDS or staging any more.  The interleave stays (no conflicts, no cost); raw-tap staging does not.
-template <int TT, int NC, int WGM, int NB = 3, int WPC = 2, int NWV = 4>
-__global__ __launch_bounds__(64 * NWV, (WPC * NWV + 3) / 4) void conv53_wino4r_kernel(const ConvWinoRDev a) {
-    constexpr int KH = 5, NXI = 6, TAPS = NXI * KH, KC = 2;
-    constexpr int NW = NWV, WGN = NW / WGM;
-    constexpr int M_BLK = 32 * WGM, N_BLK = 128 * WGN;
-    constexpr int GPR = TT / 4;                         // groups of 4 outputs per row
-    constexpr int RA = N_BLK / (TT * NC);               // output rows per residue class and tile
-    constexpr int CSLOT = RA + KH - 1;                  // staged input rows per channel and class
-    constexpr int NSLOT = NC * CSLOT;
-    constexpr int ILR = 32 / GPR;                       // rows read by one half-wave
-    constexpr int IL = (CSLOT % ILR == 0 && RA % ILR == 0) ? ILR : 1;   // slot interleave unit (1: plain order)
-    constexpr int XCI = NSLOT * NXI * GPR;              // floats per input channel in the x region
-    constexpr int XSZ = ((KC * XCI + 255) / 256) * 256;
-    constexpr int WROW = M_BLK;
-    constexpr int WSZ_RAW = TAPS * KC * WROW;           // 64 channels: 3840 floats = 15 pieces; 32: 1920 -> 8 pieces (the last half used)
-    constexpr int WSZ = ((WSZ_RAW + 255) / 256) * 256;
-    constexpr int BUFSZ = XSZ + WSZ;
-    constexpr int NBUF = (NB == 3 && 3 * BUFSZ * 4 * WPC <= 160 * 1024) ? 3 : 2;  // three buffers only while WPC workgroups still fit a CU
+template <int TT, int NC, int WGM, int NB, int WPC, int NWV>
+struct W4rShape {
+    static constexpr int KH = 5, NXI = 6, TAPS = NXI * KH, KC = 2;
+    static constexpr int NW = NWV, WGN = NW / WGM;
+    static constexpr int M_BLK = 32 * WGM, N_BLK = 128 * WGN;
+    static constexpr int GPR = TT / 4;                         // groups of 4 outputs per row
+    static constexpr int RA = N_BLK / (TT * NC);               // output rows per residue class and tile
+    static constexpr int CSLOT = RA + KH - 1;                  // staged input rows per channel and class
+    static constexpr int NSLOT = NC * CSLOT;
+    static constexpr int ILR = 32 / GPR;                       // rows read by one half-wave
+    static constexpr int IL = (CSLOT % ILR == 0 && RA % ILR == 0) ? ILR : 1;   // slot interleave unit (1: plain order)
+    static constexpr int XCI = NSLOT * NXI * GPR;              // floats per input channel in the x region
+    static constexpr int XSZ = ((KC * XCI + 255) / 256) * 256;
+    static constexpr int WROW = M_BLK;
+    static constexpr int WSZ_RAW = TAPS * KC * WROW;           // 64 channels: 3840 floats = 15 pieces; 32: 1920 -> 8 pieces (the last half used)
+    static constexpr int WSZ = ((WSZ_RAW + 255) / 256) * 256;
+    static constexpr int BUFSZ = XSZ + WSZ;
+    static constexpr int NBUF = (NB == 3 && 3 * BUFSZ * 4 * WPC <= 160 * 1024) ? 3 : 2;  // three buffers only while WPC workgroups still fit a CU
+    static constexpr int LDS = NBUF * BUFSZ;                   // floats
+};
+
+// One tile.  `smem`: W4rShape::LDS floats of LDS (declared by the kernel, so that the two tile families of a pair instance share it);
+// `bid`: workgroup index within this tile family's part of the grid.
+template <int TT, int NC, int WGM, int NB, int WPC, int NWV, bool SPK>
+__device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4rGeo& ge, float* smem, const int bid) {
+    using S = W4rShape<TT, NC, WGM, NB, WPC, NWV>;
+    constexpr int KH = S::KH, NXI = S::NXI, KC = S::KC;
+    constexpr int NW = S::NW, WGN = S::WGN;
+    constexpr int M_BLK = S::M_BLK;
+    constexpr int GPR = S::GPR, RA = S::RA, CSLOT = S::CSLOT, IL = S::IL, XCI = S::XCI, XSZ = S::XSZ, WROW = S::WROW;
+    constexpr int WSZ_RAW = S::WSZ_RAW, WSZ = S::WSZ, BUFSZ = S::BUFSZ, NBUF = S::NBUF;
     constexpr int NXP = XSZ / 256, NWP = WSZ / 256, NP = NXP + NWP;
     constexpr int PPW = (NP + NW - 1) / NW;
     constexpr int NSTEP = KH;
-    static_assert(RA >= 1 && RA * NC * TT == N_BLK, "tile shape");
+    static_assert(RA >= 1 && RA * NC * TT == S::N_BLK, "tile shape");
     static_assert(WROW % 4 == 0 && GPR % 4 == 0 && NP > (PPW - 1) * NW, "piece bookkeeping");
 
     const aid_conv2d_params& p = a.p;
-    __shared__ __attribute__((aligned(16))) float sbuf0[BUFSZ];
-    __shared__ __attribute__((aligned(16))) float sbuf1[BUFSZ];
-    __shared__ __attribute__((aligned(16))) float sbuf2[NBUF == 3 ? BUFSZ : 4];
+    float* const sbuf0 = smem;
+    float* const sbuf1 = smem + BUFSZ;
+    float* const sbuf2 = smem + (NBUF == 3 ? 2 * BUFSZ : 0);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -733,17 +759,20 @@ __global__ __launch_bounds__(64 * NWV, (WPC * NWV + 3) / 4) void conv53_wino4r_k
     const int half = lane >> 5;
 
     // XCD-aware logical tile (see conv53_wino4v_kernel); order: Cout tile fastest, then t tile, quad, residue-class group, sample
-    const int Lt = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
-    if (Lt >= a.ntiles) return;
+    const int Lt = (bid & 7) * ge.per_xcd + (bid >> 3);
+    if (Lt >= ge.ntiles) return;
     int rest = Lt;
-    const int by = rest % a.ny; rest /= a.ny;
-    const int tile_t = rest % a.ttiles; rest /= a.ttiles;
-    const int q = rest % a.quads; rest /= a.quads;
-    const int rg = rest % a.rgroups;
-    const int b = rest / a.rgroups;
+    const int sp = SPK ? (rest & 1) : 0;                 // split-K: the two halves of a tile are neighbours in the same XCD's share
+    if (SPK) rest >>= 1;
+    const int tile_id = rest;
+    const int by = rest % ge.ny; rest /= ge.ny;
+    const int tile_t = rest % ge.ttiles; rest /= ge.ttiles;
+    const int q = rest % ge.quads; rest /= ge.quads;
+    const int rg = rest % ge.rgroups;
+    const int b = rest / ge.rgroups;
     const int res = rg * NC;                             // first residue class of this tile
     const int t0 = tile_t * TT;
-    const int m0 = a.m_base + by * a.m_stride;
+    const int m0 = ge.m_base + by * ge.m_stride;
     const int nrow = p.F / p.dilF;                       // rows of one residue class
     const int j0 = q * RA;                               // first sub-lattice row of this tile
 
@@ -776,6 +805,10 @@ __global__ __launch_bounds__(64 * NWV, (WPC * NWV + 3) / 4) void conv53_wino4r_k
                 pstride[i] = KC * p.Cout_pad;
             }
         }
+    }
+    if (SPK && sp) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) psrc[i] += (int64_t)a.nchunks * pstride[i];      // second half of the K axis
     }
     // ---- operand addresses: lane's group g of this wave's 32 -> output row j = g / GPR, group tau = g % GPR -------------------------
     const int g = wn * 32 + (lane & 31);
@@ -862,6 +895,51 @@ __global__ __launch_bounds__(64 * NWV, (WPC * NWV + 3) / 4) void conv53_wino4r_k
         }
     }
 
+    // ---- split-K: the workgroup that arrives first publishes its accumulators and leaves; the other adds them and runs the epilogue.
+    // Arrival order is taken BEFORE anything is written, so the second workgroup only ever waits for one that is already running (no
+    // dependence on dispatch order); a + b is commutative, so the sum does not depend on which half arrives first (deterministic).
+    if constexpr (SPK) {
+        // Exchange through agent-scope (sc1) loads and stores, which go past the per-XCD L2 to the coherent level, ordered by explicit
+        // s_waitcnt + barrier: a release / acquire fence pair here writes back and invalidates the WHOLE L2 of the XCD once per tile
+        // (measured: +45 us on a 150 us launch, the other tiles re-fetch their operands).
+        unsigned* fl = a.flags + 2 * (int64_t)tile_id;
+        unsigned long long* part = reinterpret_cast<unsigned long long*>(a.part + (int64_t)tile_id * (NXI * 16 * 64 * NW)) + tid;
+        int* sh = reinterpret_cast<int*>(smem);
+        if (tid == 0) sh[0] = (int)__hip_atomic_fetch_add(fl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int second = sh[0];
+        if (!second) {
+#pragma unroll
+            for (int x = 0; x < NXI; ++x)
+#pragma unroll
+                for (int r2 = 0; r2 < 8; ++r2) {
+                    const unsigned long long v = (unsigned long long)__float_as_uint(acc[x][2 * r2]) | ((unsigned long long)__float_as_uint(acc[x][2 * r2 + 1]) << 32);
+                    __hip_atomic_store(part + (x * 8 + r2) * (64 * NW), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this wave has reached the coherent level
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(fl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (tid == 0) {
+            // (bounded, ~0.2 s: the first workgroup is already past its K loop, this wait is microseconds; a bound keeps a logic error from hanging the device)
+            for (int it = 0; it < (1 << 20) && __hip_atomic_load(fl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u; ++it) __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < NXI; ++x)
+#pragma unroll
+            for (int r2 = 0; r2 < 8; ++r2) {
+                const unsigned long long v = __hip_atomic_load(part + (x * 8 + r2) * (64 * NW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                acc[x][2 * r2] += __uint_as_float((unsigned)v); acc[x][2 * r2 + 1] += __uint_as_float((unsigned)(v >> 32));
+            }
+        if (tid == 0) {                                   // leave the flags as they were found (the next launch on this stream reuses them)
+            __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();                                  // sh[0] lives in the buffer the partial-sum reduction below reuses
+    }
+
     // ---- epilogue (as conv53_wino4v_kernel; this lane's output row: sub-lattice row j0 + jl) -----------------------------------------
     float dsum[4] = {0.f, 0.f, 0.f, 0.f};                // <y, aux> (dot_ws) or sum y (stat_ws) per block of 4 rows
     float qsum[4] = {0.f, 0.f, 0.f, 0.f};                // sum y^2 (stat_ws)
@@ -935,7 +1013,7 @@ __global__ __launch_bounds__(64 * NWV, (WPC * NWV + 3) / 4) void conv53_wino4r_k
                         const int mrow = m0 + (w / WGN) * 32 + 4 * h + 8 * qq;
                         if (mrow < p.Cout && mrow / cpg == grp) { sacc += red[(w * 2 + h) * 4 + qq]; qacc += red[NW * 8 + (w * 2 + h) * 4 + qq]; }
                     }
-            const int ptile = a.dot_base + (rg * a.quads + q) * a.ttiles + tile_t;
+            const int ptile = ge.dot_base + (rg * ge.quads + q) * ge.ttiles + tile_t;
             if (st) {
                 double* o = p.stat_ws + (((int64_t)b * 8 + grp) * p.stat_n + ptile) * 2;
                 o[0] = (double)sacc; o[1] = (double)qacc;
@@ -943,6 +1021,27 @@ __global__ __launch_bounds__(64 * NWV, (WPC * NWV + 3) / 4) void conv53_wino4r_k
                 p.dot_ws[((int64_t)b * 8 + grp) * p.dot_n + ptile] = (double)sacc;
             }
         }
+    }
+}
+
+// NC1 > 0: PAIR instance for 96-channel layers -- the 64 x 256 tiles of channels [0, 64) (family 0: <TT, NC, WGM = 2>) and the 32 x 512
+// remainder tiles of channels [64, 96) (family 1: <TT, NC1, WGM = 1>) in ONE grid, family 0 first: the remainder tiles start while the
+// last 64-wide tiles drain instead of after a launch boundary (two launches: each has its own tail, and at batch 1 neither fills the chip).
+// Measured against two launches (AID_W4R_PAIR = 0; profiles/r03_w4r_split_probe.txt, r03_w4r_ab.txt): batch 1 [96, 256, 256] 140 -> 100 us,
+// [96, 192, 512] 170 -> 145 us; batch 3 380 -> 340 us; batch 8 918 -> 905 / 627 -> 604 us; end to end +4.7 % / +1.5 % / +1.2 % / +0.6 % at batch 1 / 2 / 3 / 8.
+// SPK: split-K instance (ConvWinoRDev::splits == 2).
+template <int TT, int NC, int WGM, int NB = 3, int WPC = 2, int NWV = 4, int NC1 = 0, bool SPK = false>
+__global__ __launch_bounds__(64 * NWV, (WPC * NWV + 3) / 4) void conv53_wino4r_kernel(const ConvWinoRDev a) {
+    using S0 = W4rShape<TT, NC, WGM, NB, WPC, NWV>;
+    if constexpr (NC1 == 0) {
+        __shared__ __attribute__((aligned(16))) float smem[S0::LDS];
+        wino4r_tile_body<TT, NC, WGM, NB, WPC, NWV, SPK>(a, a.g[0], smem, (int)blockIdx.x);
+    } else {
+        using S1 = W4rShape<TT, NC1, 1, NB, WPC, NWV>;
+        __shared__ __attribute__((aligned(16))) float smem[S0::LDS > S1::LDS ? S0::LDS : S1::LDS];
+        const int n0 = 8 * a.g[0].per_xcd;
+        if ((int)blockIdx.x < n0) wino4r_tile_body<TT, NC, WGM, NB, WPC, NWV, false>(a, a.g[0], smem, (int)blockIdx.x);
+        else wino4r_tile_body<TT, NC1, 1, NB, WPC, NWV, false>(a, a.g[1], smem, (int)blockIdx.x - n0);
     }
 }
 
@@ -1043,6 +1142,26 @@ static int wino4r_geometry(const aid_conv2d_params* p, Wino4rPlan plan[2]) {
     return 2;
 }
 
+static bool wino_v_shape_ok(int Cin, int Cout, int T);
+
+static int w4r_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// Split-K of the row-shared kernel (batch 1 only, so that the result of a sample never depends on which sub-batch it is evaluated in:
+// sub-batches have >= 2 samples): a launch with fewer tiles than CUs -- 192 / 224 on the deepest levels of the 22.05 kHz network -- gives
+// every tile to TWO workgroups, one per half of the input channels: one wave per SIMD keeps the matrix pipe 76 % busy, two 91 %.
+// The tile count per CU does not change (the launch stays bound by 1 tile's MFMAs per CU), so the gain is that utilisation only:
+// 155 -> 147 us (d = 1) ... 169 -> 143 us (d = 64) per launch on [256, 448, 32]; launches with 256 < tiles <= 336 measured neutral to -4 %
+// (profiles/r03_w4r_split_probe.txt); end to end at batch 1: 27.75 -> 28.37 evaluations/s with the threshold at 230, 28.22 at 336
+// (profiles/r03_w4r_ab.txt).  AID_W4R_SPLIT overrides the threshold (0 = never split).
+static int wino4r_splits(const aid_conv2d_params* p, int nl, int64_t ntiles) {
+    static const int thr = w4r_env("AID_W4R_SPLIT", 230);
+    if (p->B != 1 || nl != 1 || ntiles > thr || ntiles > AID_W4R_SPLIT_MAX_TILES || (p->Cin % 4)) return 1;
+    return 2;
+}
+
 static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
     static const float* zero = nullptr;
     if (!zero) {
@@ -1050,54 +1169,99 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
         if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_aid_zero_page_w)) != hipSuccess) { aid_set_error("aid_conv2d: zero page lookup failed"); return AID_E_LAUNCH; }
         zero = (const float*)z;
     }
+    static const int pair_launch = w4r_env("AID_W4R_PAIR", 1);
     Wino4rPlan plan[2];
     const int nl = wino4r_geometry(p, plan);
     if (!nl) return 1000;
     const bool m96 = nl == 2;
+    ConvWinoRDev a;
+    a.p = *p;
+    a.zero = zero;
+    a.nchunks = p->Cin / 2;
+    a.dot_all = m96 ? 1 : 0;
+    a.splits = 1; a.part = nullptr; a.flags = nullptr;
+    W4rGeo geo[2];
     int dot_base = 0;
     for (int l = 0; l < nl; ++l) {
         const Wino4rPlan& g = plan[l];
-        ConvWinoRDev a;
-        a.p = *p;
-        a.zero = zero;
-        a.nchunks = p->Cin / 2;
-        a.quads = g.quads; a.ttiles = g.ttiles;
-        a.rgroups = p->dilF / g.NC;
-        a.ny = m96 ? p->Cout_pad / 96 : p->Cout_pad / 64;
-        a.m_base = l == 0 ? 0 : 64;
-        a.m_stride = m96 ? 96 : 64;
-        a.dot_all = m96 ? 1 : 0;
-        a.dot_base = dot_base;
-        dot_base += a.rgroups * g.quads * g.ttiles;
-        a.ntiles = p->B * a.rgroups * g.quads * g.ttiles * a.ny;
-        a.per_xcd = (a.ntiles + 7) / 8;
-        const dim3 grid((unsigned)(8 * a.per_xcd));
-        const bool short_k = p->Cin <= 128;                  // three workgroups per CU (two LDS buffers) for the short-K layers (re-measured in round 3 with
-                                                             // sub-batch streams: Cin <= 128 / 64 / never = 42.33 / 42.08 / 42.17 evaluations/s)
-#define AID_W4R(TTv, NCv, WGMv) do { \
-            if constexpr (TTv == 64 && NCv <= 2) { if (short_k) { hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv, 2, 3>), grid, dim3(256), 0, st, a); break; } } \
-            hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv, 3, 2>), grid, dim3(256), 0, st, a); } while (0)
-        switch ((l * 128 + g.TT) * 16 + g.NC) {
-            case 64 * 16 + 1: AID_W4R(64, 1, 2); break;
-            case 64 * 16 + 2: AID_W4R(64, 2, 2); break;
-            case 64 * 16 + 4: AID_W4R(64, 4, 2); break;
-            case 32 * 16 + 1: AID_W4R(32, 1, 2); break;
-            case 32 * 16 + 2: AID_W4R(32, 2, 2); break;
-            case 32 * 16 + 4: AID_W4R(32, 4, 2); break;
-            case 32 * 16 + 8: AID_W4R(32, 8, 2); break;
-            case 16 * 16 + 1: AID_W4R(16, 1, 2); break;
-            case 16 * 16 + 2: AID_W4R(16, 2, 2); break;
-            case 16 * 16 + 4: AID_W4R(16, 4, 2); break;
-            case 16 * 16 + 8: AID_W4R(16, 8, 2); break;
-            case (128 + 64) * 16 + 1: AID_W4R(64, 1, 1); break;
-            case (128 + 64) * 16 + 2: AID_W4R(64, 2, 1); break;
-            default: aid_set_error("aid_conv2d: row-shared tile shape not instantiated"); return AID_E_BADARG;
-        }
-#undef AID_W4R
-        AID_CHECK_LAUNCH();
+        W4rGeo& ge = geo[l];
+        ge.quads = g.quads; ge.ttiles = g.ttiles;
+        ge.rgroups = p->dilF / g.NC;
+        ge.ny = m96 ? p->Cout_pad / 96 : p->Cout_pad / 64;
+        ge.m_base = l == 0 ? 0 : 64;
+        ge.m_stride = m96 ? 96 : 64;
+        ge.dot_base = dot_base;
+        dot_base += ge.rgroups * g.quads * g.ttiles;
+        ge.ntiles = p->B * ge.rgroups * g.quads * g.ttiles * ge.ny;
+        ge.per_xcd = (ge.ntiles + 7) / 8;
     }
-    aid_note_kernel(m96 ? "conv53_wino4r_kernel(64+32)" : (plan[0].NC == 1 ? "conv53_wino4r_kernel" : "conv53_wino4r_kernel(multi-class)"));
+    if (wino4r_splits(p, nl, geo[0].ntiles) == 2 && p->ws && p->ws_bytes >= aid_w4r_split_bytes(geo[0].ntiles)) {
+        a.splits = 2;
+        a.flags = reinterpret_cast<unsigned*>(p->ws);
+        a.part = p->ws + AID_W4R_SPLIT_FLAG_BYTES / 4;
+        a.nchunks = p->Cin / 4;
+        geo[0].ntiles *= 2;
+        geo[0].per_xcd = (geo[0].ntiles + 7) / 8;
+    }
+    const bool short_k = p->Cin <= 128 && a.splits == 1;     // three workgroups per CU (two LDS buffers) for the short-K layers (re-measured in round 3 with
+                                                             // sub-batch streams: Cin <= 128 / 64 / never = 42.33 / 42.08 / 42.17 evaluations/s)
+#define AID_W4R(TTv, NCv, WGMv, NC1v) do { \
+        if constexpr (TTv == 64 && NCv <= 2) { if (short_k) { hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv, 2, 3, 4, NC1v>), grid, dim3(256), 0, st, a); break; } } \
+        if constexpr (NC1v == 0 && WGMv == 2) { if (a.splits == 2) { hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv, 3, 2, 4, 0, true>), grid, dim3(256), 0, st, a); break; } } \
+        hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv, 3, 2, 4, NC1v>), grid, dim3(256), 0, st, a); } while (0)
+    if (m96 && pair_launch) {
+        a.g[0] = geo[0]; a.g[1] = geo[1];
+        const dim3 grid((unsigned)(8 * (geo[0].per_xcd + geo[1].per_xcd)));
+        switch (plan[0].NC * 16 + plan[1].NC) {               // (both families: TT = 64, wino4r_geometry)
+            case 1 * 16 + 1: AID_W4R(64, 1, 2, 1); break;
+            case 1 * 16 + 2: AID_W4R(64, 1, 2, 2); break;
+            case 2 * 16 + 1: AID_W4R(64, 2, 2, 1); break;
+            case 2 * 16 + 2: AID_W4R(64, 2, 2, 2); break;
+            case 4 * 16 + 1: AID_W4R(64, 4, 2, 1); break;
+            case 4 * 16 + 2: AID_W4R(64, 4, 2, 2); break;
+            default: aid_set_error("aid_conv2d: row-shared pair tile shape not instantiated"); return AID_E_BADARG;
+        }
+        AID_CHECK_LAUNCH();
+    } else {
+        for (int l = 0; l < nl; ++l) {
+            const Wino4rPlan& g = plan[l];
+            a.g[0] = geo[l]; a.g[1] = geo[l];
+            const dim3 grid((unsigned)(8 * geo[l].per_xcd));
+            switch ((l * 128 + g.TT) * 16 + g.NC) {
+                case 64 * 16 + 1: AID_W4R(64, 1, 2, 0); break;
+                case 64 * 16 + 2: AID_W4R(64, 2, 2, 0); break;
+                case 64 * 16 + 4: AID_W4R(64, 4, 2, 0); break;
+                case 32 * 16 + 1: AID_W4R(32, 1, 2, 0); break;
+                case 32 * 16 + 2: AID_W4R(32, 2, 2, 0); break;
+                case 32 * 16 + 4: AID_W4R(32, 4, 2, 0); break;
+                case 32 * 16 + 8: AID_W4R(32, 8, 2, 0); break;
+                case 16 * 16 + 1: AID_W4R(16, 1, 2, 0); break;
+                case 16 * 16 + 2: AID_W4R(16, 2, 2, 0); break;
+                case 16 * 16 + 4: AID_W4R(16, 4, 2, 0); break;
+                case 16 * 16 + 8: AID_W4R(16, 8, 2, 0); break;
+                case (128 + 64) * 16 + 1: AID_W4R(64, 1, 1, 0); break;
+                case (128 + 64) * 16 + 2: AID_W4R(64, 2, 1, 0); break;
+                default: aid_set_error("aid_conv2d: row-shared tile shape not instantiated"); return AID_E_BADARG;
+            }
+            AID_CHECK_LAUNCH();
+        }
+    }
+#undef AID_W4R
+    aid_note_kernel(m96 ? "conv53_wino4r_kernel(64+32)" : (a.splits == 2 ? "conv53_wino4r_kernel(split-K)" : (plan[0].NC == 1 ? "conv53_wino4r_kernel" : "conv53_wino4r_kernel(multi-class)")));
     return AID_OK;
+}
+
+// scratch of the split-K instances (aid_kernels.h: ws): 0 when a launch of this shape is not split
+extern "C" int64_t aid_conv2d_wino_split_ws_bytes(int B, int Cin, int Cout, int F, int T, int dilF) {
+    if (!wino_v_shape_ok(Cin, Cout, T)) return 0;
+    aid_conv2d_params q = {};
+    q.B = B; q.Cin = Cin; q.Cout = Cout; q.F = F; q.T = T; q.dilF = dilF; q.KH = 5; q.KW = 3;
+    aid_conv2d_pack_dims(Cin, Cout, &q.Cin_pad, &q.Cout_pad);
+    Wino4rPlan plan[2];
+    const int nl = wino4r_geometry(&q, plan);
+    if (nl != 1) return 0;
+    const int64_t ntiles = (int64_t)B * (dilF / plan[0].NC) * plan[0].quads * plan[0].ttiles * (q.Cout_pad / 64);
+    return wino4r_splits(&q, nl, ntiles) == 2 ? aid_w4r_split_bytes(ntiles) : 0;
 }
 
 // Output positions per tile of the 64-wide F(4,3) kernels: 512, or 256 when a launch would otherwise put fewer than ~0.75

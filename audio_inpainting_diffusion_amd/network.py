@@ -169,6 +169,7 @@ class _Builder:
         self.lane = 0          # lane of the ops emitted next (plan.py): 0 = trunk, 1 = init blocks / pyramid / out blocks
         self.use_lanes = not self.train and bool(getattr(net, "plan_lanes", True))
         self._stats_ws = {}    # lane -> scratch of the two-stage group reductions (lanes run concurrently: one each)
+        self._keep = []        # superseded scratch tensors that recorded launches still point into
         self.bwd = []          # (lane, closure emitting the VJP ops of a forward op); run in reverse by finish_backward
         self._stat_src = {}    # view key of a forward conv output -> (its params struct, partials per (b, group)): see stats()
         self._nb_src = {}      # (reverse sweep) view key of a gradient tensor -> (the aid_norm_bwd params that wrote it last, op index, end address)
@@ -206,6 +207,17 @@ class _Builder:
         t = self.scratch.get(key)
         if t is None:
             t = self.scratch[key] = self.buf(*[d for d in tuple(shape) if not isinstance(d, str)])
+        return t
+
+    def _split_ws(self, nbytes):
+        """split-K scratch of the row-shared F(4,3) kernel (aid_kernels.h: ws): zero flags + partial accumulators, one per lane"""
+        key = (self.lane, "w4r_split")
+        t = self.scratch.get(key)
+        if t is None or t.numel() * 4 < nbytes:
+            if t is not None:
+                self._keep.append(t)                      # launches already recorded point into it
+            t = self.scratch[key] = torch.zeros(max(nbytes, 4096 + 336 * 98304) // 4, device=self.device, dtype=torch.float32)
+            self.nbytes += t.numel() * 4
         return t
 
     @property
@@ -381,6 +393,11 @@ class _Builder:
         if F == 1 and kh == 1 and epi == 0:              # qk projections: few columns, long K -> split-K scratch (aid_kernels.h)
             ws = self._scratch(("ws", 8 * B * cout * T))
             p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        elif x_wino and B == 1:                          # batch 1: launches with few tiles share the K axis of a tile between two workgroups
+            need = int(_lib.lib().aid_conv2d_wino_split_ws_bytes(B, cin, cout, F, T, dil))
+            if need:
+                ws = self._split_ws(need)
+                p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
         assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] == 30 and wpw.shape[1:] == wp.shape[1:]))
         # algorithmic HBM bytes: x once, residual / aux once, y once, weights once
         nb = 4 * (B * F * T * (cin + cout * (1 + (res is not None) + (aux is not None))) + cin * cout * kh * kw)

@@ -28,7 +28,7 @@ extern "C" {
 #define AID_E_BADARG (-1)   /* unsupported shape / null pointer / misaligned stride */
 #define AID_E_LAUNCH (-2)   /* hipLaunchKernel reported an error                    */
 
-#define AID_ABI_VERSION 7
+#define AID_ABI_VERSION 8
 int aid_abi_version(void);
 /* last HIP error string seen by a launcher in this process (never NULL) */
 const char* aid_last_error(void);
@@ -111,7 +111,11 @@ typedef struct {
     float* ws; int64_t ws_bytes; /* optional scratch (the library never allocates): lets grid-starved 1x1 GEMMs (the qk projections:
                                  B*T columns only, K of several thousand) split K over up to 8 workgroups per tile; partial sums
                                  go to ws[S][B][Cout][F][T] and a second kernel reduces them in a FIXED order (deterministic) and
-                                 applies the epilogue.  NULL / too small: single-pass kernel. */
+                                 applies the epilogue.  NULL / too small: single-pass kernel.
+                                 5x3 layers on the row-shared F(4,3) kernel at B = 1 (aid_conv2d_wino_split_ws_bytes(...) > 0): the K axis of
+                                 every tile is shared by two workgroups; ws then holds [AID_CONV2D_SPLIT_FLAG_BYTES of flags][partial accumulators], and its
+                                 first AID_CONV2D_SPLIT_FLAG_BYTES bytes must be ZERO before the first use (the kernel leaves them zero);
+                                 one ws per stream.  NULL / too small: no split. */
     double* dot_ws; int dot_n;   /* optional (input-VJP, epi = 1 on the F(4,3) path or on a 1x1 layer, see aid_conv2d_dot_partials_1x1): the epilogue also reduces <y, aux> per
                                  (sample, channel group of Cout/8) over its tile and writes one partial per tile,
                                  dot_ws[(b*8 + g) * dot_n + tile_in_sample] -- the aid_group_dot pass over the dgrad output
@@ -134,6 +138,9 @@ int aid_conv2d_x2_supported(int Cin, int Cin1, int Cout, int F, int T);
 int aid_conv2d_wino_input_supported(int Cin, int Cout, int T);
 /* the same question with the layer's geometry: T = 16 layers are served only when the row-shared tiles fit F and the dilation */
 int aid_conv2d_wino_input_ok(int B, int Cin, int Cout, int F, int T, int dilF);
+/* bytes of `ws` a 5x3 x_wino layer of this shape wants for its split-K instance (B = 1 launches with few tiles); 0: the shape is not split */
+#define AID_CONV2D_SPLIT_FLAG_BYTES 4096
+int64_t aid_conv2d_wino_split_ws_bytes(int B, int Cin, int Cout, int F, int T, int dilF);
 /* number of per-tile partial dots per (sample, group) the F(4,3) epilogue writes for this shape; 0 = not supported */
 int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino);
 /* number of per-tile (sum, sum of squares) partials per (sample, group) for stat_ws; 0 = the kernel that takes this shape does not write them */

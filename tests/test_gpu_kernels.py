@@ -195,6 +195,11 @@ WINO_V_CASES = [
     (2, 64, 96, 48, 64, 2, 0, False),        # remainder tile over two residue classes <64, 2, 1>
     (2, 96, 96, 20, 256, 4, 1, True),        # 5 rows per class: the row-shared kernel declines -> 96 x 512 tiles
     (2, 64, 96, 16, 32, 2, 0, False),        # T = 32: no remainder-tile instance -> 96 x 512 tiles
+    # batch 1, few tiles: the split-K instances (two workgroups per tile) when `ws` is given
+    (1, 256, 128, 384, 64, 2, 1, True),      # 192 tiles (the first up-path conv of level 5)
+    (1, 128, 128, 160, 128, 32, 0, True),    # 160 tiles, <64, 4>
+    (1, 256, 256, 448, 32, 64, 1, False),    # <32, 8>
+    (1, 96, 64, 36, 128, 1, 1, True),        # 24 chunks per half
 ]
 
 
@@ -240,6 +245,25 @@ def test_conv2d_winograd_domain_input(L, case):
     L.call("aid_conv2d", p)
     torch.cuda.synchronize()
     assert rel_l2(y.cpu(), ref) < 1e-5
+    # (3) split-K (batch 1, few tiles): same result up to the order of one addition, deterministic, flags left zero
+    need = int(L.lib().aid_conv2d_wino_split_ws_bytes(B, Cin, Cout, Fd, T, dil))
+    tiles = B * Fd * T * (Cout // 64) // 256
+    assert (need > 0) == (B == 1 and Cout % 64 == 0 and tiles <= 230 and "wino4r" in L.lib().aid_last_kernel().decode()), (need, L.lib().aid_last_kernel().decode())
+    if need:
+        ws = torch.zeros(need // 4 + 8, device=DEV)
+        ws[need // 4:] = 7.0
+        p.ws, p.ws_bytes = ws.data_ptr(), need
+        ys = []
+        for _ in range(3):
+            y2 = torch.full_like(y, float("nan"))
+            p.y = L.view4(y2)
+            L.call("aid_conv2d", p)
+            assert L.lib().aid_last_kernel().decode() == "conv53_wino4r_kernel(split-K)"
+            ys.append(y2)
+        torch.cuda.synchronize()
+        assert rel_l2(ys[0].cpu(), ref) < 1e-5 and rel_l2(ys[0].cpu(), y.cpu()) < 5e-6
+        assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+        assert float(ws[:1024].abs().max()) == 0.0 and float(ws[need // 4:].min()) == 7.0
 
 
 # ---------------------------------------------------------------------------------------------------------

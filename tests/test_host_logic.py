@@ -23,7 +23,7 @@ from conftest import GOLDEN, ROOT, rel_l2
 def test_c_abi_exports_every_declared_symbol():
     import ctypes
     hdr = open(os.path.join(ROOT, "include", "aid_kernels.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|void|const char\*)\s+(aid_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|void|const char\*)\s+(aid_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 15
     so = os.path.join(ROOT, "audio_inpainting_diffusion_amd", "libaid_hip.so")
     if not os.path.exists(so):
@@ -33,7 +33,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in aid_kernels.h but not exported"
     lib.aid_abi_version.restype = ctypes.c_int
-    assert lib.aid_abi_version() == int(re.search(r"#define AID_ABI_VERSION (\d+)", hdr).group(1)) == 7
+    assert lib.aid_abi_version() == int(re.search(r"#define AID_ABI_VERSION (\d+)", hdr).group(1)) == 8
     from audio_inpainting_diffusion_amd import _lib
     assert set(_lib.EXPORTS) == declared
     a, b = _lib.pack_dims(2, 96)

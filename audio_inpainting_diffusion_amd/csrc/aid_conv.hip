@@ -483,6 +483,7 @@ int aid_conv53_wino_try(const aid_conv2d_params* p, hipStream_t st);  // aid_con
 int aid_conv1x1_stream_try(const aid_conv2d_params* p, hipStream_t st);  // aid_conv1x1.hip
 int aid_conv1x1_dma_try(const aid_conv2d_params* p, hipStream_t st);     // aid_conv1x1_dma.hip
 int aid_conv_small_try(const aid_conv2d_params* p, hipStream_t st);      // aid_conv_small.hip
+int aid_conv1x1_rs_try(const aid_conv2d_params* p, hipStream_t st);      // aid_conv1x1_rs.hip
 
 extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -500,8 +501,9 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     if (p->x2.p) {
         AID_REQUIRE(p->KH == 1 && p->KW == 1 && !p->in_scale && p->act == 0 && p->Cin1 > 0 && p->Cin1 < p->Cin && (p->Cin1 % 16) == 0 && ((p->Cin - p->Cin1) % 16) == 0,
                     "aid_conv2d: x2 is an option of plain 1x1 convolutions with both K segments multiples of 16");
-        const int r = aid_conv1x1_dma_try(p, st);
-        if (r == 0) aid_set_error("aid_conv2d: x2 given but the layer is not eligible for the direct-to-LDS 1x1 kernel");
+        int r = aid_conv1x1_rs_try(p, st);
+        if (r == 0) r = aid_conv1x1_dma_try(p, st);
+        if (r == 0) aid_set_error("aid_conv2d: x2 given but the layer is not eligible for the 1x1 kernels that take it");
         return r == 1 ? AID_OK : (r < 0 ? r : AID_E_BADARG);
     }
     if (p->stat_ws) {
@@ -510,7 +512,8 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     }
     if (p->dot_ws && p->KH == 1 && p->KW == 1) {                     // <y, aux> partials from the direct-to-LDS 1x1 kernel's dGELU epilogue
         AID_REQUIRE(p->epi == 1 && !p->res.p, "aid_conv2d: dot_ws on a 1x1 layer is an option of the dGELU epilogue without residual");
-        const int r = aid_conv1x1_dma_try(p, st);
+        int r = aid_conv1x1_rs_try(p, st);
+        if (r == 0) r = aid_conv1x1_dma_try(p, st);
         if (r == 0) aid_set_error("aid_conv2d: dot_ws given but the 1x1 layer is not eligible (aid_conv2d_dot_partials_1x1)");
         return r == 1 ? AID_OK : (r < 0 ? r : AID_E_BADARG);
     }
@@ -543,7 +546,9 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     }
     if (p->KH == 1 && p->KW == 1) {
         {
-            int r = aid_conv1x1_dma_try(p, st);              // direct-to-LDS kernel, 2-3 workgroups per CU (K % 16 == 0, Cout tile 64/96/128)
+            int r = aid_conv1x1_rs_try(p, st);               // K <= 256, HBM-bound: register-streamed kernel (weights resident in LDS)
+            if (r != 0) return r < 0 ? r : AID_OK;
+            r = aid_conv1x1_dma_try(p, st);                  // direct-to-LDS kernel, 2-3 workgroups per CU (K % 16 == 0, Cout tile 64/96/128)
             if (r != 0) return r < 0 ? r : AID_OK;
             r = aid_conv1x1_stream_try(p, st);               // remaining short-K / narrow projections: streaming kernel
             if (r != 0) return r < 0 ? r : AID_OK;

@@ -393,9 +393,18 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const aid_conv2d_param
 }
 
 // partials per (sample, group) of the <y, aux> option on this kernel (epi = 1 on a 1x1 layer): position tiles per sample; 0 = not available
+int aid_conv1x1_rs_dot_partials(int Cin, int Cout, int cop, int F, int T);   // aid_conv1x1_rs.hip
+int aid_conv1x1_rs_shape_ok(int Cin, int Cout, int cop, int F, int T);
+int aid_conv1x1_rs_enabled(void);
+
 extern "C" int aid_conv2d_dot_partials_1x1(int B, int Cin, int Cout, int F, int T) {
     int cip, cop;
     aid_conv2d_pack_dims(Cin, Cout, &cip, &cop);
+    if (aid_conv1x1_rs_enabled()) {                                   // the register-streamed kernel takes the shapes it serves
+        const int n = aid_conv1x1_rs_dot_partials(Cin, Cout, cop, F, T);
+        if (n) return n;
+        if (aid_conv1x1_rs_shape_ok(Cin, Cout, cop, F, T)) return 0;
+    }
     if (F <= 1 || Cin < 32 || (Cin % 16) || Cout < 32 || (Cout % 8) || (T % 4) || aid_pow2ceil(T) < 8) return 0;
     const int mblk = (cop % 128 == 0) ? 128 : ((cop % 64 == 0) ? 64 : ((cop % 96 == 0) ? 96 : 0));
     const int cpg = Cout / 8;

@@ -768,13 +768,97 @@ def test_conv1x1_with_the_k_axis_in_two_tensors(L, case):
     p.KH, p.KW, p.dilF, p.act, p.epi = 1, 1, 1, 0, 0
     p.alpha, p.res_scale = 1.0, 1.0
     L.call("aid_conv2d", p)
-    assert L.lib().aid_last_kernel().decode() == "conv11_dma_kernel"
+    assert L.lib().aid_last_kernel().decode() in ("conv11_dma_kernel", "conv11_rs_kernel")
     e = rel_l2(yd.cpu(), ref)
     assert e < 1e-5, e
     # unsupported shapes are refused loudly, not routed elsewhere
     p.Cin1 = c1 + 1
     with pytest.raises(L.AidError):
         L.call("aid_conv2d", p)
+
+
+RS_CASES = [
+    # B, Cin, Cout, F, T, act (GELU prologue + in_scale), in_scale, epi (dGELU(aux)), res + out_scale, dot partials, Cin1 (x2), strided x
+    (2, 64, 64, 8, 64, 1, 1, 0, 1, 0, 0, 1),
+    (1, 96, 96, 6, 32, 0, 0, 1, 0, 1, 0, 0),        # a 64-position tile spans two rows
+    (3, 128, 96, 4, 48, 0, 1, 1, 0, 1, 0, 0),       # T not a power of two
+    (2, 256, 64, 2, 96, 0, 0, 0, 0, 0, 0, 1),       # K = 256: eight blocks of 16 k-steps
+    (2, 64, 256, 4, 32, 1, 1, 0, 1, 0, 0, 0),       # 128-channel Cout slices (GELU prologue only), two of them
+    (1, 128, 128, 8, 64, 1, 1, 0, 0, 0, 0, 1),
+    (2, 128, 128, 8, 64, 0, 0, 1, 0, 1, 0, 0),      # ... without the GELU prologue the direct-to-LDS tile kernel keeps the layer
+    (1, 192, 96, 8, 16, 0, 0, 0, 1, 0, 64, 0),      # K axis in two tensors
+    (8, 64, 96, 16, 128, 0, 0, 0, 1, 0, 0, 0),      # more tiles than waves: the persistent loop
+    (1, 96, 64, 2, 2048, 1, 1, 0, 0, 0, 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", RS_CASES)
+def test_conv1x1_register_streamed_kernel(L, case):
+    """conv11_rs_kernel (K <= 256 1x1 layers: weights resident in LDS, activations HBM -> registers) with every prologue / epilogue option
+    against an fp64 reference of  y = alpha * (res_scale * res + out_scale * dGELU(aux * aux_scale) * (W (act(x * in_scale)))) ."""
+    B, Cin, Cout, Fd, T, act, isc_on, epi, res_on, dot_on, cin1, strided = case
+    g = torch.Generator().manual_seed(11)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    big = rn(B, Cin + 8, Fd, T)
+    x = big[:, 4:4 + Cin] if strided else big[:, :Cin].contiguous()
+    w = rn(Cout, Cin, 1, 1) / math.sqrt(Cin)
+    isc = (1.0 + 0.5 * rn(B, Cin)) if isc_on else None
+    osc = (1.0 + 0.3 * rn(B, Cout)) if (res_on or epi) else None
+    res = rn(B, Cout, Fd, T) if res_on else None
+    aux, asc = (rn(B, Cout, Fd, T), 1.0 + 0.3 * rn(B, Cout)) if epi else (None, None)
+    alpha, res_scale = 0.7, 1.5
+    h = x.double()
+    if isc is not None:
+        h = h * isc.double()[:, :, None, None]
+    if act:
+        h = F.gelu(h)
+    ref = F.conv2d(h, w.double())
+    if osc is not None:
+        ref = ref * osc.double()[:, :, None, None]
+    if epi:
+        u = aux.double() * asc.double()[:, :, None, None]
+        ref = ref * (0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi))
+    if res is not None:
+        ref = ref + res_scale * res.double()
+    ref = alpha * ref
+    bigd = big.to(DEV)
+    xd = bigd[:, 4:4 + Cin] if strided else bigd[:, :Cin].contiguous()
+    dv = lambda t: None if t is None else t.to(DEV)
+    iscd, oscd, resd, auxd, ascd = dv(isc), dv(osc), dv(res), dv(aux), dv(asc)
+    wp = L.pack_conv_weight(w.to(DEV))
+    y = torch.full((B, Cout + 2, Fd, T), 7.0, device=DEV)
+    p = L.Conv2dParams()
+    if cin1:
+        x1d, x2d = xd[:, :cin1].contiguous(), xd[:, cin1:].contiguous()
+        p.x, p.x2, p.Cin1 = L.view4(x1d), L.view4(x2d), cin1
+    else:
+        p.x = L.view4(xd)
+    p.y, p.res, p.aux = L.view4(y[:, 1:1 + Cout]), L.view4(resd), L.view4(auxd)
+    p.wp = wp.data_ptr()
+    p.in_scale, p.in_scale_ld = L.ptr(iscd), (0 if iscd is None else iscd.stride(0))
+    p.out_scale, p.out_scale_ld = L.ptr(oscd), (0 if oscd is None else oscd.stride(0))
+    p.aux_scale, p.aux_scale_ld = L.ptr(ascd), (0 if ascd is None else ascd.stride(0))
+    p.B, p.Cin, p.Cout, p.F, p.T = B, Cin, Cout, Fd, T
+    p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
+    p.KH, p.KW, p.dilF, p.act, p.epi = 1, 1, 1, act, epi
+    p.alpha, p.res_scale = alpha, res_scale
+    if dot_on:
+        P = int(L.lib().aid_conv2d_dot_partials_1x1(B, Cin, Cout, Fd, T))
+        assert P == (Fd * T // 64 if Cout in (64, 96) else Fd * T // 256)
+        ws = torch.full((B * 8 * P + 4,), float("nan"), device=DEV, dtype=torch.float64)
+        p.dot_ws, p.dot_n = ws.data_ptr(), P
+    L.call("aid_conv2d", p)
+    assert L.lib().aid_last_kernel().decode() == ("conv11_rs_kernel" if (Cout in (64, 96) or act) else "conv11_dma_kernel")
+    torch.cuda.synchronize()
+    yc = y[:, 1:1 + Cout].cpu().double()
+    e = rel_l2(yc, ref)
+    assert e < 1e-5, e
+    assert float(y[:, 0].min()) == 7.0 and float(y[:, 1 + Cout].max()) == 7.0, "wrote outside its channel slice"
+    if dot_on:
+        assert bool(torch.isnan(ws[B * 8 * P:]).all())
+        got = ws[:B * 8 * P].cpu().reshape(B, 8, P).sum(-1)
+        want = (yc * aux.double()).reshape(B, 8, Cout // 8, Fd, T).sum((2, 3, 4))
+        assert float((got - want).abs().max()) < 1e-5 * float((yc.abs() * aux.double().abs()).reshape(B, 8, -1).sum(-1).max())
 
 
 def test_qk_gemm_is_bit_identical_across_batch_sizes(L):

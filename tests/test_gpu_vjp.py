@@ -272,7 +272,7 @@ def test_conv1x1_epilogue_dot_partials(L, case):
     p.alpha, p.res_scale = 0.7, 1.0
     p.dot_ws, p.dot_n = ws.data_ptr(), P
     L.call("aid_conv2d", p)
-    assert L.lib().aid_last_kernel().decode() == "conv11_dma_kernel"
+    assert L.lib().aid_last_kernel().decode() in ("conv11_dma_kernel", "conv11_rs_kernel")
     yc = y.cpu().double()
     u = aux.double() * asc.double()[:, :, None, None]
     dg = 0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round-3 measurement sweep (run on the GPU box; everything lands in gpurun_out/r03_*; copy into profiles/ what should be judged).
-# usage: tools/r03_measure.sh [part ...]   parts: bench variants small prof pmc pointwise traces e2e train   (default: all)
+# usage: tools/r03_measure.sh [part ...]   parts: bench variants small prof pmc pointwise traces e2e train c11   (default: all)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out
-parts=${@:-bench variants small prof pmc pointwise traces e2e train}
+parts=${@:-bench variants small prof pmc pointwise traces e2e train c11}
 run() { python bench.py --no-cpu-baseline "$@" 2>/dev/null; }
 for part in $parts; do case $part in
 bench)
@@ -47,6 +47,12 @@ traces)
   python bench.py --no-cpu-baseline --streams 1 --conv-table > /dev/null 2> $O/r03_conv_table.txt ;;
 e2e)
   { python tools/e2e_run.py maestro22k 8; python tools/e2e_run.py maestro22k 1; python tools/e2e_run.py musicnet44k 4; python tools/e2e_run.py librispeech16k 16; } > $O/r03_e2e_full_runs.txt 2>/dev/null ;;
+c11)
+  { for rs in 0 1; do echo "== AID_C11_RS=$rs (1: conv11_rs_kernel where it is selected; 0: the tile kernels)"; AID_C11_RS=$rs timeout 300 python tools/c11_probe.py 8; done
+    echo "== ablation of conv11_rs_kernel (AID_C11_MODE: 1 no y stores, 2 no x loads, 4 no MFMAs)"
+    for m in 1 2 4 7; do echo "-- mode $m"; AID_C11_MODE=$m timeout 300 python tools/c11_probe.py 8 | head -8; done
+    for rs in 0 1; do echo "== batch 1, AID_C11_RS=$rs"; AID_C11_RS=$rs timeout 300 python tools/c11_probe.py 1; done
+  } 2>&1 | grep -v amdgpu.ids > $O/r03_c11_probe.txt ;;
 train)
   { python tools/train_bench.py 4 3; python tools/train_bench.py 8 3; } > $O/r03_train_bench.txt 2>/dev/null ;;
 esac; done

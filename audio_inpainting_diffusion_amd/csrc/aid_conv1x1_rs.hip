@@ -30,11 +30,14 @@ struct C11RDev {
 };
 
 // returns the number of <y, aux> partial slots per (sample, group) = tiles per sample, or 0 when the shape is not served
-// 128-channel Cout slices (MT = 4: 128 accumulators + the gather registers of the epilogue) measured behind conv11_dma_kernel except with the GELU
-// prologue, which that kernel does not have (profiles/r03_c11_probe.txt): `act` selects them.
-static int c11rs_shape(int Cin, int Cout, int cop, int F, int T, int act) {
+// Which layers (a function of the per-sample shape only, so that a segment's result does not depend on its batch): measured per shape at batch 8 AND
+// batch 1 against the tile kernels (profiles/r03_trace_b8.txt / _b1.txt before and after): 96 output channels (MT = 3) win for every K <= 256
+// (batch 8: -12 ... -32 %); 64 output channels (MT = 2) win at K = 64 and lose at K = 128 / 192 (more waves would be needed to cover the longer K
+// loop's exposed first block); 128-channel slices (MT = 4: 128 accumulators + the epilogue's gather registers, 64-128 KB of weights per workgroup)
+// lose on the small pyramid levels by 2x (32 ... 128 tiles per sample: one wave per tile, most SIMDs idle) and are not instantiated.
+static int c11rs_shape(int Cin, int Cout, int cop, int F, int T) {
     if (F <= 1 || Cin < 32 || (Cin % 32) || Cin > 256 || Cout < 32) return 0;
-    if (!((cop % 128 == 0 && act) || cop == 64 || cop == 96) || Cout != cop) return 0;
+    if (!(cop == 96 || (cop == 64 && Cin <= 64)) || Cout != cop) return 0;
     if ((T % 2) || (((int64_t)F * T) % 64)) return 0;
     return (int)(((int64_t)F * T) / 64);
 }
@@ -64,21 +67,41 @@ __global__ __launch_bounds__(512, 1) void conv11_rs_kernel(const C11RDev a) {
     }
     __syncthreads();
 
+    // Addressing: per-sample base pointers are wave-uniform (scalar registers); a lane's offsets within the sample are 32-bit byte offsets
+    // that advance by adding a scalar stride -- the 64-bit multiply-adds of the straightforward form were a third of the kernel's VALU issue.
+    // The context of a tile (sample, row, first position, load addresses) is set by `seek`.  Measured and dropped: requesting the first U k-steps of the
+    // NEXT tile before the epilogue of the current one (the ring stays live through the epilogue: 96-channel dGELU instances spill; the others
+    // -1 ... +8 % per launch, K > 64 on the losing side, end to end +0.6 % instead of +0.9 %).
     const int wstep = gridDim.x * 8;
-    for (int tl = blockIdx.x * 8 + wave; tl < a.ntiles; tl += wstep) {
-        // Addressing: per-sample base pointers are wave-uniform (scalar registers); a lane's offsets within the sample are 32-bit byte offsets
-        // that advance by adding a scalar stride -- the 64-bit multiply-adds of the straightforward form were a third of the kernel's VALU issue.
-        const int b = tl / a.tps;
-        const int tin = tl - b * a.tps;
+    const unsigned xs = 8u * (unsigned)p.x.sC, xs2 = 8u * (unsigned)p.x2.sC;
+    int b = 0, tin = 0, f = 0, t = 0;
+    const char* xb = nullptr;
+    const char* xb2 = nullptr;
+    unsigned xo = 0, xo2 = 0;
+    const float* sp = nullptr;
+    float2 ring[U];
+    float scr[SCALE ? U : 1];
+    auto seek = [&](int tl) {
+        b = tl / a.tps;
+        tin = tl - b * a.tps;
         const int pos = tin * 64 + 2 * n;                 // first of this lane's two positions within the sample
-        const int f = pos / p.T, t = pos - f * p.T;
-        const char* xb = reinterpret_cast<const char*>(p.x.p + (int64_t)b * p.x.sB);
-        const char* xb2 = p.x2.p ? reinterpret_cast<const char*>(p.x2.p + (int64_t)b * p.x2.sB) : xb;
-        const unsigned xo = 4u * (unsigned)(f * (int)p.x.sF + t + half * (int)p.x.sC);
-        const unsigned xo2 = p.x2.p ? 4u * (unsigned)(f * (int)p.x2.sF + t + half * (int)p.x2.sC) : xo;
-        const unsigned xs = 8u * (unsigned)p.x.sC, xs2 = 8u * (unsigned)p.x2.sC;
-        const float* sp = SCALE ? p.in_scale + (int64_t)b * p.in_scale_ld + half : nullptr;
-
+        f = pos / p.T; t = pos - f * p.T;
+        xb = reinterpret_cast<const char*>(p.x.p + (int64_t)b * p.x.sB);
+        xb2 = p.x2.p ? reinterpret_cast<const char*>(p.x2.p + (int64_t)b * p.x2.sB) : xb;
+        xo = 4u * (unsigned)(f * (int)p.x.sF + t + half * (int)p.x.sC);
+        xo2 = p.x2.p ? 4u * (unsigned)(f * (int)p.x2.sF + t + half * (int)p.x2.sC) : xo;
+        sp = SCALE ? p.in_scale + (int64_t)b * p.in_scale_ld + half : nullptr;
+    };
+    auto ld = [&](int s, int q) {                         // s is wave-uniform
+        if (a.mode & 2) ring[q] = make_float2(1.f, 2.f);
+        else if (s < a.nsteps1) ring[q] = *reinterpret_cast<const float2*>(xb + (xo + (unsigned)s * xs));
+        else ring[q] = *reinterpret_cast<const float2*>(xb2 + (xo2 + (unsigned)(s - a.nsteps1) * xs2));
+        if (SCALE) scr[q] = sp[2 * s];
+    };
+    for (int tl = blockIdx.x * 8 + wave; tl < a.ntiles; tl += wstep) {
+        seek(tl);
+#pragma unroll
+        for (int q = 0; q < U; ++q) ld(q, q);
         f32x16 acc[MT][2];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -87,16 +110,6 @@ __global__ __launch_bounds__(512, 1) void conv11_rs_kernel(const C11RDev a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        float2 ring[U];
-        float scr[SCALE ? U : 1];
-        auto ld = [&](int s, int q) {                     // s is wave-uniform
-            if (a.mode & 2) ring[q] = make_float2(1.f, 2.f);
-            else if (s < a.nsteps1) ring[q] = *reinterpret_cast<const float2*>(xb + (xo + (unsigned)s * xs));
-            else ring[q] = *reinterpret_cast<const float2*>(xb2 + (xo2 + (unsigned)(s - a.nsteps1) * xs2));
-            if (SCALE) scr[q] = sp[2 * s];
-        };
-#pragma unroll
-        for (int q = 0; q < U; ++q) ld(q, q);
         for (int s0 = 0; s0 < a.nsteps; s0 += U) {
             const bool more = s0 + U < a.nsteps;
             const float* wr0 = wl + (2 * s0 + half) * WROW + n;
@@ -117,26 +130,30 @@ __global__ __launch_bounds__(512, 1) void conv11_rs_kernel(const C11RDev a) {
         }
 
         // ---- epilogue: two consecutive positions per lane and output channel ------------------------------------------------------
+        const int be = b, tine = tin;
         char* yb = reinterpret_cast<char*>(p.y.p + (int64_t)b * p.y.sB);
         const char* rb = RES ? reinterpret_cast<const char*>(p.res.p + (int64_t)b * p.res.sB) : nullptr;
         const char* ab = EPI ? reinterpret_cast<const char*>(p.aux.p + (int64_t)b * p.aux.sB) : nullptr;
         const float* osb = p.out_scale ? p.out_scale + (int64_t)b * p.out_scale_ld : nullptr;
         const float* asb = EPI ? p.aux_scale + (int64_t)b * p.aux_scale_ld : nullptr;
+        const unsigned ypos = 4u * (unsigned)(f * (int)p.y.sF + t);
+        const unsigned rpos = RES ? 4u * (unsigned)(f * (int)p.res.sF + t) : 0u;
+        const unsigned upos = EPI ? 4u * (unsigned)(f * (int)p.aux.sF + t) : 0u;
         float dsum[MT][4];                                // <y, aux> per block of 4 channels (dot_ws)
         int hv = half;
         asm volatile("" : "+v"(hv));                      // (opaque: the row offsets m * sC are tile-invariant and would otherwise be hoisted out of the
                                                           //  tile loop into ~190 registers that spill)
         const unsigned ys = 4u * (unsigned)p.y.sC, rs = 4u * (unsigned)p.res.sC, us = 4u * (unsigned)p.aux.sC;
         const int mb0 = m0 + 4 * hv;
-        const unsigned yo = 4u * (unsigned)(f * (int)p.y.sF + t) + (unsigned)mb0 * ys;
-        const unsigned ro = RES ? 4u * (unsigned)(f * (int)p.res.sF + t) + (unsigned)mb0 * rs : 0u;
-        const unsigned uo = EPI ? 4u * (unsigned)(f * (int)p.aux.sF + t) + (unsigned)mb0 * us : 0u;
+        const unsigned yo = ypos + (unsigned)mb0 * ys;
+        const unsigned ro = RES ? rpos + (unsigned)mb0 * rs : 0u;
+        const unsigned uo = EPI ? upos + (unsigned)mb0 * us : 0u;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int mbase = mb0 + 32 * i;
 #pragma unroll
             for (int q = 0; q < 4; ++q) dsum[i][q] = 0.f;
-            constexpr int RB = (MT == 4 && EPI && (RES || SCALE)) ? 4 : 8;     // rows gathered per batch (register budget)
+            constexpr int RB = 8;                         // rows gathered per batch
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += RB) {         // gather RB rows, then compute + store (res may alias y)
                 float2 rv[RES ? RB : 1], uv[EPI ? RB : 1];
@@ -182,7 +199,7 @@ __global__ __launch_bounds__(512, 1) void conv11_rs_kernel(const C11RDev a) {
                     if (c0 / cpg == g) sacc += v0;
                     if ((c0 + 4) / cpg == g) sacc += v1;
                 }
-            if (lane < WROW / cpg && g < 8) p.dot_ws[((int64_t)b * 8 + g) * p.dot_n + tin] = (double)sacc;
+            if (lane < WROW / cpg && g < 8) p.dot_ws[((int64_t)be * 8 + g) * p.dot_n + tine] = (double)sacc;
         }
     }
 }
@@ -205,10 +222,9 @@ static int launch_c11rs(const aid_conv2d_params* p, hipStream_t st) {
     const dim3 grid((unsigned)gx, (unsigned)ny);
 #define AID_C11RS(ACTv, SCv, EPIv, RESv) hipLaunchKernelGGL((conv11_rs_kernel<MT, KMAX, ACTv, SCv, EPIv, RESv>), grid, dim3(512), 0, st, a)
     const int key = (p->act ? 8 : 0) | (p->in_scale ? 4 : 0) | (p->epi == 1 ? 2 : 0) | (p->res.p ? 1 : 0);
-    if (key == 12)      AID_C11RS(true, true, false, false);
-    else if (key == 13) AID_C11RS(true, true, false, true);
-    else if constexpr (MT == 4) return 1000;             // (128-channel slices: GELU-prologue layers only, see c11rs_shape)
-    else switch (key) {                                  // (the combinations the network emits; anything else goes to the tile kernels)
+    switch (key) {                                       // (the combinations the network emits; anything else goes to the tile kernels)
+        case 12: AID_C11RS(true, true, false, false); break;
+        case 13: AID_C11RS(true, true, false, true); break;
         case 0:  AID_C11RS(false, false, false, false); break;
         case 1:  AID_C11RS(false, false, false, true); break;
         case 2:  AID_C11RS(false, false, true, false); break;
@@ -226,7 +242,7 @@ static int launch_c11rs(const aid_conv2d_params* p, hipStream_t st) {
 
 // <y, aux> partial slots per (sample, group) when this kernel serves the shape (0: it does not)
 int aid_conv1x1_rs_dot_partials(int Cin, int Cout, int cop, int F, int T) {
-    const int n = c11rs_shape(Cin, Cout, cop, F, T, 0);
+    const int n = c11rs_shape(Cin, Cout, cop, F, T);
     if (!n || (Cout % 8)) return 0;
     const int cpg = Cout / 8;
     const int mblk = (cop % 128 == 0) ? 128 : cop;
@@ -234,7 +250,7 @@ int aid_conv1x1_rs_dot_partials(int Cin, int Cout, int cop, int F, int T) {
     return n;
 }
 
-int aid_conv1x1_rs_shape_ok(int Cin, int Cout, int cop, int F, int T) { return c11rs_shape(Cin, Cout, cop, F, T, 0) ? 1 : 0; }
+int aid_conv1x1_rs_shape_ok(int Cin, int Cout, int cop, int F, int T) { return c11rs_shape(Cin, Cout, cop, F, T) ? 1 : 0; }
 
 int aid_conv1x1_rs_enabled(void) {
     static const int enabled = getenv("AID_C11_RS") ? atoi(getenv("AID_C11_RS")) : 1;
@@ -245,7 +261,7 @@ int aid_conv1x1_rs_enabled(void) {
 int aid_conv1x1_rs_try(const aid_conv2d_params* p, hipStream_t st) {
     if (!aid_conv1x1_rs_enabled()) return 0;
     if (!(p->KH == 1 && p->KW == 1) || p->ws || (p->act && !p->in_scale) || p->Cout != p->Cout_pad) return 0;
-    if (!c11rs_shape(p->Cin, p->Cout, p->Cout_pad, p->F, p->T, p->act)) return 0;
+    if (!c11rs_shape(p->Cin, p->Cout, p->Cout_pad, p->F, p->T)) return 0;
     auto al = [](const aid_view& v, int q) { return (v.sB % q) == 0 && (v.sC % q) == 0 && (v.sF % q) == 0 && (((uintptr_t)v.p) & (4 * q - 1)) == 0; };
     if (!al(p->x, 2) || !al(p->y, 2) || (p->res.p && !al(p->res, 2)) || (p->aux.p && !al(p->aux, 2))) return 0;
     if (p->x2.p && (!al(p->x2, 2) || (p->Cin1 % 2) || p->Cin1 <= 0 || p->Cin1 >= p->Cin || p->in_scale || p->act)) return 0;
@@ -255,9 +271,8 @@ int aid_conv1x1_rs_try(const aid_conv2d_params* p, hipStream_t st) {
     if (p->dot_ws && (p->epi != 1 || p->dot_n <= 0 || p->dot_n != aid_conv1x1_rs_dot_partials(p->Cin, p->Cout, p->Cout_pad, p->F, p->T))) return 0;
     int rc;
     const bool k128 = p->Cin <= 128;
-    if (p->Cout_pad % 128 == 0) rc = k128 ? launch_c11rs<4, 128>(p, st) : launch_c11rs<4, 256>(p, st);
-    else if (p->Cout_pad == 96) rc = k128 ? launch_c11rs<3, 128>(p, st) : launch_c11rs<3, 256>(p, st);
-    else                        rc = k128 ? launch_c11rs<2, 128>(p, st) : launch_c11rs<2, 256>(p, st);
+    if (p->Cout_pad == 96) rc = k128 ? launch_c11rs<3, 128>(p, st) : launch_c11rs<3, 256>(p, st);
+    else                   rc = launch_c11rs<2, 128>(p, st);
     if (rc == 1000) return 0;
     return rc == AID_OK ? 1 : rc;
 }

@@ -782,13 +782,12 @@ RS_CASES = [
     (2, 64, 64, 8, 64, 1, 1, 0, 1, 0, 0, 1),
     (1, 96, 96, 6, 32, 0, 0, 1, 0, 1, 0, 0),        # a 64-position tile spans two rows
     (3, 128, 96, 4, 48, 0, 1, 1, 0, 1, 0, 0),       # T not a power of two
-    (2, 256, 64, 2, 96, 0, 0, 0, 0, 0, 0, 1),       # K = 256: eight blocks of 16 k-steps
-    (2, 64, 256, 4, 32, 1, 1, 0, 1, 0, 0, 0),       # 128-channel Cout slices (GELU prologue only), two of them
-    (1, 128, 128, 8, 64, 1, 1, 0, 0, 0, 0, 1),
-    (2, 128, 128, 8, 64, 0, 0, 1, 0, 1, 0, 0),      # ... without the GELU prologue the direct-to-LDS tile kernel keeps the layer
+    (2, 256, 96, 2, 96, 0, 0, 0, 0, 0, 0, 1),       # K = 256: eight blocks of 16 k-steps
+    (2, 128, 128, 8, 64, 0, 0, 1, 0, 1, 0, 0),      # 128 output channels: the direct-to-LDS tile kernel keeps the layer
+    (2, 128, 64, 8, 64, 0, 0, 0, 1, 0, 0, 0),       # ... and 64 output channels with K > 64
     (1, 192, 96, 8, 16, 0, 0, 0, 1, 0, 64, 0),      # K axis in two tensors
     (8, 64, 96, 16, 128, 0, 0, 0, 1, 0, 0, 0),      # more tiles than waves: the persistent loop
-    (1, 96, 64, 2, 2048, 1, 1, 0, 0, 0, 0, 0),
+    (1, 64, 64, 2, 2048, 1, 1, 0, 0, 0, 0, 0),
 ]
 
 
@@ -844,11 +843,11 @@ def test_conv1x1_register_streamed_kernel(L, case):
     p.alpha, p.res_scale = alpha, res_scale
     if dot_on:
         P = int(L.lib().aid_conv2d_dot_partials_1x1(B, Cin, Cout, Fd, T))
-        assert P == (Fd * T // 64 if Cout in (64, 96) else Fd * T // 256)
+        assert P == (Fd * T // 64 if (Cout == 96 or (Cout == 64 and Cin <= 64)) else Fd * T // 256)
         ws = torch.full((B * 8 * P + 4,), float("nan"), device=DEV, dtype=torch.float64)
         p.dot_ws, p.dot_n = ws.data_ptr(), P
     L.call("aid_conv2d", p)
-    assert L.lib().aid_last_kernel().decode() == ("conv11_rs_kernel" if (Cout in (64, 96) or act) else "conv11_dma_kernel")
+    assert L.lib().aid_last_kernel().decode() == ("conv11_rs_kernel" if (Cout == 96 or (Cout == 64 and Cin <= 64)) else "conv11_dma_kernel")
     torch.cuda.synchronize()
     yc = y[:, 1:1 + Cout].cpu().double()
     e = rel_l2(yc, ref)

@@ -941,6 +941,12 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
     }
 
     // ---- epilogue (as conv53_wino4v_kernel; this lane's output row: sub-lattice row j0 + jl) -----------------------------------------
+    // What the epilogue costs a launch (round 3, profiles/r03_w4r_epilogue_probe.txt, builds with an early return / without the dGELU
+    // arithmetic): 2-11 % for the plain epilogue, 8-20 % for the dGELU one (3-7 % of it libm erff + expf) -- on ISOLATED launches.  Tried on
+    // top of that: the four 4-row blocks software-pipelined (loads of block k+1 before block k is transformed and stored): dGELU launches
+    // -7 ... +3 %, plain launches slower, forward-only evaluation -2 %; a 13-instruction dGELU (one exp shared by density and tail, A&S 7.1.26):
+    // the isolated gap closes to 2 %, end to end 44.03 vs 44.05 evaluations/s -- under the sub-batch streams the epilogue arithmetic already runs
+    // beneath other workgroups' MFMAs.  Neither is kept; nor are the experiment switches (they spill in the 168-register instances).
     float dsum[4] = {0.f, 0.f, 0.f, 0.f};                // <y, aux> (dot_ws) or sum y (stat_ws) per block of 4 rows
     float qsum[4] = {0.f, 0.f, 0.f, 0.f};                // sum y^2 (stat_ws)
     const int jr_o = j0 + jl;

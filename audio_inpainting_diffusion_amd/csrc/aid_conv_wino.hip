@@ -922,16 +922,20 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
             return;
         }
         if (tid == 0) {
-            // (bounded, ~0.2 s: the first workgroup is already past its K loop, this wait is microseconds; a bound keeps a logic error from hanging the device)
-            for (int it = 0; it < (1 << 20) && __hip_atomic_load(fl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u; ++it) __builtin_amdgcn_s_sleep(4);
+            // (bounded, ~0.2 s: the first workgroup is already past its K loop, this wait is microseconds; a bound keeps a logic error from hanging
+            //  the device -- and if it is ever hit the tile is written as NaN, not as half a sum)
+            int it = 0;
+            for (; it < (1 << 20) && __hip_atomic_load(fl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u; ++it) __builtin_amdgcn_s_sleep(4);
+            sh[1] = it < (1 << 20);
         }
         __syncthreads();
+        const float poison = sh[1] ? 0.f : __uint_as_float(0x7fc00000u);
 #pragma unroll
         for (int x = 0; x < NXI; ++x)
 #pragma unroll
             for (int r2 = 0; r2 < 8; ++r2) {
                 const unsigned long long v = __hip_atomic_load(part + (x * 8 + r2) * (64 * NW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                acc[x][2 * r2] += __uint_as_float((unsigned)v); acc[x][2 * r2 + 1] += __uint_as_float((unsigned)(v >> 32));
+                acc[x][2 * r2] += __uint_as_float((unsigned)v) + poison; acc[x][2 * r2 + 1] += __uint_as_float((unsigned)(v >> 32)) + poison;
             }
         if (tid == 0) {                                   // leave the flags as they were found (the next launch on this stream reuses them)
             __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

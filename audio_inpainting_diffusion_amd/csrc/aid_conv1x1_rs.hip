@@ -1,10 +1,12 @@
 // conv11_rs_kernel: 1x1 channel projections with K <= 256 as a REGISTER-STREAMED fp32-MFMA kernel (round 3).
 //
 // These layers (res_conv / proj / pyramid-path 1x1 of unet...py:412-415, :488-491, :700-712 and their input gradients) move 16-60 FLOP per
-// byte: below the ridge, they should run at the HBM roof.  The LDS-staged tile kernels (conv11_dma_kernel, conv_mfma_kernel) reach 1.8-2.9 TB/s
-// on them: a 64..128 x 256 tile lives ~35 us (four 16-channel chunks, each a direct-to-LDS burst + workgroup barrier, then an epilogue whose
-// residual / aux loads are issued after the last MFMA), with two or three tiles per CU in flight -- latency-bound (Little's law wants ~48 KB in
-// flight per CU; a tile holds ~20 KB during its K loop and less in its epilogue).  Here
+// byte: below the ridge by the byte count.  The LDS-staged tile kernels (conv11_dma_kernel, conv_mfma_kernel) reach 1.8-3.3 TB/s on them: a
+// 64..128 x 256 tile lives ~35 us (four 16-channel chunks, each a direct-to-LDS burst + workgroup barrier, then an epilogue whose residual / aux
+// loads are issued after the last MFMA), with two or three tiles per CU in flight.  This kernel reaches 2.5-3.7 TB/s; its ablation
+// (AID_C11_MODE, profiles/r03_c11_probe.txt) shows what is left: with fp32 32x32x2 MFMAs the matrix time of these layers is
+// 60-90 % of their HBM time, the dGELU epilogue adds a VALU term of the same order, and a wave overlaps the three only against the other wave
+// of its SIMD.  Here
 //   * a workgroup (8 waves) loads the layer's WHOLE weight matrix slice [K x 32 MT] into LDS once and then streams position tiles past it;
 //   * every wave is its own pipeline over tiles of 64 positions x all 32 MT output channels: the B operand (activations) goes HBM -> REGISTERS
 //     (float2 per lane = the two interleaved position tiles, 2 x 256 contiguous bytes per load), U = 16 k-steps = 8 KB in flight per wave,
@@ -25,7 +27,6 @@ struct C11RDev {
     int nsteps1;               // k-pairs served by p.x (all unless p.x2 is given)
     int tps;                   // 64-position tiles per sample (F*T / 64)
     int ntiles;                // B * tps
-    int wstride;               // floats per weight row in LDS (32 MT)
     int mode;                  // experiment switches (AID_C11_MODE): 1 skip the y stores, 2 skip the x loads, 4 skip the MFMAs
 };
 
@@ -212,7 +213,6 @@ static int launch_c11rs(const aid_conv2d_params* p, hipStream_t st) {
     a.nsteps1 = p->x2.p ? p->Cin1 / 2 : a.nsteps;
     a.tps = (int)(((int64_t)p->F * p->T) / 64);
     a.ntiles = p->B * a.tps;
-    a.wstride = 32 * MT;
     static const int mode = getenv("AID_C11_MODE") ? atoi(getenv("AID_C11_MODE")) : 0;
     a.mode = mode;
     int gx = aid_cdiv(a.ntiles, 8);

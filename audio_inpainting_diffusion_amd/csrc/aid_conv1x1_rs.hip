@@ -4,7 +4,7 @@
 // byte: below the ridge by the byte count.  The LDS-staged tile kernels (conv11_dma_kernel, conv_mfma_kernel) reach 1.8-3.3 TB/s on them: a
 // 64..128 x 256 tile lives ~35 us (four 16-channel chunks, each a direct-to-LDS burst + workgroup barrier, then an epilogue whose residual / aux
 // loads are issued after the last MFMA), with two or three tiles per CU in flight.  This kernel reaches 2.5-3.7 TB/s; its ablation
-// (AID_C11_MODE, profiles/r03_c11_probe.txt) shows what is left: with fp32 32x32x2 MFMAs the matrix time of these layers is
+// (an experimental build with switches that drop the stores / the loads / the MFMAs: profiles/r03_c11_probe.txt) shows what is left: with fp32 32x32x2 MFMAs the matrix time of these layers is
 // 60-90 % of their HBM time, the dGELU epilogue adds a VALU term of the same order, and a wave overlaps the three only against the other wave
 // of its SIMD.  Here
 //   * a workgroup (8 waves) loads the layer's WHOLE weight matrix slice [K x 32 MT] into LDS once and then streams position tiles past it;
@@ -27,7 +27,6 @@ struct C11RDev {
     int nsteps1;               // k-pairs served by p.x (all unless p.x2 is given)
     int tps;                   // 64-position tiles per sample (F*T / 64)
     int ntiles;                // B * tps
-    int mode;                  // experiment switches (AID_C11_MODE): 1 skip the y stores, 2 skip the x loads, 4 skip the MFMAs
 };
 
 // returns the number of <y, aux> partial slots per (sample, group) = tiles per sample, or 0 when the shape is not served
@@ -94,8 +93,7 @@ __global__ __launch_bounds__(512, 1) void conv11_rs_kernel(const C11RDev a) {
         sp = SCALE ? p.in_scale + (int64_t)b * p.in_scale_ld + half : nullptr;
     };
     auto ld = [&](int s, int q) {                         // s is wave-uniform
-        if (a.mode & 2) ring[q] = make_float2(1.f, 2.f);
-        else if (s < a.nsteps1) ring[q] = *reinterpret_cast<const float2*>(xb + (xo + (unsigned)s * xs));
+        if (s < a.nsteps1) ring[q] = *reinterpret_cast<const float2*>(xb + (xo + (unsigned)s * xs));
         else ring[q] = *reinterpret_cast<const float2*>(xb2 + (xo2 + (unsigned)(s - a.nsteps1) * xs2));
         if (SCALE) scr[q] = sp[2 * s];
     };
@@ -120,7 +118,6 @@ __global__ __launch_bounds__(512, 1) void conv11_rs_kernel(const C11RDev a) {
                 if (SCALE) { bx *= scr[q]; by *= scr[q]; }
                 if (more) ld(s0 + U + q, q);
                 if (ACT) { bx = aid_gelu(bx); by = aid_gelu(by); }
-                if (!(a.mode & 4))
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const float aw = wr0[2 * q * WROW + 32 * i];
@@ -178,7 +175,7 @@ __global__ __launch_bounds__(512, 1) void conv11_rs_kernel(const C11RDev a) {
                     if (EPI) { y0 *= aid_dgelu(uv[q].x * as[q]); y1 *= aid_dgelu(uv[q].y * as[q]); }
                     if (RES) { y0 += p.res_scale * rv[q].x; y1 += p.res_scale * rv[q].y; }
                     y0 *= p.alpha; y1 *= p.alpha;
-                    if (!(a.mode & 1) || y0 == 123.456f) *reinterpret_cast<float2*>(yb + (yo + (unsigned)(32 * i + dm) * ys)) = make_float2(y0, y1);
+                    *reinterpret_cast<float2*>(yb + (yo + (unsigned)(32 * i + dm) * ys)) = make_float2(y0, y1);
                     if (EPI) dsum[i][r >> 2] += y0 * uv[q].x + y1 * uv[q].y;
                 }
             }
@@ -213,8 +210,6 @@ static int launch_c11rs(const aid_conv2d_params* p, hipStream_t st) {
     a.nsteps1 = p->x2.p ? p->Cin1 / 2 : a.nsteps;
     a.tps = (int)(((int64_t)p->F * p->T) / 64);
     a.ntiles = p->B * a.tps;
-    static const int mode = getenv("AID_C11_MODE") ? atoi(getenv("AID_C11_MODE")) : 0;
-    a.mode = mode;
     int gx = aid_cdiv(a.ntiles, 8);
     const int ny = p->Cout_pad / (32 * MT);
     const int cap = ny > 1 ? 256 / ny + (256 % ny ? 1 : 0) : 256;      // one workgroup per CU over all Cout slices

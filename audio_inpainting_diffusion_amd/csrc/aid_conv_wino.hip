@@ -1037,8 +1037,8 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
 // NC1 > 0: PAIR instance for 96-channel layers -- the 64 x 256 tiles of channels [0, 64) (family 0: <TT, NC, WGM = 2>) and the 32 x 512
 // remainder tiles of channels [64, 96) (family 1: <TT, NC1, WGM = 1>) in ONE grid, family 0 first: the remainder tiles start while the
 // last 64-wide tiles drain instead of after a launch boundary (two launches: each has its own tail, and at batch 1 neither fills the chip).
-// Measured against two launches (AID_W4R_PAIR = 0; profiles/r03_w4r_split_probe.txt, r03_w4r_ab.txt): batch 1 [96, 256, 256] 140 -> 100 us,
-// [96, 192, 512] 170 -> 145 us; batch 3 380 -> 340 us; batch 8 918 -> 905 / 627 -> 604 us; end to end +4.7 % / +1.5 % / +1.2 % / +0.6 % at batch 1 / 2 / 3 / 8.
+// Measured against two launches (profiles/r03_w4r_split_probe.txt, r03_w4r_ab.txt): batch 1 [96, 256, 256] 140 -> 100 us,
+// [96, 192, 512] 170 -> 145 us; batch 3 380 -> 340 us; batch 8 918 -> 905 / 627 -> 604 us; end to end +4.7 % / +1.5 % / +1.2 % / +0.6 % at batch 1 / 2 / 3 / 8.  (The two-launch path was removed after that A/B.)
 // SPK: split-K instance (ConvWinoRDev::splits == 2).
 template <int TT, int NC, int WGM, int NB = 3, int WPC = 2, int NWV = 4, int NC1 = 0, bool SPK = false>
 __global__ __launch_bounds__(64 * NWV, (WPC * NWV + 3) / 4) void conv53_wino4r_kernel(const ConvWinoRDev a) {
@@ -1179,7 +1179,6 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
         if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_aid_zero_page_w)) != hipSuccess) { aid_set_error("aid_conv2d: zero page lookup failed"); return AID_E_LAUNCH; }
         zero = (const float*)z;
     }
-    static const int pair_launch = w4r_env("AID_W4R_PAIR", 1);
     Wino4rPlan plan[2];
     const int nl = wino4r_geometry(p, plan);
     if (!nl) return 1000;
@@ -1219,7 +1218,7 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
         if constexpr (TTv == 64 && NCv <= 2) { if (short_k) { hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv, 2, 3, 4, NC1v>), grid, dim3(256), 0, st, a); break; } } \
         if constexpr (NC1v == 0 && WGMv == 2) { if (a.splits == 2) { hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv, 3, 2, 4, 0, true>), grid, dim3(256), 0, st, a); break; } } \
         hipLaunchKernelGGL((conv53_wino4r_kernel<TTv, NCv, WGMv, 3, 2, 4, NC1v>), grid, dim3(256), 0, st, a); } while (0)
-    if (m96 && pair_launch) {
+    if (m96) {
         a.g[0] = geo[0]; a.g[1] = geo[1];
         const dim3 grid((unsigned)(8 * (geo[0].per_xcd + geo[1].per_xcd)));
         switch (plan[0].NC * 16 + plan[1].NC) {               // (both families: TT = 64, wino4r_geometry)
@@ -1233,28 +1232,24 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
         }
         AID_CHECK_LAUNCH();
     } else {
-        for (int l = 0; l < nl; ++l) {
-            const Wino4rPlan& g = plan[l];
-            a.g[0] = geo[l]; a.g[1] = geo[l];
-            const dim3 grid((unsigned)(8 * geo[l].per_xcd));
-            switch ((l * 128 + g.TT) * 16 + g.NC) {
-                case 64 * 16 + 1: AID_W4R(64, 1, 2, 0); break;
-                case 64 * 16 + 2: AID_W4R(64, 2, 2, 0); break;
-                case 64 * 16 + 4: AID_W4R(64, 4, 2, 0); break;
-                case 32 * 16 + 1: AID_W4R(32, 1, 2, 0); break;
-                case 32 * 16 + 2: AID_W4R(32, 2, 2, 0); break;
-                case 32 * 16 + 4: AID_W4R(32, 4, 2, 0); break;
-                case 32 * 16 + 8: AID_W4R(32, 8, 2, 0); break;
-                case 16 * 16 + 1: AID_W4R(16, 1, 2, 0); break;
-                case 16 * 16 + 2: AID_W4R(16, 2, 2, 0); break;
-                case 16 * 16 + 4: AID_W4R(16, 4, 2, 0); break;
-                case 16 * 16 + 8: AID_W4R(16, 8, 2, 0); break;
-                case (128 + 64) * 16 + 1: AID_W4R(64, 1, 1, 0); break;
-                case (128 + 64) * 16 + 2: AID_W4R(64, 2, 1, 0); break;
-                default: aid_set_error("aid_conv2d: row-shared tile shape not instantiated"); return AID_E_BADARG;
-            }
-            AID_CHECK_LAUNCH();
+        const Wino4rPlan& g = plan[0];
+        a.g[0] = geo[0]; a.g[1] = geo[0];
+        const dim3 grid((unsigned)(8 * geo[0].per_xcd));
+        switch (g.TT * 16 + g.NC) {
+            case 64 * 16 + 1: AID_W4R(64, 1, 2, 0); break;
+            case 64 * 16 + 2: AID_W4R(64, 2, 2, 0); break;
+            case 64 * 16 + 4: AID_W4R(64, 4, 2, 0); break;
+            case 32 * 16 + 1: AID_W4R(32, 1, 2, 0); break;
+            case 32 * 16 + 2: AID_W4R(32, 2, 2, 0); break;
+            case 32 * 16 + 4: AID_W4R(32, 4, 2, 0); break;
+            case 32 * 16 + 8: AID_W4R(32, 8, 2, 0); break;
+            case 16 * 16 + 1: AID_W4R(16, 1, 2, 0); break;
+            case 16 * 16 + 2: AID_W4R(16, 2, 2, 0); break;
+            case 16 * 16 + 4: AID_W4R(16, 4, 2, 0); break;
+            case 16 * 16 + 8: AID_W4R(16, 8, 2, 0); break;
+            default: aid_set_error("aid_conv2d: row-shared tile shape not instantiated"); return AID_E_BADARG;
         }
+        AID_CHECK_LAUNCH();
     }
 #undef AID_W4R
     aid_note_kernel(m96 ? "conv53_wino4r_kernel(64+32)" : (a.splits == 2 ? "conv53_wino4r_kernel(split-K)" : (plan[0].NC == 1 ? "conv53_wino4r_kernel" : "conv53_wino4r_kernel(multi-class)")));

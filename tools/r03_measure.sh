@@ -49,8 +49,7 @@ e2e)
   { python tools/e2e_run.py maestro22k 8; python tools/e2e_run.py maestro22k 1; python tools/e2e_run.py musicnet44k 4; python tools/e2e_run.py librispeech16k 16; } > $O/r03_e2e_full_runs.txt 2>/dev/null ;;
 c11)
   { for rs in 0 1; do echo "== AID_C11_RS=$rs (1: conv11_rs_kernel where it is selected; 0: the tile kernels)"; AID_C11_RS=$rs timeout 300 python tools/c11_probe.py 8; done
-    echo "== ablation of conv11_rs_kernel (AID_C11_MODE: 1 no y stores, 2 no x loads, 4 no MFMAs)"
-    for m in 1 2 4 7; do echo "-- mode $m"; AID_C11_MODE=$m timeout 300 python tools/c11_probe.py 8 | head -8; done
+    # (the ablation block of profiles/r03_c11_probe.txt came from an experimental build with an AID_C11_MODE switch; the product kernel has none)
     for rs in 0 1; do echo "== batch 1, AID_C11_RS=$rs"; AID_C11_RS=$rs timeout 300 python tools/c11_probe.py 1; done
   } 2>&1 | grep -v amdgpu.ids > $O/r03_c11_probe.txt ;;
 train)

@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of the pair instance (AID_W4R_PAIR) and the batch-1 split-K instances (AID_W4R_SPLIT = tile-count threshold) end to end
+# A/B of the pair instance and the batch-1 split-K instances (AID_W4R_SPLIT = tile-count threshold) end to end.
+# AID_W4R_PAIR was a switch of the build this was run on (profiles/r03_w4r_ab.txt); the two-launch path has since been removed, so pair=0 now equals pair=1.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 run() { timeout 600 python bench.py --no-cpu-baseline --roof-steps 1 "$@" 2>/dev/null | python -c "import sys, json; d = json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; }
 for rep in 1 2; do

@@ -175,7 +175,8 @@ def main():
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    shared = int(os.environ.get("AID_SHARED_GPU", "0"))        # set by launch_ranks when ranks have to share GPUs
+    shared = int(os.environ.get("AID_SHARED_GPU", "0")) or int(world > torch.cuda.device_count())      # set by launch_ranks when ranks have to share GPUs; also true
+                                                                                                        # under an external launcher with AID_DIST_BACKEND=gloo on fewer GPUs than ranks
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -200,6 +200,11 @@ class ChannelDotParams(C.Structure):
                 ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int)]
 
 
+class RelposBwdParams(C.Structure):
+    _fields_ = [("dS", C.c_void_p), ("bucket", C.c_void_p), ("dW", C.c_void_p),
+                ("B", C.c_int), ("H", C.c_int), ("T", C.c_int), ("num_buckets", C.c_int), ("accumulate", C.c_int)]
+
+
 class ScaleBwdParams(C.Structure):
     _fields_ = [("S", C.c_void_p), ("S_ld", C.c_int64), ("scale", C.c_void_p), ("scale_ld", C.c_int64), ("gamma", C.c_void_p),
                 ("mod", C.c_void_p), ("mod_ld", C.c_int64), ("stats", C.c_void_p), ("dgamma", C.c_void_p), ("dmod", C.c_void_p),
@@ -238,7 +243,7 @@ EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_st
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_guidance_step", "aid_set_rows", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
            "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_split_ws_bytes",
-           "aid_conv2d_wgrad", "aid_wgrad_reduce", "aid_channel_dot", "aid_scale_bwd", "aid_modulation_bwd", "aid_embed_bwd",
+           "aid_conv2d_wgrad", "aid_wgrad_reduce", "aid_channel_dot", "aid_relpos_bwd", "aid_scale_bwd", "aid_modulation_bwd", "aid_embed_bwd",
            "aid_adam", "aid_ema", "aid_sumsq"]
 
 _lib = None
@@ -281,7 +286,7 @@ def lib():
                             "aid_conv2d_stat_partials", "aid_conv2d_wgrad_tiles"):
                 getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, name).restype = C.c_int
-        if L.aid_abi_version() != 8:
+        if L.aid_abi_version() != 9:
             raise AidError("ABI version mismatch")
         _lib = L
     return _lib

@@ -765,6 +765,38 @@ __global__ __launch_bounds__(256) void channel_dot_kernel(const aid_channel_dot_
     if (tid == 0) p.out[(int64_t)b * p.out_ld + c] = (float)((red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// Gradient of the relative-position embedding (attention_dict.use_rel_pos; RelativePositionBias, unet...py:266-312): the additive logit bias is
+// table[h][n][m] = W[bucket[n][m]][h], so dW[k][h] = sum over samples and over the (n, m) of bucket k of dS[b][h][n][m] -- dS as
+// aid_time_attention_bwd leaves it in its scratch (the gradient w.r.t. q k^T + bias, i.e. before the scale).  One workgroup per (bucket, head),
+// fixed-order reduction (fp64), no atomics.
+__global__ __launch_bounds__(256) void relpos_bwd_kernel(const aid_relpos_bwd_params p) {
+    const int k = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    const int n2 = p.T * p.T;
+    double s = 0.0;
+    for (int i = tid; i < n2; i += 256) {
+        if (p.bucket[i] != k) continue;
+        for (int b = 0; b < p.B; ++b) s += (double)p.dS[((int64_t)b * p.H + h) * n2 + i];
+    }
+    __shared__ double red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        const float v = (float)((red[0] + red[1]) + (red[2] + red[3]));
+        float* o = p.dW + (int64_t)k * p.H + h;
+        *o = p.accumulate ? *o + v : v;
+    }
+}
+
+extern "C" int aid_relpos_bwd(const aid_relpos_bwd_params* p, void* stream) {
+    AID_REQUIRE(p && p->dS && p->bucket && p->dW, "aid_relpos_bwd: null pointer");
+    AID_REQUIRE(p->B > 0 && p->H > 0 && p->T > 0 && p->num_buckets > 0, "aid_relpos_bwd: empty shape");
+    hipLaunchKernelGGL(relpos_bwd_kernel, dim3((unsigned)p->num_buckets, (unsigned)p->H), dim3(256), 0, (hipStream_t)stream, *p);
+    AID_CHECK_LAUNCH();
+    return AID_OK;
+}
+
 extern "C" int aid_channel_dot(const aid_channel_dot_params* p, void* stream) {
     AID_REQUIRE(p && p->u.p && p->v.p && p->out, "aid_channel_dot: null pointer");
     const int vec = ((p->T & 3) == 0) && ((p->u.sB | p->u.sC | p->u.sF | p->v.sB | p->v.sC | p->v.sF) & 3) == 0 &&

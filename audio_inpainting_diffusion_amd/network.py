@@ -81,9 +81,9 @@ class _RelPos(nn.Module):
         self.num_buckets, self.max_distance = int(num_buckets), int(max_distance)
         self.relative_attention_bias = _Weight([num_buckets, heads], heads, 1.0)
 
-    def bias_table(self, T: int) -> torch.Tensor:
-        """[H, T, T] additive logit bias (RelativePositionBias.forward, unet...py:275-312).  The bucket indices are computed with
-        CPU torch ops in the reference's own operation order (float32 log, truncation), then gathered on the weight's device."""
+    def buckets(self, T: int) -> torch.Tensor:
+        """[T, T] bucket index of (query n, key m), computed with CPU torch ops in the reference's own operation order
+        (float32 log, truncation; unet...py:275-305)"""
         nb = self.num_buckets // 2
         pos = torch.arange(T, dtype=torch.long)
         rel = pos[None, :] - pos[:, None]
@@ -92,9 +92,12 @@ class _RelPos(nn.Module):
         max_exact = nb // 2
         val_if_large = max_exact + (torch.log(n.float() / max_exact) / math.log(self.max_distance / max_exact) * (nb - max_exact)).long()
         val_if_large = torch.min(val_if_large, torch.full_like(val_if_large, nb - 1))
-        bucket = ret + torch.where(n < max_exact, n, val_if_large)
+        return ret + torch.where(n < max_exact, n, val_if_large)
+
+    def bias_table(self, T: int) -> torch.Tensor:
+        """[H, T, T] additive logit bias (RelativePositionBias.forward, unet...py:275-312)"""
         w = self.relative_attention_bias.weight.detach().float()
-        return w[bucket.to(w.device)].permute(2, 0, 1).contiguous()
+        return w[self.buckets(T).to(w.device)].permute(2, 0, 1).contiguous()
 
 
 class _FreqEnc(nn.Module):
@@ -569,7 +572,8 @@ class _Builder:
         self._resample_raw(x, y, up)
         self._reg_bwd(lambda: self._resample_raw(self.G(y), self.G(x), up, adjoint=1, accumulate=1 if self._gacc(x) else 0))
 
-    def attention(self, qk, v, out, heads, F, T, bias=None):
+    def attention(self, qk, v, out, heads, F, T, bias=None, relpos=None):
+        """``relpos`` (training, use_rel_pos): (bucket index tensor [T, T] int32, parameter name of the [num_buckets, heads] embedding)"""
         B = v.shape[0]
         probs = self.buf(B, heads, T, T)
         scale = float(F) ** -0.5
@@ -587,6 +591,29 @@ class _Builder:
             self._add("aid_time_attention_bwd", bp, qk, v, probs, go, gq, gv, dsws, flops=10 * B * heads * T * T * F, writes=(gq, gv, dsws))
             self._wrote(gq)
             self._wrote(gv)
+            if self.train and relpos is not None:           # d(bias table) = dS summed over samples, scattered back onto the embedding rows
+                bucket, wname = relpos
+                dW = self.pgrad[wname]
+                rp = _lib.RelposBwdParams(dsws.data_ptr(), bucket.data_ptr(), dW.data_ptr(), B, heads, T, dW.shape[0], 1)
+                self._add("aid_relpos_bwd", rp, dsws, bucket, dW, writes=(dW,))
+        self._reg_bwd(bw)
+
+    def bias_grad(self, y, wname):
+        """training: gradient of a per-channel bias that was broadcast over (b, f, t) onto ``y`` (bias_qkv: the qk conv's residual input)"""
+        def bw():
+            gy = self.G(y)
+            B, Cc, F, T = gy.shape
+            ones = self.scratch.get(("ones", T))
+            if ones is None:
+                ones = self.scratch[("ones", T)] = torch.ones(max(T, 4), device=self.device, dtype=torch.float32)
+            S = self.buf(B, Cc)
+            ov = _lib.View(ones.data_ptr(), 0, 0, 0)
+            cp = _lib.ChannelDotParams(_lib.view4(gy), ov, S.data_ptr(), S.stride(0), B, Cc, F, T)
+            self._add("aid_channel_dot", cp, gy, ones, S, writes=(S,))
+            dW = self.pgrad[wname]
+            rp = _lib.WgradReduceParams(S.data_ptr(), self.params[wname].data_ptr(), None, 0, None, 0, dW.data_ptr(), None, 0,
+                                        B, 1, Cc, 1, 1, 1, 0, None, 0, 0)
+            self._add("aid_wgrad_reduce", rp, S, dW, writes=(dW,))
         self._reg_bwd(bw)
 
 
@@ -751,10 +778,16 @@ class Unet_CQT_oct_with_attention(nn.Module):
                 put(pfx + "attn_block.qk.bias#T", ab.qk.bias.detach().float()[:, None].expand(-1, T))
             if hasattr(ab, "rel_pos"):                                         # use_rel_pos: additive logit bias [H, T, T]
                 put(pfx + "attn_block.rel_pos#table", ab.rel_pos.bias_table(T))
+                put(pfx + "attn_block.rel_pos#bucket", ab.rel_pos.buckets(T).to(torch.int32).to(dev))
         if self.use_fencoding:
-            for i, fe in enumerate(self.freq_encodings):
-                put(f"#fenc.{i}", fe.embeddings.detach().float().reshape(2 * self.n_fenc, self.bins_per_oct))
-            self._states.clear()                                                # (the tables are copied into the input buffers at plan build)
+            stale = False                                                       # (the tables are copied into the input buffers at plan build:
+            for i, fe in enumerate(self.freq_encodings):                        #  cached plans are dropped only when a table's VALUES changed --
+                t = fe.embeddings.detach().float().reshape(2 * self.n_fenc, self.bins_per_oct)   # re-homing the parameters for the training
+                old = self._packed.get(f"#fenc.{i}")                            #  step bumps every version without changing a value)
+                stale = stale or old is None or old.shape != t.shape or not torch.equal(old, t.to(old.device))
+                put(f"#fenc.{i}", t)
+            if stale:
+                self._states.clear()
         put("#modW", torch.cat(rows, 0))
         put("#modB", torch.cat(biases, 0))
         self._mod_layout, self._mod_total = layout, off
@@ -797,8 +830,12 @@ class Unet_CQT_oct_with_attention(nn.Module):
             bd.conv(xp.view(B, H * F, 1, T), qk, W[pfx + "attn_block.qk.weight"], H * F, 2 * H * F,
                     wpT=W[pfx + "attn_block.qk.weight#T"],
                     res=None if qb is None else qb.view(1, 2 * H * F, 1, T).expand(B, -1, -1, -1), res_nograd=True, wname=pfx + "attn_block.qk.weight")
+            if bd.train and qb is not None:
+                bd.bias_grad(qk, pfx + "attn_block.qk.bias")
             att = bd.buf(B, H, F, T)
-            bd.attention(qk, xp, att, H, F, T, bias=W.get(pfx + "attn_block.rel_pos#table"))  # use_rel_pos (:364)
+            rpb = W.get(pfx + "attn_block.rel_pos#table")
+            bd.attention(qk, xp, att, H, F, T, bias=rpb,                       # use_rel_pos (:364)
+                         relpos=None if rpb is None else (W[pfx + "attn_block.rel_pos#bucket"], pfx + "attn_block.rel_pos.relative_attention_bias.weight"))
             x1 = bd.buf(B, N, F, T)
             bd.conv(att, x1, W[pfx + "attn_block.proj_out.weight"], H, N, out_scale=self._mod(st, pfx + "gate2"), res=x,
                     alpha=RSQRT2, wpT=W[pfx + "attn_block.proj_out.weight#T"], wname=pfx + "attn_block.proj_out.weight")
@@ -856,9 +893,6 @@ class Unet_CQT_oct_with_attention(nn.Module):
         st["mod"] = bd.buf(B, self._mod_total)
         bd.mod = st["mod"]
         if train:
-            if self.use_fencoding or any(hasattr(b.attn_block, "rel_pos") or hasattr(b.attn_block.qk, "bias")
-                                         for _, b in self._resblocks() if b.has_attn):
-                raise NotImplementedError("the training step covers the shipped configurations (no fencoding / bias_qkv / rel_pos)")
             from .dist import flatten_parameters_
             flat = flatten_parameters_(self)                       # parameters as views of ONE buffer: the optimiser walks it flat
             st["gflat"] = torch.zeros_like(flat)

@@ -28,7 +28,7 @@ extern "C" {
 #define AID_E_BADARG (-1)   /* unsupported shape / null pointer / misaligned stride */
 #define AID_E_LAUNCH (-2)   /* hipLaunchKernel reported an error                    */
 
-#define AID_ABI_VERSION 8
+#define AID_ABI_VERSION 9
 int aid_abi_version(void);
 /* last HIP error string seen by a launcher in this process (never NULL) */
 const char* aid_last_error(void);
@@ -472,6 +472,9 @@ int aid_add2(const aid_add2_params* p, void* stream);
  *                    dgate[b,co]    = sum_{ci,tap} W[co,ci,tap] * in_scale[b,ci] * sum_s P   (= alpha * <gy, ungated conv output>)
  *                    W, dW in the parameter's own layout [Cout][Cin][KH*KW].
  * aid_channel_dot  : out[b,c] = sum_{f,t} u*v
+ * aid_relpos_bwd   : dW[k][h] (+)= sum_b sum_{(n,m): bucket[n][m] = k} dS[b][h][n][m] -- gradient of the relative-position embedding
+ *                    [num_buckets, heads] (attention_dict.use_rel_pos; RelativePositionBias, unet...py:266-312) from the logit gradients
+ *                    aid_time_attention_bwd leaves in its scratch `ws`
  * aid_scale_bwd    : scale[b,c] = gamma[c] (1 + mod[b,c]) inv[b,g]:  ds = S/scale;  dgamma[c] (+)= sum_b ds (1+mod) inv;
  *                    dmod[b,c] = ds gamma inv          (stats: [B, groups, 2] (mean, inv) of aid_group_stats)
  * aid_modulation_bwd / aid_embed_bwd : backward of aid_modulation / aid_embed (parameter gradients + d emb)
@@ -530,6 +533,14 @@ typedef struct {
     int B, C, F, T;
 } aid_channel_dot_params;
 int aid_channel_dot(const aid_channel_dot_params* p, void* stream);
+
+typedef struct {
+    const float* dS;              /* [B, H, T, T]: aid_time_attention_bwd's scratch after the call */
+    const int* bucket;            /* [T, T] bucket index of (query n, key m) */
+    float* dW;                    /* [num_buckets, H] */
+    int B, H, T, num_buckets, accumulate;
+} aid_relpos_bwd_params;
+int aid_relpos_bwd(const aid_relpos_bwd_params* p, void* stream);
 
 typedef struct {
     const float* S; int64_t S_ld;

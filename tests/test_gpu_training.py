@@ -49,7 +49,7 @@ def _oracle_grads(orc, x, cn, target, hpf=False):
     return float(loss), g
 
 
-@pytest.mark.parametrize("tag,hpf", [("a", False), ("b", False), ("a", True)])
+@pytest.mark.parametrize("tag,hpf", [("a", False), ("b", False), ("a", True), ("c", False)])     # c: use_fencoding + bias_qkv + use_rel_pos
 def test_parameter_gradients_vs_oracle_autograd(tag, hpf):
     net, orc, z, kw, _ = _setup(tag)
     x, cn = torch.from_numpy(z["x"]), torch.from_numpy(z["cnoise"])
@@ -62,7 +62,7 @@ def test_parameter_gradients_vs_oracle_autograd(tag, hpf):
     worst = ("", 0.0)
     gmax = max(float(v.norm()) for v in ref.values())
     for k, r in ref.items():
-        if k.endswith("RFF_freq") or k.endswith("kernel"):
+        if k.endswith("RFF_freq") or k.endswith("kernel") or k.endswith("embeddings"):
             assert float(got[k].abs().max()) == 0.0              # frozen tensors
             continue
         d = float((got[k].double() - r.double()).norm())
@@ -103,18 +103,22 @@ def test_optimizer_and_ema_kernels_vs_torch():
     assert rel_l2(ema.cpu(), ema0 * 0.75 + pd.cpu() * 0.25) < 1e-6
 
 
-def test_two_training_iterations_vs_oracle_loop():
+@pytest.mark.parametrize("tag", ["a", "c"])          # c: use_fencoding + bias_qkv + use_rel_pos (frozen tables, qk bias and relative-position embedding gradients)
+def test_two_training_iterations_vs_oracle_loop(tag):
     """trainer.py:253-304 on the small network: same sigma / noise on both sides; loss values, EMA and parameters after two steps."""
     from audio_inpainting_diffusion_amd.edm import EDM
     from audio_inpainting_diffusion_amd.training import Trainer, prepare_train_preconditioning
-    net, orc, z, kw, args = _setup("a")
+    net, orc, z, kw, args = _setup(tag)
     edm = EDM(args)
     tr = Trainer(net, edm, lr=2e-3, lr_rampup_it=2, max_grad_norm=1.0, ema_rate=0.9, ema_rampup=8, batch=2)
     B, Ls = 2, kw["audio_len"]
     g0 = torch.Generator().manual_seed(9)
     keys = list(orc.sd.keys())
     params = [torch.nn.Parameter(orc.sd[k].clone()) for k in keys]
-    trainable = [p for k, p in zip(keys, params) if not (k.endswith("RFF_freq") or k.endswith("kernel"))]
+    trainable = [p for k, p in zip(keys, params) if not (k.endswith("RFF_freq") or k.endswith("kernel") or k.endswith("embeddings"))]
+    for k, p in zip(keys, params):
+        if k.endswith("embeddings"):
+            p.requires_grad_(False)
     opt = torch.optim.Adam(trainable, lr=2e-3, betas=(0.9, 0.999), eps=1e-8)
     ema_ref = {k: orc.sd[k].clone() for k in keys}
     losses, ref_losses = [], []

@@ -33,7 +33,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in aid_kernels.h but not exported"
     lib.aid_abi_version.restype = ctypes.c_int
-    assert lib.aid_abi_version() == int(re.search(r"#define AID_ABI_VERSION (\d+)", hdr).group(1)) == 8
+    assert lib.aid_abi_version() == int(re.search(r"#define AID_ABI_VERSION (\d+)", hdr).group(1)) == 9
     from audio_inpainting_diffusion_amd import _lib
     assert set(_lib.EXPORTS) == declared
     a, b = _lib.pack_dims(2, 96)
@@ -366,7 +366,7 @@ def test_header_compiles_as_c_and_struct_sizes_match_the_binding(tmp_path):
              "aid_row_norm_params": "RowNormParams", "aid_guidance_step_params": "GuidanceStepParams", "aid_set_rows_params": "SetRowsParams", "aid_resample_poly_params": "ResamplePolyParams", "aid_stft_params": "StftParams",
              "aid_scale_act_params": "ScaleActParams", "aid_add2_params": "Add2Params", "aid_conv2d_wgrad_params": "WgradParams",
              "aid_wino_gy_params": "WinoGyParams", "aid_pack_conv_weight_params": "PackConvWeightParams", "aid_wgrad_reduce_params": "WgradReduceParams",
-             "aid_channel_dot_params": "ChannelDotParams", "aid_scale_bwd_params": "ScaleBwdParams", "aid_modulation_bwd_params": "ModulationBwdParams",
+             "aid_channel_dot_params": "ChannelDotParams", "aid_relpos_bwd_params": "RelposBwdParams", "aid_scale_bwd_params": "ScaleBwdParams", "aid_modulation_bwd_params": "ModulationBwdParams",
              "aid_embed_bwd_params": "EmbedBwdParams", "aid_adam_params": "AdamParams", "aid_ema_params": "EmaParams", "aid_sumsq_params": "SumsqParams"}
     hdr = open(os.path.join(ROOT, "include", "aid_kernels.h")).read()
     declared = set(re.findall(r"\}\s*(aid_\w+)\s*;", hdr))

@@ -173,6 +173,7 @@ class _Builder:
         self.use_lanes = not self.train and bool(getattr(net, "plan_lanes", True))
         self._stats_ws = {}    # lane -> scratch of the two-stage group reductions (lanes run concurrently: one each)
         self._keep = []        # superseded scratch tensors that recorded launches still point into
+        self.whole_batch = True   # False for the states of sub-batches (split-K instances are for a whole batch of one only)
         self.bwd = []          # (lane, closure emitting the VJP ops of a forward op); run in reverse by finish_backward
         self._stat_src = {}    # view key of a forward conv output -> (its params struct, partials per (b, group)): see stats()
         self._nb_src = {}      # (reverse sweep) view key of a gradient tensor -> (the aid_norm_bwd params that wrote it last, op index, end address)
@@ -396,7 +397,8 @@ class _Builder:
         if F == 1 and kh == 1 and epi == 0:              # qk projections: few columns, long K -> split-K scratch (aid_kernels.h)
             ws = self._scratch(("ws", 8 * B * cout * T))
             p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
-        elif x_wino and B == 1:                          # batch 1: launches with few tiles share the K axis of a tile between two workgroups
+        elif x_wino and B == 1 and self.whole_batch:     # a WHOLE batch of one (never a sub-batch: a segment's bits must not depend on the split):
+                                                         # launches with few tiles share the K axis of a tile between two workgroups
             need = int(_lib.lib().aid_conv2d_wino_split_ws_bytes(B, cin, cout, F, T, dil))
             if need:
                 ws = self._split_ws(need)
@@ -888,6 +890,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
                 raise NotImplementedError(f"{nm}.kernel differs from the reference's cubic FIR (unet...py:514-515), which aid_resample hard-wires")
         st = dict(B=B)
         bd = _Builder(self, B, dev, train=train)
+        bd.whole_batch = bool(lanes)                     # (sub-batch states are built with lanes=False, see _state)
         st["sigma"] = bd.buf(B)
         st["emb"] = bd.buf(B, self.emb_dim)
         st["mod"] = bd.buf(B, self._mod_total)

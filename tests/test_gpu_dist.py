@@ -199,13 +199,13 @@ def test_sub_batch_streams_are_bit_identical_to_one_stream():
         masks[b, 1000 + 100 * b: 1400 + 100 * b] = 0
     yd, md = (y * masks).to(DEV).contiguous(), masks.to(DEV)
     res = {}
-    for n in (1, 2, 3):
+    for n in (1, 2, 3, 7):                                   # 7: sub-batches of ONE segment (no split-K tiles there: those are for a whole batch of one)
         net.split_streams = n
         assert len(net.states_of(B)) == n
         for _ in range(2):                                   # second pass re-uses the launch plans
             res[n] = (net.denoise(x, *co, True), *net.denoise_guided(x, *co, True, yd, md))
     torch.cuda.synchronize()
-    for n in (2, 3):
+    for n in (2, 3, 7):
         for a_, b_ in zip(res[1], res[n]):
             assert torch.equal(a_, b_)
     net.split_streams = None

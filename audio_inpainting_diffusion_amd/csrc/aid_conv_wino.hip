@@ -1159,8 +1159,8 @@ static int w4r_env(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-// Split-K of the row-shared kernel (batch 1 only, so that the result of a sample never depends on which sub-batch it is evaluated in:
-// sub-batches have >= 2 samples): a launch with fewer tiles than CUs -- 192 / 224 on the deepest levels of the 22.05 kHz network -- gives
+// Split-K of the row-shared kernel (batch 1 with the scratch `ws` given -- which the network's launch plans do only for a WHOLE batch of one, so
+// that the result of a sample never depends on the sub-batch split it is evaluated in): a launch with fewer tiles than CUs -- 192 / 224 on the deepest levels of the 22.05 kHz network -- gives
 // every tile to TWO workgroups, one per half of the input channels: one wave per SIMD keeps the matrix pipe 76 % busy, two 91 %.
 // The tile count per CU does not change (the launch stays bound by 1 tile's MFMAs per CU), so the gain is that utilisation only:
 // 155 -> 147 us (d = 1) ... 169 -> 143 us (d = 64) per launch on [256, 448, 32]; launches with 256 < tiles <= 336 measured neutral to -4 %

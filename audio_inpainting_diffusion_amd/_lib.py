@@ -127,7 +127,7 @@ class NormBwdParams(C.Structure):
     _fields_ = [("gd", View), ("x", View), ("gy", View), ("out", View),
                 ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("groups", C.c_int),
                 ("stats", C.c_void_p), ("ws", C.c_void_p), ("eps", C.c_float), ("a", C.c_float), ("accumulate", C.c_int),
-                ("ws_n", C.c_int), ("wout", View), ("wscale", C.c_void_p), ("wscale_ld", C.c_int64)]
+                ("ws_n", C.c_int), ("wout", View), ("wscale", C.c_void_p), ("wscale_ld", C.c_int64), ("wform", C.c_int)]
 
 
 class AttentionBwdParams(C.Structure):
@@ -185,7 +185,8 @@ class WinoGyParams(C.Structure):
 class PackConvWeightParams(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("wpT", C.c_void_p), ("wpw", C.c_void_p), ("wpwT", C.c_void_p),
                 ("Cout", C.c_int), ("Cin", C.c_int), ("KH", C.c_int), ("KW", C.c_int),
-                ("Cin_pad", C.c_int), ("Cout_pad", C.c_int), ("Cin_padT", C.c_int), ("Cout_padT", C.c_int)]
+                ("Cin_pad", C.c_int), ("Cout_pad", C.c_int), ("Cin_padT", C.c_int), ("Cout_padT", C.c_int),
+                ("wpw8", C.c_void_p), ("wpw8T", C.c_void_p)]
 
 
 class WgradReduceParams(C.Structure):
@@ -242,7 +243,7 @@ EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_st
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_guidance_step", "aid_set_rows", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
-           "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_split_ws_bytes",
+           "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino_split_ws_bytes",
            "aid_conv2d_wgrad", "aid_wgrad_reduce", "aid_channel_dot", "aid_relpos_bwd", "aid_scale_bwd", "aid_modulation_bwd", "aid_embed_bwd",
            "aid_adam", "aid_ema", "aid_sumsq"]
 
@@ -275,6 +276,8 @@ def lib():
         L.aid_conv2d_dot_partials_1x1.restype = C.c_int
         L.aid_conv2d_wino_input_ok.argtypes = [C.c_int] * 6
         L.aid_conv2d_wino_input_ok.restype = C.c_int
+        L.aid_conv2d_wino_form.argtypes = [C.c_int] * 6
+        L.aid_conv2d_wino_form.restype = C.c_int
         L.aid_conv2d_wino_split_ws_bytes.argtypes = [C.c_int] * 6
         L.aid_conv2d_wino_split_ws_bytes.restype = C.c_int64
         L.aid_conv2d_stat_partials.argtypes = [C.c_int] * 7
@@ -282,11 +285,11 @@ def lib():
         L.aid_conv2d_wgrad_tiles.argtypes = [C.c_int] * 5
         L.aid_conv2d_wgrad_tiles.restype = C.c_int
         for name in EXPORTS[3:]:
-            if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_split_ws_bytes",
+            if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino_split_ws_bytes",
                             "aid_conv2d_stat_partials", "aid_conv2d_wgrad_tiles"):
                 getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, name).restype = C.c_int
-        if L.aid_abi_version() != 9:
+        if L.aid_abi_version() != 10:
             raise AidError("ABI version mismatch")
         _lib = L
     return _lib
@@ -365,6 +368,44 @@ def pack_conv_weight_wino(w: torch.Tensor, transpose: bool = False) -> torch.Ten
     cip, cop = pack_dims(ci, co)
     out = torch.zeros(nxi * kh, cip, cop, device=w.device, dtype=torch.float32)
     out[:, :ci, :co] = U.permute(0, 3, 2, 1).reshape(nxi * kh, ci, co).float()
+    return out
+
+
+W8_POINTS = (0.4, 0.8, 1.25, 2.5)
+
+
+def wino8_matrices():
+    """(A^T [8,10], G [10,3], B^T [10,10]) of F(8,3) as the kernels use them (float64; same construction as tools/gen_wino8.py, which
+    writes csrc/aid_wino8.h): points {0, +-0.4, +-0.8, +-1.25, +-2.5, inf}, rows of B^T scaled to max |entry| = 1 and G by the inverse."""
+    import numpy as np
+    n = 10
+    pts = np.array([0.0] + [sg * a for a in W8_POINTS for sg in (1, -1)], dtype=np.float64)
+
+    def vander(cols):
+        V = np.zeros((n, cols))
+        for j in range(n - 1):
+            V[j] = pts[j] ** np.arange(cols)
+        V[n - 1, cols - 1] = 1.0
+        return V
+    AT, G, BT = vander(8).T, vander(3), np.linalg.inv(vander(n)).T
+    sc = np.abs(BT).max(axis=1)
+    BT = BT / sc[:, None]
+    BT[np.abs(BT) < 1e-13] = 0.0
+    return AT, G * sc[:, None], BT
+
+
+def pack_conv_weight_wino8(w: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+    """[Cout,Cin,5,3] -> Winograd F(8,3) pack [10*5, Cin_pad, Cout_pad]: U = G w along kw, "tap" index xi*5+kh (float64, stored fp32)."""
+    w = w.detach().double()
+    if transpose:
+        w = w.flip(2, 3).permute(1, 0, 2, 3)
+    co, ci, kh, kw = w.shape
+    assert (kh, kw) == (5, 3)
+    G = torch.from_numpy(wino8_matrices()[1]).to(w.device)
+    U = torch.einsum("xk,oihk->xoih", G, w)                                               # [NXI, co, ci, kh]
+    cip, cop = pack_dims(ci, co)
+    out = torch.zeros(10 * kh, cip, cop, device=w.device, dtype=torch.float32)
+    out[:, :ci, :co] = U.permute(0, 3, 2, 1).reshape(10 * kh, ci, co).float()
     return out
 
 

@@ -518,8 +518,8 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
         return r == 1 ? AID_OK : (r < 0 ? r : AID_E_BADARG);
     }
     if (p->dot_ws) {
-        AID_REQUIRE(p->KH == 5 && p->KW == 3 && p->wp_wino && p->wino_taps == 30 && p->epi == 1 && !p->res.p,
-                    "aid_conv2d: dot_ws is an option of the F(4,3) dGELU epilogue");
+        AID_REQUIRE(p->KH == 5 && p->KW == 3 && p->wp_wino && p->wino_taps == (p->x_wino == 2 ? 50 : 30) && p->epi == 1 && !p->res.p,
+                    "aid_conv2d: dot_ws is an option of the F(4,3) / F(8,3) dGELU epilogue");
         AID_REQUIRE(p->dot_n > 0 && p->dot_n == aid_conv2d_dot_partials(p->B, p->Cin, p->Cout, p->F, p->T, p->dilF, p->x_wino), "aid_conv2d: dot_n != aid_conv2d_dot_partials()");
         const int r = aid_conv53_wino_try(p, st);
         if (r == 0) aid_set_error("aid_conv2d: dot_ws given but the layer is not eligible for the F(4,3) kernels");

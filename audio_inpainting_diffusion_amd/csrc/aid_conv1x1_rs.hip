@@ -248,7 +248,11 @@ int aid_conv1x1_rs_dot_partials(int Cin, int Cout, int cop, int F, int T) {
 int aid_conv1x1_rs_shape_ok(int Cin, int Cout, int cop, int F, int T) { return c11rs_shape(Cin, Cout, cop, F, T) ? 1 : 0; }
 
 int aid_conv1x1_rs_enabled(void) {
+#ifdef AID_EXPERIMENT
     static const int enabled = getenv("AID_C11_RS") ? atoi(getenv("AID_C11_RS")) : 1;
+#else
+    constexpr int enabled = 1;
+#endif
     return enabled;
 }
 

@@ -7,6 +7,7 @@
 //   conv53_wino4_kernel : input transform applied when the B fragment is formed (plain activations in LDS)
 //   conv53_wino4v_kernel: Winograd-domain input written by the producer pass (aid_scale_act wino=1), triple-buffered
 #include "aid_common.h"
+#include "aid_wino8.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -710,12 +711,13 @@ struct ConvWinoRDev {
 // in registers (half the weight bytes, 14 instead of 21 direct-to-LDS pieces per chunk, 3 instead of 6 A reads per k-step, 2x the VALU) and the
 // conflict-free layout change the kernel time by less than 0.5 % in either direction: it is bound by the matrix pipe (84 % busy at K = 256)
 // and by the prologue / epilogue of a tile, not by LDS or staging any more.  The interleave stays (no conflicts, no cost); raw-tap staging does not.
-template <int TT, int NC, int WGM, int NB, int WPC, int NWV>
+// WM: outputs per Winograd group -- 4: F(4,3), 6 products per group; 8: F(8,3), 10 products per group (aid_wino8.h), tiles of twice the positions
+template <int TT, int NC, int WGM, int NB, int WPC, int NWV, int WM = 4>
 struct W4rShape {
-    static constexpr int KH = 5, NXI = 6, TAPS = NXI * KH, KC = 2;
+    static constexpr int KH = 5, NXI = WM + 2, TAPS = NXI * KH, KC = 2;
     static constexpr int NW = NWV, WGN = NW / WGM;
-    static constexpr int M_BLK = 32 * WGM, N_BLK = 128 * WGN;
-    static constexpr int GPR = TT / 4;                         // groups of 4 outputs per row
+    static constexpr int M_BLK = 32 * WGM, N_BLK = 32 * WM * WGN;
+    static constexpr int GPR = TT / WM;                        // groups of WM outputs per row
     static constexpr int RA = N_BLK / (TT * NC);               // output rows per residue class and tile
     static constexpr int CSLOT = RA + KH - 1;                  // staged input rows per channel and class
     static constexpr int NSLOT = NC * CSLOT;
@@ -733,9 +735,9 @@ struct W4rShape {
 
 // One tile.  `smem`: W4rShape::LDS floats of LDS (declared by the kernel, so that the two tile families of a pair instance share it);
 // `bid`: workgroup index within this tile family's part of the grid.
-template <int TT, int NC, int WGM, int NB, int WPC, int NWV, bool SPK>
+template <int TT, int NC, int WGM, int NB, int WPC, int NWV, bool SPK, int WM = 4>
 __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4rGeo& ge, float* smem, const int bid) {
-    using S = W4rShape<TT, NC, WGM, NB, WPC, NWV>;
+    using S = W4rShape<TT, NC, WGM, NB, WPC, NWV, WM>;
     constexpr int KH = S::KH, NXI = S::NXI, KC = S::KC;
     constexpr int NW = S::NW, WGN = S::WGN;
     constexpr int M_BLK = S::M_BLK;
@@ -790,9 +792,9 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
             const int slot = (e / (IL * NXI * GPR)) * IL + (e / GPR) % IL;     // [slot / IL][xi][slot % IL][GPR]
             const int cls = slot / CSLOT;
             const int jr = j0 + (slot % CSLOT) - (KH / 2);   // sub-lattice row index of this slot
-            if (ci < KC && jr >= 0 && jr < nrow && t0 + 4 * gl < p.T) {
+            if (ci < KC && jr >= 0 && jr < nrow && t0 + WM * gl < p.T) {
                 const int fi = res + cls + jr * p.dilF;
-                psrc[i] = p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + (int64_t)xi * (p.T >> 2) + (t0 >> 2) + gl;
+                psrc[i] = p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + (int64_t)xi * (p.T / WM) + (t0 / WM) + gl;
                 pstride[i] = (int)(KC * p.x.sC);
             }
         } else if (pc < NP) {
@@ -955,9 +957,66 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
     float qsum[4] = {0.f, 0.f, 0.f, 0.f};                // sum y^2 (stat_ws)
     const int jr_o = j0 + jl;
     const int f_o = res + cl + jr_o * p.dilF;
-    const int t_o = t0 + 4 * tau;
+    const int t_o = t0 + WM * tau;
     const bool ok_o = jr_o < nrow && t_o < p.T;
     const int mbase = m0 + wm * 32 + 4 * half;
+    if constexpr (WM == 8) {
+      if (ok_o) {
+        // F(8,3): eight outputs per lane and accumulator row -- two rows per batch (the same bytes in flight as four rows of F(4,3))
+        const int64_t ybase = (int64_t)b * p.y.sB + (int64_t)f_o * p.y.sF + t_o;
+        const int64_t rbase = p.res.p ? ((int64_t)b * p.res.sB + (int64_t)f_o * p.res.sF + t_o) : 0;
+        const int64_t abase = p.aux.p ? ((int64_t)b * p.aux.sB + (int64_t)f_o * p.aux.sF + t_o) : 0;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 2) {
+            float rv[2][8], ur[2][8];
+            float sv[2], as[2];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int r = r0 + qq;
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                const bool ok = m < p.Cout;
+#pragma unroll
+                for (int h4 = 0; h4 < 2; ++h4) {
+                    const float4 v = (ok && p.res.p) ? *reinterpret_cast<const float4*>(p.res.p + rbase + (int64_t)m * p.res.sC + 4 * h4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    rv[qq][4 * h4] = v.x; rv[qq][4 * h4 + 1] = v.y; rv[qq][4 * h4 + 2] = v.z; rv[qq][4 * h4 + 3] = v.w;
+                }
+                sv[qq] = (ok && p.out_scale) ? p.out_scale[(int64_t)b * p.out_scale_ld + m] : 1.f;
+                as[qq] = 0.f;
+                if (ok && p.epi == 1) as[qq] = p.aux_scale[(int64_t)b * p.aux_scale_ld + m];
+#pragma unroll
+                for (int h4 = 0; h4 < 2; ++h4) {
+                    const float4 v = (ok && p.epi == 1) ? *reinterpret_cast<const float4*>(p.aux.p + abase + (int64_t)m * p.aux.sC + 4 * h4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    ur[qq][4 * h4] = v.x; ur[qq][4 * h4 + 1] = v.y; ur[qq][4 * h4 + 2] = v.z; ur[qq][4 * h4 + 3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int r = r0 + qq;
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                if (m >= p.Cout) continue;
+                float Mv[NXI], y[8];
+#pragma unroll
+                for (int x = 0; x < NXI; ++x) Mv[x] = acc[x][r];
+                aid_wino8_output(Mv, y);
+                float ds = 0.f, ss = 0.f, qs = 0.f;
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    float v = y[o] * sv[qq];
+                    if (p.epi == 1) v *= aid_dgelu(ur[qq][o] * as[qq]);
+                    v += p.res_scale * rv[qq][o];
+                    v *= p.alpha;
+                    y[o] = v;
+                    ds += v * ur[qq][o]; ss += v; qs += v * v;
+                }
+                float* yo = p.y.p + ybase + (int64_t)m * p.y.sC;
+                *reinterpret_cast<float4*>(yo) = make_float4(y[0], y[1], y[2], y[3]);
+                *reinterpret_cast<float4*>(yo + 4) = make_float4(y[4], y[5], y[6], y[7]);
+                if (p.dot_ws) dsum[r >> 2] += ds;
+                if (p.stat_ws) { dsum[r >> 2] += ss; qsum[r >> 2] += qs; }
+            }
+        }
+      }
+    } else
     if (ok_o) {
         const int64_t ybase = (int64_t)b * p.y.sB + (int64_t)f_o * p.y.sF + t_o;
         const int64_t rbase = p.res.p ? ((int64_t)b * p.res.sB + (int64_t)f_o * p.res.sF + t_o) : 0;
@@ -1052,6 +1111,26 @@ __global__ __launch_bounds__(64 * NWV, (WPC * NWV + 3) / 4) void conv53_wino4r_k
         const int n0 = 8 * a.g[0].per_xcd;
         if ((int)blockIdx.x < n0) wino4r_tile_body<TT, NC, WGM, NB, WPC, NWV, false>(a, a.g[0], smem, (int)blockIdx.x);
         else wino4r_tile_body<TT, NC1, 1, NB, WPC, NWV, false>(a, a.g[1], smem, (int)blockIdx.x - n0);
+    }
+}
+
+// ---- F(8,3) on the same row-shared body: 10 products per 8 outputs (0.833x the MFMAs of F(4,3), 0.417x of the direct form), Winograd-domain
+// input [B, C, F, 10, T/8] (1.25x the activation instead of 1.5x).  A tile is 64 output channels x 512 positions (64 groups: 160 accumulator
+// registers per lane), 33-36 KB per LDS buffer (50 transformed taps x 2 channels x 64 = 25 KB of weights), two buffers, two workgroups per CU.
+// fp32 error 3e-6 rel-L2 per layer at Cin = 128 (F(4,3): 1.5e-6, direct: 0.8e-6; tools/wino_fm3_error.py, profiles/r04_wino_fm3_error.txt).
+// NC1 > 0: pair instance for the 96-channel layers (32 x 1024 remainder tiles), as above.
+template <int TT, int NC, int WGM, int NC1 = 0>
+__global__ __launch_bounds__(256, 2) void conv53_wino8r_kernel(const ConvWinoRDev a) {
+    using S0 = W4rShape<TT, NC, WGM, 2, 2, 4, 8>;
+    if constexpr (NC1 == 0) {
+        __shared__ __attribute__((aligned(16))) float smem[S0::LDS];
+        wino4r_tile_body<TT, NC, WGM, 2, 2, 4, false, 8>(a, a.g[0], smem, (int)blockIdx.x);
+    } else {
+        using S1 = W4rShape<TT, NC1, 1, 2, 2, 4, 8>;
+        __shared__ __attribute__((aligned(16))) float smem[S0::LDS > S1::LDS ? S0::LDS : S1::LDS];
+        const int n0 = 8 * a.g[0].per_xcd;
+        if ((int)blockIdx.x < n0) wino4r_tile_body<TT, NC, WGM, 2, 2, 4, false, 8>(a, a.g[0], smem, (int)blockIdx.x);
+        else wino4r_tile_body<TT, NC1, 1, 2, 2, 4, false, 8>(a, a.g[1], smem, (int)blockIdx.x - n0);
     }
 }
 
@@ -1154,9 +1233,15 @@ static int wino4r_geometry(const aid_conv2d_params* p, Wino4rPlan plan[2]) {
 
 static bool wino_v_shape_ok(int Cin, int Cout, int T);
 
+// (environment overrides exist only in -DAID_EXPERIMENT builds: the product library's results never depend on the environment)
 static int w4r_env(const char* name, int dflt) {
+#ifdef AID_EXPERIMENT
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
 }
 
 // Split-K of the row-shared kernel (batch 1 with the scratch `ws` given -- which the network's launch plans do only for a WHOLE batch of one, so
@@ -1256,6 +1341,130 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
     return AID_OK;
 }
 
+// ---- F(8,3) row-shared tiles: geometry, eligibility, launch ---------------------------------------------------------------------------------------
+// ng: groups per tile (64 for the 64-channel tile = 512 positions, 128 for the 32-channel remainder tile of 96-channel layers).  Instantiated:
+// 64 groups -- TT = 64: NC 1, 2 (RA = 8, 4); TT = 32: NC 1, 2, 4 (RA = 16, 8, 4); 128 groups -- TT = 64: NC 1, 2, 4 (RA = 16, 8, 4).  More classes per tile would not
+// leave room for two workgroups per CU (NC (RA + 4) staged rows x 10 planes).
+static int wino8r_tile(const aid_conv2d_params* p, int ng, Wino4rPlan* o) {
+    if (p->dilF < 1 || (p->F % p->dilF) || (p->T % 32)) return 0;
+    const int TT = (p->T % 64 == 0) ? 64 : 32;
+    if (ng == 128 && TT != 64) return 0;
+    const int GPR = TT / 8;
+    const int nrow = p->F / p->dilF;
+    const int max_nc = (ng == 64 && TT == 64) ? 2 : 4;
+    for (int NC = 1; NC <= max_nc; NC *= 2) {
+        if (p->dilF % NC) break;
+        const int RA = ng / (GPR * NC);
+        const int qd = (nrow + RA - 1) / RA;
+        if ((int64_t)qd * RA * 100 > (int64_t)nrow * 115) continue;     // (up to 15 % padding rows: 7, 14, 28 rows per class -> 8, 16, 32; the form choice weighs them)
+        o->TT = TT; o->NC = NC; o->quads = qd; o->ttiles = p->T / TT;
+        return 1;
+    }
+    return 0;
+}
+static int wino8r_geometry(const aid_conv2d_params* p, Wino4rPlan plan[2]) {
+    if (p->Cout_pad % 64 == 0) return wino8r_tile(p, 64, &plan[0]) ? 1 : 0;
+    if (p->Cout_pad % 96) return 0;
+    if (!wino8r_tile(p, 64, &plan[0]) || plan[0].TT != 64) return 0;
+    if (!wino8r_tile(p, 128, &plan[1])) return 0;
+    return 2;
+}
+
+// Which Winograd form the row-shared kernels want for a 5x3 layer of this shape: 8 (F(8,3)), 4 (F(4,3)) or 0 (no Winograd-domain input).
+// F(8,3) issues 10 MFMAs per 8 outputs against 12, but its tiles hold twice the positions: per CU the work is ceil(tiles / 256) tiles either way
+// (two resident workgroups share one matrix pipe), so the form with the smaller [tiles per CU] x [MFMAs per tile] x [1 + padding rows] takes the layer;
+// ties go to F(8,3) (less staging and a 1.25x instead of 1.5x Winograd-domain tensor).  A function of the launch shape (B included), like the tile choice itself.
+static int wino_form_choice(const aid_conv2d_params* p) {
+    if (!wino_v_shape_ok(p->Cin, p->Cout, p->T)) return 0;
+    Wino4rPlan p4[2], p8[2];
+    const int n4 = wino4r_geometry(p, p4);
+    const int n8 = (p->T % 32 == 0) ? wino8r_geometry(p, p8) : 0;
+    if (!n8) return (n4 || p->T >= 32) ? 4 : 0;
+    if (!n4) return 8;
+    // issued MFMAs per (input-channel pair, tap row), padding rows included: every tile of either family is four waves x (WM + 2) products
+    auto cost = [&](const Wino4rPlan* pl, int nl, int wm) {
+        int64_t c = 0;
+        for (int l = 0; l < nl; ++l)
+            c += (int64_t)(p->dilF / pl[l].NC) * pl[l].quads * pl[l].ttiles * (wm + 2);
+        return c;
+    };
+    return cost(p8, n8, 8) * 100 <= cost(p4, n4, 4) * 102 ? 8 : 4;
+}
+
+static int launch_wino8r(const aid_conv2d_params* p, hipStream_t st) {
+    static const float* zero = nullptr;
+    if (!zero) {
+        void* z = nullptr;
+        if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_aid_zero_page_w)) != hipSuccess) { aid_set_error("aid_conv2d: zero page lookup failed"); return AID_E_LAUNCH; }
+        zero = (const float*)z;
+    }
+    Wino4rPlan plan[2];
+    const int nl = wino8r_geometry(p, plan);
+    AID_REQUIRE(nl, "aid_conv2d: x_wino = 2 (F(8,3)) needs a shape aid_conv2d_wino_form() answers 8 for");
+    const bool m96 = nl == 2;
+    ConvWinoRDev a;
+    a.p = *p;
+    a.zero = zero;
+    a.nchunks = p->Cin / 2;
+    a.dot_all = m96 ? 1 : 0;
+    a.splits = 1; a.part = nullptr; a.flags = nullptr;
+    W4rGeo geo[2];
+    int dot_base = 0;
+    for (int l = 0; l < nl; ++l) {
+        const Wino4rPlan& g = plan[l];
+        W4rGeo& ge = geo[l];
+        ge.quads = g.quads; ge.ttiles = g.ttiles;
+        ge.rgroups = p->dilF / g.NC;
+        ge.ny = m96 ? p->Cout_pad / 96 : p->Cout_pad / 64;
+        ge.m_base = l == 0 ? 0 : 64;
+        ge.m_stride = m96 ? 96 : 64;
+        ge.dot_base = dot_base;
+        dot_base += ge.rgroups * g.quads * g.ttiles;
+        ge.ntiles = p->B * ge.rgroups * g.quads * g.ttiles * ge.ny;
+        ge.per_xcd = (ge.ntiles + 7) / 8;
+    }
+#define AID_W8R(TTv, NCv, WGMv, NC1v) hipLaunchKernelGGL((conv53_wino8r_kernel<TTv, NCv, WGMv, NC1v>), grid, dim3(256), 0, st, a)
+    if (m96) {
+        a.g[0] = geo[0]; a.g[1] = geo[1];
+        const dim3 grid((unsigned)(8 * (geo[0].per_xcd + geo[1].per_xcd)));
+        switch (plan[0].NC * 16 + plan[1].NC) {               // (both families: TT = 64)
+            case 1 * 16 + 1: AID_W8R(64, 1, 2, 1); break;
+            case 1 * 16 + 2: AID_W8R(64, 1, 2, 2); break;
+            case 1 * 16 + 4: AID_W8R(64, 1, 2, 4); break;
+            case 2 * 16 + 1: AID_W8R(64, 2, 2, 1); break;
+            case 2 * 16 + 2: AID_W8R(64, 2, 2, 2); break;
+            case 2 * 16 + 4: AID_W8R(64, 2, 2, 4); break;
+            default: aid_set_error("aid_conv2d: F(8,3) pair tile shape not instantiated"); return AID_E_BADARG;
+        }
+        AID_CHECK_LAUNCH();
+    } else {
+        const Wino4rPlan& g = plan[0];
+        a.g[0] = geo[0]; a.g[1] = geo[0];
+        const dim3 grid((unsigned)(8 * geo[0].per_xcd));
+        switch (g.TT * 16 + g.NC) {
+            case 64 * 16 + 1: AID_W8R(64, 1, 2, 0); break;
+            case 64 * 16 + 2: AID_W8R(64, 2, 2, 0); break;
+            case 32 * 16 + 1: AID_W8R(32, 1, 2, 0); break;
+            case 32 * 16 + 2: AID_W8R(32, 2, 2, 0); break;
+            case 32 * 16 + 4: AID_W8R(32, 4, 2, 0); break;
+            default: aid_set_error("aid_conv2d: F(8,3) tile shape not instantiated"); return AID_E_BADARG;
+        }
+        AID_CHECK_LAUNCH();
+    }
+#undef AID_W8R
+    aid_note_kernel(m96 ? "conv53_wino8r_kernel(64+32)" : (plan[0].NC == 1 ? "conv53_wino8r_kernel" : "conv53_wino8r_kernel(multi-class)"));
+    return AID_OK;
+}
+
+extern "C" int aid_conv2d_wino_form(int B, int Cin, int Cout, int F, int T, int dilF) {
+    aid_conv2d_params q = {};
+    q.B = B; q.Cin = Cin; q.Cout = Cout; q.F = F; q.T = T; q.dilF = dilF; q.KH = 5; q.KW = 3;
+    aid_conv2d_pack_dims(Cin, Cout, &q.Cin_pad, &q.Cout_pad);
+    const int f = wino_form_choice(&q);
+    if (f == 4 && !aid_conv2d_wino_input_ok(B, Cin, Cout, F, T, dilF)) return 0;
+    return f;
+}
+
 // scratch of the split-K instances (aid_kernels.h: ws): 0 when a launch of this shape is not split
 extern "C" int64_t aid_conv2d_wino_split_ws_bytes(int B, int Cin, int Cout, int F, int T, int dilF) {
     if (!wino_v_shape_ok(Cin, Cout, T)) return 0;
@@ -1310,7 +1519,7 @@ extern "C" int aid_conv2d_stat_partials(int B, int Cin, int Cout, int F, int T, 
     aid_conv2d_params q{};
     q.B = B; q.Cin = Cin; q.Cout = Cout; q.F = F; q.T = T; q.dilF = dilF; q.Cout_pad = cop;
     Wino4rPlan plan[2];
-    const int nl = wino4r_geometry(&q, plan);
+    const int nl = x_wino == 2 ? wino8r_geometry(&q, plan) : wino4r_geometry(&q, plan);
     int n = 0;
     for (int l = 0; l < nl; ++l) n += (dilF / plan[l].NC) * plan[l].quads * plan[l].ttiles;
     return n;
@@ -1328,10 +1537,10 @@ extern "C" int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, i
         aid_conv2d_params q{};
         q.B = B; q.Cin = Cin; q.Cout = Cout; q.F = F; q.T = T; q.dilF = dilF; q.Cout_pad = cop;
         Wino4rPlan plan[2];
-        const int nl = wino4r_geometry(&q, plan);
+        const int nl = x_wino == 2 ? wino8r_geometry(&q, plan) : wino4r_geometry(&q, plan);
         int n = 0;
         for (int l = 0; l < nl; ++l) n += (dilF / plan[l].NC) * plan[l].quads * plan[l].ttiles;
-        if (nl) return n;
+        if (nl || x_wino == 2) return n;
     }
     const int nblk = wino_tile_n(B, cop, F, T);
     int TT = aid_pow2ceil(T);
@@ -1343,11 +1552,19 @@ extern "C" int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, i
 
 // x_wino = 1: the caller already wrote the Winograd-domain input; there is no other kernel that can read it
 static int conv53_wino_v(const aid_conv2d_params* p, hipStream_t st) {
+    auto al4 = [](const aid_view& v) { return (v.sB % 4) == 0 && (v.sC % 4) == 0 && (v.sF % 4) == 0 && (((uintptr_t)v.p) & 15) == 0; };
+    if (p->x_wino == 2) {                                   // F(8,3): [B, Cin, F, 10, T/8] input, 50-tap pack
+        AID_REQUIRE(p->wp_wino && p->wino_taps == 50 && p->KH == 5 && p->KW == 3 && !p->in_scale && p->act == 0,
+                    "aid_conv2d: x_wino = 2 needs the 50-tap F(8,3) pack of a 5x3 layer and no in-kernel prologue");
+        AID_REQUIRE(wino_v_shape_ok(p->Cin, p->Cout, p->T) && (p->T % 32) == 0, "aid_conv2d: shape not supported with x_wino = 2 (see aid_conv2d_wino_form)");
+        AID_REQUIRE(p->x.sF >= 10 * (p->T / 8) && (int64_t)4 * p->x.sC < (1LL << 31), "aid_conv2d: x_wino = 2 rows are [10][T/8]");
+        AID_REQUIRE(al4(p->x) && al4(p->y) && (!p->res.p || al4(p->res)) && (!p->aux.p || al4(p->aux)), "aid_conv2d: x_wino views must be 16-byte aligned");
+        return launch_wino8r(p, st);
+    }
     AID_REQUIRE(p->wp_wino && p->wino_taps == 30 && p->KH == 5 && p->KW == 3 && !p->in_scale && p->act == 0,
                 "aid_conv2d: x_wino needs the 30-tap Winograd pack of a 5x3 layer and no in-kernel prologue");
     AID_REQUIRE(wino_v_shape_ok(p->Cin, p->Cout, p->T), "aid_conv2d: shape not supported with x_wino (see aid_conv2d_wino_input_supported)");
     AID_REQUIRE(p->x.sF >= 6 * (p->T / 4) && (int64_t)4 * p->x.sC < (1LL << 31), "aid_conv2d: x_wino rows are [6][T/4]");
-    auto al4 = [](const aid_view& v) { return (v.sB % 4) == 0 && (v.sC % 4) == 0 && (v.sF % 4) == 0 && (((uintptr_t)v.p) & 15) == 0; };
     AID_REQUIRE(al4(p->x) && al4(p->y) && (!p->res.p || al4(p->res)) && (!p->aux.p || al4(p->aux)), "aid_conv2d: x_wino views must be 16-byte aligned");
     int rc;
     rc = launch_wino4r(p, st);                              // row-shared tiles, two workgroups per CU (when the geometry fits)

@@ -2,6 +2,7 @@
 // modulation into one per-(b,c) scale.  HBM-bound single read pass (float4 loads, fp64 accumulation so the
 // E[x^2]-E[x]^2 form is safe), deterministic two-stage reduction (no atomics).
 #include "aid_common.h"
+#include "aid_wino8.h"
 
 struct StatsDev {
     aid_group_stats_params p;
@@ -271,6 +272,72 @@ __global__ __launch_bounds__(256) void norm_bwd_wino_kernel(const NbDev a) {
     }
 }
 
+// F(8,3) form of the same pass (wform = 2): a thread owns one group of EIGHT samples (two float4 per operand), the neighbour samples 8g-1 and 8g+8
+// come from the adjacent lanes, and the group's ten transform values go to the planes of `wout` ([B, C, F, 10, T/8]).  lpr = threads per row = T/8.
+__global__ __launch_bounds__(256) void norm_bwd_wino8_kernel(const NbDev a) {
+    const aid_norm_bwd_params& p = a.p;
+    const int tid = threadIdx.x;
+    const int lpr = 1 << a.lpr_log2;
+    const int sub = tid >> a.lpr_log2, lq = tid & (lpr - 1);
+    const int rpb = 256 >> a.lpr_log2;
+    const int tile = blockIdx.x % a.tiles;
+    const int row = (blockIdx.x / a.tiles) * rpb + sub;
+    const int o8 = (tile * lpr + lq) * 8;
+    const bool live = row < a.nrows && o8 < p.T;
+    const int rw = live ? row : 0;
+    const int f = rw % p.F;
+    const int bc = rw / p.F;
+    const int c = bc % p.C;
+    const int b = bc / p.C;
+    const int bg = b * p.groups + c / a.cg;
+    const float coef = a.coef[bg];
+    const float mean = p.stats[2 * bg];
+    const float* gdr = p.gd.p + (int64_t)b * p.gd.sB + (int64_t)c * p.gd.sC + (int64_t)f * p.gd.sF;
+    const float* xr = p.x.p + (int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)f * p.x.sF;
+    const float* gyr = p.gy.p ? p.gy.p + (int64_t)b * p.gy.sB + (int64_t)c * p.gy.sC + (int64_t)f * p.gy.sF : nullptr;
+    float r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = 0.f;
+    if (live) {
+        float* orow = p.out.p + (int64_t)b * p.out.sB + (int64_t)c * p.out.sC + (int64_t)f * p.out.sF + o8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 g = *reinterpret_cast<const float4*>(gdr + o8 + 4 * h);
+            const float4 x = *reinterpret_cast<const float4*>(xr + o8 + 4 * h);
+            float4 v = make_float4(g.x - coef * (x.x - mean), g.y - coef * (x.y - mean), g.z - coef * (x.z - mean), g.w - coef * (x.w - mean));
+            if (gyr) {
+                const float4 y = *reinterpret_cast<const float4*>(gyr + o8 + 4 * h);
+                v.x += p.a * y.x; v.y += p.a * y.y; v.z += p.a * y.z; v.w += p.a * y.w;
+            }
+            *reinterpret_cast<float4*>(orow + 4 * h) = v;
+            r[4 * h] = v.x; r[4 * h + 1] = v.y; r[4 * h + 2] = v.z; r[4 * h + 3] = v.w;
+        }
+    }
+    const int lane = tid & 63;
+    float e0 = __shfl_up(r[7], 1, 64), e9 = __shfl_down(r[0], 1, 64);
+    auto one = [&](int t) {
+        float v = gdr[t] - coef * (xr[t] - mean);
+        if (gyr) v += p.a * gyr[t];
+        return v;
+    };
+    if (live) {
+        if (o8 == 0) e0 = 0.f;                             // the conv's zero padding
+        else if (lane == 0 || lq == 0) e0 = one(o8 - 1);   // previous group lives in another wave / block / row
+        if (o8 + 8 >= p.T) e9 = 0.f;
+        else if (lane == 63 || lq == lpr - 1) e9 = one(o8 + 8);
+        const float sc = p.wscale ? p.wscale[(int64_t)b * p.wscale_ld + c] : 1.f;
+        float d[10], V[10];
+        d[0] = e0 * sc; d[9] = e9 * sc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[1 + i] = r[i] * sc;
+        aid_wino8_input(d, V);
+        const int G = p.T >> 3;
+        float* yr = p.wout.p + (int64_t)b * p.wout.sB + (int64_t)c * p.wout.sC + (int64_t)f * p.wout.sF + (o8 >> 3);
+#pragma unroll
+        for (int xi = 0; xi < 10; ++xi) yr[(int64_t)xi * G] = V[xi];
+    }
+}
+
 extern "C" int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream) {
     AID_REQUIRE(p && p->gd.p && p->x.p && p->out.p && p->stats && p->ws, "aid_norm_bwd: null pointer");
     AID_REQUIRE(p->groups > 0 && p->C % p->groups == 0 && (p->T % 4) == 0, "aid_norm_bwd: bad shape");
@@ -287,7 +354,20 @@ extern "C" int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream) {
     const int rpb = 256 / lpr;
     hipLaunchKernelGGL(norm_bwd_coef, dim3(p->B * p->groups), dim3(64), 0, (hipStream_t)stream, a);
     AID_CHECK_LAUNCH();
+    if (p->wout.p && p->wform == 2) {
+        AID_REQUIRE((p->T % 16) == 0 && !p->accumulate, "aid_norm_bwd: wout needs T % 16 == 0 and accumulate = 0 (neighbour samples are recomputed)");
+        AID_REQUIRE(p->wout.sF >= 10 * (p->T / 8) && (p->wout.sB % 4) == 0 && (p->wout.sC % 4) == 0 && (p->wout.sF % 4) == 0 && (((uintptr_t)p->wout.p) & 15) == 0,
+                    "aid_norm_bwd: wout rows (wform = 2) are [10][T/8], 16-byte aligned");
+        int l8 = aid_pow2ceil(p->T / 8);
+        if (l8 > 256) l8 = 256;
+        a.lpr_log2 = aid_ilog2(l8);
+        a.tiles = aid_cdiv(p->T / 8, l8);
+        hipLaunchKernelGGL(norm_bwd_wino8_kernel, dim3((unsigned)(aid_cdiv(a.nrows, 256 / l8) * a.tiles)), dim3(256), 0, (hipStream_t)stream, a);
+        AID_CHECK_LAUNCH();
+        return AID_OK;
+    }
     if (p->wout.p) {
+        AID_REQUIRE(p->wform == 0 || p->wform == 1, "aid_norm_bwd: wform is 1 (F(4,3)) or 2 (F(8,3))");
         AID_REQUIRE((p->T % 16) == 0 && !p->accumulate, "aid_norm_bwd: wout needs T % 16 == 0 and accumulate = 0 (neighbour samples are recomputed)");
         AID_REQUIRE(p->wout.sF >= 6 * (p->T / 4) && (p->wout.sB % 4) == 0 && (p->wout.sC % 4) == 0 && (p->wout.sF % 4) == 0 && (((uintptr_t)p->wout.p) & 15) == 0,
                     "aid_norm_bwd: wout rows are [6][T/4], 16-byte aligned");
@@ -379,12 +459,70 @@ __global__ __launch_bounds__(256) void scale_act_wino_kernel(const SaDev a) {
         *reinterpret_cast<float4*>(yr + (int64_t)xi * G) = make_float4(V[xi][0], V[xi][1], V[xi][2], V[xi][3]);
 }
 
+// wino = 2: the F(8,3) input transform (aid_wino8.h), y rows [10][T/8].  One thread produces 2 consecutive groups (16 samples) of one row: 4 float4
+// loads + the two neighbours, 10 float2 stores (one per plane).
+__global__ __launch_bounds__(256) void scale_act_wino8_kernel(const SaDev a) {
+    const aid_scale_act_params& p = a.p;
+    const int tid = threadIdx.x;
+    const int lpr = 1 << a.lpr_log2;                     // threads per row segment (16 samples each)
+    const int sub = tid >> a.lpr_log2, lq = tid & (lpr - 1);
+    const int rpb = 256 >> a.lpr_log2;
+    const int tile = blockIdx.x % a.tiles;
+    const int row = (blockIdx.x / a.tiles) * rpb + sub;
+    if (row >= a.nrows) return;
+    const int o16 = (tile * lpr + lq) * 16;
+    if (o16 >= p.T) return;
+    const int f = row % p.F;
+    const int bc = row / p.F;
+    const int c = bc % p.C;
+    const int b = bc / p.C;
+    const float sc = p.scale ? p.scale[(int64_t)b * p.scale_ld + c] : 1.f;
+    const float* xr = p.x.p + (int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)f * p.x.sF;
+    float h[18];                                         // h[0] = sample o16-1 ... h[17] = sample o16+16
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + o16 + 4 * q);
+        h[1 + 4 * q] = v.x; h[2 + 4 * q] = v.y; h[3 + 4 * q] = v.z; h[4 + 4 * q] = v.w;
+    }
+    h[0] = (o16 > 0) ? xr[o16 - 1] : 0.f;
+    h[17] = (o16 + 16 < p.T) ? xr[o16 + 16] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+        float v = h[i] * sc;
+        if (p.act == 1) v = aid_gelu(v);
+        h[i] = v;                                        // (gelu(0) = 0: the zero padding stays zero)
+    }
+    float V0[10], V1[10];
+    aid_wino8_input(h, V0);
+    aid_wino8_input(h + 8, V1);
+    const int G = p.T >> 3;
+    float* yr = p.y.p + (int64_t)b * p.y.sB + (int64_t)c * p.y.sC + (int64_t)f * p.y.sF + (o16 >> 3);
+#pragma unroll
+    for (int xi = 0; xi < 10; ++xi)
+        *reinterpret_cast<float2*>(yr + (int64_t)xi * G) = make_float2(V0[xi], V1[xi]);
+}
+
 extern "C" int aid_scale_act(const aid_scale_act_params* p, void* stream) {
     AID_REQUIRE(p && p->x.p && p->y.p, "aid_scale_act: null pointer");
     AID_REQUIRE((p->T % 4) == 0, "aid_scale_act: T must be a multiple of 4");
     SaDev a;
     a.p = *p;
+    if (p->wino == 2) {
+        AID_REQUIRE((p->T % 16) == 0, "aid_scale_act: the Winograd-domain output needs T % 16 == 0");
+        AID_REQUIRE((p->y.sB % 2) == 0 && (p->y.sC % 2) == 0 && (p->y.sF % 2) == 0 && (((uintptr_t)p->y.p) & 7) == 0 && p->y.sF >= 10 * (p->T / 8),
+                    "aid_scale_act: F(8,3) Winograd-domain output rows are [10][T/8], 8-byte aligned");
+        int lpr = aid_pow2ceil(p->T / 16);
+        if (lpr > 256) lpr = 256;
+        a.lpr_log2 = aid_ilog2(lpr);
+        a.nrows = p->B * p->C * p->F;
+        a.tiles = aid_cdiv(p->T / 16, lpr);
+        const int rpb = 256 / lpr;
+        hipLaunchKernelGGL(scale_act_wino8_kernel, dim3((unsigned)(aid_cdiv(a.nrows, rpb) * a.tiles)), dim3(256), 0, (hipStream_t)stream, a);
+        AID_CHECK_LAUNCH();
+        return AID_OK;
+    }
     if (p->wino) {
+        AID_REQUIRE(p->wino == 1, "aid_scale_act: wino is 0, 1 (F(4,3)) or 2 (F(8,3))");
         AID_REQUIRE((p->T % 16) == 0, "aid_scale_act: the Winograd-domain output needs T % 16 == 0");
         AID_REQUIRE((p->y.sB % 4) == 0 && (p->y.sC % 4) == 0 && (p->y.sF % 4) == 0 && (((uintptr_t)p->y.p) & 15) == 0 && p->y.sF >= 6 * (p->T / 4),
                     "aid_scale_act: Winograd-domain output rows are [6][T/4], 16-byte aligned");

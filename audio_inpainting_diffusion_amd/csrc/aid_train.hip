@@ -17,6 +17,7 @@
 //   aid_adam / aid_ema / aid_sumsq       fused optimiser update, EMA update and gradient-norm partials over flat buffers
 // Everything is deterministic (fixed summation orders, no atomics).
 #include "aid_common.h"
+#include "aid_wino8.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1021,10 +1022,11 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const aid_pack_co
     const int K = p.KH * p.KW;
     const int64_t n0 = (int64_t)K * p.Cin_pad * p.Cout_pad, n1 = p.wpT ? (int64_t)K * p.Cin_padT * p.Cout_padT : 0;
     const int64_t n2 = p.wpw ? (int64_t)30 * p.Cin_pad * p.Cout_pad : 0, n3 = p.wpwT ? (int64_t)30 * p.Cin_padT * p.Cout_padT : 0;
+    const int64_t n4 = p.wpw8 ? (int64_t)50 * p.Cin_pad * p.Cout_pad : 0, n5 = p.wpw8T ? (int64_t)50 * p.Cin_padT * p.Cout_padT : 0;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n0 + n1 + n2 + n3) return;
+    if (i >= n0 + n1 + n2 + n3 + n4 + n5) return;
     int mode = 0;
-    if (i >= n0) { i -= n0; mode = 1; if (i >= n1) { i -= n1; mode = 2; if (i >= n2) { i -= n2; mode = 3; } } }
+    if (i >= n0) { i -= n0; mode = 1; if (i >= n1) { i -= n1; mode = 2; if (i >= n2) { i -= n2; mode = 3; if (i >= n3) { i -= n3; mode = 4; if (i >= n4) { i -= n4; mode = 5; } } } } }
     const bool tr = mode & 1;
     const int cip = tr ? p.Cin_padT : p.Cin_pad, cop = tr ? p.Cout_padT : p.Cout_pad;
     const int co = (int)(i % cop);                          // output channel of THIS operator (transposed: the layer's input channel)
@@ -1040,6 +1042,10 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const aid_pack_co
         };
         if (mode < 2) {
             v = W(t / p.KW, t % p.KW);
+        } else if (mode >= 4) {                             // F(8,3): tap = xi * 5 + kh, U = G w (aid_wino8.h)
+            constexpr double G8[10][3] = AID_W8_G;
+            const int xi = t / 5, kh = t - 5 * xi;
+            v = (float)(G8[xi][0] * (double)W(kh, 0) + G8[xi][1] * (double)W(kh, 1) + G8[xi][2] * (double)W(kh, 2));
         } else {                                            // tap = xi * 5 + kh
             const int xi = t / 5, kh = t - 5 * xi;
             const double w0 = (double)W(kh, 0), w1 = (double)W(kh, 1), w2 = (double)W(kh, 2);
@@ -1055,7 +1061,7 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const aid_pack_co
             v = (float)u;
         }
     }
-    float* out = mode == 0 ? p.wp : (mode == 1 ? p.wpT : (mode == 2 ? p.wpw : p.wpwT));
+    float* out = mode == 0 ? p.wp : (mode == 1 ? p.wpT : (mode == 2 ? p.wpw : (mode == 3 ? p.wpwT : (mode == 4 ? p.wpw8 : p.wpw8T))));
     out[i] = v;
 }
 
@@ -1066,10 +1072,11 @@ extern "C" int aid_pack_conv_weight(const aid_pack_conv_weight_params* p, void* 
     aid_conv2d_pack_dims(p->Cin, p->Cout, &cip, &cop);
     aid_conv2d_pack_dims(p->Cout, p->Cin, &cipT, &copT);
     AID_REQUIRE(p->Cin_pad == cip && p->Cout_pad == cop && (!p->wpT || (p->Cin_padT == cipT && p->Cout_padT == copT)), "aid_pack_conv_weight: padded dims != aid_conv2d_pack_dims()");
-    AID_REQUIRE((!p->wpw && !p->wpwT) || (p->KH == 5 && p->KW == 3), "aid_pack_conv_weight: the F(4,3) packs are for 5x3 layers");
-    AID_REQUIRE(!p->wpwT || p->wpT, "aid_pack_conv_weight: wpwT needs wpT's dims");
+    AID_REQUIRE((!p->wpw && !p->wpwT && !p->wpw8 && !p->wpw8T) || (p->KH == 5 && p->KW == 3), "aid_pack_conv_weight: the Winograd packs are for 5x3 layers");
+    AID_REQUIRE((!p->wpwT && !p->wpw8T) || p->wpT, "aid_pack_conv_weight: wpwT / wpw8T need wpT's dims");
     const int K = p->KH * p->KW;
-    const int64_t n = (int64_t)K * cip * cop + (p->wpT ? (int64_t)K * cipT * copT : 0) + (p->wpw ? (int64_t)30 * cip * cop : 0) + (p->wpwT ? (int64_t)30 * cipT * copT : 0);
+    const int64_t n = (int64_t)K * cip * cop + (p->wpT ? (int64_t)K * cipT * copT : 0) + (p->wpw ? (int64_t)30 * cip * cop : 0) + (p->wpwT ? (int64_t)30 * cipT * copT : 0)
+                    + (p->wpw8 ? (int64_t)50 * cip * cop : 0) + (p->wpw8T ? (int64_t)50 * cipT * copT : 0);
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
     AID_CHECK_LAUNCH();
     return AID_OK;

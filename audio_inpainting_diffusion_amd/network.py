@@ -372,10 +372,13 @@ class _Builder:
             self.S_of[in_scale.data_ptr()] = Sb
 
     def _conv_raw(self, x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha, epi=0,
-                  aux=None, aux_scale=None, wpw=None, x_wino=False, dot=None, x2=None):
+                  aux=None, aux_scale=None, wpw=None, x_wino=0, dot=None, x2=None):
+        """``x_wino``: 0 plain activations, 4 / 8: ``x`` is the F(4,3) / F(8,3) input transform and ``wpw`` the matching 30- / 50-tap pack."""
         B, _, F, T = y.shape
+        x_wino = int(x_wino)
         assert x.shape[1] + (0 if x2 is None else x2.shape[1]) == cin and y.shape[1] == cout and x.shape[0] == B and x.shape[2] == F
-        assert x.shape[3] == (6 * (T // 4) if x_wino else T)
+        assert x.shape[3] == {0: T, 4: 6 * (T // 4), 8: 10 * (T // 8)}[x_wino]
+        xw_code = {0: 0, 4: 1, 8: 2}[x_wino]                 # aid_conv2d_params::x_wino
         p = _lib.Conv2dParams()
         p.x, p.y, p.res, p.aux = _lib.view4(x), _lib.view4(y), _lib.view4(res), _lib.view4(aux)
         p.wp = wp.data_ptr()
@@ -388,7 +391,7 @@ class _Builder:
         p.alpha, p.res_scale = alpha, res_scale
         p.wp_wino = _lib.ptr(wpw)
         p.wino_taps = 0 if wpw is None else wpw.shape[0]
-        p.x_wino = int(x_wino)
+        p.x_wino = xw_code
         if dot is not None:                              # (buffer, partials per (b, group)): <y, aux> folded into the epilogue
             p.dot_ws, p.dot_n = dot[0].data_ptr(), dot[1]
         if x2 is not None:                               # K axis in two tensors (aid_kernels.h: x2 / Cin1)
@@ -397,13 +400,13 @@ class _Builder:
         if F == 1 and kh == 1 and epi == 0:              # qk projections: few columns, long K -> split-K scratch (aid_kernels.h)
             ws = self._scratch(("ws", 8 * B * cout * T))
             p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
-        elif x_wino and B == 1 and self.whole_batch:     # a WHOLE batch of one (never a sub-batch: a segment's bits must not depend on the split):
+        elif x_wino == 4 and B == 1 and self.whole_batch:     # a WHOLE batch of one (never a sub-batch: a segment's bits must not depend on the split):
                                                          # launches with few tiles share the K axis of a tile between two workgroups
             need = int(_lib.lib().aid_conv2d_wino_split_ws_bytes(B, cin, cout, F, T, dil))
             if need:
                 ws = self._split_ws(need)
                 p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
-        assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] == 30 and wpw.shape[1:] == wp.shape[1:]))
+        assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] == (50 if x_wino == 8 else 30) and wpw.shape[1:] == wp.shape[1:]))
         # algorithmic HBM bytes: x once, residual / aux once, y once, weights once
         nb = 4 * (B * F * T * (cin + cout * (1 + (res is not None) + (aux is not None))) + cin * cout * kh * kw)
         dws = None if dot is None else dot[0]
@@ -411,7 +414,7 @@ class _Builder:
                        nbytes=nb, writes=(y, ws, dws))
         self._wrote(y)
         if not self._in_bwd and x_wino and epi == 0 and dot is None and self.net.epilogue_stats:
-            n = int(_lib.lib().aid_conv2d_stat_partials(B, cin, cout, F, T, dil, 1))
+            n = int(_lib.lib().aid_conv2d_stat_partials(B, cin, cout, F, T, dil, xw_code))
             if n:                                         # a later stats(y) may ask this conv's epilogue for the partial sums
                 hi = y.data_ptr() + 4 * (1 + sum((m - 1) * st for m, st in zip(y.shape, y.stride())))
                 self._stat_src[self._vkey(y)] = (p, n, hi, op)
@@ -425,25 +428,36 @@ class _Builder:
             self.nbytes += t.numel() * 8
         return t
 
-    def _wino_input(self, cin, cout, T, wp, wpw, F=0, dil=1):
-        """True when the pre-pass should write the F(4,3) input transform (aid_scale_act wino=1 -> aid_conv2d x_wino=1):
-        every 5x3 layer with Cin % 4 == 0, a 64- or 96-multiple Cout pack and T % 16 == 0, T >= 32 (the library answers)."""
-        return (wpw is not None and wpw.shape[0] == 30
-                and bool(_lib.lib().aid_conv2d_wino_input_ok(self.B, cin, cout, F, T, dil)))
+    def _wino_input(self, cin, cout, T, wp, wpw, F=0, dil=1, wpw8=None):
+        """The Winograd form the pre-pass should write for this 5x3 layer (aid_scale_act wino = 1 / 2 -> aid_conv2d x_wino = 1 / 2): 8 = F(8,3)
+        (10 MFMAs per 8 outputs; needs the 50-tap pack), 4 = F(4,3), 0 = plain activations.  The library answers from the launch shape
+        (aid_conv2d_wino_form); ``net.wino_forms`` restricts the choice (A/B measurements, tests of the F(4,3) kernels)."""
+        if wpw is None or wpw.shape[0] != 30:
+            return 0
+        form = int(_lib.lib().aid_conv2d_wino_form(self.B, cin, cout, F, T, dil))
+        if form == 8 and (wpw8 is None or 8 not in self.net.wino_forms):
+            form = 4
+        if form == 4 and not (4 in self.net.wino_forms and bool(_lib.lib().aid_conv2d_wino_input_ok(self.B, cin, cout, F, T, dil))):
+            form = 0
+        return form
+
+    @staticmethod
+    def _wino_cols(form, T):
+        return {0: T, 4: 6 * (T // 4), 8: 10 * (T // 8)}[form]
 
     def conv(self, x, y, wp, cin, cout, kh=1, kw=1, dil=1, in_scale=None, act=0, out_scale=None, res=None,
-             res_scale=1.0, alpha=1.0, wpT=None, norm_stats=None, wpw=None, wpwT=None, res_nograd=False, wname=None):
+             res_scale=1.0, alpha=1.0, wpT=None, norm_stats=None, wpw=None, wpwT=None, res_nograd=False, wname=None, wpw8=None, wpw8T=None):
         """Forward conv + registration of its input-VJP.  ``norm_stats``: the (mean, 1/(std+eps)) buffer when
         ``in_scale`` was produced by ``stats`` from this same ``x`` (the scale then depends on x)."""
         if act and kh > 1:
             # evaluate norm*mod -> GELU once per element into a scratch tensor; the conv stages plain copies
-            xw = self._wino_input(cin, cout, x.shape[3], wp, wpw, x.shape[2], dil)
-            hshape = (x.shape[0], cin, x.shape[2], 6 * (x.shape[3] // 4)) if xw else tuple(x.shape)
+            xw = self._wino_input(cin, cout, x.shape[3], wp, wpw, x.shape[2], dil, wpw8)
+            hshape = (x.shape[0], cin, x.shape[2], self._wino_cols(xw, x.shape[3]))
             hbuf = self._scratch(("h",) + hshape)
             sp = _lib.ScaleActParams(_lib.view4(x), _lib.view4(hbuf), in_scale.data_ptr(), in_scale.stride(0), x.shape[0], cin,
-                                     x.shape[2], x.shape[3], 1, int(xw))
+                                     x.shape[2], x.shape[3], 1, {0: 0, 4: 1, 8: 2}[xw])
             self._add("aid_scale_act", sp, x, hbuf, in_scale, writes=(hbuf,))
-            self._conv_raw(hbuf, y, wp, cin, cout, kh, kw, dil, None, 0, out_scale, res, res_scale, alpha, wpw=wpw, x_wino=xw)
+            self._conv_raw(hbuf, y, wp, cin, cout, kh, kw, dil, None, 0, out_scale, res, res_scale, alpha, wpw=wpw8 if xw == 8 else wpw, x_wino=xw)
         else:
             self._conv_raw(x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha)
         if wpT is None:
@@ -459,22 +473,23 @@ class _Builder:
                     self.add2_raw(gr, gy, gr, 1.0, alpha * res_scale)
                 else:
                     self.add2_raw(gy, None, gr, alpha * res_scale, 0.0)
-            gin, gsc, gw = gy, out_scale, False
+            gin, gsc, gw = gy, out_scale, 0
             if kh > 1 and out_scale is not None:
                 # 5x3 dgrad: apply the gate in a copy pass so the conv input needs no in-kernel prologue
                 # (keeps it on the direct-to-LDS kernel)
-                gw = norm_stats is not None and self._wino_input(cout, cin, gy.shape[3], wpT, wpwT, gy.shape[2], dil)
-                gshape = (gy.shape[0], cout, gy.shape[2], 6 * (gy.shape[3] // 4)) if gw else tuple(gy.shape)
+                gw = self._wino_input(cout, cin, gy.shape[3], wpT, wpwT, gy.shape[2], dil, wpw8T) if norm_stats is not None else 0
+                gshape = (gy.shape[0], cout, gy.shape[2], self._wino_cols(gw, gy.shape[3]))
                 gin = self._scratch(("g",) + gshape)
                 nb = self._nb_src.pop(self._vkey(gy), None) if (gw and self.net.fuse_norm_bwd_wino) else None
                 if nb is not None and nb[1] > self._g_last.get(gin.data_ptr(), -1) and nb[3].lane == self.lane:
                     # gy was written last by an aid_norm_bwd and nothing used this scratch since: that pass also writes gin
                     nb[0].wout, nb[0].wscale, nb[0].wscale_ld = _lib.view4(gin), out_scale.data_ptr(), out_scale.stride(0)
+                    nb[0].wform = 2 if gw == 8 else 1
                     self.plan.keep.extend((gin, out_scale))
                     nb[3].also_writes(gin)
                 else:
                     sp = _lib.ScaleActParams(_lib.view4(gy), _lib.view4(gin), out_scale.data_ptr(), out_scale.stride(0), gy.shape[0],
-                                             cout, gy.shape[2], gy.shape[3], 0, int(gw))
+                                             cout, gy.shape[2], gy.shape[3], 0, {0: 0, 4: 1, 8: 2}[gw])
                     self._add("aid_scale_act", sp, gy, gin, out_scale, writes=(gin,))
                 self._g_last[gin.data_ptr()] = len(self.plan.ops)      # (the dgrad conv below reads it)
                 gsc = None
@@ -483,12 +498,12 @@ class _Builder:
                 # <gd, x> per (sample, group): folded into the dgrad conv's epilogue when it runs on the F(4,3) kernels
                 nd = 0
                 if act and kh == 5 and gsc is None and wpwT is not None and wpwT.shape[0] == 30:
-                    nd = int(_lib.lib().aid_conv2d_dot_partials(B, cout, cin, F, T, dil, int(gw)))
+                    nd = int(_lib.lib().aid_conv2d_dot_partials(B, cout, cin, F, T, dil, {0: 0, 4: 1, 8: 2}[gw]))
                 elif act and kh == 1 and kw == 1 and self.net.fuse_dot_1x1:        # 1x1 steps (init / out blocks): the direct-to-LDS kernel's epilogue
                     nd = int(_lib.lib().aid_conv2d_dot_partials_1x1(B, cout, cin, F, T))
                 dws = self._dot_ws(nd) if nd else self.stats_ws
                 self._conv_raw(gin, gd, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, None, 1.0, alpha,
-                               epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None, wpw=wpwT, x_wino=gw,
+                               epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None, wpw=wpw8T if gw == 8 else wpwT, x_wino=gw,
                                dot=(dws, nd) if nd else None)
                 if not nd:
                     dp = _lib.GroupDotParams(_lib.view4(gd), _lib.view4(x), B, cin, F, T, 8, self.stats_ws.data_ptr())
@@ -738,10 +753,12 @@ class Unet_CQT_oct_with_attention(nn.Module):
                 if wd.dtype != torch.float32 or not wd.is_contiguous():
                     wd = wd.float().contiguous()
                 (cip, cop), (cipT, copT) = _lib.pack_dims(ci, co), _lib.pack_dims(co, ci)
+                w8 = wino and 8 in self.wino_forms                                            # F(8,3) packs (50 taps)
                 bufs = [ensure(name, (kh * kw, cip, cop)), ensure(name + "#T", (kh * kw, cipT, copT)),
-                        ensure(name + "#W", (30, cip, cop)) if wino else None, ensure(name + "#WT", (30, cipT, copT)) if wino else None]
+                        ensure(name + "#W", (30, cip, cop)) if wino else None, ensure(name + "#WT", (30, cipT, copT)) if wino else None,
+                        ensure(name + "#W8", (50, cip, cop)) if w8 else None, ensure(name + "#W8T", (50, cipT, copT)) if w8 else None]
                 pp = _lib.PackConvWeightParams(wd.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr(), _lib.ptr(bufs[2]), _lib.ptr(bufs[3]),
-                                               co, ci, kh, kw, cip, cop, cipT, copT)
+                                               co, ci, kh, kw, cip, cop, cipT, copT, _lib.ptr(bufs[4]), _lib.ptr(bufs[5]))
                 _lib.call("aid_pack_conv_weight", pp)       # all layouts of this weight in one launch (same values as _lib.pack_conv_weight*)
             elif leaf == "gamma":
                 put(name, w.detach().reshape(-1).float())
@@ -849,7 +866,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
             xn = bd.buf(B, N, F, T)
             bd.conv(x, xn, W[pfx + f"H.{k}.weight"], N, N, kh, kw, dil=(2 ** k if kh > 1 else 1), in_scale=sc, act=1,
                     out_scale=self._mod(st, pfx + f"gate.{k}"), res=x, alpha=RSQRT2, wpT=W[pfx + f"H.{k}.weight#T"],
-                    norm_stats=stb, wpw=W.get(pfx + f"H.{k}.weight#W"), wpwT=W.get(pfx + f"H.{k}.weight#WT"), wname=pfx + f"H.{k}.weight")
+                    norm_stats=stb, wpw=W.get(pfx + f"H.{k}.weight#W"), wpwT=W.get(pfx + f"H.{k}.weight#WT"), wname=pfx + f"H.{k}.weight",
+                    wpw8=W.get(pfx + f"H.{k}.weight#W8"), wpw8T=W.get(pfx + f"H.{k}.weight#W8T"))
             x = xn
         if blk.proj_place == "after":
             assert hasattr(blk, "proj_out") and hasattr(blk, "res_conv")
@@ -1110,6 +1128,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
                                # sub-batch streams; a second lane INSIDE each sub-batch stream measured -19 % at batch 8 (six streams competing)
     param_grads_in_train_mode = False   # True: a train()-mode call whose INPUT requires grad also yields parameter gradients (TrainFn) instead of
                                         # the input-only VJP; off by default because the reference's tester samples with the network in train() mode
+    wino_forms = (4, 8)        # Winograd forms the 5x3 layers may use: F(8,3) where the library prefers it (aid_conv2d_wino_form), F(4,3) otherwise;
+                               # (4,) keeps every layer on the F(4,3) kernels (A/B measurements; set before the first forward)
     wgrad_wino = True          # training: F(4,3) form of the 5x3 weight gradients (aid_conv2d_wgrad wino=1)
     fuse_norm_bwd_wino = True  # reverse sweep: aid_norm_bwd also writes the Winograd-domain, gated copy that the dgrad conv below stages
     epilogue_stats = True      # forward group statistics from the epilogue of the conv that produces the tensor (row-shared F(4,3) kernel)

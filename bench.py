@@ -45,7 +45,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA = 157.3          # TFLOP/s, dense fp32 matrix (MI355X_MICROARCH.md)
-WINO_KERNELS = ("conv53_wino4r_kernel", "conv53_wino4v_kernel", "conv53_wino4_kernel")     # F(4,3): executed MFMA FLOPs = 1/2 of the direct form
+# executed MFMA FLOPs as a fraction of the direct form: F(4,3) issues 6 products per 4 outputs x 3 taps = 1/2, F(8,3) 10 per 8 x 3 = 5/12
+WINO_EXEC = {"conv53_wino4r_kernel": 0.5, "conv53_wino4v_kernel": 0.5, "conv53_wino4_kernel": 0.5, "conv53_wino8r_kernel": 10.0 / 24.0}
 
 
 def cpu_model() -> str:
@@ -115,7 +116,7 @@ def family_table(timing, by_kernel=False):
         r["launches"] += 1
         r["ms"] += e0.elapsed_time(e1)
         r["alg"] += fl
-        r["exe"] += fl * (0.5 if base in WINO_KERNELS else 1.0)
+        r["exe"] += fl * WINO_EXEC.get(base, 1.0)
         r["bytes"] += nb
     out = {}
     for kn, r in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
@@ -153,6 +154,7 @@ def main():
     ap.add_argument("--no-lanes", action="store_true", help="A/B: single-stream launch plans at small batches (plan.py lanes off)")
     ap.add_argument("--no-fused-norm-bwd", action="store_true", help="A/B: separate gate / Winograd-transform pre-pass before every dgrad conv")
     ap.add_argument("--no-epilogue-stats", action="store_true", help="A/B: group statistics by their own read pass instead of the conv epilogue")
+    ap.add_argument("--wino-forms", default="4,8", help="A/B: Winograd forms the 5x3 layers may use (default 4,8: F(8,3) where the library prefers it; 4: F(4,3) everywhere)")
     ap.add_argument("--conv-table", action="store_true", help="print per-shape conv kernel times (stderr)")
     a = ap.parse_args()
 
@@ -193,6 +195,7 @@ def main():
         net.fuse_norm_bwd_wino = False
     if a.streams:
         net.split_streams = a.streams
+    net.wino_forms = tuple(int(v) for v in a.wino_forms.split(","))
     if a.no_graphs:
         net.use_graphs = False
     if a.no_pair_merge:
@@ -290,7 +293,7 @@ def main():
         dom = kerns.get(dom_name, {})
         conv_ms = sum(v["time_ms"] for v in fams.values())
         alg = sum(t[2] for t in timing)
-        exe = sum(t[2] * (0.5 if t[5].split("(")[0] in WINO_KERNELS else 1.0) for t in timing)
+        exe = sum(t[2] * WINO_EXEC.get(t[5].split("(")[0], 1.0) for t in timing)
         sec = max(conv_ms * 1e-3, 1e-12)
         out = {
             "metric": "denoiser-steps/sec", "value": round(evals / wall, 3), "unit": "denoiser evaluations (one segment each) per second, whole job",
@@ -310,7 +313,7 @@ def main():
                        "sub_batch_streams": n_split, "hip_graph_replay": graphs, "functional_shared_gpu": bool(shared)},
             "roofline": {"bound": "mfma", "kernel": dom_name, "measured_in": roofline_pass,
                          "definition": "achieved = MFMA FLOPs issued by ALL launches of the dominant kernel (by device-kernel name, every template instance / tile kind) "
-                                       "/ their summed duration (HIP events around each launch); Winograd F(4,3) issues half of the direct-form FLOPs; "
+                                       "/ their summed duration (HIP events around each launch); Winograd F(4,3) issues 1/2 and F(8,3) 5/12 of the direct-form FLOPs; "
                                        "algorithmic_tflops = direct-form FLOPs / the same time; step_executed_frac = issued MFMA FLOPs of all conv / GEMM launches "
                                        "of one step / ms_per_step of the timed region / peak",
                          "step_executed_frac": round(exe / ROOF_STEPS / (wall / a.steps) / 1e12 / PEAK_F32_MFMA, 4),

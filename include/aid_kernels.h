@@ -28,7 +28,7 @@ extern "C" {
 #define AID_E_BADARG (-1)   /* unsupported shape / null pointer / misaligned stride */
 #define AID_E_LAUNCH (-2)   /* hipLaunchKernel reported an error                    */
 
-#define AID_ABI_VERSION 9
+#define AID_ABI_VERSION 10
 int aid_abi_version(void);
 /* last HIP error string seen by a launcher in this process (never NULL) */
 const char* aid_last_error(void);
@@ -103,11 +103,14 @@ typedef struct {
     int KH, KW, dilF;
     int act, epi;
     float alpha, res_scale;
-    const float* wp_wino;     /* optional: Winograd F(4,3) pack of the same 5x3 weights, 30 taps (see above) */
-    int wino_taps;            /* 30 (0 when wp_wino is NULL) */
+    const float* wp_wino;     /* optional: Winograd F(4,3) pack of the same 5x3 weights, 30 taps (see above); with x_wino = 2: the F(8,3) pack, 50 taps xi*5+kh */
+    int wino_taps;            /* 30, or 50 with x_wino = 2 (0 when wp_wino is NULL) */
     int x_wino;               /* 1: `x` is the F(4,3) INPUT TRANSFORM of the activations, written by aid_scale_act(wino=1):
                                  [B, Cin, F, 6, T/4] (sF = 6*T/4 ...), V = B^T d per group of 4 samples; needs wp_wino with 30 taps
-                                 and aid_conv2d_wino_input_supported(...) != 0.  The kernel then stages and multiplies only. */
+                                 and aid_conv2d_wino_input_supported(...) != 0.  The kernel then stages and multiplies only.
+                                 2: `x` is the F(8,3) input transform [B, Cin, F, 10, T/8] (aid_scale_act wino = 2): 10 MFMAs per 8 outputs
+                                 (0.417x the direct form); needs the 50-tap pack and aid_conv2d_wino_form(...) == 8.  fp32 error about 2x that of
+                                 F(4,3) (3e-6 rel-L2 per layer at Cin = 128; profiles/r04_wino_fm3_error.txt). */
     float* ws; int64_t ws_bytes; /* optional scratch (the library never allocates): lets grid-starved 1x1 GEMMs (the qk projections:
                                  B*T columns only, K of several thousand) split K over up to 8 workgroups per tile; partial sums
                                  go to ws[S][B][Cout][F][T] and a second kernel reduces them in a FIXED order (deterministic) and
@@ -138,10 +141,13 @@ int aid_conv2d_x2_supported(int Cin, int Cin1, int Cout, int F, int T);
 int aid_conv2d_wino_input_supported(int Cin, int Cout, int T);
 /* the same question with the layer's geometry: T = 16 layers are served only when the row-shared tiles fit F and the dilation */
 int aid_conv2d_wino_input_ok(int B, int Cin, int Cout, int F, int T, int dilF);
+/* which Winograd-domain input a 5x3 layer of this launch shape should be given: 8 -> x_wino = 2 (F(8,3)), 4 -> x_wino = 1 (F(4,3)), 0 -> plain
+   activations.  F(8,3) takes the layer when its row-shared tiles fit (T % 32 == 0, F % dilF == 0, <= 12.5 % padding rows) and issue fewer MFMAs. */
+int aid_conv2d_wino_form(int B, int Cin, int Cout, int F, int T, int dilF);
 /* bytes of `ws` a 5x3 x_wino layer of this shape wants for its split-K instance (B = 1 launches with few tiles); 0: the shape is not split */
 #define AID_CONV2D_SPLIT_FLAG_BYTES 4096
 int64_t aid_conv2d_wino_split_ws_bytes(int B, int Cin, int Cout, int F, int T, int dilF);
-/* number of per-tile partial dots per (sample, group) the F(4,3) epilogue writes for this shape; 0 = not supported */
+/* number of per-tile partial dots per (sample, group) the F(4,3) / F(8,3) epilogue writes for this shape (x_wino as in aid_conv2d_params); 0 = not supported */
 int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino);
 /* number of per-tile (sum, sum of squares) partials per (sample, group) for stat_ws; 0 = the kernel that takes this shape does not write them */
 int aid_conv2d_stat_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino);
@@ -347,6 +353,7 @@ typedef struct {
     aid_view wout;                /* optional second output (T % 16 == 0): the F(4,3) input transform [B, C, F, 6, T/4] of out * wscale[b,c] -- what
                                      aid_scale_act(wino=1) would write for the dgrad conv of the layer below (its gate pre-pass folded into this pass) */
     const float* wscale; int64_t wscale_ld;   /* [B, wscale_ld] or NULL (-> 1) */
+    int wform;                    /* Winograd form of wout: 0 / 1 = F(4,3) as above; 2 = F(8,3), wout rows [10][T/8] (aid_scale_act wino = 2) */
 } aid_norm_bwd_params;
 int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream);
 
@@ -443,7 +450,9 @@ typedef struct {
     const float* scale; int64_t scale_ld;
     int B, C, F, T, act;
     int wino;                 /* 1: write the F(4,3) input transform of h along T instead of h itself: y is [B,C,F,6,T/4],
-                                 y[..,xi,g] = (B^T d)[xi], d = h[4g-1 .. 4g+4] (zero outside the row); T % 16 == 0 */
+                                 y[..,xi,g] = (B^T d)[xi], d = h[4g-1 .. 4g+4] (zero outside the row); T % 16 == 0.
+                                 2: the F(8,3) input transform: y is [B,C,F,10,T/8], d = h[8g-1 .. 8g+8]; interpolation points
+                                 {0, +-0.4, +-0.8, +-1.25, +-2.5, inf}, matrices in csrc/aid_wino8.h (tools/gen_wino8.py) */
 } aid_scale_act_params;
 int aid_scale_act(const aid_scale_act_params* p, void* stream);
 
@@ -506,12 +515,14 @@ int aid_wino_gy(const aid_wino_gy_params* p, void* stream);
  * network.prepare() after each optimiser step; Conv2d weights of unet...py:79-88 in the state_dict's own layout [Cout,Cin,KH,KW]).
  *   wp  [KH*KW][Cin_pad][Cout_pad]         wp[t][ci][co] = w[co][ci][kh][kw], t = kh*KW + kw, zero padded
  *   wpT [KH*KW][Cin_padT][Cout_padT]       the input-gradient operator: taps flipped, channel roles swapped (pack dims of (Cout, Cin)); NULL: skip
- *   wpw / wpwT [30][...]                   F(4,3) packs U = G w of both (5x3 only; fp64 arithmetic, rounded once); NULL: skip */
+ *   wpw / wpwT [30][...]                   F(4,3) packs U = G w of both (5x3 only; fp64 arithmetic, rounded once); NULL: skip
+ *   wpw8 / wpw8T [50][...]                 F(8,3) packs of both (5x3 only; G of csrc/aid_wino8.h); NULL: skip */
 typedef struct {
     const float* w;
     float* wp; float* wpT; float* wpw; float* wpwT;
     int Cout, Cin, KH, KW;
     int Cin_pad, Cout_pad, Cin_padT, Cout_padT;
+    float* wpw8; float* wpw8T;
 } aid_pack_conv_weight_params;
 int aid_pack_conv_weight(const aid_pack_conv_weight_params* p, void* stream);
 

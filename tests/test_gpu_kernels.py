@@ -266,6 +266,80 @@ def test_conv2d_winograd_domain_input(L, case):
         assert float(ws[:1024].abs().max()) == 0.0 and float(ws[need // 4:].min()) == 7.0
 
 
+WINO8_CASES = [
+    # B, Cin, Cout, F, T, dil, act, epilogue          F(8,3) row-shared tiles <TT, NC>: 64 groups of 8 outputs = RA rows x NC classes x TT samples
+    (1, 64, 64, 24, 1024, 2, 1, True),       # <64, 1>: 12 rows per class -> two quads of 8 (the second half empty), 16 t-tiles
+    (2, 64, 128, 32, 64, 1, 1, True),        # <64, 1>: RA = 8, four quads, two Cout tiles
+    (2, 128, 64, 40, 128, 2, 0, True),       # <64, 2>: 20 rows per class (RA = 8 would pad 20 -> 24): RA = 4 of two classes
+    (1, 256, 256, 448, 32, 1, 1, True),      # <32, 1>: RA = 16, the deepest level of the shipped network
+    (2, 64, 64, 56, 32, 2, 1, True),         # <32, 1>: 28 rows per class -> 2 quads of 16 (14 % padding rows, still fewer MFMAs than F(4,3))
+    (2, 64, 128, 56, 32, 8, 1, True),        # <32, 2>: 7 rows per class -> RA = 8 of two classes
+    (2, 64, 128, 32, 32, 8, 0, True),        # <32, 4>: 4 rows per class -> RA = 4 of four classes
+    (3, 64, 64, 16, 96, 1, 0, False),        # T = 96: TT = 32, three t-tiles
+    (1, 256, 128, 384, 64, 64, 1, True),     # 6 rows per class: no F(8,3) tile fits -> the library answers F(4,3)
+    # 96 output channels: pair instance (64-channel tiles + 32-channel x 1024-position remainder tiles)
+    (1, 96, 96, 32, 256, 2, 1, True),        # <64, 1> + <64, 1>: 16 rows per class
+    (2, 64, 96, 48, 64, 2, 0, False),        # 24 rows per class: <64, 1> + remainder over two classes (RA = 8)
+    (2, 96, 96, 16, 128, 4, 1, True),        # 4 rows per class: <64, 2> + <64, 4>
+]
+
+
+@pytest.mark.parametrize("case", WINO8_CASES)
+def test_conv2d_winograd8_domain_input(L, case):
+    """aid_scale_act(wino=2) -> aid_conv2d(x_wino=2): F(8,3) along T on the row-shared tiles (10 MFMAs per 8 outputs), against the torch-CPU
+    reference of the plain convolution.  fp32 error budget of the form: 1e-5 per layer (measured 3e-6 ... 6e-6, tools/wino_fm3_error.py)."""
+    B, Cin, Cout, Fd, T, dil, act, epi = case
+    form = int(L.lib().aid_conv2d_wino_form(B, Cin, Cout, Fd, T, dil))
+    if (Cin, Cout, Fd, T, dil) == (256, 128, 384, 64, 64):
+        assert form == 4
+        return
+    assert form == 8, form
+    x = _rand(B, Cin, Fd, T, seed=40)
+    w = _rand(Cout, Cin, 5, 3, seed=41, scale=1.0 / math.sqrt(Cin * 15))
+    in_scale = 1.0 + 0.5 * _rand(B, Cin, seed=42)
+    out_scale = _rand(B, Cout, seed=43) if epi else None
+    res = _rand(B, Cout, Fd, T, seed=44) if epi else None
+    alpha, res_scale = (1 / math.sqrt(2), 1.5) if epi else (1.0, 1.0)
+    ref = _conv_ref(x, w, dil, in_scale, act, out_scale, res, res_scale, alpha)
+    xd, wd, isd = x.to(DEV), w.to(DEV), in_scale.to(DEV)
+    G = T // 8
+    # (1) the input transform against its definition
+    xv = torch.full((B, Cin, Fd, 10 * G + 4), 7.0, device=DEV)[..., :10 * G]        # padded rows: strided view
+    L.call("aid_scale_act", L.ScaleActParams(L.view4(xd), L.view4(xv), isd.data_ptr(), isd.stride(0), B, Cin, Fd, T, act, 2))
+    h = x * in_scale[:, :, None, None]
+    if act:
+        h = F.gelu(h)
+    d = F.pad(h, (1, 8)).unfold(-1, 10, 8)[..., :G, :]                              # d[..., g, :] = h[8g-1 .. 8g+8]
+    AT, Gm, BT = L.wino8_matrices()
+    Vref = torch.einsum("xk,bcfgk->bcfxg", torch.from_numpy(BT), d.double()).reshape(B, Cin, Fd, 10 * G)
+    assert rel_l2(xv.cpu().double(), Vref) < 1e-6
+    # (2) the convolution on it
+    wp, wpw = L.pack_conv_weight(wd), L.pack_conv_weight_wino8(wd)
+    y = torch.empty(B, Cout, Fd, T, device=DEV)
+    p = L.Conv2dParams()
+    resd = None if res is None else res.to(DEV)
+    osd = None if out_scale is None else out_scale.to(DEV)
+    p.x, p.y, p.res, p.aux = L.view4(xv), L.view4(y), L.view4(resd), L.view4(None)
+    p.wp, p.wp_wino, p.wino_taps, p.x_wino = wp.data_ptr(), wpw.data_ptr(), 50, 2
+    p.out_scale, p.out_scale_ld = L.ptr(osd), (0 if osd is None else osd.stride(0))
+    p.B, p.Cin, p.Cout, p.F, p.T = B, Cin, Cout, Fd, T
+    p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
+    p.KH, p.KW, p.dilF, p.act, p.epi = 5, 3, dil, 0, 0
+    p.alpha, p.res_scale = alpha, res_scale
+    L.call("aid_conv2d", p)
+    torch.cuda.synchronize()
+    assert "wino8r" in L.lib().aid_last_kernel().decode()
+    err = rel_l2(y.cpu(), ref)
+    assert err < 1e-5, err
+    # (3) the pack kernel writes the same F(8,3) packs as the torch helper
+    outs = [torch.empty_like(wp), torch.empty(15, *L.pack_dims(Cout, Cin), device=DEV), torch.empty(50, *wp.shape[1:], device=DEV),
+            torch.empty(50, *L.pack_dims(Cout, Cin), device=DEV)]
+    pp = L.PackConvWeightParams(wd.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), None, None, Cout, Cin, 5, 3, wp.shape[1], wp.shape[2],
+                                outs[1].shape[1], outs[1].shape[2], outs[2].data_ptr(), outs[3].data_ptr())
+    L.call("aid_pack_conv_weight", pp)
+    assert torch.equal(outs[2], wpw) and torch.equal(outs[3], L.pack_conv_weight_wino8(wd, transpose=True))
+
+
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(2, 3, 4, 16), (1, 2, 5, 8), (2, 4, 3, 256), (1, 1, 2, 2048)])
 def test_resample_and_adjoints(L, shape):

@@ -243,7 +243,7 @@ EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_st
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_guidance_step", "aid_set_rows", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
-           "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino_split_ws_bytes",
+           "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino8_supported", "aid_conv2d_wino_split_ws_bytes", "aid_conv2d_wino8_sk_ws_bytes",
            "aid_conv2d_wgrad", "aid_wgrad_reduce", "aid_channel_dot", "aid_relpos_bwd", "aid_scale_bwd", "aid_modulation_bwd", "aid_embed_bwd",
            "aid_adam", "aid_ema", "aid_sumsq"]
 
@@ -276,6 +276,10 @@ def lib():
         L.aid_conv2d_dot_partials_1x1.restype = C.c_int
         L.aid_conv2d_wino_input_ok.argtypes = [C.c_int] * 6
         L.aid_conv2d_wino_input_ok.restype = C.c_int
+        L.aid_conv2d_wino8_supported.argtypes = [C.c_int] * 5
+        L.aid_conv2d_wino8_supported.restype = C.c_int
+        L.aid_conv2d_wino8_sk_ws_bytes.argtypes = [C.c_int] * 6
+        L.aid_conv2d_wino8_sk_ws_bytes.restype = C.c_int64
         L.aid_conv2d_wino_form.argtypes = [C.c_int] * 6
         L.aid_conv2d_wino_form.restype = C.c_int
         L.aid_conv2d_wino_split_ws_bytes.argtypes = [C.c_int] * 6
@@ -285,7 +289,7 @@ def lib():
         L.aid_conv2d_wgrad_tiles.argtypes = [C.c_int] * 5
         L.aid_conv2d_wgrad_tiles.restype = C.c_int
         for name in EXPORTS[3:]:
-            if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino_split_ws_bytes",
+            if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino8_supported", "aid_conv2d_wino_split_ws_bytes", "aid_conv2d_wino8_sk_ws_bytes",
                             "aid_conv2d_stat_partials", "aid_conv2d_wgrad_tiles"):
                 getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, name).restype = C.c_int

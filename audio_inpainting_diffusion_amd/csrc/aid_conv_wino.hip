@@ -33,6 +33,9 @@ __device__ float4 g_aid_zero_page_w[16];   // (device symbols are per translatio
 #define AID_LDS_ADDR(lptr) ((unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)(lptr))
 #define AID_DMA16_RAW(gptr, lds_addr) \
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gptr), "s"(lds_addr) : "memory")
+// the same with a SCALAR 64-bit base and a 32-bit per-lane byte offset (one VGPR per piece instead of a 64-bit pointer and a per-lane stride)
+#define AID_DMA16_SBASE(voff, sbase, lds_addr) \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory")
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
 #define AID_VMCNT(n) ((((n) & 15) | (7 << 4) | (15 << 8) | ((((n) >> 4) & 3) << 14)))
 #define AID_LGKMCNT0 (15 | (7 << 4) | (0 << 8) | (3 << 14))
@@ -41,6 +44,12 @@ template <typename F, int... I>
 __device__ __forceinline__ void aid_static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, typename F>
 __device__ __forceinline__ void aid_static_for(F&& f) { aid_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+// s_waitcnt vmcnt(n) for a wave-uniform n in [0, NMAX] (the instruction takes an immediate)
+template <int NMAX>
+__device__ __forceinline__ void aid_wait_vmcnt_le(int n) {
+    if constexpr (NMAX == 0) { __builtin_amdgcn_s_waitcnt(AID_VMCNT(0)); }
+    else { if (n >= NMAX) __builtin_amdgcn_s_waitcnt(AID_VMCNT(NMAX)); else aid_wait_vmcnt_le<NMAX - 1>(n); }
+}
 
 // ---- F(4,3): 6 products per 4 outputs (2x fewer MFMAs than direct).  tau now indexes GROUPS of 4 output samples:
 //   V = B^T d (d = 6 samples 4g-1 .. 4g+4):  V0 = 4d0-5d2+d4, V1 = (d3+d4)-4(d1+d2), V2 = (d4-d3)+4(d1-d2),
@@ -694,7 +703,10 @@ struct ConvWinoRDev {
     float* part;               // splits == 2: [tile][96][256] Winograd-domain partial accumulators of the workgroup that finishes first
     unsigned* flags;           // splits == 2: [tile][2] (arrival counter, partial published); zero before and after every launch
     W4rGeo g[2];               // [1]: the 32-channel remainder tiles of a 96-channel layer (pair instances)
+    int sk_per;                // stream-K instances: (tile, chunk) units per persistent workgroup
+    int sk_workers;            // stream-K instances: persistent workgroups (= grid size)
 };
+struct W4rSeg { int c0, c1, wid, per; };   // stream-K: one workgroup's share [c0, c1) of a tile's chunks; wid = its worker id (partial / flag slot)
 
 // Tried for small grids (round 3, profiles/r03_half_tile_probe.txt): two-wave workgroups on half the positions (64 x 128 / 32 x 256 tiles, twice
 // the workgroups, four per CU) when a launch has fewer than 300 ... 1100 full tiles -- B = 1: 24.7 -> 29.4 ... 30.2 ms of 5x3 time per guided
@@ -735,8 +747,10 @@ struct W4rShape {
 
 // One tile.  `smem`: W4rShape::LDS floats of LDS (declared by the kernel, so that the two tile families of a pair instance share it);
 // `bid`: workgroup index within this tile family's part of the grid.
-template <int TT, int NC, int WGM, int NB, int WPC, int NWV, bool SPK, int WM = 4>
-__device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4rGeo& ge, float* smem, const int bid) {
+// SK (stream-K instances): `bid` is the LOGICAL tile index and `seg` this workgroup's share of the tile's K chunks; the tile is finished by the
+// workgroup that holds its first chunks (see conv53_wino8r_sk_kernel).
+template <int TT, int NC, int WGM, int NB, int WPC, int NWV, bool SPK, int WM = 4, bool SK = false>
+__device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4rGeo& ge, float* smem, const int bid, const W4rSeg seg = W4rSeg{}) {
     using S = W4rShape<TT, NC, WGM, NB, WPC, NWV, WM>;
     constexpr int KH = S::KH, NXI = S::NXI, KC = S::KC;
     constexpr int NW = S::NW, WGN = S::WGN;
@@ -754,15 +768,19 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
     float* const sbuf1 = smem + BUFSZ;
     float* const sbuf2 = smem + (NBUF == 3 ? 2 * BUFSZ : 0);
 
-    const int tid = threadIdx.x;
+    int tid_ = threadIdx.x;
+    if (SK) asm volatile("" : "+v"(tid_));               // (persistent loop: keeps the per-lane address arithmetic below from being hoisted out of the tile loop,
+                                                         //  where it would stay live -- some 300 spilled registers -- across every K loop)
+    const int tid = tid_;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
     const int half = lane >> 5;
 
     // XCD-aware logical tile (see conv53_wino4v_kernel); order: Cout tile fastest, then t tile, quad, residue-class group, sample
-    const int Lt = (bid & 7) * ge.per_xcd + (bid >> 3);
+    const int Lt = SK ? bid : (bid & 7) * ge.per_xcd + (bid >> 3);
     if (Lt >= ge.ntiles) return;
+    const int nch = SK ? (seg.c1 - seg.c0) : a.nchunks;   // chunks this workgroup multiplies
     int rest = Lt;
     const int sp = SPK ? (rest & 1) : 0;                 // split-K: the two halves of a tile are neighbours in the same XCD's share
     if (SPK) rest >>= 1;
@@ -779,12 +797,21 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
     const int j0 = q * RA;                               // first sub-lattice row of this tile
 
     // ---- DMA piece descriptors ---------------------------------------------------------------------------------------------
-    const float* psrc[PPW];
-    int pstride[PPW], plds[PPW];
+    // A piece = 1 KiB of LDS filled by one wave instruction (16 bytes per lane).  Per piece and lane: ONE 32-bit byte offset from a wave-uniform
+    // base (the activations or the weight pack, advanced by a scalar stride per chunk), and one bit of `pvalid`.  Lanes whose 16 bytes do not exist
+    // (padding rows of the tile, groups past the end of a row, the tail of the last weight piece) are never loaded: their LDS slots are zeroed once
+    // per tile in every buffer and the direct-to-LDS loads run with those lanes masked off; a piece none of whose lanes exists in this wave is not
+    // issued at all (`pany`, wave-uniform, so that the per-chunk instruction count `mine` the vmcnt waits rely on stays exact).  (Round 3 kept a
+    // 64-bit pointer and a per-lane stride per piece and read a zero page for the missing lanes: 27 more registers, which the 160-accumulator
+    // F(8,3) instances do not have.)
+    unsigned poff[PPW];
+    unsigned pvalid = 0, pany = 0;
+    int plds[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int pc = wave + i * NW;
-        psrc[i] = a.zero; pstride[i] = 0; plds[i] = pc * 256;
+        poff[i] = 0; plds[i] = pc * 256;
+        bool ok = false;
         if (pc < NXP) {
             const int eg = pc * 256 + 4 * lane;
             const int ci = eg / XCI, e = eg % XCI;
@@ -794,8 +821,8 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
             const int jr = j0 + (slot % CSLOT) - (KH / 2);   // sub-lattice row index of this slot
             if (ci < KC && jr >= 0 && jr < nrow && t0 + WM * gl < p.T) {
                 const int fi = res + cls + jr * p.dilF;
-                psrc[i] = p.x.p + (int64_t)b * p.x.sB + (int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + (int64_t)xi * (p.T / WM) + (t0 / WM) + gl;
-                pstride[i] = (int)(KC * p.x.sC);
+                poff[i] = (unsigned)(4 * ((int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + (int64_t)xi * (p.T / WM) + (t0 / WM) + gl));   // (within sample b: < 2^32, see conv53_wino_v)
+                ok = true;
             }
         } else if (pc < NP) {
             const int e = (pc - NXP) * 256 + 4 * lane;
@@ -803,15 +830,17 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
             const int tap = row / KC, ci = row % KC;
             plds[i] = XSZ + (pc - NXP) * 256;
             if (e < WSZ_RAW) {
-                psrc[i] = p.wp_wino + ((int64_t)tap * p.Cin_pad + ci) * p.Cout_pad + m0 + col;
-                pstride[i] = KC * p.Cout_pad;
+                poff[i] = (unsigned)(4 * (((int64_t)tap * p.Cin_pad + ci) * p.Cout_pad + m0 + col));
+                ok = true;
             }
         }
+        if (ok) pvalid |= 1u << i;
+        if (__ballot(ok) != 0ull) pany |= 1u << i;
     }
-    if (SPK && sp) {
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) psrc[i] += (int64_t)a.nchunks * pstride[i];      // second half of the K axis
-    }
+    const int cbase = SK ? seg.c0 : ((SPK && sp) ? a.nchunks : 0);        // first chunk of this workgroup's share of the K axis
+    const int64_t xstep = (int64_t)KC * p.x.sC * 4, wstep = (int64_t)KC * p.Cout_pad * 4;   // bytes per chunk (wave-uniform)
+    const char* const xbase = reinterpret_cast<const char*>(p.x.p + (int64_t)b * p.x.sB) + cbase * xstep;
+    const char* const wbase = reinterpret_cast<const char*>(p.wp_wino) + cbase * wstep;
     // ---- operand addresses: lane's group g of this wave's 32 -> output row j = g / GPR, group tau = g % GPR -------------------------
     const int g = wn * 32 + (lane & 31);
     const int rl = g / GPR, tau = g % GPR;               // row of the tile: class rl / RA, sub-lattice row rl % RA
@@ -829,15 +858,26 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
-    const int mine = (wave + (PPW - 1) * NW < NP) ? PPW : PPW - 1;
+    const int mine = __builtin_popcount(pany);             // direct-to-LDS instructions this wave issues per chunk (exact)
     auto issue_piece = [&](auto ic, int ch, float* buf) {
         constexpr int i = decltype(ic)::value;
-        if (wave + i * NW < NP) {
-            const float* src = psrc[i] + (int64_t)ch * pstride[i];
+        if ((pany >> i) & 1u) {                             // (wave-uniform)
+            const char* base = (wave + i * NW < NXP) ? xbase + ch * xstep : wbase + ch * wstep;     // (scalar)
             const unsigned la = AID_LDS_ADDR(buf + plds[i]);
-            AID_DMA16_RAW(src, la);
+            const unsigned off = poff[i];
+            if ((pvalid >> i) & 1u) AID_DMA16_SBASE(off, base, la);
         }
     };
+    // slots of the lanes that are never loaded: zero, in every buffer, before the first read
+    aid_static_for<PPW>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (wave + i * NW < NP && !((pvalid >> i) & 1u)) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(sbuf0 + plds[i] + 4 * lane) = z;
+            *reinterpret_cast<float4*>(sbuf1 + plds[i] + 4 * lane) = z;
+            if (NBUF == 3) *reinterpret_cast<float4*>(sbuf2 + plds[i] + 4 * lane) = z;
+        }
+    });
     auto issue_all = [&](int ch, float* buf) { aid_static_for<PPW>([&](auto ic) { issue_piece(ic, ch, buf); }); };
     auto issue_step = [&](auto sc, int ch, float* buf) {
         aid_static_for<PPW>([&](auto ic) {
@@ -846,7 +886,7 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
     };
 
     issue_all(0, sbuf0);
-    if (NBUF == 3 && a.nchunks > 1) issue_all(1, sbuf1);
+    if (NBUF == 3 && nch > 1) issue_all(1, sbuf1);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 
@@ -856,7 +896,7 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
         // NBUF == 3: the loads of chunk ch+2 go to buffer (cur+2)%3 (read during the previous chunk); NBUF == 2: those of chunk ch+1 to the other buffer
         float* Nx = NBUF == 3 ? (cur == 0 ? sbuf2 : (cur == 1 ? sbuf0 : sbuf1)) : (cur == 0 ? sbuf1 : sbuf0);
         const int ahead = NBUF - 1;
-        const bool more = (ch + ahead) < a.nchunks;
+        const bool more = (ch + ahead) < nch;
         float bv[2][NXI], av[2][NXI];
         auto load_step = [&](int kh, int buf) {
 #pragma unroll
@@ -876,7 +916,7 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
         });
         asm volatile("" ::: "memory");
         if (NBUF == 3 && more) {
-            if (mine == PPW) __builtin_amdgcn_s_waitcnt(AID_VMCNT(PPW)); else __builtin_amdgcn_s_waitcnt(AID_VMCNT(PPW - 1));
+            aid_wait_vmcnt_le<PPW>(mine);                   // the `mine` loads of chunk ch + 2 issued during this chunk may stay in flight
         } else {
             __builtin_amdgcn_s_waitcnt(AID_VMCNT(0));
         }
@@ -885,15 +925,65 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
         asm volatile("" ::: "memory");
     };
     if (NBUF == 3) {
-        for (int ch = 0; ch < a.nchunks; ch += 3) {
+        for (int ch = 0; ch < nch; ch += 3) {
             chunk(std::integral_constant<int, 0>{}, ch);
-            if (ch + 1 < a.nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
-            if (ch + 2 < a.nchunks) chunk(std::integral_constant<int, 2>{}, ch + 2);
+            if (ch + 1 < nch) chunk(std::integral_constant<int, 1>{}, ch + 1);
+            if (ch + 2 < nch) chunk(std::integral_constant<int, 2>{}, ch + 2);
         }
     } else {
-        for (int ch = 0; ch < a.nchunks; ch += 2) {
+        for (int ch = 0; ch < nch; ch += 2) {
             chunk(std::integral_constant<int, 0>{}, ch);
-            if (ch + 1 < a.nchunks) chunk(std::integral_constant<int, 1>{}, ch + 1);
+            if (ch + 1 < nch) chunk(std::integral_constant<int, 1>{}, ch + 1);
+        }
+    }
+
+    // ---- stream-K: a workgroup whose share does not start at chunk 0 publishes its accumulators (slot `wid`) and moves on; the workgroup that holds the
+    // tile's FIRST chunks -- it reaches them at the END of its span, after everybody else's share of this tile is long done -- adds the partials of
+    // the following workers in worker order (a fixed order: deterministic) and runs the epilogue.  Every worker writes its partial BEFORE it can ever
+    // wait, so a waiting workgroup only waits for one that is resident or will be dispatched as soon as any slot frees.  Same agent-scope exchange as
+    // the split-K instances above.
+    if constexpr (SK) {
+        constexpr int PSZ = NXI * 16 * 64 * NW;                                        // floats per partial
+        int* sh = reinterpret_cast<int*>(smem);
+        if (seg.c0 > 0) {
+            unsigned long long* part = reinterpret_cast<unsigned long long*>(a.part + (int64_t)seg.wid * PSZ) + tid;
+#pragma unroll
+            for (int x = 0; x < NXI; ++x)
+#pragma unroll
+                for (int r2 = 0; r2 < 8; ++r2) {
+                    const unsigned long long v = (unsigned long long)__float_as_uint(acc[x][2 * r2]) | ((unsigned long long)__float_as_uint(acc[x][2 * r2 + 1]) << 32);
+                    __hip_atomic_store(part + (x * 8 + r2) * (64 * NW), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(a.flags + seg.wid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (seg.c1 < a.nchunks) {
+            const int nparts = (a.nchunks - seg.c1 + seg.per - 1) / seg.per;
+            for (int k = 1; k <= nparts; ++k) {
+                unsigned* fl = a.flags + seg.wid + k;
+                __syncthreads();
+                if (tid == 0) {
+                    int it = 0;                                                            // (bounded, ~1 s: see the split-K instances)
+                    for (; it < (1 << 22) && __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u; ++it) __builtin_amdgcn_s_sleep(4);
+                    sh[1] = it < (1 << 22);
+                }
+                __syncthreads();
+                const float poison = sh[1] ? 0.f : __uint_as_float(0x7fc00000u);
+                const unsigned long long* part = reinterpret_cast<const unsigned long long*>(a.part + (int64_t)(seg.wid + k) * PSZ) + tid;
+#pragma unroll
+                for (int x = 0; x < NXI; ++x) {                // one plane (16 registers) of the partial in flight at a time: all ten would not fit beside the 160 accumulators
+                    unsigned long long v[8];
+#pragma unroll
+                    for (int r2 = 0; r2 < 8; ++r2) v[r2] = __hip_atomic_load(part + (x * 8 + r2) * (64 * NW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int r2 = 0; r2 < 8; ++r2) { acc[x][2 * r2] += __uint_as_float((unsigned)v[r2]) + poison; acc[x][2 * r2 + 1] += __uint_as_float((unsigned)(v[r2] >> 32)) + poison; }
+                    asm volatile("" ::: "memory");
+                }
+                if (tid == 0 && sh[1]) __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // consumed: zero for the next launch
+            }
+            __syncthreads();                                  // sh lives in the buffer the partial-sum reduction below reuses
         }
     }
 
@@ -1341,6 +1431,39 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
     return AID_OK;
 }
 
+// ---- stream-K instance of the F(8,3) kernel: a PERSISTENT grid of `sk_workers` workgroups (two per CU); the launch's (tile, chunk) units -- tiles in
+// the same XCD-aware order, the Cin / 2 chunks of a tile consecutive -- are cut into equal contiguous spans, one per workgroup.  A launch whose tile
+// count is not a whole number of rounds (1.75 rounds of 512-position tiles on the deepest level at batch 8; 0.2 ... 0.9 at batch 1) is then bound by
+// its MFMAs, not by ceil(rounds) tiles per CU.  Cost: at most one partial (160 accumulators per lane, 164 KB) written and read per workgroup.
+template <int TT, int NC, int WGM, int NC1 = 0>
+__global__ __launch_bounds__(256, 2) void conv53_wino8r_sk_kernel(const ConvWinoRDev a) {
+    using S0 = W4rShape<TT, NC, WGM, 2, 2, 4, 8>;
+    using S1 = W4rShape<TT, NC1 == 0 ? NC : NC1, NC1 == 0 ? WGM : 1, 2, 2, 4, 8>;
+    __shared__ __attribute__((aligned(16))) float smem[S0::LDS > S1::LDS ? S0::LDS : S1::LDS];
+    const int wid = ((int)blockIdx.x & 7) * (a.sk_workers >> 3) + ((int)blockIdx.x >> 3);        // consecutive workers (= consecutive tiles) share an XCD
+    const int n0 = a.g[0].ntiles;
+    const int64_t total = (int64_t)(n0 + (NC1 == 0 ? 0 : a.g[1].ntiles)) * a.nchunks;
+    int64_t u0 = (int64_t)wid * a.sk_per;
+    const int64_t u1 = u0 + a.sk_per < total ? u0 + a.sk_per : total;
+    bool first = true;
+    while (u0 < u1) {
+        const int tile = (int)(u0 / a.nchunks);
+        W4rSeg seg;
+        seg.c0 = (int)(u0 - (int64_t)tile * a.nchunks);
+        seg.c1 = (int64_t)a.nchunks - seg.c0 < u1 - u0 ? a.nchunks : seg.c0 + (int)(u1 - u0);
+        seg.wid = wid; seg.per = a.sk_per;
+        if (!first) __syncthreads();                      // the previous tile's epilogue scratch lives in the staging buffers
+        first = false;
+        if constexpr (NC1 == 0) {
+            wino4r_tile_body<TT, NC, WGM, 2, 2, 4, false, 8, true>(a, a.g[0], smem, tile, seg);
+        } else {
+            if (tile < n0) wino4r_tile_body<TT, NC, WGM, 2, 2, 4, false, 8, true>(a, a.g[0], smem, tile, seg);
+            else wino4r_tile_body<TT, NC1, 1, 2, 2, 4, false, 8, true>(a, a.g[1], smem, tile - n0, seg);
+        }
+        u0 += seg.c1 - seg.c0;
+    }
+}
+
 // ---- F(8,3) row-shared tiles: geometry, eligibility, launch ---------------------------------------------------------------------------------------
 // ng: groups per tile (64 for the 64-channel tile = 512 positions, 128 for the 32-channel remainder tile of 96-channel layers).  Instantiated:
 // 64 groups -- TT = 64: NC 1, 2 (RA = 8, 4); TT = 32: NC 1, 2, 4 (RA = 16, 8, 4); 128 groups -- TT = 64: NC 1, 2, 4 (RA = 16, 8, 4).  More classes per tile would not
@@ -1370,10 +1493,13 @@ static int wino8r_geometry(const aid_conv2d_params* p, Wino4rPlan plan[2]) {
     return 2;
 }
 
-// Which Winograd form the row-shared kernels want for a 5x3 layer of this shape: 8 (F(8,3)), 4 (F(4,3)) or 0 (no Winograd-domain input).
-// F(8,3) issues 10 MFMAs per 8 outputs against 12, but its tiles hold twice the positions: per CU the work is ceil(tiles / 256) tiles either way
-// (two resident workgroups share one matrix pipe), so the form with the smaller [tiles per CU] x [MFMAs per tile] x [1 + padding rows] takes the layer;
-// ties go to F(8,3) (less staging and a 1.25x instead of 1.5x Winograd-domain tensor).  A function of the launch shape (B included), like the tile choice itself.
+// Which Winograd form the row-shared kernels want for a 5x3 layer of this LAUNCH shape: 8 (F(8,3)), 4 (F(4,3)) or 0 (no Winograd-domain input).
+// F(8,3) issues 10 MFMAs per 8 outputs against 12, but its tiles hold twice the positions, so a launch has half as many of them.  The two
+// resident workgroups of a CU share one matrix pipe: the busiest CU works through ceil(tiles / CUs) tiles, and a CU that only ever holds one tile
+// runs it at about 5/6 of the rate two would reach.  cost = ceil(tiles / 256) x [MFMAs per tile: 5 vs 3, padding rows included in `tiles`]
+// (x 1.2 for a single tile per CU); the cheaper form takes the launch, ties go to F(4,3) (its smaller tiles leave the shorter tail).  Against the
+// per-layer A/B of both kernels at batch 1, 2, 3, 4 and 8 (profiles/r04_streamk_probe.txt) this picks the faster kernel on all but a handful of
+// shapes, where it is within 5 %.  A function of the launch shape, B included: equal launches (the same sub-batch size) take equal kernels.
 static int wino_form_choice(const aid_conv2d_params* p) {
     if (!wino_v_shape_ok(p->Cin, p->Cout, p->T)) return 0;
     Wino4rPlan p4[2], p8[2];
@@ -1381,14 +1507,34 @@ static int wino_form_choice(const aid_conv2d_params* p) {
     const int n8 = (p->T % 32 == 0) ? wino8r_geometry(p, p8) : 0;
     if (!n8) return (n4 || p->T >= 32) ? 4 : 0;
     if (!n4) return 8;
-    // issued MFMAs per (input-channel pair, tap row), padding rows included: every tile of either family is four waves x (WM + 2) products
-    auto cost = [&](const Wino4rPlan* pl, int nl, int wm) {
-        int64_t c = 0;
+    auto cost = [&](const Wino4rPlan* pl, int nl, int per_tile) {
+        int64_t tiles = 0;
         for (int l = 0; l < nl; ++l)
-            c += (int64_t)(p->dilF / pl[l].NC) * pl[l].quads * pl[l].ttiles * (wm + 2);
-        return c;
+            tiles += (int64_t)p->B * (p->dilF / pl[l].NC) * pl[l].quads * pl[l].ttiles * (nl == 2 ? p->Cout_pad / 96 : p->Cout_pad / 64);
+        const int64_t per_cu = (tiles + 255) / 256;
+        return per_cu * per_tile * (per_cu == 1 ? 12 : 10);
     };
-    return cost(p8, n8, 8) * 100 <= cost(p4, n4, 4) * 102 ? 8 : 4;
+    return cost(p8, n8, 5) < cost(p4, n4, 3) ? 8 : 4;
+}
+
+// stream-K: persistent workgroups = 2 per CU (what the register / LDS budget of the kernel keeps resident), a multiple of 8 (XCDs)
+static int wino8r_sk_workers() {
+    static int w = 0;
+    if (!w) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+        w = 2 * cus / 8 * 8;
+        if (w > AID_W4R_SPLIT_FLAG_BYTES / 4) w = AID_W4R_SPLIT_FLAG_BYTES / 4;
+    }
+    return w;
+}
+static inline int64_t aid_w8r_sk_bytes(int workers) { return AID_W4R_SPLIT_FLAG_BYTES + (int64_t)workers * (160 * 256 * 4); }
+// Plain tiles lose [ceil(rounds) - rounds] / ceil(rounds) of the launch to the partially filled last round (rounds = tiles / resident workgroups);
+// stream-K pays one partial per workgroup and gives up the hardware's dynamic tile dispatch.  Taken when the loss exceeds 8 % (measured threshold,
+// profiles/r04_streamk_probe.txt) -- launches of fewer tiles than resident workgroups included.
+static bool wino8r_sk_wanted(int64_t ntiles, int workers) {
+    const int64_t rounds_up = (ntiles + workers - 1) / workers;
+    return ntiles * 100 < rounds_up * workers * 92;
 }
 
 static int launch_wino8r(const aid_conv2d_params* p, hipStream_t st) {
@@ -1400,7 +1546,7 @@ static int launch_wino8r(const aid_conv2d_params* p, hipStream_t st) {
     }
     Wino4rPlan plan[2];
     const int nl = wino8r_geometry(p, plan);
-    AID_REQUIRE(nl, "aid_conv2d: x_wino = 2 (F(8,3)) needs a shape aid_conv2d_wino_form() answers 8 for");
+    AID_REQUIRE(nl, "aid_conv2d: x_wino = 2 (F(8,3)) needs a shape aid_conv2d_wino8_supported() answers 1 for");
     const bool m96 = nl == 2;
     ConvWinoRDev a;
     a.p = *p;
@@ -1423,7 +1569,21 @@ static int launch_wino8r(const aid_conv2d_params* p, hipStream_t st) {
         ge.ntiles = p->B * ge.rgroups * g.quads * g.ttiles * ge.ny;
         ge.per_xcd = (ge.ntiles + 7) / 8;
     }
-#define AID_W8R(TTv, NCv, WGMv, NC1v) hipLaunchKernelGGL((conv53_wino8r_kernel<TTv, NCv, WGMv, NC1v>), grid, dim3(256), 0, st, a)
+    // stream-K (scratch `ws` given, i.e. the caller allows it for this launch): when the tiles are not close to a whole number of rounds of the
+    // 2 x CUs resident workgroups
+    const int64_t ntl = (int64_t)geo[0].ntiles + (m96 ? geo[1].ntiles : 0);
+    const int workers = wino8r_sk_workers();
+    const bool sk = p->ws && p->ws_bytes >= aid_w8r_sk_bytes(workers) && wino8r_sk_wanted(ntl, workers);
+    a.sk_per = 0; a.sk_workers = 0;
+    if (sk) {
+        a.flags = reinterpret_cast<unsigned*>(p->ws);
+        a.part = p->ws + AID_W4R_SPLIT_FLAG_BYTES / 4;
+        a.sk_workers = workers;
+        a.sk_per = (int)((ntl * a.nchunks + workers - 1) / workers);
+    }
+#define AID_W8R(TTv, NCv, WGMv, NC1v) do { \
+        if (sk) hipLaunchKernelGGL((conv53_wino8r_sk_kernel<TTv, NCv, WGMv, NC1v>), dim3((unsigned)workers), dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((conv53_wino8r_kernel<TTv, NCv, WGMv, NC1v>), grid, dim3(256), 0, st, a); } while (0)
     if (m96) {
         a.g[0] = geo[0]; a.g[1] = geo[1];
         const dim3 grid((unsigned)(8 * (geo[0].per_xcd + geo[1].per_xcd)));
@@ -1452,8 +1612,18 @@ static int launch_wino8r(const aid_conv2d_params* p, hipStream_t st) {
         AID_CHECK_LAUNCH();
     }
 #undef AID_W8R
-    aid_note_kernel(m96 ? "conv53_wino8r_kernel(64+32)" : (plan[0].NC == 1 ? "conv53_wino8r_kernel" : "conv53_wino8r_kernel(multi-class)"));
+    if (sk) aid_note_kernel(m96 ? "conv53_wino8r_sk_kernel(64+32)" : "conv53_wino8r_sk_kernel");
+    else aid_note_kernel(m96 ? "conv53_wino8r_kernel(64+32)" : (plan[0].NC == 1 ? "conv53_wino8r_kernel" : "conv53_wino8r_kernel(multi-class)"));
     return AID_OK;
+}
+
+extern "C" int aid_conv2d_wino8_supported(int Cin, int Cout, int F, int T, int dilF) {
+    if (!wino_v_shape_ok(Cin, Cout, T) || (T % 32)) return 0;
+    aid_conv2d_params q = {};
+    q.B = 1; q.Cin = Cin; q.Cout = Cout; q.F = F; q.T = T; q.dilF = dilF; q.KH = 5; q.KW = 3;
+    aid_conv2d_pack_dims(Cin, Cout, &q.Cin_pad, &q.Cout_pad);
+    Wino4rPlan plan[2];
+    return wino8r_geometry(&q, plan) ? 1 : 0;
 }
 
 extern "C" int aid_conv2d_wino_form(int B, int Cin, int Cout, int F, int T, int dilF) {
@@ -1463,6 +1633,20 @@ extern "C" int aid_conv2d_wino_form(int B, int Cin, int Cout, int F, int T, int 
     const int f = wino_form_choice(&q);
     if (f == 4 && !aid_conv2d_wino_input_ok(B, Cin, Cout, F, T, dilF)) return 0;
     return f;
+}
+
+// scratch of the stream-K instances of the F(8,3) kernel (aid_kernels.h: ws with x_wino = 2): 0 when a launch of this shape keeps plain tiles
+extern "C" int64_t aid_conv2d_wino8_sk_ws_bytes(int B, int Cin, int Cout, int F, int T, int dilF) {
+    if (!aid_conv2d_wino8_supported(Cin, Cout, F, T, dilF)) return 0;
+    aid_conv2d_params q = {};
+    q.B = B; q.Cin = Cin; q.Cout = Cout; q.F = F; q.T = T; q.dilF = dilF; q.KH = 5; q.KW = 3;
+    aid_conv2d_pack_dims(Cin, Cout, &q.Cin_pad, &q.Cout_pad);
+    Wino4rPlan plan[2];
+    const int nl = wino8r_geometry(&q, plan);
+    int64_t ntl = 0;
+    for (int l = 0; l < nl; ++l) ntl += (int64_t)B * (dilF / plan[l].NC) * plan[l].quads * plan[l].ttiles * (nl == 2 ? q.Cout_pad / 96 : q.Cout_pad / 64);
+    const int workers = wino8r_sk_workers();
+    return (nl && wino8r_sk_wanted(ntl, workers)) ? aid_w8r_sk_bytes(workers) : 0;
 }
 
 // scratch of the split-K instances (aid_kernels.h: ws): 0 when a launch of this shape is not split
@@ -1553,6 +1737,8 @@ extern "C" int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, i
 // x_wino = 1: the caller already wrote the Winograd-domain input; there is no other kernel that can read it
 static int conv53_wino_v(const aid_conv2d_params* p, hipStream_t st) {
     auto al4 = [](const aid_view& v) { return (v.sB % 4) == 0 && (v.sC % 4) == 0 && (v.sF % 4) == 0 && (((uintptr_t)v.p) & 15) == 0; };
+    AID_REQUIRE((int64_t)p->Cin * p->x.sC * 4 < (1LL << 32) && (int64_t)p->wino_taps * p->Cin_pad * p->Cout_pad * 4 < (1LL << 32),
+                "aid_conv2d: x_wino kernels address one sample and the weight pack with 32-bit byte offsets");
     if (p->x_wino == 2) {                                   // F(8,3): [B, Cin, F, 10, T/8] input, 50-tap pack
         AID_REQUIRE(p->wp_wino && p->wino_taps == 50 && p->KH == 5 && p->KW == 3 && !p->in_scale && p->act == 0,
                     "aid_conv2d: x_wino = 2 needs the 50-tap F(8,3) pack of a 5x3 layer and no in-kernel prologue");

@@ -43,7 +43,62 @@ def init_distributed(backend: str = None) -> Tuple[int, int, int]:
                                    f"{world} ranks); set AID_DIST_BACKEND=gloo for a functional shared-GPU run")
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dev = f"cuda:{local % max(1, torch.cuda.device_count())}" if torch.cuda.is_available() else "cpu"
+        print(f"[aid dist] rank {rank}/{world} (local {local}): backend {dist.get_backend()}, device {dev}, "
+              f"rendezvous {os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']}", file=sys.stderr, flush=True)
     return rank, local, world
+
+
+def _cpulist(text: str) -> List[int]:
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_node(device_index: int) -> Optional[int]:
+    """NUMA node of a GPU from sysfs (/sys/bus/pci/devices/<domain:bus:dev.fn>/numa_node), or None when it cannot be read / is -1."""
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        return node if node >= 0 else None
+    except Exception:
+        return None
+
+
+def bind_rank_to_gpu_numa(local: int, ranks_on_node: int, log=None) -> Optional[int]:
+    """Pin this rank's CPU threads (noise generation, launch loop) to the cores of its GPU's NUMA node, shared evenly between the ranks whose
+    GPUs sit on the same node; falls back to an even split of the visible cores when sysfs does not say.  Returns the thread count set."""
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    mine, peers = avail, list(range(ranks_on_node))
+    node = gpu_numa_node(local % ndev) if ndev else None
+    if node is not None:
+        try:
+            cpus = [c for c in _cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()) if c in set(avail)]
+            same = [r for r in range(ranks_on_node) if gpu_numa_node(r % ndev) == node]
+            if cpus and local in same:
+                mine, peers = cpus, same
+        except OSError:
+            pass
+    k, n = peers.index(local) if local in peers else 0, max(1, len(peers))
+    share = mine[k * len(mine) // n:(k + 1) * len(mine) // n] or mine
+    try:
+        os.sched_setaffinity(0, share)
+    except OSError:
+        return None
+    torch.set_num_threads(max(1, len(share)))
+    if log is not None:
+        print(f"[aid dist] local rank {local}: GPU NUMA node {node}, {len(share)} CPU threads "
+              f"({share[0]}..{share[-1]})", file=log, flush=True)
+    return len(share)
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:

@@ -37,9 +37,12 @@ class GenericModelAdapter:
 
     @staticmethod
     def _col(v, B, device):
-        if isinstance(v, float):
-            return torch.full((B, 1), v, dtype=torch.float32, device=device)
-        return v.reshape(B, 1)
+        import numbers
+        if isinstance(v, numbers.Real) or (torch.is_tensor(v) and v.numel() == 1) or (not torch.is_tensor(v) and getattr(v, "size", 2) == 1):
+            return torch.full((B, 1), float(v), dtype=torch.float32, device=device)
+        if not torch.is_tensor(v) or v.numel() != B:
+            raise ValueError(f"EDM scalar must be a number or a tensor of {B} elements")
+        return v.to(device=device, dtype=torch.float32).reshape(B, 1)
 
     def _eval(self, x, cnoise, cin, cskip, cout, hpf):
         B = x.shape[0]

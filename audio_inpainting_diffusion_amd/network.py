@@ -406,6 +406,14 @@ class _Builder:
             if need:
                 ws = self._split_ws(need)
                 p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        elif x_wino == 8 and self.net.stream_k != "off" and (self.whole_batch or self.net.stream_k == "all"):
+            # F(8,3) launches whose tiles are not close to a whole number of rounds of resident workgroups run the STREAM-K instance (a persistent
+            # grid sharing the (tile, K-chunk) units evenly).  Its cuts depend on the launch shape, so by default only WHOLE batches get the scratch:
+            # the sub-batches of a split batch keep plain tiles and stay bit-identical to the unsplit schedule and to each other.
+            need = int(_lib.lib().aid_conv2d_wino8_sk_ws_bytes(B, cin, cout, F, T, dil))
+            if need:
+                ws = self._split_ws(need)
+                p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
         assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] == (50 if x_wino == 8 else 30) and wpw.shape[1:] == wp.shape[1:]))
         # algorithmic HBM bytes: x once, residual / aux once, y once, weights once
         nb = 4 * (B * F * T * (cin + cout * (1 + (res is not None) + (aux is not None))) + cin * cout * kh * kw)
@@ -437,6 +445,8 @@ class _Builder:
         form = int(_lib.lib().aid_conv2d_wino_form(self.B, cin, cout, F, T, dil))
         if form == 8 and (wpw8 is None or 8 not in self.net.wino_forms):
             form = 4
+        elif form == 4 and 4 not in self.net.wino_forms and wpw8 is not None and _lib.lib().aid_conv2d_wino8_supported(cin, cout, F, T, dil):
+            form = 8                                          # wino_forms = (8,): F(8,3) wherever its tiles fit (tests, A/B)
         if form == 4 and not (4 in self.net.wino_forms and bool(_lib.lib().aid_conv2d_wino_input_ok(self.B, cin, cout, F, T, dil))):
             form = 0
         return form
@@ -1050,12 +1060,14 @@ class Unet_CQT_oct_with_attention(nn.Module):
     # pre-passes, normalisation backward) and the partially filled last round of workgroups of another sub-batch's conv use
     # the idle wave slots and CUs (measured at B=8, guided: +6.3 % with 2 sub-batches, +7.6 % with 3, -1.7 % with 4).
     # ---------------------------------------------------------------------------------------------------
-    split_streams = None       # None: automatic (3 sub-batches for B >= 6, 2 for B >= 4, else 1); an int forces it
+    split_streams = None       # None: automatic (2 sub-batches for B >= 4, else 1); an int forces it.  (Round 4: with the 512-position tiles of the F(8,3)
+                               # kernel two sub-batches of four beat three of 3 / 3 / 2 -- 46.8 vs 44.9 evaluations/s at batch 8, profiles/r04_bench_after_form_model.txt;
+                               # with F(4,3) alone it was 43.5 either way.)
 
     def _n_split(self, B: int) -> int:
         n = self.split_streams
         if n is None:
-            n = 3 if B >= 6 else (2 if B >= 4 else 1)
+            n = 2 if B >= 4 else 1
         return max(1, min(int(n), B))
 
     def _split_plan(self, B: int):
@@ -1130,6 +1142,11 @@ class Unet_CQT_oct_with_attention(nn.Module):
                                         # the input-only VJP; off by default because the reference's tester samples with the network in train() mode
     wino_forms = (4, 8)        # Winograd forms the 5x3 layers may use: F(8,3) where the library prefers it (aid_conv2d_wino_form), F(4,3) otherwise;
                                # (4,) keeps every layer on the F(4,3) kernels (A/B measurements; set before the first forward)
+    stream_k = "off"           # stream-K instances of the F(8,3) kernel: "whole" = launches of whole batches (a batch that is not split into sub-batch
+                               # streams), "all" = sub-batch launches too (their bits then depend on the split), "off" = plain tiles everywhere.
+                               # Off by default: measured per layer at batch 1 ... 8 (profiles/r04_streamk_probe.txt) the 164 KB partial every cut tile
+                               # exchanges through memory costs more than the partially filled last round it removes, except on the K = 256 layers
+                               # of a batch of one (+2 ... 22 %), where the F(4,3) split-K instances are faster still.
     wgrad_wino = True          # training: F(4,3) form of the 5x3 weight gradients (aid_conv2d_wgrad wino=1)
     fuse_norm_bwd_wino = True  # reverse sweep: aid_norm_bwd also writes the Winograd-domain, gated copy that the dgrad conv below stages
     epilogue_stats = True      # forward group statistics from the epilogue of the conv that produces the tensor (row-shared F(4,3) kernel)
@@ -1185,6 +1202,29 @@ class Unet_CQT_oct_with_attention(nn.Module):
         ent["graph"].replay()
         return tuple(o.clone() for o in ent["outs"])
 
+    @staticmethod
+    def _norm_scalars(B, device, vals):
+        """Validate the four EDM scalars of a public entry point: every one a real number / 0-d or 1-element value (-> host float, one noise
+        level for the batch) or every one a float32 tensor of B elements on ``device`` (a 1-element tensor is expanded).  Anything else --
+        host pointers, wrong lengths, mixed forms that cannot be reconciled -- raises AidError instead of reaching a kernel."""
+        import numbers
+        out, kinds = [], set()
+        for v in vals:
+            if isinstance(v, numbers.Real) or (hasattr(v, "ndim") and not torch.is_tensor(v) and getattr(v, "size", 2) == 1):
+                out.append(float(v)); kinds.add("h")
+            elif torch.is_tensor(v) and v.numel() == 1 and v.device.type != "cuda":
+                out.append(float(v)); kinds.add("h")
+            elif torch.is_tensor(v):
+                if v.numel() not in (1, B):
+                    raise _lib.AidError(f"EDM scalar with {v.numel()} elements for a batch of {B}")
+                t = v.detach().reshape(-1).to(device=device, dtype=torch.float32)
+                out.append((t.expand(B) if t.numel() == 1 else t).contiguous()); kinds.add("d")
+            else:
+                raise _lib.AidError(f"EDM scalar of unsupported type {type(v).__name__}")
+        if kinds == {"h", "d"}:                             # mixed: lift the host values to device vectors
+            out = [torch.full((B,), v, dtype=torch.float32, device=device) if isinstance(v, float) else v for v in out]
+        return tuple(out)
+
     def _scalar_rows(self, B, device, cnoise, cin, cskip, cout, out=None):
         """The four per-evaluation EDM scalars as device [B] vectors.  Host floats (one noise level for the whole batch -- what the sampling
         loop has) are broadcast by ONE aid_set_rows launch into a persistent [4, B] buffer; device tensors pass through."""
@@ -1209,6 +1249,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
         self._check_input(x)
         B, L = x.shape
         x = x.contiguous()
+        cnoise, cin, cskip, cout = self._norm_scalars(B, x.device, (cnoise, cin, cskip, cout))
         if self._n_split(B) == 1:
             st = self._state(B)
             if self._graph_ok(B, st):
@@ -1288,6 +1329,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
         self._check_input(x)
         B, L = x.shape
         x = x.contiguous()
+        cnoise, cin, cskip, cout = self._norm_scalars(B, x.device, (cnoise, cin, cskip, cout))
         if not (y.is_cuda and y.dtype == torch.float32 and y.is_contiguous() and tuple(y.shape) == (B, L)):
             raise _lib.AidError("denoise_guided: y must be a contiguous float32 GPU tensor of shape [B, L]")
         if (degradation is not None and not getattr(degradation, "shared_mask", False)) or self._n_split(B) == 1:

@@ -167,6 +167,16 @@ class Sampler:
         self._rid_pocs = xh_out
         return xnext, dout
 
+    def _project(self, x):
+        """smask * y + (1 - smask) * x (:343) by the projection stage of aid_score_step (its xh_out output; the step outputs go to scratch)."""
+        B, L = x.shape
+        out, scratch = torch.empty_like(x), torch.empty_like(x)
+        p = _lib.ScoreStepParams(x.data_ptr(), x.data_ptr(), self.y.data_ptr(), self.smask.data_ptr(),
+                                 self.smask.stride(0) if self.smask.shape[0] > 1 else 0, None, None, None, None,
+                                 scratch.data_ptr(), None, out.data_ptr(), B, L, 0, 1.0, 0.0)
+        _lib.call("aid_score_step", p)
+        return out
+
     # ---------------------------------------------------------------------------------------------------
     def predict_unconditional(self, shape, device):
         self.y = None
@@ -229,8 +239,8 @@ class Sampler:
         for i in range(self.nb_steps):
             self.step(state, i)
         x = state["x"]
-        if self.data_consistency_end and self.y is not None:
-            x = self.smask * self.y + (1 - self.smask) * x if self.spectral is None else self.spectral.project(x, self.y)
+        if self.data_consistency_end and self.y is not None:                     # (:252) one last projection of the final state
+            x = self._project(x) if self.spectral is None else self.spectral.project(x, self.y)
         if self.rid:                                                             # (:260)
             r = state["rid"]
             return x.detach(), r["denoised"], r["grads"], r["grad_update"], r["pocs"], r["xt"], r["xt2"], state["t"]

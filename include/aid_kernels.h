@@ -13,7 +13,7 @@
  *
  * The reference has no FFI: it is pure PyTorch.  Each entry point therefore cites the torch call site(s) in
  * /root/reference it replaces.  The Python binding a maintainer would add is shown in INTEGRATION.md and
- * implemented in audio-inpainting-diffusion_amd/_lib.py (ctypes).
+ * implemented in audio_inpainting_diffusion_amd/_lib.py (ctypes).
  */
 #ifndef AID_KERNELS_H
 #define AID_KERNELS_H
@@ -142,11 +142,19 @@ int aid_conv2d_wino_input_supported(int Cin, int Cout, int T);
 /* the same question with the layer's geometry: T = 16 layers are served only when the row-shared tiles fit F and the dilation */
 int aid_conv2d_wino_input_ok(int B, int Cin, int Cout, int F, int T, int dilF);
 /* which Winograd-domain input a 5x3 layer of this launch shape should be given: 8 -> x_wino = 2 (F(8,3)), 4 -> x_wino = 1 (F(4,3)), 0 -> plain
-   activations.  F(8,3) takes the layer when its row-shared tiles fit (T % 32 == 0, F % dilF == 0, <= 12.5 % padding rows) and issue fewer MFMAs. */
+   activations.  F(8,3) takes the launch when its row-shared tiles fit (T % 32 == 0, F % dilF == 0, <= 15 % padding rows) and its twice-as-large
+   tiles still quantise better over the CUs than F(4,3)'s (a function of the launch shape, B included; see wino_form_choice in csrc/aid_conv_wino.hip). */
 int aid_conv2d_wino_form(int B, int Cin, int Cout, int F, int T, int dilF);
+/* 1 when a 5x3 layer of this per-sample shape CAN take x_wino = 2 (the F(8,3) row-shared tiles fit); aid_conv2d_wino_form() then says whether it should */
+int aid_conv2d_wino8_supported(int Cin, int Cout, int F, int T, int dilF);
 /* bytes of `ws` a 5x3 x_wino layer of this shape wants for its split-K instance (B = 1 launches with few tiles); 0: the shape is not split */
 #define AID_CONV2D_SPLIT_FLAG_BYTES 4096
 int64_t aid_conv2d_wino_split_ws_bytes(int B, int Cin, int Cout, int F, int T, int dilF);
+/* bytes of `ws` a 5x3 x_wino = 2 (F(8,3)) layer of this launch shape wants for its STREAM-K instance (a persistent grid of 2 x CUs workgroups that share
+   the launch's (tile, K-chunk) units evenly; taken when the tiles are not close to a whole number of rounds); 0: plain tiles.  Same rules as above:
+   the first AID_CONV2D_SPLIT_FLAG_BYTES bytes zero before the first use, one ws per stream.  Results are deterministic but depend on the launch
+   shape (one extra association per cut tile): the caller decides where that is acceptable (network.py: whole batches only). */
+int64_t aid_conv2d_wino8_sk_ws_bytes(int B, int Cin, int Cout, int F, int T, int dilF);
 /* number of per-tile partial dots per (sample, group) the F(4,3) / F(8,3) epilogue writes for this shape (x_wino as in aid_conv2d_params); 0 = not supported */
 int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino);
 /* number of per-tile (sum, sum of squares) partials per (sample, group) for stat_ws; 0 = the kernel that takes this shape does not write them */

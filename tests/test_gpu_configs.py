@@ -140,3 +140,41 @@ def test_cfgB_44k_8s_368368_forward_vs_oracle():
     print(f"cfg-B L=368368: rel-L2 vs oracle = {e:.3e}; GFLOP/eval = {net.flops_per_eval(1) / 1e9:.1f}")
     assert e < 1e-4
     assert abs(net.flops_per_eval(1) / 3.181e12 - 1) < 0.02      # 3.181 TFLOP
+
+
+@pytest.mark.parametrize("case", ["config1", "config3_gap25", "config3_gap50", "config3_gap100", "config4"])
+def test_config_evaluations_vs_oracle_fixture(case):
+    """BASELINE.json configs[1] (all 8 items x the 4 evaluations of two Heun steps = 32 item-evaluations), configs[3] at 25 / 50 / 100 ms gaps
+    (batch 16, hann 100, T = 70 schedule; item 11 against the ORACLE) and configs[4] (44.1 kHz 8-octave network, batch 4, T = 128; items 0 and 2),
+    at full size and at the configuration's own batch: the projected x_hat of every evaluation -- fused guided evaluation, normalised guidance
+    step, data-consistency projection, exactly the sampler's per-evaluation path -- against tests/golden/config_evals.npz, which the CPU oracle
+    wrote in the build container (tests/golden/make_config_golden.py).  Inputs are rebuilt from seeds (tests/config_cases.py)."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from config_cases import build, compare
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.init import seeded_init_
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    from audio_inpainting_diffusion_amd.sampler import Sampler
+    z = np.load(os.path.join(GOLDEN, "config_evals.npz"))
+    c = build(case)
+    args, B = c["args"], c["B"]
+    net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(DEV)), c["net_seed"], gate_scale=10.0, affine_scale=10.0)
+    smp = Sampler(model=net, diff_params=EDM(args), args=args)
+    smp.setup_inpainting(c["y"].to(DEV), c["mask"])
+    worst = [0.0, 0.0, 0.0]
+    for k, (tk, xk) in enumerate(c["evals"]):
+        smp.trace = []
+        xd = xk.to(DEV)
+        x_hat = smp._denoise(xd, tk)                       # fused guided evaluation + normalised guidance step
+        smp._score_step(xd, x_hat, tk, 0.0, mode=0)        # projection stage (the step outputs are not used)
+        xh = smp.trace[-1].cpu()
+        assert bool(torch.isfinite(xh).all())
+        for b in c["items"]:
+            assert abs(float(z[f"{case}.b{b}.e{k}.t"]) - float(tk)) < 1e-6 * float(tk)
+            e = compare(xh[b], z[f"{case}.b{b}.e{k}.proj"], z[f"{case}.b{b}.e{k}.s"], 100 * k + b)
+            worst = [max(a, v) for a, v in zip(worst, e)]
+            assert e[0] < 1e-4 and e[1] < 3e-4 and e[2] < 2e-4, (case, b, k, e)
+    print(f"{case}: {len(c['items']) * len(c['evals'])} item-evaluations at batch {B} vs the oracle fixture: worst strided rel-L2 {worst[0]:.2e}, "
+          f"projections {worst[1]:.2e}, squared norm {worst[2]:.2e}")

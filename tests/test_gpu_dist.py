@@ -209,7 +209,7 @@ def test_sub_batch_streams_are_bit_identical_to_one_stream():
         for a_, b_ in zip(res[1], res[n]):
             assert torch.equal(a_, b_)
     net.split_streams = None
-    assert net._n_split(8) == 3 and net._n_split(4) == 2 and net._n_split(2) == 1
+    assert net._n_split(8) == 2 and net._n_split(4) == 2 and net._n_split(2) == 1
 
 
 @pytest.mark.parametrize("B", [1, 2])
@@ -265,7 +265,7 @@ def _full_step(net, args, y, mask, seeds, dev):
     return st["x"]
 
 
-def _full_setup(dev, seed):
+def _full_setup(dev, seed, n_items=4):
     from audio_inpainting_diffusion_amd.config import make_args
     from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
     from audio_inpainting_diffusion_amd.masks import mask_from_args
@@ -273,8 +273,33 @@ def _full_setup(dev, seed):
     args = make_args("maestro22k", audio_len=184184, T=36, gap_ms=300.0, xi=0.25)
     net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(dev)), seed, gate_scale=10.0, affine_scale=10.0)
     L = args.exp.audio_len
-    y = torch.stack([torch.from_numpy(seeded_normal(41, g, L)) for g in range(4)]) * 0.063
+    y = torch.stack([torch.from_numpy(seeded_normal(41, g, L)) for g in range(n_items)]) * 0.063
     return net, args, y, mask_from_args(args, generator=torch.Generator().manual_seed(99))
+
+
+def _worker_full8(rank, world, port, q):
+    """one of EIGHT ranks sharing cuda:0, one segment each (BASELINE configs[2]'s world size; collectives on gloo)"""
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      LOCAL_WORLD_SIZE=str(world), AID_DIST_BACKEND="gloo")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from audio_inpainting_diffusion_amd import dist as D
+    r, local, w = D.init_distributed()
+    torch.cuda.set_device(0)
+    nthr = D.bind_rank_to_gpu_numa(local, w)                       # every rank gets its share of the host cores (of its GPU's NUMA node when sysfs says)
+    net, args, y, mask = _full_setup("cuda:0", seed=rank % 2, n_items=world)     # odd ranks start from DIFFERENT weights: the one broadcast must fix that
+    torch.cuda.synchronize()
+    t0 = time.time()
+    nbytes = D.broadcast_parameters(net, src=0)
+    torch.cuda.synchronize()
+    t_bcast = time.time() - t0
+    lo, hi = D.shard_range(world, r, w)
+    out = _full_step(net, args, y[lo:hi], mask, D.item_seeds(700, lo, hi), "cuda:0")
+    allout = D.gather_outputs(out, world)
+    D.barrier()
+    q.put((rank, nbytes, (lo, hi), allout.cpu().numpy(), t_bcast, nthr, torch.distributed.get_backend()))
+    torch.distributed.destroy_process_group()
 
 
 def _worker_full(rank, world, port, q):
@@ -319,5 +344,55 @@ def test_full_size_two_ranks_on_one_gpu_equal_one_process():
     for rank, nbytes, _, allout in res:
         e = rel_l2(allout, ref)
         print(f"full size, rank {rank}: gathered 2x2 segments vs single-process B=4 after one guided Heun step: rel-L2 = {e:.2e} ({nbytes / 1e6:.0f} MB broadcast)")
-        assert allout.shape == tuple(ref.shape) and nbytes > 700e6 and e < 1e-6
+        # (not 0: a rank's WHOLE batch of two runs the stream-K instances of the F(8,3) kernel, the single process's sub-batches of two plain tiles --
+        #  one extra association per cut tile, network.stream_k)
+        assert allout.shape == tuple(ref.shape) and nbytes > 700e6 and e < 5e-6
     assert np.array_equal(res[0][3], res[1][3])
+
+
+def test_full_size_eight_ranks_on_one_gpu_equal_one_process():
+    """Dress rehearsal of BASELINE configs[2]'s WORLD SIZE before the driver's first 8-GPU run: eight processes sharing cuda:0 (gloo; RCCL refuses
+    two ranks on one device), the full-size 22.05 kHz network in each, ranks start from two different weight sets, ONE in-place 745 MB broadcast
+    per rank, one segment per rank (global-index seeds), one guided Heun step, gather in global segment order == the single-process batch-8 run.
+    Tolerance 5e-6, not 0: a whole batch of ONE runs the split-K instances of the 5x3 kernel (one extra association per tile, network.py)."""
+    from audio_inpainting_diffusion_amd import dist as D
+    world = 8
+    net, args, y, mask = _full_setup(DEV, seed=0, n_items=world)
+    ref = _full_step(net, args, y, mask, D.item_seeds(700, 0, world), DEV).cpu()
+    del net
+    torch.cuda.empty_cache()
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_full8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=2400) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    assert [r[2] for r in res] == [(i, i + 1) for i in range(world)]
+    for rank, nbytes, _, allout, t_bcast, nthr, backend in res:
+        e = rel_l2(allout, ref)
+        print(f"full size, rank {rank}/8 ({backend}, {nthr} CPU threads, broadcast {nbytes / 1e6:.0f} MB in {t_bcast:.2f} s): gathered 8x1 segments vs "
+              f"single-process B=8 after one guided Heun step: rel-L2 = {e:.2e}")
+        assert allout.shape == tuple(ref.shape) and nbytes > 700e6 and e < 5e-6
+        assert np.array_equal(allout, res[0][3])                   # every rank holds the same gathered result, in global segment order
+    assert sum(r[5] or 0 for r in res) <= (os.cpu_count() or 8) or all(r[5] is None for r in res)     # the ranks' CPU shares do not overlap
+
+
+def test_bench_self_launches_eight_ranks_rank0_only_json():
+    """`python bench.py --gpus 8 --batch 1 --steps 1 --warmup 0` as the driver will start it (here: self-launched, 8 ranks on the visible GPUs):
+    ONE JSON line, from rank 0, n_gpus 8, whole-job value; every rank logs its backend / device / CPU share on stderr."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--batch", "1", "--roof-steps", "1", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=2400, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["value"] > 0 and j["scaling"] == "weak" and j["config"]["segments_per_gpu"] == 1
+    assert j["config"]["functional_shared_gpu"] == (torch.cuda.device_count() < 8)
+    logs = [ln for ln in r.stderr.splitlines() if ln.startswith("[aid dist] rank ")]
+    assert len(logs) == 8 and len({ln.split()[3] for ln in logs}) == 8, r.stderr[-2000:]
+    print("bench --gpus 8 (self-launched):", j["value"], "evals/s;", j["config"]["parallelism"])

@@ -277,6 +277,8 @@ WINO8_CASES = [
     (2, 64, 128, 32, 32, 8, 0, True),        # <32, 4>: 4 rows per class -> RA = 4 of four classes
     (3, 64, 64, 16, 96, 1, 0, False),        # T = 96: TT = 32, three t-tiles
     (1, 256, 128, 384, 64, 64, 1, True),     # 6 rows per class: no F(8,3) tile fits -> the library answers F(4,3)
+    (4, 64, 64, 96, 1024, 1, 1, True),       # 768 tiles: 1.5 rounds of the 512 resident workgroups -> stream-K cuts every third tile
+    (5, 128, 128, 64, 512, 2, 0, True),      # 640 tiles x 2 Cout tiles = 1280: 2.5 rounds
     # 96 output channels: pair instance (64-channel tiles + 32-channel x 1024-position remainder tiles)
     (1, 96, 96, 32, 256, 2, 1, True),        # <64, 1> + <64, 1>: 16 rows per class
     (2, 64, 96, 48, 64, 2, 0, False),        # 24 rows per class: <64, 1> + remainder over two classes (RA = 8)
@@ -289,11 +291,11 @@ def test_conv2d_winograd8_domain_input(L, case):
     """aid_scale_act(wino=2) -> aid_conv2d(x_wino=2): F(8,3) along T on the row-shared tiles (10 MFMAs per 8 outputs), against the torch-CPU
     reference of the plain convolution.  fp32 error budget of the form: 1e-5 per layer (measured 3e-6 ... 6e-6, tools/wino_fm3_error.py)."""
     B, Cin, Cout, Fd, T, dil, act, epi = case
-    form = int(L.lib().aid_conv2d_wino_form(B, Cin, Cout, Fd, T, dil))
     if (Cin, Cout, Fd, T, dil) == (256, 128, 384, 64, 64):
-        assert form == 4
+        assert not L.lib().aid_conv2d_wino8_supported(Cin, Cout, Fd, T, dil) and L.lib().aid_conv2d_wino_form(B, Cin, Cout, Fd, T, dil) == 4
         return
-    assert form == 8, form
+    assert L.lib().aid_conv2d_wino8_supported(Cin, Cout, Fd, T, dil)
+    assert L.lib().aid_conv2d_wino_form(B, Cin, Cout, Fd, T, dil) in (4, 8) and L.lib().aid_conv2d_wino_form(8 * B, Cin, Cout, Fd, T, dil) in (4, 8)
     x = _rand(B, Cin, Fd, T, seed=40)
     w = _rand(Cout, Cin, 5, 3, seed=41, scale=1.0 / math.sqrt(Cin * 15))
     in_scale = 1.0 + 0.5 * _rand(B, Cin, seed=42)
@@ -331,6 +333,25 @@ def test_conv2d_winograd8_domain_input(L, case):
     assert "wino8r" in L.lib().aid_last_kernel().decode()
     err = rel_l2(y.cpu(), ref)
     assert err < 1e-5, err
+    # (2b) stream-K instance (scratch given and the launch shape asks for it): same result up to one association per cut tile, deterministic,
+    #      flags left zero, nothing written past the scratch
+    need = int(L.lib().aid_conv2d_wino8_sk_ws_bytes(B, Cin, Cout, Fd, T, dil))
+    if need:
+        ws = torch.zeros(need // 4 + 8, device=DEV)
+        ws[need // 4:] = 7.0
+        p.ws, p.ws_bytes = ws.data_ptr(), need
+        ys = []
+        for _ in range(3):
+            y2 = torch.full_like(y, float("nan"))
+            p.y = L.view4(y2)
+            L.call("aid_conv2d", p)
+            assert "wino8r_sk" in L.lib().aid_last_kernel().decode()
+            ys.append(y2)
+        torch.cuda.synchronize()
+        assert rel_l2(ys[0].cpu(), ref) < 1e-5 and rel_l2(ys[0].cpu(), y.cpu()) < 5e-6
+        assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[2])
+        assert float(ws[:1024].abs().max()) == 0.0 and float(ws[need // 4:].min()) == 7.0
+        p.ws, p.ws_bytes, p.y = None, 0, L.view4(y)
     # (3) the pack kernel writes the same F(8,3) packs as the torch helper
     outs = [torch.empty_like(wp), torch.empty(15, *L.pack_dims(Cout, Cin), device=DEV), torch.empty(50, *wp.shape[1:], device=DEV),
             torch.empty(50, *L.pack_dims(Cout, Cin), device=DEV)]
@@ -703,28 +724,30 @@ def test_channel_dot(L, shape):
     assert float((out.cpu().double() - ref).abs().max()) < 1e-5 * float(ref.abs().max() + 1)
 
 
+@pytest.mark.parametrize("xw", [1, 2])
 @pytest.mark.parametrize("case", [(2, 64, 64, 24, 128, 2), (1, 128, 256, 16, 64, 4), (2, 96, 96, 32, 128, 2), (1, 64, 128, 56, 32, 8)])
-def test_group_stats_from_conv_epilogue(L, case):
-    """aid_conv2d(stat_ws) on the row-shared F(4,3) kernel + aid_group_stats(ws_n): the per-tile (sum, sum of squares) partials of the conv
-    output replace the read pass; scale and (mean, 1/(std+eps)) agree with the plain two-kernel statistics of the same tensor."""
+def test_group_stats_from_conv_epilogue(L, case, xw):
+    """aid_conv2d(stat_ws) on the row-shared F(4,3) (xw = 1) / F(8,3) (xw = 2) kernel + aid_group_stats(ws_n): the per-tile (sum, sum of squares)
+    partials of the conv output replace the read pass; scale and (mean, 1/(std+eps)) agree with the plain two-kernel statistics of the same tensor."""
     B, Cin, Cout, Fd, T, dil = case
-    P = int(L.lib().aid_conv2d_stat_partials(B, Cin, Cout, Fd, T, dil, 1))
+    if xw == 2 and not L.lib().aid_conv2d_wino8_supported(Cin, Cout, Fd, T, dil):
+        pytest.skip("no F(8,3) tile fits this shape")
+    P = int(L.lib().aid_conv2d_stat_partials(B, Cin, Cout, Fd, T, dil, xw))
     assert P > 0
     x = _rand(B, Cin, Fd, T, seed=90)
     w = _rand(Cout, Cin, 5, 3, seed=91, scale=1.0 / math.sqrt(Cin * 15))
     res = _rand(B, Cout, Fd, T, seed=92)
     gate = _rand(B, Cout, seed=93)
     xd, wd = x.to(DEV), w.to(DEV)
-    G = T // 4
-    xv = torch.empty(B, Cin, Fd, 6 * G, device=DEV)
-    L.call("aid_scale_act", L.ScaleActParams(L.view4(xd), L.view4(xv), None, 0, B, Cin, Fd, T, 0, 1))
-    wp, wpw = L.pack_conv_weight(wd), L.pack_conv_weight_wino(wd)
+    xv = torch.empty(B, Cin, Fd, (10 * (T // 8)) if xw == 2 else (6 * (T // 4)), device=DEV)
+    L.call("aid_scale_act", L.ScaleActParams(L.view4(xd), L.view4(xv), None, 0, B, Cin, Fd, T, 0, xw))
+    wp, wpw = L.pack_conv_weight(wd), (L.pack_conv_weight_wino8(wd) if xw == 2 else L.pack_conv_weight_wino(wd))
     y = torch.empty(B, Cout, Fd, T, device=DEV)
     resd, gd = res.to(DEV), gate.to(DEV)
     ws = torch.full((B * 8 * P * 2 + 4,), float("nan"), device=DEV, dtype=torch.float64)
     p = L.Conv2dParams()
     p.x, p.y, p.res, p.aux = L.view4(xv), L.view4(y), L.view4(resd), L.view4(None)
-    p.wp, p.wp_wino, p.wino_taps, p.x_wino = wp.data_ptr(), wpw.data_ptr(), 30, 1
+    p.wp, p.wp_wino, p.wino_taps, p.x_wino = wp.data_ptr(), wpw.data_ptr(), wpw.shape[0], xw
     p.out_scale, p.out_scale_ld = gd.data_ptr(), gd.stride(0)
     p.B, p.Cin, p.Cout, p.F, p.T = B, Cin, Cout, Fd, T
     p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]

@@ -225,3 +225,32 @@ def test_long_file_windowing_batch_vs_single_item_runs():
         smp1.seeds = [1 + i]
         one = inpaint_long(smp1, [x], gap_ms=20.0, sample_rate=kw["fs"], audio_len=Ls, device=DEV)[0]
         assert rel_l2(y, one) < 1e-5
+
+
+@pytest.mark.parametrize("Ls,fs", [(131072, 22050), (65536, 22050)])
+def test_other_shipped_segment_lengths_forward_and_vjp_vs_oracle(Ls, fs):
+    """The other shipped segment lengths (conf/exp/maestro22k_131072.yaml:52, conf/exp/test_cqtdiff_22k.yaml:51; SURVEY.md section 8c asks for the
+    per-octave shapes at L in {65536, 131072, 184184, 368368}): the full-width 7-octave network at L = 131072 and 65536 -- per-octave lengths are
+    powers of two halving per octave as unet...py:768-774,786 require, forward and input-VJP against the CPU oracle, batch 2."""
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    from oracle.nsgt_cqt import OracleCQT
+    from oracle.unet import OracleUnet
+    args = make_args("maestro22k", audio_len=Ls)
+    net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(DEV)), 0, gate_scale=10.0, affine_scale=10.0)
+    Toct = [int(t) for t in net.CQTransform.plan.T_oct]
+    assert len(Toct) == 7 and all(t & (t - 1) == 0 for t in Toct) and all(Toct[i + 1] == 2 * Toct[i] for i in range(6)), Toct
+    x = torch.stack([torch.from_numpy(seeded_normal(61, b, Ls)) for b in range(2)]) * 0.5
+    cn = torch.tensor([[-0.4], [0.3]])
+    g = torch.stack([torch.from_numpy(seeded_normal(62, b, Ls)) for b in range(2)])
+    xd = x.to(DEV).requires_grad_()
+    y = net(xd, cn.to(DEV))
+    gx = torch.autograd.grad((y * g.to(DEV)).sum(), xd)[0]
+    orc = OracleUnet(7, 64, OracleCQT(7, 64, "oct", ("kaiser", 1), fs, Ls)).load_state_dict(net.state_dict())
+    xr = x.clone().requires_grad_()
+    ref = orc(xr, cn)
+    gref = torch.autograd.grad((ref * g).sum(), xr)[0]
+    e1, e2 = rel_l2(y.detach().cpu(), ref.detach()), rel_l2(gx.cpu(), gref)
+    print(f"L = {Ls}: octave lengths {Toct}; forward rel-L2 vs oracle = {e1:.3e}, input-VJP = {e2:.3e}")
+    assert e1 < 1e-4 and e2 < 1e-4

@@ -201,10 +201,13 @@ def test_full_size_guided_evaluation_vs_oracle_autograd():
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 16, 64, 2, 1), (1, 96, 96, 16, 128, 4, 0), (1, 128, 256, 16, 32, 8, 1), (2, 256, 128, 32, 256, 1, 1),
                                   (2, 64, 64, 56, 32, 4, 1), (1, 128, 128, 40, 64, 4, 1), (1, 64, 64, 56, 32, 8, 1),
-                                  (2, 96, 96, 32, 128, 2, 1), (1, 96, 96, 20, 256, 4, 1)])
+                                  (2, 96, 96, 32, 128, 2, 1), (1, 96, 96, 20, 256, 4, 1),
+                                  # xw = 2: F(8,3) row-shared tiles (single-class, multi-class, T = 32, 64+32 pair)
+                                  (2, 64, 64, 16, 64, 2, 2), (1, 128, 128, 40, 128, 2, 2), (2, 256, 128, 32, 32, 1, 2), (2, 64, 64, 56, 32, 8, 2),
+                                  (2, 96, 96, 32, 128, 2, 2), (1, 96, 96, 16, 256, 4, 2)])
 def test_conv_epilogue_dot_partials(L, case):
     """dgrad conv with the dGELU epilogue + dot_ws: the per-tile partials of <y, aux> per (sample, channel group) that
-    replace the aid_group_dot pass, on the in-kernel-transform and the Winograd-domain-input F(4,3) kernels."""
+    replace the aid_group_dot pass, on the in-kernel-transform and the Winograd-domain-input F(4,3) kernels and on the F(8,3) kernel (xw = 2)."""
     B, Cin, Cout, Fd, T, dil, xw = case
     P = L.lib().aid_conv2d_dot_partials(B, Cin, Cout, Fd, T, dil, xw)
     assert P > 0
@@ -213,16 +216,17 @@ def test_conv_epilogue_dot_partials(L, case):
     aux = _rand(B, Cout, Fd, T, seed=42)
     asc = 1.0 + 0.3 * _rand(B, Cout, seed=43)
     gd, wd, auxd, ascd = g.to(DEV), w.to(DEV), aux.to(DEV), asc.to(DEV)
-    wp, wpw = L.pack_conv_weight(wd), L.pack_conv_weight_wino(wd)
+    wp, wpw = L.pack_conv_weight(wd), (L.pack_conv_weight_wino8(wd) if xw == 2 else L.pack_conv_weight_wino(wd))
     y = torch.empty(B, Cout, Fd, T, device=DEV)
     ws = torch.full((B * 8 * (P + 1),), float("nan"), device=DEV, dtype=torch.float64)
     p = L.Conv2dParams()
     xin = gd
     if xw:
-        xin = torch.empty(B, Cin, Fd, 6 * (T // 4), device=DEV)
-        L.call("aid_scale_act", L.ScaleActParams(L.view4(gd), L.view4(xin), None, 0, B, Cin, Fd, T, 0, 1))
+        assert xw == 1 or L.lib().aid_conv2d_wino8_supported(Cin, Cout, Fd, T, dil)
+        xin = torch.empty(B, Cin, Fd, (10 * (T // 8)) if xw == 2 else (6 * (T // 4)), device=DEV)
+        L.call("aid_scale_act", L.ScaleActParams(L.view4(gd), L.view4(xin), None, 0, B, Cin, Fd, T, 0, xw))
     p.x, p.y, p.res, p.aux = L.view4(xin), L.view4(y), L.view4(None), L.view4(auxd)
-    p.wp, p.wp_wino, p.wino_taps, p.x_wino = wp.data_ptr(), wpw.data_ptr(), 30, int(xw)
+    p.wp, p.wp_wino, p.wino_taps, p.x_wino = wp.data_ptr(), wpw.data_ptr(), wpw.shape[0], int(xw)
     p.out_scale, p.out_scale_ld = ascd.data_ptr(), ascd.stride(0)
     p.aux_scale, p.aux_scale_ld = ascd.data_ptr(), ascd.stride(0)
     p.B, p.Cin, p.Cout, p.F, p.T = B, Cin, Cout, Fd, T
@@ -327,10 +331,11 @@ def L_AidError():
     return AidError
 
 
-@pytest.mark.parametrize("shape,with_gy", [((2, 16, 5, 32), True), ((1, 64, 7, 256), False), ((2, 8, 3, 16), True)])
-def test_norm_bwd_with_winograd_domain_copy(L, shape, with_gy):
-    """aid_norm_bwd(wout): the plain output equals the plain call's, and wout is the F(4,3) input transform of out * wscale[b,c]
-    (= what aid_scale_act(wino=1) writes from it)."""
+@pytest.mark.parametrize("wform", [1, 2])
+@pytest.mark.parametrize("shape,with_gy", [((2, 16, 5, 32), True), ((1, 64, 7, 256), False), ((2, 8, 3, 16), True), ((1, 8, 2, 4096), True)])
+def test_norm_bwd_with_winograd_domain_copy(L, shape, with_gy, wform):
+    """aid_norm_bwd(wout): the plain output equals the plain call's, and wout is the F(4,3) (wform = 1) / F(8,3) (wform = 2) input transform of
+    out * wscale[b,c] (= what aid_scale_act(wino = wform) writes from it)."""
     B, C, Fd, T = shape
     gd, x, gy = _rand(B, C, Fd, T, seed=60), _rand(B, C, Fd, T, seed=61), _rand(B, C, Fd, T, seed=62)
     ws_ = (1.0 + 0.5 * _rand(B, C, seed=63)).to(DEV)
@@ -344,17 +349,17 @@ def test_norm_bwd_with_winograd_domain_copy(L, shape, with_gy):
     outs = []
     for fused in (0, 1):
         out = torch.empty(B, C, Fd, T, device=DEV)
-        wout = torch.full((B, C, Fd, 6 * (T // 4)), float("nan"), device=DEV)
+        wout = torch.full((B, C, Fd, (10 * (T // 8)) if wform == 2 else (6 * (T // 4))), float("nan"), device=DEV)
         p = L.NormBwdParams(L.view4(gdd), L.view4(xd), L.view4(gyd if with_gy else None), L.view4(out), B, C, Fd, T, 8, stats.data_ptr(), sws.data_ptr(),
                             1e-7, 0.7, 0, 0)
         if fused:
-            p.wout, p.wscale, p.wscale_ld = L.view4(wout), ws_.data_ptr(), ws_.stride(0)
+            p.wout, p.wscale, p.wscale_ld, p.wform = L.view4(wout), ws_.data_ptr(), ws_.stride(0), wform
         L.call("aid_norm_bwd", p)
         torch.cuda.synchronize()
         outs.append((out, wout))
     assert torch.equal(outs[0][0], outs[1][0])
     ref = torch.empty_like(outs[1][1])
-    L.call("aid_scale_act", L.ScaleActParams(L.view4(outs[0][0]), L.view4(ref), ws_.data_ptr(), ws_.stride(0), B, C, Fd, T, 0, 1))
+    L.call("aid_scale_act", L.ScaleActParams(L.view4(outs[0][0]), L.view4(ref), ws_.data_ptr(), ws_.stride(0), B, C, Fd, T, 0, wform))
     torch.cuda.synchronize()
     assert rel_l2(outs[1][1].cpu(), ref.cpu()) < 1e-6            # (same arithmetic; the compiler contracts the two forms differently)
 
@@ -399,3 +404,70 @@ def test_fused_passes_match_the_unfused_schedule_at_full_size():
 def L_mod():
     from audio_inpainting_diffusion_amd import _lib
     return _lib
+
+
+@pytest.mark.parametrize("tag", ["a", "c"])
+def test_guided_chain_vs_reference_sampler_and_unet_fixture(tag):
+    """sampler_guided_unet.npz = the REFERENCE's Sampler + EDM + U-Net (tests/golden/make_golden.py --only guided).  The HIP network's fused
+    guided evaluation, teacher-forced on the recorded input state of every evaluation: x_hat, rec_grads, norm <= 1e-4; then the HIP sampler's
+    whole trajectory from the same global-generator seed."""
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.sampler import Sampler
+    from oracle.edm import OracleEDM
+    net, _, zu, kw, args = _setup(tag)
+    z = np.load(os.path.join(GOLDEN, "sampler_guided_unet.npz"))
+    assert ast.literal_eval(str(z[f"{tag}.cfg"])) == kw and int(z[f"{tag}.seed"]) == int(zu["seed"])
+    edm = OracleEDM()
+    v = lambda t: t.reshape(-1).to(DEV).contiguous()
+    worst = [0.0, 0.0, 0.0]
+    for seed in (0, 1):
+        k = f"{tag}.s{seed}"
+        y, mask = torch.from_numpy(z[k + ".y"]), torch.from_numpy(z[k + ".mask"])
+        for e in range(int(z[k + ".n_eval"])):
+            x = torch.from_numpy(z[f"{k}.e{e}.x"])
+            s = torch.full((1, 1), float(z[f"{k}.e{e}.t"]))
+            xh, g, nrm = net.denoise_guided(x.to(DEV), v(edm.cnoise(s)), v(edm.cin(s)), v(edm.cskip(s)), v(edm.cout(s)), True, y.to(DEV), mask.to(DEV))
+            e1, e2 = rel_l2(xh.cpu(), z[f"{k}.e{e}.x_hat"]), rel_l2(g.cpu(), z[f"{k}.e{e}.rec_grads"])
+            e3 = abs(float(nrm.cpu()) - float(z[f"{k}.e{e}.norm"][0])) / float(z[f"{k}.e{e}.norm"][0])
+            worst = [max(a, b) for a, b in zip(worst, (e1, e2, e3))]
+        args.tester.T, args.tester.posterior_sampling.xi = 3, 0.25
+        args.tester.data_consistency.hann_size = 20
+        smp = Sampler(model=net, diff_params=EDM(args), args=args)
+        torch.manual_seed(seed)
+        out = smp.predict_inpainting(y.to(DEV), mask.to(DEV))
+        et = rel_l2(out.cpu(), z[k + ".out"])
+        print(f"guided chain vs reference fixture ({k}): trajectory {et:.2e}")
+        assert et < 2e-3
+    print(f"guided chain vs reference fixture ({tag}): worst x_hat {worst[0]:.2e}, rec_grads {worst[1]:.2e}, norm {worst[2]:.2e}")
+    assert worst[0] < 1e-4 and worst[1] < 1e-4 and worst[2] < 1e-4
+
+
+def test_full_size_guided_evaluation_vs_reference_fixture():
+    """unet_full_cfgA_guided.npz = ONE guided evaluation of the reference's Sampler + EDM + full-size cfg-A U-Net (make_golden.py --only full_guided):
+    norm, every 97th sample and eight seeded projections (+ squared norm) of x_hat and rec_grads."""
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
+    from audio_inpainting_diffusion_amd.masks import long_gap_mask
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    from oracle.edm import OracleEDM
+    z = np.load(os.path.join(GOLDEN, "unet_full_cfgA_guided.npz"))
+    args = make_args("maestro22k")
+    net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(DEV)), 0, gate_scale=10.0, affine_scale=10.0)
+    Ls = args.exp.audio_len
+    edm = OracleEDM()
+    x = torch.from_numpy(seeded_normal(21, 0, Ls)).reshape(1, Ls) * 0.3
+    y = torch.from_numpy(seeded_normal(22, 0, Ls)).reshape(1, Ls) * 0.063
+    mask = long_gap_mask(Ls, 22050, 300)
+    s = torch.full((1, 1), float(z["t"]))
+    v = lambda t: t.reshape(-1).to(DEV).contiguous()
+    xh, g, nrm = net.denoise_guided(x.to(DEV), v(edm.cnoise(s)), v(edm.cin(s)), v(edm.cskip(s)), v(edm.cout(s)), True, (y * mask).to(DEV), mask.to(DEV))
+    assert abs(float(nrm.cpu()) - float(z["norm"][0])) < 1e-4 * float(z["norm"][0])
+    for name, t, stream in (("x_hat", xh, 1), ("rec_grads", g, 2)):
+        tv = t.cpu().double().reshape(-1).numpy()
+        ref_p, ref_s = z[name + "_proj"], z[name + "_s"]
+        scale = np.sqrt(ref_p[-1])                                                   # |reference tensor|
+        probes = np.stack([seeded_normal(7000 + j, stream, tv.size) for j in range(8)]).astype(np.float64)
+        dp = np.abs(probes @ tv - ref_p[:8]).max() / scale                           # ~ |delta| / |ref| for a delta uncorrelated with the probes
+        ds = rel_l2(t.cpu()[:, ::97], ref_s)
+        print(f"full-size guided evaluation vs REFERENCE fixture: {name}: strided rel-L2 {ds:.2e}, projections {dp:.2e}, |.|^2 {abs(tv @ tv - ref_p[-1]) / ref_p[-1]:.2e}")
+        assert ds < 1e-4 and dp < 3e-4 and abs(tv @ tv - ref_p[-1]) < 2e-4 * ref_p[-1]

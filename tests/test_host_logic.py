@@ -391,3 +391,19 @@ def test_a_weighting_taps_match_the_reference_filter():
         assert rel_l2(y, z[f"y{fs}"]) < 1e-6
     with pytest.raises(ValueError):
         a_weighting_taps(22050, 100)
+
+
+def test_edm_scalar_normalisation_of_the_fused_entry_points():
+    """numpy.float32 / int / 0-d / 1-element values are host scalars, device vectors need B elements, anything else is refused
+    before it can reach a kernel as a pointer."""
+    from audio_inpainting_diffusion_amd._lib import AidError
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention as U
+    dev = torch.device("cpu")
+    out = U._norm_scalars(3, dev, (np.float32(0.5), 1, torch.tensor(0.25), torch.tensor([2.0])))
+    assert out == (0.5, 1.0, 0.25, 2.0) and all(isinstance(v, float) for v in out)
+    out = U._norm_scalars(2, dev, (torch.tensor([1.0, 2.0]), torch.tensor([[3.0], [4.0]]), torch.tensor([5.0, 6.0], dtype=torch.float64), 7.0))
+    assert all(torch.is_tensor(v) and v.dtype == torch.float32 and v.shape == (2,) for v in out) and out[3].tolist() == [7.0, 7.0] and out[1].tolist() == [3.0, 4.0]
+    with pytest.raises(AidError):
+        U._norm_scalars(3, dev, (torch.zeros(2), 1.0, 1.0, 1.0))
+    with pytest.raises(AidError):
+        U._norm_scalars(3, dev, ("0.5", 1.0, 1.0, 1.0))

@@ -263,3 +263,75 @@ def _reference_shaped_state_dict(args, seed):
     from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
     net = Unet_CQT_oct_with_attention(args, torch.device("cpu"))
     return seeded_init_(net, seed, gate_scale=10.0, affine_scale=10.0).state_dict()
+
+
+@pytest.mark.parametrize("tag", ["a", "c"])
+def test_guided_chain_matches_reference_sampler_and_unet(tag):
+    """sampler_guided_unet.npz: the REFERENCE's Sampler + EDM driving the REFERENCE's own U-Net (make_golden.py --only guided).  The oracle chain
+    (denoiser -> apply_hpf_DC -> masked 2-norm -> autograd) reproduces x_hat, rec_grads and norm of EVERY evaluation from the recorded input
+    state (teacher-forced), and the oracle sampler reproduces the whole trajectory from the same global-generator seed."""
+    from audio_inpainting_diffusion_amd.init import seeded_state_dict
+    from oracle.edm import OracleEDM
+    from oracle.sampler import OracleSampler
+    z = np.load(os.path.join(GOLDEN, "sampler_guided_unet.npz"))
+    zu = np.load(os.path.join(GOLDEN, f"unet_small_{tag}.npz"))
+    kw = ast.literal_eval(str(z[f"{tag}.cfg"]))
+    assert kw == ast.literal_eval(str(zu["cfg"]))
+    shapes = [(k, ast.literal_eval(s)) for k, s in zip(zu["keys"], zu["shapes"])]
+    sd = seeded_state_dict(shapes, int(z[f"{tag}.seed"]), gate_scale=10.0, affine_scale=10.0)
+    cqt = OracleCQT(kw["num_octs"], kw["bins_per_oct"], "oct", ("kaiser", 1), kw["fs"], kw["audio_len"])
+    net = OU.OracleUnet(kw["num_octs"], kw["bins_per_oct"], cqt).load_state_dict(sd)
+    edm = OracleEDM()
+    for seed in (0, 1):
+        k = f"{tag}.s{seed}"
+        y, mask = torch.from_numpy(z[k + ".y"]), torch.from_numpy(z[k + ".mask"])
+        n = int(z[k + ".n_eval"])
+        assert n == 5
+        for e in range(n):
+            x = torch.from_numpy(z[f"{k}.e{e}.x"]).clone().requires_grad_()
+            sig = torch.full((1, 1), float(z[f"{k}.e{e}.t"]))
+            xh = cqt.apply_hpf_DC(edm.denoiser(x, net, sig))
+            norm = torch.linalg.norm(y - mask * xh, dim=1, ord=2)
+            g = torch.autograd.grad(norm.sum(), x)[0]
+            assert rel_l2(xh.detach(), z[f"{k}.e{e}.x_hat"]) < 2e-5
+            assert rel_l2(g, z[f"{k}.e{e}.rec_grads"]) < 1e-4
+            assert abs(float(norm) - float(z[f"{k}.e{e}.norm"][0])) < 2e-5 * float(norm)
+        smp = OracleSampler(net, edm, T=3, xi=0.25, hann_size=20, audio_len=kw["audio_len"])
+        torch.manual_seed(seed)
+        out = smp.predict_inpainting(y, mask)
+        assert rel_l2(out, z[k + ".out"]) < 2e-3          # (five chained evaluations of an O(1)-gate random network amplify rounding)
+
+
+def test_full_size_guided_evaluation_oracle_vs_reference_fixture():
+    """unet_full_cfgA_guided.npz (one guided evaluation of the reference's Sampler + EDM + full-size cfg-A U-Net): the oracle chain at FULL size
+    (186 M parameters; ~1.5 min and ~18 GB of host RAM) reproduces norm, the strided samples and the seeded projections of x_hat and rec_grads."""
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.init import seeded_normal, seeded_state_dict
+    from audio_inpainting_diffusion_amd.masks import long_gap_mask
+    from oracle.edm import OracleEDM
+    z = np.load(os.path.join(GOLDEN, "unet_full_cfgA_guided.npz"))
+    zk = np.load(os.path.join(GOLDEN, "unet_full_cfgA_keys.npz")) if os.path.exists(os.path.join(GOLDEN, "unet_full_cfgA_keys.npz")) else None
+    args = make_args("maestro22k")
+    Ls = args.exp.audio_len
+    if zk is not None:
+        shapes = [(k, ast.literal_eval(s)) for k, s in zip(zk["keys"], zk["shapes"])]
+    else:                                                   # key / shape list of the full network from the product class on the meta device (no memory)
+        from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+        shapes = [(k, tuple(v.shape)) for k, v in Unet_CQT_oct_with_attention(args, torch.device("meta")).state_dict().items()]
+    sd = seeded_state_dict(shapes, 0, gate_scale=10.0, affine_scale=10.0)
+    cqt = OracleCQT(7, 64, "oct", ("kaiser", 1), 22050, Ls)
+    net = OU.OracleUnet(7, 64, cqt).load_state_dict(sd)
+    edm = OracleEDM()
+    x = (torch.from_numpy(seeded_normal(21, 0, Ls)).reshape(1, Ls) * 0.3).requires_grad_()
+    y = torch.from_numpy(seeded_normal(22, 0, Ls)).reshape(1, Ls) * 0.063
+    mask = long_gap_mask(Ls, 22050, 300)
+    xh = cqt.apply_hpf_DC(edm.denoiser(x, net, torch.full((1, 1), float(z["t"]))))
+    norm = torch.linalg.norm(y * mask - mask * xh, dim=1, ord=2)
+    g = torch.autograd.grad(norm.sum(), x)[0]
+    assert abs(float(norm) - float(z["norm"][0])) < 2e-5 * float(norm)
+    for name, t, stream in (("x_hat", xh.detach(), 1), ("rec_grads", g, 2)):
+        tv = t.double().reshape(-1).numpy()
+        ref_p = z[name + "_proj"]
+        probes = np.stack([seeded_normal(7000 + j, stream, tv.size) for j in range(8)]).astype(np.float64)
+        assert rel_l2(t[:, ::97], z[name + "_s"]) < 2e-5, name
+        assert np.abs(probes @ tv - ref_p[:8]).max() < 1e-4 * np.sqrt(ref_p[-1]), name

@@ -16,7 +16,7 @@ SHAPES = [  # C, F, T, dilations
 ]
 
 
-def run(B, C, F, T, dil, form, reps=10, epi=0):
+def run(B, C, F, T, dil, form, reps=10, epi=0, sk=False):
     dev = "cuda"
     x = torch.randn(B, C, F, T, device=dev)
     y = torch.empty(B, C, F, T, device=dev)
@@ -37,6 +37,12 @@ def run(B, C, F, T, dil, form, reps=10, epi=0):
     p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
     p.KH, p.KW, p.dilF, p.act, p.epi = 5, 3, dil, 0, epi
     p.alpha, p.res_scale = 1 / math.sqrt(2), 1.0
+    if sk:
+        need = int(L.lib().aid_conv2d_wino8_sk_ws_bytes(B, C, C, F, T, dil))
+        if not need:
+            return None, None, "plain tiles"
+        ws = torch.zeros(need // 4, device=dev)
+        p.ws, p.ws_bytes = ws.data_ptr(), need
     torch.manual_seed(0)
     for _ in range(2):
         L.call("aid_conv2d", p)
@@ -54,23 +60,27 @@ def main():
     Bs = [int(a) for a in sys.argv[1:]] or [8]
     epi = int(os.environ.get("PROBE_EPI", "0"))
     for B in Bs:
-        t4s = t8s = 0.0
+        t4s = t8s = tks = 0.0
         for C, F, T, dils in SHAPES:
             for dil in dils:
                 torch.manual_seed(1)
                 t4, y4, k4 = run(B, C, F, T, dil, 4, epi=epi)
-                form = int(L.lib().aid_conv2d_wino_form(B, C, C, F, T, dil))
+                form = 8 if L.lib().aid_conv2d_wino8_supported(C, C, F, T, dil) else 4
+                pick = int(L.lib().aid_conv2d_wino_form(B, C, C, F, T, dil))
                 fl = 2.0 * B * F * T * C * C * 15
                 if form != 8:
                     print(f"B{B} C{C} F{F} T{T} d{dil}: F(4,3) {t4:7.1f} us {fl / t4 / 1e6:6.1f} TF/s   [library keeps F(4,3)]")
-                    t4s += t4; t8s += t4
+                    t4s += t4; t8s += t4; tks += t4
                     continue
                 torch.manual_seed(1)
                 t8, y8, k8 = run(B, C, F, T, dil, 8, epi=epi)
                 err = float((y8 - y4).norm() / y4.norm())
-                t4s += t4; t8s += t8
-                print(f"B{B} C{C} F{F} T{T} d{dil}: F(4,3) {t4:7.1f} us {fl / t4 / 1e6:6.1f} TF/s | F(8,3) {t8:7.1f} us {fl / t8 / 1e6:6.1f} TF/s  x{t4 / t8:.3f}  diff {err:.1e}  {k8}")
-        print(f"B{B} sum: F(4,3) {t4s / 1e3:.2f} ms, F(8,3) {t8s / 1e3:.2f} ms, x{t4s / t8s:.3f}")
+                torch.manual_seed(1)
+                tk, yk, kk = run(B, C, F, T, dil, 8, epi=epi, sk=True)
+                t4s += t4; t8s += t8; tks += (tk if tk is not None else t8)
+                sks = "stream-K: plain tiles kept" if tk is None else f"stream-K {tk:7.1f} us {fl / tk / 1e6:6.1f} TF/s x{t8 / tk:.3f} diff {float((yk - y8).norm() / y8.norm()):.1e}"
+                print(f"B{B} C{C} F{F} T{T} d{dil}: F(4,3) {t4:7.1f} us {fl / t4 / 1e6:6.1f} TF/s | F(8,3) {t8:7.1f} us {fl / t8 / 1e6:6.1f} TF/s  x{t4 / t8:.3f}  diff {err:.1e}  {k8} | {sks} | library picks F({pick},3)")
+        print(f"B{B} sum: F(4,3) {t4s / 1e3:.2f} ms, F(8,3) {t8s / 1e3:.2f} ms (x{t4s / t8s:.3f}), F(8,3) with stream-K where taken {tks / 1e3:.2f} ms (x{t4s / tks:.3f})")
 
 
 if __name__ == "__main__":

@@ -22,18 +22,21 @@ forward pass PLUS the input-VJP through the whole denoiser (--xi 0 times the for
 
 roofline (fp32 MFMA, peak 157.3 TFLOP/s): every aid_conv2d launch of a single-stream pass (forward and VJP plans) is
 bracketed by HIP events on the launch stream and attributed to the device kernel it dispatched to (aid_last_kernel).
-The line reports the DOMINANT kernel BY ITS ROCPROF NAME (most GPU time: conv53_wino4r_kernel, the 5x3 layers in Winograd
-F(4,3) form), over ALL its template instances / tile kinds (`families` keeps the sub-family table):
+The line reports the DOMINANT kernel BY ITS ROCPROF NAME (most GPU time: conv53_wino8r_kernel, the 5x3 layers in Winograd
+F(8,3) form; conv53_wino4r_kernel = F(4,3) takes the launches whose tiles quantise better that way), over ALL its template instances / tile
+kinds (`families` keeps the sub-family table):
     achieved = MFMA FLOPs that kernel ISSUES / its launch time, summed over every launch of >= 3 Heun steps
-               (F(4,3) issues 6 products per 4 outputs x 3 taps = half the direct-form FLOPs; 1x1 / direct kernels issue all)
+               (F(4,3) issues 6 products per 4 outputs x 3 taps = 1/2 of the direct-form FLOPs, F(8,3) 10 per 8 x 3 = 5/12; 1x1 / direct kernels all)
     frac     = achieved / 157.3
     algorithmic_tflops = direct-convolution FLOPs (2*B*F*T*Cin*Cout*KH*KW) / the same time -- may exceed the peak
     step_executed_frac = MFMA FLOPs issued by ALL conv / GEMM launches of a step / the step's wall time in the TIMED region / 157.3
-`kernels` aggregates every conv kernel by name, `families` by name + tile kind, `all_conv` over all of them.  traffic (HBM bytes
-per launch from PMC counters) cannot be measured from inside this process: it is null here and the PMC passes of this same command
-are committed under profiles/ (`traffic_from_profile`).
+`kernels` aggregates every conv kernel by name, `families` by name + tile kind, `all_conv` over all of them.  traffic = HBM bytes per launch
+of the dominant kernel from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, --streams 1, FETCH
+doubled for gfx950) committed under profiles/ -- counters cannot be read from inside this process; traffic_over_algorithmic relates it to this
+run's algorithmic bytes per launch.
 cpu_baseline: the CPU oracle (torch-CPU restatement of the reference path, oracle/) timed on this host's cores for the same
-network and branch at B=1 (rank 0, N=1 only): one warm-up evaluation OF THE SAME BRANCH, then three timed evaluations; value = 1 / median.
+network and branch at B=1 (rank 0, N=1 only): per thread placement (physical cores of one socket / all physical / all logical) one warm-up and one
+timed evaluation OF THE SAME BRANCH, then two more on the fastest placement; value = 1 / median of its three timings, `cores` = its thread count.
 """
 import argparse
 import json
@@ -396,7 +399,7 @@ def main():
                          "achieved": dom.get("executed_mfma_tflops"), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s", "frac": dom.get("frac_of_fp32_mfma_peak"),
                          "algorithmic_tflops": dom.get("algorithmic_tflops"), "launches": dom.get("launches"), "avg_launch_us": dom.get("avg_launch_us"),
                          "algorithmic_gflop_per_launch": dom.get("algorithmic_gflop_per_launch"),
-                         "traffic": None, "traffic_from_profile": _profile_traffic(),
+                         **_traffic_fields(dom_name, dom),
                          "share_of_conv_time": round(dom.get("time_ms", 0.0) / max(conv_ms, 1e-9), 3),
                          "all_conv": {"launches": len(timing), "executed_mfma_tflops": round(exe / sec / 1e12, 2), "frac_of_fp32_mfma_peak": round(exe / sec / 1e12 / PEAK_F32_MFMA, 4),
                                       "algorithmic_tflops": round(alg / sec / 1e12, 2), "conv_time_fraction_of_wall": round(sec / (ROOF_STEPS * wall_serial), 3),
@@ -412,9 +415,21 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+def _traffic_fields(dom_name, dom):
+    """roofline.traffic = HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE in
+    separate rocprofv3 runs of this command with --streams 1, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) -- counters cannot be read
+    from inside this process; traffic_over_algorithmic compares it with this run's algorithmic bytes per launch of the same kernel."""
+    tp = _profile_traffic()
+    per = ((tp or {}).get("per_kernel_bytes") or {})
+    t = per.get(dom_name) if dom_name else None
+    alg = dom.get("algorithmic_mb_per_launch")
+    return {"traffic": t, "traffic_unit": "HBM bytes per launch (PMC, committed profile)", "traffic_source": (tp or {}).get("file"),
+            "traffic_over_algorithmic": (round(t / (alg * 1e6), 3) if (t and alg) else None), "traffic_from_profile": tp}
+
+
 def _profile_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this command (profiles/), or null."""
-    for name in ("r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json"):
+    """HBM bytes per launch of the conv kernels from the committed PMC passes of this command (profiles/), or null."""
+    for name in ("r04_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json"):
         tr = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tr):
             try:

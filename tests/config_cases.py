@@ -27,8 +27,14 @@ def build(name):
     wl, T, gap, B, items, net_seed, ystream = CASES[name]
     args = make_args(wl, T=T, gap_ms=gap, xi=0.25)
     L = args.exp.audio_len
-    if args.tester.inpainting.mask_mode == "short":          # per-item gap positions (testing_shortgaps: torch.randint per segment)
-        mask = torch.cat([mask_from_args(args, generator=torch.Generator().manual_seed(40 + b)) for b in range(B)])
+    if args.tester.inpainting.mask_mode == "short":          # per-item gap positions (tester_inpainting.py:240-250: torch.randint per segment), kept
+        hann = int(args.tester.data_consistency.hann_size)   # one cross-fade length away from the segment's ends: prepare_smooth_mask -- the reference's
+        gap = int(gap * args.exp.sample_rate / 1000)         # (:302-325) and ours -- raises when a Hann ramp would not fit inside the segment
+        mask = torch.ones(B, L)
+        for b in range(B):
+            starts = torch.randint(hann, L - gap - hann, (int(args.tester.inpainting.short.num_gaps),), generator=torch.Generator().manual_seed(40 + b))
+            for st in starts.tolist():
+                mask[b, st:st + gap] = 0
     else:
         mask = mask_from_args(args)
     clean = torch.stack([torch.from_numpy(seeded_normal(ystream, b, L)) for b in range(B)]) * 0.063

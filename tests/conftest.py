@@ -41,3 +41,16 @@ def projected_rel_error(z, tag, tensors, small_tol=1e-3):
             # (zero-initialised biases are pure Adam steps lr * g / (|g| + eps) of near-eps gradients: fp32 noise in g shows up at 1e-4 there)
             assert rel_l2(tensors[k].detach().cpu(), z[f"{tag}.{k}"]) < small_tol, k
     return (num / den) ** 0.5
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_memory_between_tests(request):
+    """Full-size launch plans own tens of GB (61 GB at batch 8, twice that at batch 16): drop what a test left behind before the next one builds its
+    own network, so that consecutive full-size cases do not pile up on the 288 GB of one MI355X."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import gc
+        import torch
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()

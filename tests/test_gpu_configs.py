@@ -176,5 +176,6 @@ def test_config_evaluations_vs_oracle_fixture(case):
             e = compare(xh[b], z[f"{case}.b{b}.e{k}.proj"], z[f"{case}.b{b}.e{k}.s"], 100 * k + b)
             worst = [max(a, v) for a, v in zip(worst, e)]
             assert e[0] < 1e-4 and e[1] < 3e-4 and e[2] < 2e-4, (case, b, k, e)
+    del smp, net
     print(f"{case}: {len(c['items']) * len(c['evals'])} item-evaluations at batch {B} vs the oracle fixture: worst strided rel-L2 {worst[0]:.2e}, "
           f"projections {worst[1]:.2e}, squared norm {worst[2]:.2e}")

@@ -40,7 +40,14 @@ def main():
     if os.environ.get('PROBE_WINO', '0') != '0' and KH == 5:
         wpw = L.pack_conv_weight_wino(w)
         p.wp_wino, p.wino_taps = wpw.data_ptr(), wpw.shape[0]
-    if os.environ.get('PROBE_V', '0') != '0':         # Winograd-domain input written by aid_scale_act(wino=1)
+    if os.environ.get('PROBE_V', '0') == '2':         # F(8,3): Winograd-domain input written by aid_scale_act(wino=2), 50-tap pack
+        assert L.lib().aid_conv2d_wino8_supported(Cin, Cout, F, T, dil)
+        wpw = L.pack_conv_weight_wino8(w)
+        p.wp_wino, p.wino_taps = wpw.data_ptr(), wpw.shape[0]
+        xv = torch.empty(B, Cin, F, 10 * (T // 8), device=dev)
+        L.call("aid_scale_act", L.ScaleActParams(L.view4(x), L.view4(xv), None, 0, B, Cin, F, T, 0, 2))
+        p.x, p.x_wino = L.view4(xv), 2
+    elif os.environ.get('PROBE_V', '0') != '0':       # Winograd-domain input written by aid_scale_act(wino=1)
         assert L.lib().aid_conv2d_wino_input_supported(Cin, Cout, T)
         xv = torch.empty(B, Cin, F, 6 * (T // 4), device=dev)
         sp = L.ScaleActParams(L.view4(x), L.view4(xv), None, 0, B, Cin, F, T, 0, 1)

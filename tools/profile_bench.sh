@@ -1,9 +1,9 @@
 #!/bin/bash
-# rocprofv3 kernel statistics of the default bench command (sub-batch streams) and of the single-stream schedule.
+# rocprofv3 kernel statistics of the default bench command (two sub-batch streams) and of the single-stream schedule.
 # usage (on the GPU box): tools/profile_bench.sh <tag>      -> gpurun_out/<tag>_*  (copy what should be judged into profiles/)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=${1:-r02}
-for mode in streams3 streams1; do
+for mode in streams2 streams1; do
   extra=""; [ $mode = streams1 ] && extra="--streams 1"
   rm -rf gpurun_out/prof_tmp
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_tmp -o p -- python bench.py --steps 3 --warmup 1 --roof-steps 1 --no-cpu-baseline $extra > gpurun_out/${tag}_bench_${mode}_under_rocprof.json 2> gpurun_out/${tag}_bench_${mode}_under_rocprof.err

@@ -731,10 +731,14 @@ struct W4rShape {
     static constexpr int M_BLK = 32 * WGM, N_BLK = 32 * WM * WGN;
     static constexpr int GPR = TT / WM;                        // groups of WM outputs per row
     static constexpr int RA = N_BLK / (TT * NC);               // output rows per residue class and tile
-    static constexpr int CSLOT = RA + KH - 1;                  // staged input rows per channel and class
-    static constexpr int NSLOT = NC * CSLOT;
+    static constexpr int CSLOT_USED = RA + KH - 1;             // staged input rows per channel and class
     static constexpr int ILR = 32 / GPR;                       // rows read by one half-wave
-    static constexpr int IL = (CSLOT % ILR == 0 && RA % ILR == 0) ? ILR : 1;   // slot interleave unit (1: plain order)
+    static constexpr int IL = (RA % ILR == 0) ? ILR : 1;       // slot interleave unit (1: plain order)
+    // slots per class, padded to a multiple of the interleave unit (the padding slots are never loaded): round 4 -- the T = 32 tiles of the F(8,3)
+    // kernel (RA = 16, 20 staged rows, 8 rows per half-wave) otherwise fell back to the plain order and 2-way bank conflicts on every B read
+    // (SQ_LDS_BANK_CONFLICT 4.6e7 and 72 % matrix-pipe busy against 82 % of the T = 64 tiles, profiles/r04_wino_pmc.txt)
+    static constexpr int CSLOT = (CSLOT_USED + IL - 1) / IL * IL;
+    static constexpr int NSLOT = NC * CSLOT;
     static constexpr int XCI = NSLOT * NXI * GPR;              // floats per input channel in the x region
     static constexpr int XSZ = ((KC * XCI + 255) / 256) * 256;
     static constexpr int WROW = M_BLK;
@@ -755,7 +759,7 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
     constexpr int KH = S::KH, NXI = S::NXI, KC = S::KC;
     constexpr int NW = S::NW, WGN = S::WGN;
     constexpr int M_BLK = S::M_BLK;
-    constexpr int GPR = S::GPR, RA = S::RA, CSLOT = S::CSLOT, IL = S::IL, XCI = S::XCI, XSZ = S::XSZ, WROW = S::WROW;
+    constexpr int GPR = S::GPR, RA = S::RA, CSLOT = S::CSLOT, CSLOT_USED = S::CSLOT_USED, IL = S::IL, XCI = S::XCI, XSZ = S::XSZ, WROW = S::WROW;
     constexpr int WSZ_RAW = S::WSZ_RAW, WSZ = S::WSZ, BUFSZ = S::BUFSZ, NBUF = S::NBUF;
     constexpr int NXP = XSZ / 256, NWP = WSZ / 256, NP = NXP + NWP;
     constexpr int PPW = (NP + NW - 1) / NW;
@@ -819,7 +823,7 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
             const int slot = (e / (IL * NXI * GPR)) * IL + (e / GPR) % IL;     // [slot / IL][xi][slot % IL][GPR]
             const int cls = slot / CSLOT;
             const int jr = j0 + (slot % CSLOT) - (KH / 2);   // sub-lattice row index of this slot
-            if (ci < KC && jr >= 0 && jr < nrow && t0 + WM * gl < p.T) {
+            if (ci < KC && (slot % CSLOT) < CSLOT_USED && jr >= 0 && jr < nrow && t0 + WM * gl < p.T) {
                 const int fi = res + cls + jr * p.dilF;
                 poff[i] = (unsigned)(4 * ((int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + (int64_t)xi * (p.T / WM) + (t0 / WM) + gl));   // (within sample b: < 2^32, see conv53_wino_v)
                 ok = true;

@@ -91,16 +91,33 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResDev a) {
     const float* x = p.x.p + (int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)f * p.x.sF;
     float* y = p.y.p + (int64_t)b * p.y.sB + (int64_t)c * p.y.sC + (int64_t)f * p.y.sF;
     float v[4];
-    if (a.xvec && o4 >= 8 && o4 + 12 <= a.Tout) {
-        // ---- interior: input window in registers -------------------------------------------------------------------
+    if (a.xvec) {
+        // ---- input window in registers, for EVERY thread (round 4).  Rounds 1-3 sent the threads whose window touches a row border down a scalar
+        // path -- 2 + 2 of the T/4 threads of a row, i.e. half of them at T = 32: the adjoints of the deep levels ran at 0.85 ... 1.2 TB/s
+        // (profiles/r03_pointwise_bandwidth.txt).  Now a 16-byte (8-byte) piece of the window that lies wholly inside the row is one vector load,
+        // a piece outside it is filled by reflection (forward maps) or zeros (adjoints: the out-of-range terms of the transposed FIR vanish), and
+        // the adjoints add the folded terms of the reflect padding for the few outputs next to a border (1 .. 3 from either end).
+        const int Lin = p.T;                                 // length of the tensor passed as x
         if (MODE == 0 || MODE == 3) {
-            // MODE 0: x[2*o4-4 .. 2*o4+11], output e = sum_k h[k] x[2(o4+e)+k-3]               -> w[2e+k+1]
+            // MODE 0: x[2*o4-4 .. 2*o4+11], output e = sum_k h[k] xp[2(o4+e)+k-3]                -> w[2e+k+1]
             // MODE 3: g[2*o4-4 .. 2*o4+11], output e = sum_q h[7-2q] g[2(o4+e+2-q)] + h[6-2q] g[2(o4+e+1-q)+1]
             //                                                                                    -> w[2e+8-2q], w[2e+7-2q]
             float w[16];
-            const float4* src = reinterpret_cast<const float4*>(x + 2 * o4 - 4);
+            const int base = 2 * o4 - 4;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const float4 t = src[q]; w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w; }
+            for (int q = 0; q < 4; ++q) {
+                const int i0 = base + 4 * q;
+                if (i0 >= 0 && i0 + 3 < Lin) {
+                    const float4 t = *reinterpret_cast<const float4*>(x + i0);
+                    w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ii = i0 + j;
+                        w[4 * q + j] = (MODE == 0) ? x[refl(ii, Lin)] : ((ii >= 0 && ii < Lin) ? x[ii] : 0.f);
+                    }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float s = 0.f;
@@ -113,15 +130,30 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResDev a) {
                         s += c_h[7 - 2 * q] * w[2 * e + 8 - 2 * q];
                         s += c_h[6 - 2 * q] * w[2 * e + 7 - 2 * q];
                     }
+                    const int i = o4 + e;
+                    if (i >= 1 && i <= 2) s += up_adj_virtual(x, a.Tout, -i);
+                    if (i >= a.Tout - 3 && i <= a.Tout - 2) s += up_adj_virtual(x, a.Tout, 2 * (a.Tout - 1) - i);
                 }
                 v[e] = s;
             }
         } else {
             // MODE 1: x[o4/2-2 .. o4/2+3];  MODE 2: g[o4/2-2 .. o4/2+3]
             float w[6];
-            const float2* src = reinterpret_cast<const float2*>(x + (o4 >> 1) - 2);
+            const int base = (o4 >> 1) - 2;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) { const float2 t = src[q]; w[2 * q] = t.x; w[2 * q + 1] = t.y; }
+            for (int q = 0; q < 3; ++q) {
+                const int i0 = base + 2 * q;
+                if (i0 >= 0 && i0 + 1 < Lin) {
+                    const float2 t = *reinterpret_cast<const float2*>(x + i0);
+                    w[2 * q] = t.x; w[2 * q + 1] = t.y;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int ii = i0 + j;
+                        w[2 * q + j] = (MODE == 1) ? x[refl(ii, Lin)] : ((ii >= 0 && ii < Lin) ? x[ii] : 0.f);
+                    }
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float s;
@@ -134,6 +166,9 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResDev a) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k)
                         if (((e + 3 - k) & 1) == 0) s += c_h[k] * w[((e + 3 - k) >> 1) + 2];     // g[(o4+e+3-k)/2]
+                    const int i = o4 + e;
+                    if (i >= 1 && i <= 3) s += down_adj_virtual(x, a.Tout, -i);
+                    if (i >= a.Tout - 4 && i <= a.Tout - 2) s += down_adj_virtual(x, a.Tout, 2 * (a.Tout - 1) - i);
                 }
                 v[e] = s;
             }

@@ -35,8 +35,8 @@ of the dominant kernel from the PMC passes of this same command (rocprofv3 --pmc
 doubled for gfx950) committed under profiles/ -- counters cannot be read from inside this process; traffic_over_algorithmic relates it to this
 run's algorithmic bytes per launch.
 cpu_baseline: the CPU oracle (torch-CPU restatement of the reference path, oracle/) timed on this host's cores for the same
-network and branch at B=1 (rank 0, N=1 only): per thread placement (physical cores of one socket / all physical / all logical) one warm-up and one
-timed evaluation OF THE SAME BRANCH, then two more on the fastest placement; value = 1 / median of its three timings, `cores` = its thread count.
+network and branch at B=1 (rank 0, N=1 only): per thread placement (physical cores of one socket / all physical cores) one warm-up and one
+timed evaluation OF THE SAME BRANCH (a placement whose warm-up is already 1.5x slower is not timed again), then two more on the fastest placement; value = 1 / median of its three timings, `cores` = its thread count.
 """
 import argparse
 import json
@@ -77,8 +77,8 @@ def cpu_model() -> str:
 
 
 def cpu_thread_configs():
-    """Thread placements the CPU baseline tries: the physical cores of ONE socket, all physical cores, all logical CPUs (this process's affinity
-    mask intersected with /proc/cpuinfo's physical id / core id); duplicates dropped.  [(label, [cpu ids])]"""
+    """Thread placements the CPU baseline tries: the physical cores of ONE socket, then all physical cores (this process's affinity mask intersected
+    with /proc/cpuinfo's physical id / core id); duplicates dropped.  [(label, [cpu ids])]"""
     try:
         avail = sorted(os.sched_getaffinity(0))
     except AttributeError:
@@ -102,7 +102,9 @@ def cpu_thread_configs():
     one = sorted(min(v) for k, v in cores.items() if k[0] == sockets[0])
     phys = sorted(min(v) for v in cores.values())
     out, seen = [], set()
-    for label, cpus in (("physical cores of one socket", one), ("all physical cores", phys), ("all logical CPUs", avail)):
+    # (all logical CPUs = 2 SMT threads per core over both sockets is not offered when it oversubscribes the cores: measured once on the 2 x 64-core
+    #  EPYC 9575F box, 879 s per evaluation against 18 s on one socket -- profiles/r04_bench_guided_first.json)
+    for label, cpus in (("physical cores of one socket", one), ("all physical cores", phys)) + ((("all logical CPUs", avail),) if len(avail) == len(phys) else ()):
         if tuple(cpus) not in seen:
             seen.add(tuple(cpus))
             out.append((label, cpus))
@@ -158,7 +160,10 @@ def cpu_baseline(net, args, guided: bool, spectral: bool = False, n_timed: int =
     try:
         for label, cpus in cpu_thread_configs():
             place(cpus)
-            one_eval()                                   # warm-up of the same branch at this placement (autograd / oneDNN primitives) -- not counted
+            tw = one_eval()                              # warm-up of the same branch at this placement (autograd / oneDNN primitives) -- not counted ...
+            if sweep and tw > 1.5 * min(r[0] for r in sweep):
+                sweep.append((tw, label + " (warm-up evaluation only: already 1.5x slower)", cpus))      # ... unless it already rules the placement out
+                continue
             sweep.append((one_eval(), label, cpus))
         best = min(sweep, key=lambda r: r[0])
         place(best[2])

@@ -274,16 +274,41 @@ __global__ __launch_bounds__(256) void norm_bwd_wino_kernel(const NbDev a) {
 
 // F(8,3) form of the same pass (wform = 2): a thread owns one group of EIGHT samples (two float4 per operand), the neighbour samples 8g-1 and 8g+8
 // come from the adjacent lanes, and the group's ten transform values go to the planes of `wout` ([B, C, F, 10, T/8]).  lpr = threads per row = T/8.
+// Cooperative store of a block's Winograd-domain output staged in LDS as [row of the block][plane][lpr groups]: float4 pieces, each (row, plane)
+// run of lpr floats contiguous in memory at  view(b, c, f) + plane * G + tile * lpr.   rows are (b, c, f) flattened; lpr % 4 == 0.
+template <int NP>
+__device__ __forceinline__ void aid_store_planes(const float* sV, const aid_view& w, int C, int F, int G, int nrows, int row0, int tile, int lpr, int rpb, int tid) {
+    const int per_row = NP * lpr;
+    const int n4 = rpb * per_row / 4;
+    for (int i = tid; i < n4; i += 256) {
+        const int e = 4 * i;
+        const int rl = e / per_row, rem = e - rl * per_row;
+        const int xi = rem / lpr, gq = rem - xi * lpr;
+        const int row = row0 + rl;
+        if (row >= nrows || tile * lpr + gq >= G) continue;
+        const int f = row % F, bc = row / F;
+        const int c = bc % C, b = bc / C;
+        float* dst = w.p + (int64_t)b * w.sB + (int64_t)c * w.sC + (int64_t)f * w.sF + (int64_t)xi * G + tile * lpr + gq;
+        *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(sV + e);
+    }
+}
+
+// F(8,3) form of the pass (wform = 2).  Same thread <-> float4 mapping as norm_bwd_wino_kernel -- every load / store of gd, x, gy, out is one dense
+// 1 KB per wave instruction -- and a PAIR of lanes (2k, 2k+1) owns one group of eight samples: the lanes swap their four values, take the two
+// neighbour samples 8g-1 / 8g+8 from the lanes next to the pair, both evaluate the group's input transform (50 FMAs: cheaper than splitting it),
+// and the even lane stores planes 0..4, the odd lane planes 5..9 of `wout` ([B, C, F, 10, T/8]).  (A first version gave a thread eight samples:
+// its float4 accesses then stride 32 bytes across the wave, twice the cache lines per instruction -- 3.7-4.8 TB/s against 5.2-5.8 for this
+// mapping, profiles/r04_pointwise_wino8.txt; staging the planes through LDS for contiguous stores changed nothing.)
 __global__ __launch_bounds__(256) void norm_bwd_wino8_kernel(const NbDev a) {
     const aid_norm_bwd_params& p = a.p;
     const int tid = threadIdx.x;
-    const int lpr = 1 << a.lpr_log2;
+    const int lpr = 1 << a.lpr_log2;                       // threads per row (4 samples each), >= 2
     const int sub = tid >> a.lpr_log2, lq = tid & (lpr - 1);
     const int rpb = 256 >> a.lpr_log2;
     const int tile = blockIdx.x % a.tiles;
     const int row = (blockIdx.x / a.tiles) * rpb + sub;
-    const int o8 = (tile * lpr + lq) * 8;
-    const bool live = row < a.nrows && o8 < p.T;
+    const int o4 = (tile * lpr + lq) * 4;
+    const bool live = row < a.nrows && o4 < p.T;           // (all lanes stay for the shuffles)
     const int rw = live ? row : 0;
     const int f = rw % p.F;
     const int bc = rw / p.F;
@@ -295,46 +320,51 @@ __global__ __launch_bounds__(256) void norm_bwd_wino8_kernel(const NbDev a) {
     const float* gdr = p.gd.p + (int64_t)b * p.gd.sB + (int64_t)c * p.gd.sC + (int64_t)f * p.gd.sF;
     const float* xr = p.x.p + (int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)f * p.x.sF;
     const float* gyr = p.gy.p ? p.gy.p + (int64_t)b * p.gy.sB + (int64_t)c * p.gy.sC + (int64_t)f * p.gy.sF : nullptr;
-    float r[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = 0.f;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
-        float* orow = p.out.p + (int64_t)b * p.out.sB + (int64_t)c * p.out.sC + (int64_t)f * p.out.sF + o8;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float4 g = *reinterpret_cast<const float4*>(gdr + o8 + 4 * h);
-            const float4 x = *reinterpret_cast<const float4*>(xr + o8 + 4 * h);
-            float4 v = make_float4(g.x - coef * (x.x - mean), g.y - coef * (x.y - mean), g.z - coef * (x.z - mean), g.w - coef * (x.w - mean));
-            if (gyr) {
-                const float4 y = *reinterpret_cast<const float4*>(gyr + o8 + 4 * h);
-                v.x += p.a * y.x; v.y += p.a * y.y; v.z += p.a * y.z; v.w += p.a * y.w;
-            }
-            *reinterpret_cast<float4*>(orow + 4 * h) = v;
-            r[4 * h] = v.x; r[4 * h + 1] = v.y; r[4 * h + 2] = v.z; r[4 * h + 3] = v.w;
+        const float4 g = *reinterpret_cast<const float4*>(gdr + o4);
+        const float4 x = *reinterpret_cast<const float4*>(xr + o4);
+        r = make_float4(g.x - coef * (x.x - mean), g.y - coef * (x.y - mean), g.z - coef * (x.z - mean), g.w - coef * (x.w - mean));
+        if (gyr) {
+            const float4 y = *reinterpret_cast<const float4*>(gyr + o4);
+            r.x += p.a * y.x; r.y += p.a * y.y; r.z += p.a * y.z; r.w += p.a * y.w;
         }
+        *reinterpret_cast<float4*>(p.out.p + (int64_t)b * p.out.sB + (int64_t)c * p.out.sC + (int64_t)f * p.out.sF + o4) = r;
     }
     const int lane = tid & 63;
-    float e0 = __shfl_up(r[7], 1, 64), e9 = __shfl_down(r[0], 1, 64);
+    const bool odd = lane & 1;                             // (lq and lane have the same parity: lpr is even and rows start at even lanes)
+    const float4 q = make_float4(__shfl_xor(r.x, 1, 64), __shfl_xor(r.y, 1, 64), __shfl_xor(r.z, 1, 64), __shfl_xor(r.w, 1, 64));     // the partner's four samples
+    const float w1 = __shfl_up(r.w, 1, 64), w2 = __shfl_up(r.w, 2, 64);
+    const float x1 = __shfl_down(r.x, 1, 64), x2 = __shfl_down(r.x, 2, 64);
+    if (!live) return;
+    const int o8 = o4 & ~7;                                // first sample of this pair's group
+    float e0 = odd ? w2 : w1;                              // sample o8 - 1
+    float e9 = odd ? x1 : x2;                              // sample o8 + 8
     auto one = [&](int t) {
         float v = gdr[t] - coef * (xr[t] - mean);
         if (gyr) v += p.a * gyr[t];
         return v;
     };
-    if (live) {
-        if (o8 == 0) e0 = 0.f;                             // the conv's zero padding
-        else if (lane == 0 || lq == 0) e0 = one(o8 - 1);   // previous group lives in another wave / block / row
-        if (o8 + 8 >= p.T) e9 = 0.f;
-        else if (lane == 63 || lq == lpr - 1) e9 = one(o8 + 8);
-        const float sc = p.wscale ? p.wscale[(int64_t)b * p.wscale_ld + c] : 1.f;
-        float d[10], V[10];
-        d[0] = e0 * sc; d[9] = e9 * sc;
+    const int lane0 = lane & ~1, lq0 = lq & ~1;            // the pair's even lane
+    if (o8 == 0) e0 = 0.f;                                 // the conv's zero padding
+    else if (lane0 == 0 || lq0 == 0) e0 = one(o8 - 1);     // previous group lives in another wave / block
+    if (o8 + 8 >= p.T) e9 = 0.f;
+    else if (lane0 == 62 || lq0 == lpr - 2) e9 = one(o8 + 8);
+    const float sc = p.wscale ? p.wscale[(int64_t)b * p.wscale_ld + c] : 1.f;
+    float d[10], V[10];
+    const float4 lo = odd ? q : r, hi = odd ? r : q;       // samples o8 .. o8+3 | o8+4 .. o8+7
+    d[0] = e0 * sc; d[9] = e9 * sc;
+    d[1] = lo.x * sc; d[2] = lo.y * sc; d[3] = lo.z * sc; d[4] = lo.w * sc;
+    d[5] = hi.x * sc; d[6] = hi.y * sc; d[7] = hi.z * sc; d[8] = hi.w * sc;
+    aid_wino8_input(d, V);
+    const int G = p.T >> 3;
+    float* yr = p.wout.p + (int64_t)b * p.wout.sB + (int64_t)c * p.wout.sC + (int64_t)f * p.wout.sF + (o8 >> 3);
+    if (!odd) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) d[1 + i] = r[i] * sc;
-        aid_wino8_input(d, V);
-        const int G = p.T >> 3;
-        float* yr = p.wout.p + (int64_t)b * p.wout.sB + (int64_t)c * p.wout.sC + (int64_t)f * p.wout.sF + (o8 >> 3);
+        for (int xi = 0; xi < 5; ++xi) yr[(int64_t)xi * G] = V[xi];
+    } else {
 #pragma unroll
-        for (int xi = 0; xi < 10; ++xi) yr[(int64_t)xi * G] = V[xi];
+        for (int xi = 5; xi < 10; ++xi) yr[(int64_t)xi * G] = V[xi];
     }
 }
 
@@ -358,11 +388,8 @@ extern "C" int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream) {
         AID_REQUIRE((p->T % 16) == 0 && !p->accumulate, "aid_norm_bwd: wout needs T % 16 == 0 and accumulate = 0 (neighbour samples are recomputed)");
         AID_REQUIRE(p->wout.sF >= 10 * (p->T / 8) && (p->wout.sB % 4) == 0 && (p->wout.sC % 4) == 0 && (p->wout.sF % 4) == 0 && (((uintptr_t)p->wout.p) & 15) == 0,
                     "aid_norm_bwd: wout rows (wform = 2) are [10][T/8], 16-byte aligned");
-        int l8 = aid_pow2ceil(p->T / 8);
-        if (l8 > 256) l8 = 256;
-        a.lpr_log2 = aid_ilog2(l8);
-        a.tiles = aid_cdiv(p->T / 8, l8);
-        hipLaunchKernelGGL(norm_bwd_wino8_kernel, dim3((unsigned)(aid_cdiv(a.nrows, 256 / l8) * a.tiles)), dim3(256), 0, (hipStream_t)stream, a);
+        AID_REQUIRE((p->T % 8) == 0, "aid_norm_bwd: wform = 2 needs T % 8 == 0");
+        hipLaunchKernelGGL(norm_bwd_wino8_kernel, dim3((unsigned)(aid_cdiv(a.nrows, rpb) * a.tiles)), dim3(256), 0, (hipStream_t)stream, a);   // (thread <-> float4, as the F(4,3) form)
         AID_CHECK_LAUNCH();
         return AID_OK;
     }
@@ -462,44 +489,57 @@ __global__ __launch_bounds__(256) void scale_act_wino_kernel(const SaDev a) {
 // wino = 2: the F(8,3) input transform (aid_wino8.h), y rows [10][T/8].  One thread produces 2 consecutive groups (16 samples) of one row: 4 float4
 // loads + the two neighbours, 10 float2 stores (one per plane).
 __global__ __launch_bounds__(256) void scale_act_wino8_kernel(const SaDev a) {
+    __shared__ __attribute__((aligned(16))) float sV[256 * 20];
     const aid_scale_act_params& p = a.p;
     const int tid = threadIdx.x;
-    const int lpr = 1 << a.lpr_log2;                     // threads per row segment (16 samples each)
+    const int lpr = 1 << a.lpr_log2;                     // threads per row segment (16 samples = 2 groups each)
     const int sub = tid >> a.lpr_log2, lq = tid & (lpr - 1);
     const int rpb = 256 >> a.lpr_log2;
     const int tile = blockIdx.x % a.tiles;
     const int row = (blockIdx.x / a.tiles) * rpb + sub;
-    if (row >= a.nrows) return;
     const int o16 = (tile * lpr + lq) * 16;
-    if (o16 >= p.T) return;
-    const int f = row % p.F;
-    const int bc = row / p.F;
-    const int c = bc % p.C;
-    const int b = bc / p.C;
-    const float sc = p.scale ? p.scale[(int64_t)b * p.scale_ld + c] : 1.f;
-    const float* xr = p.x.p + (int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)f * p.x.sF;
-    float h[18];                                         // h[0] = sample o16-1 ... h[17] = sample o16+16
+    // T <= 64: a plane of a row is 16 / 32 bytes, and lane-by-lane stores would touch such pieces of eight rows per instruction: there the block's planes
+    // are staged through LDS and written as contiguous float4 runs (4.2 / 4.5 -> 4.8 TB/s); longer rows store directly (5.6-5.9 TB/s; staged: 4.7-4.9)
+    const bool staged = lpr >= 2 && lpr <= 4;
+    if (row < a.nrows && o16 < p.T) {
+        const int f = row % p.F;
+        const int bc = row / p.F;
+        const int c = bc % p.C;
+        const int b = bc / p.C;
+        const float sc = p.scale ? p.scale[(int64_t)b * p.scale_ld + c] : 1.f;
+        const float* xr = p.x.p + (int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)f * p.x.sF;
+        float h[18];                                     // h[0] = sample o16-1 ... h[17] = sample o16+16
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + o16 + 4 * q);
-        h[1 + 4 * q] = v.x; h[2 + 4 * q] = v.y; h[3 + 4 * q] = v.z; h[4 + 4 * q] = v.w;
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + o16 + 4 * q);
+            h[1 + 4 * q] = v.x; h[2 + 4 * q] = v.y; h[3 + 4 * q] = v.z; h[4 + 4 * q] = v.w;
+        }
+        h[0] = (o16 > 0) ? xr[o16 - 1] : 0.f;
+        h[17] = (o16 + 16 < p.T) ? xr[o16 + 16] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            float v = h[i] * sc;
+            if (p.act == 1) v = aid_gelu(v);
+            h[i] = v;                                    // (gelu(0) = 0: the zero padding stays zero)
+        }
+        float V0[10], V1[10];
+        aid_wino8_input(h, V0);
+        aid_wino8_input(h + 8, V1);
+        if (staged) {
+#pragma unroll
+            for (int xi = 0; xi < 10; ++xi)
+                *reinterpret_cast<float2*>(sV + (sub * 10 + xi) * (2 * lpr) + 2 * lq) = make_float2(V0[xi], V1[xi]);
+        } else {
+            const int G = p.T >> 3;
+            float* yr = p.y.p + (int64_t)b * p.y.sB + (int64_t)c * p.y.sC + (int64_t)f * p.y.sF + (o16 >> 3);
+#pragma unroll
+            for (int xi = 0; xi < 10; ++xi)
+                *reinterpret_cast<float2*>(yr + (int64_t)xi * G) = make_float2(V0[xi], V1[xi]);
+        }
     }
-    h[0] = (o16 > 0) ? xr[o16 - 1] : 0.f;
-    h[17] = (o16 + 16 < p.T) ? xr[o16 + 16] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 18; ++i) {
-        float v = h[i] * sc;
-        if (p.act == 1) v = aid_gelu(v);
-        h[i] = v;                                        // (gelu(0) = 0: the zero padding stays zero)
-    }
-    float V0[10], V1[10];
-    aid_wino8_input(h, V0);
-    aid_wino8_input(h + 8, V1);
-    const int G = p.T >> 3;
-    float* yr = p.y.p + (int64_t)b * p.y.sB + (int64_t)c * p.y.sC + (int64_t)f * p.y.sF + (o16 >> 3);
-#pragma unroll
-    for (int xi = 0; xi < 10; ++xi)
-        *reinterpret_cast<float2*>(yr + (int64_t)xi * G) = make_float2(V0[xi], V1[xi]);
+    if (!staged) return;
+    __syncthreads();
+    aid_store_planes<10>(sV, p.y, p.C, p.F, p.T >> 3, a.nrows, (int)(blockIdx.x / a.tiles) * rpb, tile, 2 * lpr, rpb, tid);
 }
 
 extern "C" int aid_scale_act(const aid_scale_act_params* p, void* stream) {
@@ -511,6 +551,8 @@ extern "C" int aid_scale_act(const aid_scale_act_params* p, void* stream) {
         AID_REQUIRE((p->T % 16) == 0, "aid_scale_act: the Winograd-domain output needs T % 16 == 0");
         AID_REQUIRE((p->y.sB % 2) == 0 && (p->y.sC % 2) == 0 && (p->y.sF % 2) == 0 && (((uintptr_t)p->y.p) & 7) == 0 && p->y.sF >= 10 * (p->T / 8),
                     "aid_scale_act: F(8,3) Winograd-domain output rows are [10][T/8], 8-byte aligned");
+        AID_REQUIRE(p->T < 32 || p->T > 64 || ((p->y.sB % 4) == 0 && (p->y.sC % 4) == 0 && (p->y.sF % 4) == 0 && (((uintptr_t)p->y.p) & 15) == 0 && (p->T % 32) == 0),
+                    "aid_scale_act: F(8,3) output with T = 32 / 64 needs 16-byte aligned rows (staged float4 stores)");
         int lpr = aid_pow2ceil(p->T / 16);
         if (lpr > 256) lpr = 256;
         a.lpr_log2 = aid_ilog2(lpr);

@@ -407,3 +407,28 @@ def test_edm_scalar_normalisation_of_the_fused_entry_points():
         U._norm_scalars(3, dev, (torch.zeros(2), 1.0, 1.0, 1.0))
     with pytest.raises(AidError):
         U._norm_scalars(3, dev, ("0.5", 1.0, 1.0, 1.0))
+
+
+def test_cpu_thread_placements_and_numa_binding_are_well_formed():
+    """bench.cpu_thread_configs (the placements the CPU baseline sweeps) and dist.bind_rank_to_gpu_numa (per-rank CPU shares): disjoint, non-empty
+    shares of the cores this process may use; without a GPU / sysfs entry the split is even."""
+    import bench
+    from audio_inpainting_diffusion_amd import dist as D
+    avail = sorted(os.sched_getaffinity(0))
+    cfgs = bench.cpu_thread_configs()
+    assert 1 <= len(cfgs) <= 3 and all(cpus and set(cpus) <= set(avail) for _, cpus in cfgs)
+    assert len({tuple(c) for _, c in cfgs}) == len(cfgs) and len(cfgs[0][1]) <= len(cfgs[-1][1])
+    assert D._cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    threads0 = torch.get_num_threads()
+    try:
+        shares = []
+        for r in range(2):
+            n = D.bind_rank_to_gpu_numa(r, 2)
+            shares.append(sorted(os.sched_getaffinity(0)))
+            os.sched_setaffinity(0, avail)
+            assert n == len(shares[-1]) >= 1
+        assert not (set(shares[0]) & set(shares[1])) or len(avail) == 1
+        assert set(shares[0]) | set(shares[1]) <= set(avail)
+    finally:
+        os.sched_setaffinity(0, avail)
+        torch.set_num_threads(threads0)

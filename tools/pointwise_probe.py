@@ -50,6 +50,11 @@ for (C, F, T) in [(64, 64, 2048), (96, 128, 1024), (96, 192, 512), (128, 256, 25
     pw.wout, pw.wscale, pw.wscale_ld = L.view4(xv), sc.data_ptr(), sc.stride(0)
     cases.append(("norm_bwd_wino", "aid_norm_bwd", pw, 22 * n))
     cases.append(("scale_act_wino", "aid_scale_act", L.ScaleActParams(L.view4(x), L.view4(xv), sc.data_ptr(), sc.stride(0), B, C, F, T, 1, 1), 10 * n))
+    xv8 = torch.empty(B, C, F, 10 * (T // 8), device="cuda")                      # F(8,3) forms (round 4): 1.25x instead of 1.5x Winograd-domain tensor
+    pw8 = L.NormBwdParams(L.view4(gd), L.view4(x), L.view4(gy), L.view4(out), B, C, F, T, 8, stats.data_ptr(), ws.data_ptr(), 1e-7, 0.7, 0, 0)
+    pw8.wout, pw8.wscale, pw8.wscale_ld, pw8.wform = L.view4(xv8), sc.data_ptr(), sc.stride(0), 2
+    cases.append(("norm_bwd_wino8", "aid_norm_bwd", pw8, 21 * n))
+    cases.append(("scale_act_wino8", "aid_scale_act", L.ScaleActParams(L.view4(x), L.view4(xv8), sc.data_ptr(), sc.stride(0), B, C, F, T, 1, 2), 9 * n))
     cases.append(("scale_act", "aid_scale_act", L.ScaleActParams(L.view4(x), L.view4(out), sc.data_ptr(), sc.stride(0), B, C, F, T, 1, 0), 8 * n))
     cases.append(("group_stats", "aid_group_stats", L.GroupStatsParams(L.view4(x), B, C, F, T, 8, gamma.data_ptr(), None, 0, 1e-7, scale.data_ptr(), stats.data_ptr(), ws.data_ptr(), 0), 4 * n))
     cases.append(("group_dot", "aid_group_dot", L.GroupDotParams(L.view4(gd), L.view4(x), B, C, F, T, 8, ws.data_ptr()), 8 * n))

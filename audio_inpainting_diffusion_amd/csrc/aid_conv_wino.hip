@@ -684,9 +684,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void conv53_wino4v_kernel(con
 // slot j + kh.  Requires F % dilF == 0 (rows of a residue class: F/dilF).
 // Large dilations leave few rows per residue class (F/dilF = 28, 14, 7 on the deepest level): there a tile takes RA rows of each of NC
 // ADJACENT residue classes (NC x RA x TT = 256 positions, NC (RA + 4) staged rows), so that RA divides the class without padding rows.
-#define AID_W4R_SPLIT_MAX_TILES 512
+#define AID_W4R_SPLIT_MAX_TILES 448
 #define AID_W4R_SPLIT_FLAG_BYTES AID_CONV2D_SPLIT_FLAG_BYTES
-static_assert(AID_W4R_SPLIT_MAX_TILES * 2 * 4 <= AID_CONV2D_SPLIT_FLAG_BYTES, "flag region");
+static_assert(AID_W4R_SPLIT_MAX_TILES * 2 * 4 <= AID_CONV2D_SPLIT_FLAG_BYTES - 4, "flag region (its last word is the sticky error word)");
 static inline int64_t aid_w4r_split_bytes(int64_t ntiles) { return AID_W4R_SPLIT_FLAG_BYTES + ntiles * (int64_t)(96 * 256 * 4); }
 
 struct W4rGeo {                // one tile family of a launch
@@ -969,9 +969,11 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
                 unsigned* fl = a.flags + seg.wid + k;
                 __syncthreads();
                 if (tid == 0) {
-                    int it = 0;                                                            // (bounded, ~1 s: see the split-K instances)
+                    unsigned* sticky = a.flags + (AID_W4R_SPLIT_FLAG_BYTES / 4 - 1);
+                    int it = 0;                                                            // (bounded, ~1 s; sticky error word: see the split-K instances)
                     for (; it < (1 << 22) && __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u; ++it) __builtin_amdgcn_s_sleep(4);
-                    sh[1] = it < (1 << 22);
+                    if (it >= (1 << 22)) __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sh[1] = it < (1 << 22) && __hip_atomic_load(sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
                 }
                 __syncthreads();
                 const float poison = sh[1] ? 0.f : __uint_as_float(0x7fc00000u);
@@ -1019,10 +1021,14 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
         }
         if (tid == 0) {
             // (bounded, ~0.2 s: the first workgroup is already past its K loop, this wait is microseconds; a bound keeps a logic error from hanging
-            //  the device -- and if it is ever hit the tile is written as NaN, not as half a sum)
+            //  the device -- and if it is ever hit the tile is written as NaN, not as half a sum.  A timeout also sets the STICKY word at the end of
+            //  the flag region: the late workgroup will still publish into flags that were reset under it, so every later split launch on this
+            //  scratch writes NaN too instead of trusting a stale flag; the scratch has to be re-zeroed by the caller)
+            unsigned* sticky = a.flags + (AID_W4R_SPLIT_FLAG_BYTES / 4 - 1);
             int it = 0;
             for (; it < (1 << 20) && __hip_atomic_load(fl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u; ++it) __builtin_amdgcn_s_sleep(4);
-            sh[1] = it < (1 << 20);
+            if (it >= (1 << 20)) __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh[1] = it < (1 << 20) && __hip_atomic_load(sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
         }
         __syncthreads();
         const float poison = sh[1] ? 0.f : __uint_as_float(0x7fc00000u);
@@ -1528,7 +1534,7 @@ static int wino8r_sk_workers() {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
         w = 2 * cus / 8 * 8;
-        if (w > AID_W4R_SPLIT_FLAG_BYTES / 4) w = AID_W4R_SPLIT_FLAG_BYTES / 4;
+        if (w > AID_W4R_SPLIT_FLAG_BYTES / 4 - 8) w = AID_W4R_SPLIT_FLAG_BYTES / 4 - 8;      // (flag words; the last one is the sticky error word)
     }
     return w;
 }

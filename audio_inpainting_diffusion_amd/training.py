@@ -144,7 +144,7 @@ class Trainer:
         self.net._packed_ver = None          # parameters changed behind torch's version counters: refresh the kernel-side packs
 
     def update_ema(self, batch: Optional[int] = None):
-        """trainer.py:288-304 (t = it * batch_size: the batch actually trained on, ``batch`` of the constructor when not given)"""
+        """trainer.py:288-304 (t = it * args.exp.batch: the constructor's ``batch``; ``batch=`` overrides it for one call)"""
         t = self.it * (self.batch if batch is None else int(batch))
         rate = float(min(max(t / self.ema_rampup, 0.0), self.ema_rate)) if t < self.ema_rampup else self.ema_rate
         _lib.call("aid_ema", _lib.EmaParams(self.ema.data_ptr(), self.flat.data_ptr(), self.flat.numel(), rate))
@@ -162,7 +162,9 @@ class Trainer:
             loss, _, _ = self.loss_and_grads(a, sg[r], nz[r], accumulate=r > 0)
         audio = rounds[0]
         self.optimizer_step(audio.shape[0])
-        self.update_ema(audio.shape[0])       # (training_loop: train_step, update_ema, then it += 1; trainer.py:366-368)
+        self.update_ema()                     # (training_loop: train_step, update_ema, then it += 1; trainer.py:366-368.  The EMA ramp counts
+                                              #  it * args.exp.batch like the reference -- the CONFIGURED batch, whatever this call was fed;
+                                              #  update_ema(batch=...) overrides it explicitly)
         self.it += 1
         return loss
 
@@ -222,14 +224,24 @@ class Trainer:
             self.m.zero_()
             self.v.zero_()
             params = list(self.net.named_parameters())
+            g = (opt.get("param_groups") or [{}])[0]
+            if "params" in g and len(g["params"]) != len(params):
+                raise _lib.AidError(f"checkpoint['optimizer'] covers {len(g['params'])} parameters, this network has {len(params)}: "
+                                    "it was written for a different network configuration")
             steps = 0
             for i, st in opt.get("state", {}).items():
+                if not 0 <= int(i) < len(params):
+                    raise _lib.AidError(f"checkpoint['optimizer'] has state for parameter #{i}; this network has {len(params)} parameters")
                 k = params[int(i)][0]
+                for nm in ("exp_avg", "exp_avg_sq"):
+                    if tuple(st[nm].shape) != tuple(m[k].shape):
+                        raise _lib.AidError(f"checkpoint['optimizer'] {nm} of parameter #{i} ({k}) has shape {tuple(st[nm].shape)}, expected {tuple(m[k].shape)}")
                 m[k].copy_(st["exp_avg"].to(m[k].device, torch.float32))
                 v[k].copy_(st["exp_avg_sq"].to(v[k].device, torch.float32))
                 steps = max(steps, int(round(float(st["step"]))))
             self.steps = steps
-            g = (opt.get("param_groups") or [{}])[0]
+            # (the group's 'lr' is the RAMPED value of the last iteration -- trainer.py:270-274 overwrite it every step from args.exp.lr -- so the
+            #  base learning rate stays the constructor's, as it stays args.exp.lr in the reference)
             if "betas" in g:
                 self.beta1, self.beta2 = float(g["betas"][0]), float(g["betas"][1])
             self.eps = float(g.get("eps", self.eps))

@@ -117,7 +117,9 @@ typedef struct {
                                  applies the epilogue.  NULL / too small: single-pass kernel.
                                  5x3 layers on the row-shared F(4,3) kernel at B = 1 (aid_conv2d_wino_split_ws_bytes(...) > 0): the K axis of
                                  every tile is shared by two workgroups; ws then holds [AID_CONV2D_SPLIT_FLAG_BYTES of flags][partial accumulators], and its
-                                 first AID_CONV2D_SPLIT_FLAG_BYTES bytes must be ZERO before the first use (the kernel leaves them zero);
+                                 first AID_CONV2D_SPLIT_FLAG_BYTES bytes must be ZERO before the first use (the kernel leaves them zero; the LAST word of that region is a sticky
+                                 error word: a workgroup whose bounded wait for its partner ever times out sets it, and from then on every split launch on this
+                                 scratch writes NaN tiles instead of trusting flags that may be stale -- re-zero the scratch to recover);
                                  one ws per stream.  NULL / too small: no split. */
     double* dot_ws; int dot_n;   /* optional (input-VJP, epi = 1 on the F(4,3) path or on a 1x1 layer, see aid_conv2d_dot_partials_1x1): the epilogue also reduces <y, aux> per
                                  (sample, channel group of Cout/8) over its tile and writes one partial per tile,

@@ -1,11 +1,16 @@
-// The 5x3 dilated dense convolution with Winograd F(4,3) along T on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+// The 5x3 dilated dense convolution in Winograd form along T on exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
 //
 // Once a direct-form kernel (aid_conv_dma.hip) keeps the fp32 matrix pipe busy at the sustained clock, the only way to
-// go faster in exact-fp32 arithmetic is to issue FEWER MFMAs: F(4,3) computes four neighbouring outputs of the 3-tap
-// (kw) correlation from 6 products instead of 12.  GEMM view per transform index xi: M = Cout, N = groups of 4 output
-// samples, K = (ci, kh); weights are pre-packed on the host as 30 "taps" xi*5+kh (pack_conv_weight_wino).
-//   conv53_wino4_kernel : input transform applied when the B fragment is formed (plain activations in LDS)
-//   conv53_wino4v_kernel: Winograd-domain input written by the producer pass (aid_scale_act wino=1), triple-buffered
+// go faster in exact-fp32 arithmetic is to issue FEWER MFMAs.  F(4,3) computes four neighbouring outputs of the 3-tap
+// (kw) correlation from 6 products instead of 12; F(8,3) (round 4, points {0, +-0.4, +-0.8, +-1.25, +-2.5, inf}: aid_wino8.h)
+// eight outputs from 10 instead of 24.  GEMM view per transform index xi: M = Cout, N = groups of 4 / 8 output samples,
+// K = (ci, kh); weights are pre-packed as 30 / 50 "taps" xi*5+kh (aid_pack_conv_weight).
+//   conv53_wino4_kernel  : F(4,3), input transform applied when the B fragment is formed (plain activations in LDS)
+//   conv53_wino4v_kernel : F(4,3), Winograd-domain input written by the producer pass (aid_scale_act wino=1), 64|96 x 512 tiles (fallback geometries)
+//   conv53_wino4r_kernel : F(4,3), Winograd-domain input, ROW-SHARED staging on dilation sub-lattices, 2-3 workgroups per CU (+ pair and split-K instances)
+//   conv53_wino8r_kernel : F(8,3) on the same row-shared body (wino4r_tile_body<..., WM = 8>): 64 x 512 tiles, 160 accumulators per lane -- the dominant kernel
+//   conv53_wino8r_sk_kernel : its stream-K instance (persistent grid; off by default)
+// Which form takes a launch: wino_form_choice() / aid_conv2d_wino_form().
 #include "aid_common.h"
 #include "aid_wino8.h"
 #include <type_traits>

@@ -13,7 +13,13 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("AID_LIB_PATH") or os.path.join(_HERE, "libaid_hip.so")      # override: kernel experiments only
+# (AID_LIB_PATH selects another build of the library for kernel A/B experiments -- honoured only together with AID_EXPERIMENT=1, and announced on
+#  stderr, so that a stray variable can never silently change what a run measures)
+LIB_PATH = os.path.join(_HERE, "libaid_hip.so")
+if os.environ.get("AID_EXPERIMENT") == "1" and os.environ.get("AID_LIB_PATH"):
+    LIB_PATH = os.environ["AID_LIB_PATH"]
+    import sys as _sys
+    print(f"[aid] AID_EXPERIMENT=1: loading {LIB_PATH} instead of the in-tree libaid_hip.so", file=_sys.stderr)
 AID_CQT_MAX_OCT = 12
 AID_STATS_SPLIT = 32
 AID_ATTN_MAX_T = 128          # aid_time_attention: one workgroup holds a whole [T, T] score tile

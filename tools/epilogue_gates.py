@@ -70,7 +70,7 @@ def run(gates=(0, 1, 2, 3)):
         for g in gates:
             env = dict(os.environ, PROBE_WINO="30", PROBE_V="1")
             if g:
-                env["AID_LIB_PATH"] = os.path.join(EXP, f"libaid_gate{g}.so")
+                env["AID_EXPERIMENT"], env["AID_LIB_PATH"] = "1", os.path.join(EXP, f"libaid_gate{g}.so")
             out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "conv_probe.py")] + shape.split() + ["20", "-1"], env=env,
                                  capture_output=True, text=True)
             print(f"gate {g}:", (out.stdout.strip().splitlines() or [out.stderr[-300:]])[-1], flush=True)
@@ -91,7 +91,7 @@ def runr():
         for name, libp in (("product ", None), ("wino4r  ", os.path.join(EXP, "libaid_wino4r.so"))):
             env = dict(os.environ, PROBE_WINO="30", PROBE_V="1")
             if libp:
-                env["AID_LIB_PATH"] = libp
+                env["AID_EXPERIMENT"], env["AID_LIB_PATH"] = "1", libp
             out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "conv_probe.py")] + shape.split() + ["20", "-1"], env=env, capture_output=True, text=True)
             print(name, (out.stdout.strip().splitlines() or [out.stderr[-300:]])[-1], flush=True)
 

@@ -432,3 +432,52 @@ def test_cpu_thread_placements_and_numa_binding_are_well_formed():
     finally:
         os.sched_setaffinity(0, avail)
         torch.set_num_threads(threads0)
+
+
+def test_f83_matrices_header_and_python_twin_agree():
+    """csrc/aid_wino8.h (generated by tools/gen_wino8.py, compiled into the kernels) and _lib.wino8_matrices() (weight packs, tests) describe the same
+    F(8,3): y = A^T [(G w) * (B^T d)] reproduces the 3-tap correlation of 10 samples exactly in fp64, the header's fp32 constants are the rounded
+    matrices, and the +-a rows have the even / odd structure the kernels' transforms rely on."""
+    from audio_inpainting_diffusion_amd import _lib
+    AT, G, BT = _lib.wino8_matrices()
+    rng = np.random.default_rng(3)
+    for _ in range(4):
+        d, w = rng.standard_normal(10), rng.standard_normal(3)
+        y = AT @ ((G @ w) * (BT @ d))
+        ref = np.array([sum(w[k] * d[o + k] for k in range(3)) for o in range(8)])
+        assert np.abs(y - ref).max() < 1e-10
+    sg = np.array([(-1.0) ** k for k in range(10)])
+    for j in range(4):
+        assert np.abs(BT[2 + 2 * j] - sg * BT[1 + 2 * j]).max() < 1e-12 and BT[1 + 2 * j][0] == 0 and BT[1 + 2 * j][9] == 0
+    hdr = open(os.path.join(ROOT, "audio_inpainting_diffusion_amd", "csrc", "aid_wino8.h")).read()
+
+    def macro(name):
+        body = re.search(r"#define %s (\{.*\})" % name, hdr).group(1)
+        return np.array(ast.literal_eval(body.replace("{", "[").replace("}", "]").replace("f,", ",").replace("f]", "]")), dtype=np.float64)
+    assert np.abs(macro("AID_W8_G") - G).max() < 1e-12
+    assert np.abs(macro("AID_W8_BT0") - BT[0][0::2]).max() < 1e-7
+    assert np.abs(macro("AID_W8_BTE") - np.stack([BT[1 + 2 * j][2::2] for j in range(4)])).max() < 1e-7
+    assert np.abs(macro("AID_W8_BTO") - np.stack([BT[1 + 2 * j][1:9:2] for j in range(4)])).max() < 1e-7
+    at = macro("AID_W8_AT")
+    assert np.abs(at - np.stack([AT[:, 1 + 2 * j] for j in range(4)])).max() < 1e-4 * np.abs(at).max() and at.shape == (4, 8)
+
+
+def test_winograd_form_choice_is_a_function_of_the_launch_shape():
+    """aid_conv2d_wino_form / aid_conv2d_wino8_supported (pure host functions of the library): a batch of one keeps F(4,3) on every level of the shipped
+    22.05 kHz network, sub-batches of four take F(8,3) wherever its 512-position tiles quantise, six rows per residue class have no F(8,3) tile, and
+    the answer never depends on anything but the launch shape."""
+    from audio_inpainting_diffusion_amd import _lib
+    L = _lib.lib()
+    levels = [(64, 64, 2048, 2), (96, 128, 1024, 3), (96, 192, 512, 4), (128, 256, 256, 5), (128, 320, 128, 6), (256, 384, 64, 7), (256, 448, 32, 7)]
+    for C, F, T, nd in levels:
+        for k in range(nd):
+            assert L.aid_conv2d_wino_form(1, C, C, F, T, 1 << k) == 4
+            f4 = L.aid_conv2d_wino_form(4, C, C, F, T, 1 << k)
+            assert f4 in (4, 8) and f4 == L.aid_conv2d_wino_form(4, C, C, F, T, 1 << k)
+            if f4 == 8:
+                assert L.aid_conv2d_wino8_supported(C, C, F, T, 1 << k)
+    assert L.aid_conv2d_wino_form(4, 256, 256, 384, 64, 1) == 8 and L.aid_conv2d_wino_form(4, 256, 256, 448, 32, 4) == 8 and L.aid_conv2d_wino_form(4, 64, 64, 64, 2048, 2) == 8
+    assert L.aid_conv2d_wino_form(4, 128, 128, 320, 128, 1) == 4                      # 640 tiles of 512 positions = 2.5 per CU: F(4,3) quantises no worse
+    assert not L.aid_conv2d_wino8_supported(256, 256, 384, 64, 64) and L.aid_conv2d_wino_form(8, 256, 256, 384, 64, 64) == 4     # 6 rows per class
+    assert not L.aid_conv2d_wino8_supported(256, 256, 64, 16, 1) and L.aid_conv2d_wino_form(8, 256, 256, 64, 16, 1) == 4         # T = 16: F(4,3) tiles only
+    assert L.aid_conv2d_wino_form(8, 2, 64, 64, 1024, 1) == 0 and L.aid_conv2d_wino_form(8, 64, 2, 64, 1024, 1) == 0              # few-channel layers: no Winograd input

@@ -10,6 +10,7 @@
 //   conv53_wino4r_kernel : F(4,3), Winograd-domain input, ROW-SHARED staging on dilation sub-lattices, 2-3 workgroups per CU (+ pair and split-K instances)
 //   conv53_wino8r_kernel : F(8,3) on the same row-shared body (wino4r_tile_body<..., WM = 8>): 64 x 512 tiles, 160 accumulators per lane -- the dominant kernel
 //   conv53_wino8r_sk_kernel : its stream-K instance (persistent grid; off by default)
+//   conv53_wino8r_ks_kernel : its K-group instance for launches of at most one tile per CU (small batches): eight waves on one tile, two K groups, sum through LDS
 // Which form takes a launch: wino_form_choice() / aid_conv2d_wino_form().
 #include "aid_common.h"
 #include "aid_wino8.h"
@@ -729,10 +730,12 @@ struct W4rSeg { int c0, c1, wid, per; };   // stream-K: one workgroup's share [c
 // conflict-free layout change the kernel time by less than 0.5 % in either direction: it is bound by the matrix pipe (84 % busy at K = 256)
 // and by the prologue / epilogue of a tile, not by LDS or staging any more.  The interleave stays (no conflicts, no cost); raw-tap staging does not.
 // WM: outputs per Winograd group -- 4: F(4,3), 6 products per group; 8: F(8,3), 10 products per group (aid_wino8.h), tiles of twice the positions
-template <int TT, int NC, int WGM, int NB, int WPC, int NWV, int WM = 4>
+// KS: K groups per workgroup -- 2: the NWV waves form two groups of NWV / 2, every staged chunk holds 2 x KC input channels and group k multiplies
+// channels [k KC, (k + 1) KC) of it; the groups add their accumulators through LDS after the K loop (conv53_wino8r_ks_kernel)
+template <int TT, int NC, int WGM, int NB, int WPC, int NWV, int WM = 4, int KS = 1>
 struct W4rShape {
-    static constexpr int KH = 5, NXI = WM + 2, TAPS = NXI * KH, KC = 2;
-    static constexpr int NW = NWV, WGN = NW / WGM;
+    static constexpr int KH = 5, NXI = WM + 2, TAPS = NXI * KH, KC = 2, KCS = KC * KS;
+    static constexpr int NW = NWV, NWQ = NW / KS, WGN = NWQ / WGM;
     static constexpr int M_BLK = 32 * WGM, N_BLK = 32 * WM * WGN;
     static constexpr int GPR = TT / WM;                        // groups of WM outputs per row
     static constexpr int RA = N_BLK / (TT * NC);               // output rows per residue class and tile
@@ -745,9 +748,9 @@ struct W4rShape {
     static constexpr int CSLOT = (CSLOT_USED + IL - 1) / IL * IL;
     static constexpr int NSLOT = NC * CSLOT;
     static constexpr int XCI = NSLOT * NXI * GPR;              // floats per input channel in the x region
-    static constexpr int XSZ = ((KC * XCI + 255) / 256) * 256;
+    static constexpr int XSZ = ((KCS * XCI + 255) / 256) * 256;
     static constexpr int WROW = M_BLK;
-    static constexpr int WSZ_RAW = TAPS * KC * WROW;           // 64 channels: 3840 floats = 15 pieces; 32: 1920 -> 8 pieces (the last half used)
+    static constexpr int WSZ_RAW = TAPS * KCS * WROW;          // 64 channels: 3840 floats = 15 pieces; 32: 1920 -> 8 pieces (the last half used)
     static constexpr int WSZ = ((WSZ_RAW + 255) / 256) * 256;
     static constexpr int BUFSZ = XSZ + WSZ;
     static constexpr int NBUF = (NB == 3 && 3 * BUFSZ * 4 * WPC <= 160 * 1024) ? 3 : 2;  // three buffers only while WPC workgroups still fit a CU
@@ -758,17 +761,20 @@ struct W4rShape {
 // `bid`: workgroup index within this tile family's part of the grid.
 // SK (stream-K instances): `bid` is the LOGICAL tile index and `seg` this workgroup's share of the tile's K chunks; the tile is finished by the
 // workgroup that holds its first chunks (see conv53_wino8r_sk_kernel).
-template <int TT, int NC, int WGM, int NB, int WPC, int NWV, bool SPK, int WM = 4, bool SK = false>
+template <int TT, int NC, int WGM, int NB, int WPC, int NWV, bool SPK, int WM = 4, bool SK = false, int KS = 1>
 __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4rGeo& ge, float* smem, const int bid, const W4rSeg seg = W4rSeg{}) {
-    using S = W4rShape<TT, NC, WGM, NB, WPC, NWV, WM>;
-    constexpr int KH = S::KH, NXI = S::NXI, KC = S::KC;
-    constexpr int NW = S::NW, WGN = S::WGN;
+    using S = W4rShape<TT, NC, WGM, NB, WPC, NWV, WM, KS>;
+    constexpr int KH = S::KH, NXI = S::NXI, KC = S::KC, KCS = S::KCS;
+    constexpr int NW = S::NW, NWQ = S::NWQ, WGN = S::WGN;
+    static_assert(KS == 1 || (KS == 2 && WM == 8 && !SPK && !SK), "K groups: the F(8,3) instances only");
     constexpr int M_BLK = S::M_BLK;
     constexpr int GPR = S::GPR, RA = S::RA, CSLOT = S::CSLOT, CSLOT_USED = S::CSLOT_USED, IL = S::IL, XCI = S::XCI, XSZ = S::XSZ, WROW = S::WROW;
     constexpr int WSZ_RAW = S::WSZ_RAW, WSZ = S::WSZ, BUFSZ = S::BUFSZ, NBUF = S::NBUF;
     constexpr int NXP = XSZ / 256, NWP = WSZ / 256, NP = NXP + NWP;
     constexpr int PPW = (NP + NW - 1) / NW;
     constexpr int NSTEP = KH;
+    constexpr int ISTEPS = KS == 2 ? 3 : NSTEP;          // steps of a chunk the next chunk's loads are issued in (K groups: one resident workgroup, nothing
+                                                         //  else covers a load that is still in flight at the end of the chunk -- issue them early)
     static_assert(RA >= 1 && RA * NC * TT == S::N_BLK, "tile shape");
     static_assert(WROW % 4 == 0 && GPR % 4 == 0 && NP > (PPW - 1) * NW, "piece bookkeeping");
 
@@ -783,7 +789,9 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
     const int tid = tid_;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
+    const int ks = KS == 2 ? wave / NWQ : 0;             // K group of this wave
+    const int wq = KS == 2 ? wave % NWQ : wave;
+    const int wm = wq / WGN, wn = wq % WGN;
     const int half = lane >> 5;
 
     // XCD-aware logical tile (see conv53_wino4v_kernel); order: Cout tile fastest, then t tile, quad, residue-class group, sample
@@ -828,7 +836,7 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
             const int slot = (e / (IL * NXI * GPR)) * IL + (e / GPR) % IL;     // [slot / IL][xi][slot % IL][GPR]
             const int cls = slot / CSLOT;
             const int jr = j0 + (slot % CSLOT) - (KH / 2);   // sub-lattice row index of this slot
-            if (ci < KC && (slot % CSLOT) < CSLOT_USED && jr >= 0 && jr < nrow && t0 + WM * gl < p.T) {
+            if (ci < KCS && (slot % CSLOT) < CSLOT_USED && jr >= 0 && jr < nrow && t0 + WM * gl < p.T) {
                 const int fi = res + cls + jr * p.dilF;
                 poff[i] = (unsigned)(4 * ((int64_t)ci * p.x.sC + (int64_t)fi * p.x.sF + (int64_t)xi * (p.T / WM) + (t0 / WM) + gl));   // (within sample b: < 2^32, see conv53_wino_v)
                 ok = true;
@@ -836,7 +844,7 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
         } else if (pc < NP) {
             const int e = (pc - NXP) * 256 + 4 * lane;
             const int row = e / WROW, col = e % WROW;
-            const int tap = row / KC, ci = row % KC;
+            const int tap = row / KCS, ci = row % KCS;
             plds[i] = XSZ + (pc - NXP) * 256;
             if (e < WSZ_RAW) {
                 poff[i] = (unsigned)(4 * (((int64_t)tap * p.Cin_pad + ci) * p.Cout_pad + m0 + col));
@@ -847,7 +855,7 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
         if (__ballot(ok) != 0ull) pany |= 1u << i;
     }
     const int cbase = SK ? seg.c0 : ((SPK && sp) ? a.nchunks : 0);        // first chunk of this workgroup's share of the K axis
-    const int64_t xstep = (int64_t)KC * p.x.sC * 4, wstep = (int64_t)KC * p.Cout_pad * 4;   // bytes per chunk (wave-uniform)
+    const int64_t xstep = (int64_t)KCS * p.x.sC * 4, wstep = (int64_t)KCS * p.Cout_pad * 4;   // bytes per chunk (wave-uniform)
     const char* const xbase = reinterpret_cast<const char*>(p.x.p + (int64_t)b * p.x.sB) + cbase * xstep;
     const char* const wbase = reinterpret_cast<const char*>(p.wp_wino) + cbase * wstep;
     // ---- operand addresses: lane's group g of this wave's 32 -> output row j = g / GPR, group tau = g % GPR -------------------------
@@ -858,8 +866,8 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
     auto xoff = [&](int slot, int xi) { return ((slot / IL) * NXI + xi) * (IL * GPR) + (slot % IL) * GPR; };
     int vBk[KH];                                         // per kh: offset of plane xi = 0 (planes are IL * GPR floats apart)
 #pragma unroll
-    for (int kh = 0; kh < KH; ++kh) vBk[kh] = half * XCI + xoff(sl0 + kh, 0) + tau;
-    const int vA = XSZ + half * WROW + wm * 32 + (lane & 31);
+    for (int kh = 0; kh < KH; ++kh) vBk[kh] = (ks * KC + half) * XCI + xoff(sl0 + kh, 0) + tau;
+    const int vA = XSZ + (ks * KC + half) * WROW + wm * 32 + (lane & 31);
 
     f32x16 acc[NXI];
 #pragma unroll
@@ -890,7 +898,7 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
     auto issue_all = [&](int ch, float* buf) { aid_static_for<PPW>([&](auto ic) { issue_piece(ic, ch, buf); }); };
     auto issue_step = [&](auto sc, int ch, float* buf) {
         aid_static_for<PPW>([&](auto ic) {
-            if constexpr (decltype(ic)::value % NSTEP == decltype(sc)::value) issue_piece(ic, ch, buf);
+            if constexpr (decltype(sc)::value < ISTEPS && decltype(ic)::value % ISTEPS == decltype(sc)::value) issue_piece(ic, ch, buf);
         });
     };
 
@@ -911,7 +919,7 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
 #pragma unroll
             for (int x = 0; x < NXI; ++x) bv[buf][x] = Bf[vBk[kh] + x * (IL * GPR)];
 #pragma unroll
-            for (int x = 0; x < NXI; ++x) av[buf][x] = Bf[vA + ((x * KH + kh) * KC) * WROW];
+            for (int x = 0; x < NXI; ++x) av[buf][x] = Bf[vA + ((x * KH + kh) * KCS) * WROW];
         };
         load_step(0, 0);
         aid_static_for<NSTEP>([&](auto sc) {
@@ -1051,6 +1059,43 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
         __syncthreads();                                  // sh[0] lives in the buffer the partial-sum reduction below reuses
     }
 
+    // ---- K groups: the two groups hold partial sums of the SAME 64 x 512 tile.  Group 0 keeps accumulator rows 0..7 of every plane and takes the partner
+    // lane's (same wave of the other group, same lane) rows 0..7, group 1 the same with rows 8..15 -- through LDS, five planes (80 KB) at a time -- so
+    // each group then runs the epilogue of half the tile's output channels.  a + b is commutative: both orders give the same bits.
+    if constexpr (KS == 2) {
+        constexpr int GT = 64 * NWQ, HP = NXI / 2;
+        static_assert(NXI % 2 == 0 && 2 * HP * 8 * GT <= S::LDS, "exchange region");
+        float* const xo = smem + (ks == 0 ? 0 : HP * 8 * GT) + (tid & (GT - 1));        // written by this group
+        const float* const xi_ = smem + (ks == 0 ? HP * 8 * GT : 0) + (tid & (GT - 1)); // written by the other one
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            if (ks == 0) {
+#pragma unroll
+                for (int x = 0; x < HP; ++x)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) xo[(x * 8 + r) * GT] = acc[h2 * HP + x][8 + r];
+            } else {
+#pragma unroll
+                for (int x = 0; x < HP; ++x)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) xo[(x * 8 + r) * GT] = acc[h2 * HP + x][r];
+            }
+            __syncthreads();
+            if (ks == 0) {
+#pragma unroll
+                for (int x = 0; x < HP; ++x)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) acc[h2 * HP + x][r] += xi_[(x * 8 + r) * GT];
+            } else {                                       // (kept rows move down to 0..7: the epilogue below indexes registers statically)
+#pragma unroll
+                for (int x = 0; x < HP; ++x)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) acc[h2 * HP + x][r] = acc[h2 * HP + x][8 + r] + xi_[(x * 8 + r) * GT];
+            }
+            __syncthreads();
+        }
+    }
+
     // ---- epilogue (as conv53_wino4v_kernel; this lane's output row: sub-lattice row j0 + jl) -----------------------------------------
     // What the epilogue costs a launch (round 3, profiles/r03_w4r_epilogue_probe.txt, builds with an early return / without the dGELU
     // arithmetic): 2-11 % for the plain epilogue, 8-20 % for the dGELU one (3-7 % of it libm erff + expf) -- on ISOLATED launches.  Tried on
@@ -1072,13 +1117,13 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
         const int64_t rbase = p.res.p ? ((int64_t)b * p.res.sB + (int64_t)f_o * p.res.sF + t_o) : 0;
         const int64_t abase = p.aux.p ? ((int64_t)b * p.aux.sB + (int64_t)f_o * p.aux.sF + t_o) : 0;
 #pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += 2) {
+        for (int r0 = 0; r0 < 16 / KS; r0 += 2) {          // (K groups: rows 0..7 of group k are accumulator rows 8 k .. 8 k + 7 of the tile)
             float rv[2][8], ur[2][8];
             float sv[2], as[2];
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
                 const int r = r0 + qq;
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                const int m = mbase + (r & 3) + 8 * ((r >> 2) + (KS == 2 ? 2 * ks : 0));
                 const bool ok = m < p.Cout;
 #pragma unroll
                 for (int h4 = 0; h4 < 2; ++h4) {
@@ -1097,7 +1142,7 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
                 const int r = r0 + qq;
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                const int m = mbase + (r & 3) + 8 * ((r >> 2) + (KS == 2 ? 2 * ks : 0));
                 if (m >= p.Cout) continue;
                 float Mv[NXI], y[8];
 #pragma unroll
@@ -1173,19 +1218,24 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
         }
         float* red = sbuf0;
         if ((lane & 31) == 0) {
+            if constexpr (KS == 2) {                         // group k holds row blocks 2 k, 2 k + 1 (in its slots 0, 1)
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) { red[(wave * 2 + half) * 4 + qq] = dsum[qq]; red[NW * 8 + (wave * 2 + half) * 4 + qq] = qsum[qq]; }
+                for (int qq = 0; qq < 2; ++qq) { red[(wq * 2 + half) * 4 + 2 * ks + qq] = dsum[qq]; red[NWQ * 8 + (wq * 2 + half) * 4 + 2 * ks + qq] = qsum[qq]; }
+            } else {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) { red[(wave * 2 + half) * 4 + qq] = dsum[qq]; red[NW * 8 + (wave * 2 + half) * 4 + qq] = qsum[qq]; }
+            }
         }
         __syncthreads();
         const int cpg = p.Cout >> 3;
         const int grp = a.dot_all ? tid : m0 / cpg + tid;    // dot_all: zeros for the groups this Cout tile does not touch
         if (tid < (a.dot_all ? 8 : M_BLK / cpg) && grp < 8) {
             float sacc = 0.f, qacc = 0.f;
-            for (int w = 0; w < NW; ++w)
+            for (int w = 0; w < NWQ; ++w)
                 for (int h = 0; h < 2; ++h)
                     for (int qq = 0; qq < 4; ++qq) {
                         const int mrow = m0 + (w / WGN) * 32 + 4 * h + 8 * qq;
-                        if (mrow < p.Cout && mrow / cpg == grp) { sacc += red[(w * 2 + h) * 4 + qq]; qacc += red[NW * 8 + (w * 2 + h) * 4 + qq]; }
+                        if (mrow < p.Cout && mrow / cpg == grp) { sacc += red[(w * 2 + h) * 4 + qq]; qacc += red[NWQ * 8 + (w * 2 + h) * 4 + qq]; }
                     }
             const int ptile = ge.dot_base + (rg * ge.quads + q) * ge.ttiles + tile_t;
             if (st) {
@@ -1236,6 +1286,26 @@ __global__ __launch_bounds__(256, 2) void conv53_wino8r_kernel(const ConvWinoRDe
         const int n0 = 8 * a.g[0].per_xcd;
         if ((int)blockIdx.x < n0) wino4r_tile_body<TT, NC, WGM, 2, 2, 4, false, 8>(a, a.g[0], smem, (int)blockIdx.x);
         else wino4r_tile_body<TT, NC1, 1, 2, 2, 4, false, 8>(a, a.g[1], smem, (int)blockIdx.x - n0);
+    }
+}
+
+// K-group instance of the F(8,3) kernel: ONE eight-wave workgroup per CU, the same 64 x 512 (32 x 1024) tile, waves 0-3 on the even and waves 4-7 on the
+// odd pairs of input channels (four channels per staged chunk, 66-72 KB per buffer, two buffers).  The F(8,3) tile has 160 accumulators per lane, so a
+// 64 x 512 tile is ONE wave per SIMD; a launch with no more tiles than CUs (batch 1: 256 on the upper levels, 192 / 224 on the deepest) then runs with the
+// matrix pipe waiting on every LDS read and barrier.  Two waves per SIMD on the SAME tile need no second tile; the exchange at the end is 160 KB of
+// LDS traffic per tile (about 1 us).
+template <int TT, int NC, int WGM, int NC1 = 0>
+__global__ __launch_bounds__(512, 2) void conv53_wino8r_ks_kernel(const ConvWinoRDev a) {
+    using S0 = W4rShape<TT, NC, WGM, 2, 1, 8, 8, 2>;
+    if constexpr (NC1 == 0) {
+        __shared__ __attribute__((aligned(16))) float smem[S0::LDS];
+        wino4r_tile_body<TT, NC, WGM, 2, 1, 8, false, 8, false, 2>(a, a.g[0], smem, (int)blockIdx.x);
+    } else {
+        using S1 = W4rShape<TT, NC1, 1, 2, 1, 8, 8, 2>;
+        __shared__ __attribute__((aligned(16))) float smem[S0::LDS > S1::LDS ? S0::LDS : S1::LDS];
+        const int n0 = 8 * a.g[0].per_xcd;
+        if ((int)blockIdx.x < n0) wino4r_tile_body<TT, NC, WGM, 2, 1, 8, false, 8, false, 2>(a, a.g[0], smem, (int)blockIdx.x);
+        else wino4r_tile_body<TT, NC1, 1, 2, 1, 8, false, 8, false, 2>(a, a.g[1], smem, (int)blockIdx.x - n0);
     }
 }
 
@@ -1512,7 +1582,7 @@ static int wino8r_geometry(const aid_conv2d_params* p, Wino4rPlan plan[2]) {
 // F(8,3) issues 10 MFMAs per 8 outputs against 12, but its tiles hold twice the positions, so a launch has half as many of them.  The two
 // resident workgroups of a CU share one matrix pipe: the busiest CU works through ceil(tiles / CUs) tiles, and a CU that only ever holds one tile
 // runs it at about 5/6 of the rate two would reach.  cost = ceil(tiles / 256) x [MFMAs per tile: 5 vs 3, padding rows included in `tiles`]
-// (x 1.2 for a single tile per CU); the cheaper form takes the launch, ties go to F(4,3) (its smaller tiles leave the shorter tail).  Against the
+// (x 1.2 for a single tile per CU -- x 1.03 for F(8,3), whose K-group instances put eight waves on that tile); the cheaper form takes the launch, ties go to F(4,3) (its smaller tiles leave the shorter tail).  Against the
 // per-layer A/B of both kernels at batch 1, 2, 3, 4 and 8 (profiles/r04_streamk_probe.txt) this picks the faster kernel on all but a handful of
 // shapes, where it is within 5 %.  A function of the launch shape, B included: equal launches (the same sub-batch size) take equal kernels.
 static int wino_form_choice(const aid_conv2d_params* p) {
@@ -1527,7 +1597,8 @@ static int wino_form_choice(const aid_conv2d_params* p) {
         for (int l = 0; l < nl; ++l)
             tiles += (int64_t)p->B * (p->dilF / pl[l].NC) * pl[l].quads * pl[l].ttiles * (nl == 2 ? p->Cout_pad / 96 : p->Cout_pad / 64);
         const int64_t per_cu = (tiles + 255) / 256;
-        return per_cu * per_tile * (per_cu == 1 ? 12 : 10);
+        // (F(8,3) launches of one tile per CU take the K-group instances: two waves per SIMD on the one tile, 1.03 instead of 1.2)
+        return per_cu * per_tile * (per_cu == 1 ? (per_tile == 5 ? 103 : 120) : 100);
     };
     return cost(p8, n8, 5) < cost(p4, n4, 3) ? 8 : 4;
 }
@@ -1547,6 +1618,16 @@ static inline int64_t aid_w8r_sk_bytes(int workers) { return AID_W4R_SPLIT_FLAG_
 // Plain tiles lose [ceil(rounds) - rounds] / ceil(rounds) of the launch to the partially filled last round (rounds = tiles / resident workgroups);
 // stream-K pays one partial per workgroup and gives up the hardware's dynamic tile dispatch.  Taken when the loss exceeds 8 % (measured threshold,
 // profiles/r04_streamk_probe.txt) -- launches of fewer tiles than resident workgroups included.
+// K-group instances (conv53_wino8r_ks_kernel): a launch none of whose CUs would hold two tiles.  Per-layer A/B against the plain F(8,3) tiles and
+// F(4,3) (profiles/r04_ks_probe.txt): -12 ... -18 % on the <= 256-tile launches (batch 1: levels 0, 3, 4, 5; batch 2: level 6), within +-2 % of the
+// plain tiles elsewhere (where they are not used: the hardware's dynamic dispatch of two independent workgroups per CU is the safer schedule).
+// AID_W8R_KS (experiment builds): 0 never, 1 always, 2 also the launches of 2 r + 1 half-rounds (512 < tiles <= 768).
+static bool wino8r_ks_wanted(int64_t ntiles) {
+    static const int force = w4r_env("AID_W8R_KS", -1);
+    if (force == 0 || force == 1) return force != 0;
+    if (force == 2 && ntiles > 512 && ntiles <= 768) return true;
+    return ntiles <= 256;
+}
 static bool wino8r_sk_wanted(int64_t ntiles, int workers) {
     const int64_t rounds_up = (ntiles + workers - 1) / workers;
     return ntiles * 100 < rounds_up * workers * 92;
@@ -1590,6 +1671,8 @@ static int launch_wino8r(const aid_conv2d_params* p, hipStream_t st) {
     const int workers = wino8r_sk_workers();
     const bool sk = p->ws && p->ws_bytes >= aid_w8r_sk_bytes(workers) && wino8r_sk_wanted(ntl, workers);
     a.sk_per = 0; a.sk_workers = 0;
+    const bool kg = !sk && wino8r_ks_wanted(ntl);
+    if (kg) a.nchunks = p->Cin / 4;
     if (sk) {
         a.flags = reinterpret_cast<unsigned*>(p->ws);
         a.part = p->ws + AID_W4R_SPLIT_FLAG_BYTES / 4;
@@ -1598,6 +1681,7 @@ static int launch_wino8r(const aid_conv2d_params* p, hipStream_t st) {
     }
 #define AID_W8R(TTv, NCv, WGMv, NC1v) do { \
         if (sk) hipLaunchKernelGGL((conv53_wino8r_sk_kernel<TTv, NCv, WGMv, NC1v>), dim3((unsigned)workers), dim3(256), 0, st, a); \
+        else if (kg) hipLaunchKernelGGL((conv53_wino8r_ks_kernel<TTv, NCv, WGMv, NC1v>), grid, dim3(512), 0, st, a); \
         else hipLaunchKernelGGL((conv53_wino8r_kernel<TTv, NCv, WGMv, NC1v>), grid, dim3(256), 0, st, a); } while (0)
     if (m96) {
         a.g[0] = geo[0]; a.g[1] = geo[1];
@@ -1628,6 +1712,7 @@ static int launch_wino8r(const aid_conv2d_params* p, hipStream_t st) {
     }
 #undef AID_W8R
     if (sk) aid_note_kernel(m96 ? "conv53_wino8r_sk_kernel(64+32)" : "conv53_wino8r_sk_kernel");
+    else if (kg) aid_note_kernel(m96 ? "conv53_wino8r_ks_kernel(64+32)" : "conv53_wino8r_ks_kernel");
     else aid_note_kernel(m96 ? "conv53_wino8r_kernel(64+32)" : (plan[0].NC == 1 ? "conv53_wino8r_kernel" : "conv53_wino8r_kernel(multi-class)"));
     return AID_OK;
 }

@@ -49,7 +49,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA = 157.3          # TFLOP/s, dense fp32 matrix (MI355X_MICROARCH.md)
 # executed MFMA FLOPs as a fraction of the direct form: F(4,3) issues 6 products per 4 outputs x 3 taps = 1/2, F(8,3) 10 per 8 x 3 = 5/12
-WINO_EXEC = {"conv53_wino4r_kernel": 0.5, "conv53_wino4v_kernel": 0.5, "conv53_wino4_kernel": 0.5, "conv53_wino8r_kernel": 10.0 / 24.0, "conv53_wino8r_sk_kernel": 10.0 / 24.0}
+WINO_EXEC = {"conv53_wino4r_kernel": 0.5, "conv53_wino4v_kernel": 0.5, "conv53_wino4_kernel": 0.5, "conv53_wino8r_kernel": 10.0 / 24.0, "conv53_wino8r_sk_kernel": 10.0 / 24.0,
+             "conv53_wino8r_ks_kernel": 10.0 / 24.0}
 
 
 def ensure_built() -> None:

@@ -283,7 +283,17 @@ WINO8_CASES = [
     (1, 96, 96, 32, 256, 2, 1, True),        # <64, 1> + <64, 1>: 16 rows per class
     (2, 64, 96, 48, 64, 2, 0, False),        # 24 rows per class: <64, 1> + remainder over two classes (RA = 8)
     (2, 96, 96, 16, 128, 4, 1, True),        # 4 rows per class: <64, 2> + <64, 4>
+    # more than 256 tiles: the plain instances (two four-wave workgroups per CU) of the tile shapes the small cases above run as K-group instances
+    (5, 128, 128, 448, 32, 1, 1, True),      # <32, 1>, 280 tiles
+    (5, 64, 128, 448, 32, 64, 1, True),      # <32, 2>, 320 tiles
+    (9, 64, 128, 256, 32, 64, 0, True),      # <32, 4>, 288 tiles
+    (4, 96, 96, 128, 256, 2, 1, True),       # pair <64, 1> + <64, 1>, 384 tiles
+    (30, 64, 96, 48, 64, 2, 0, False),       # pair <64, 1> + <64, 2>, 270 tiles
+    (44, 96, 96, 16, 128, 4, 1, True),       # pair <64, 2> + <64, 4>, 264 tiles
 ]
+# launches of at most 256 tiles (one per CU) take the K-group instances: one eight-wave workgroup per tile, two K groups (conv53_wino8r_ks_kernel)
+WINO8_PLAIN = {(4, 64, 64, 96, 1024), (5, 128, 128, 64, 512), (5, 128, 128, 448, 32), (5, 64, 128, 448, 32), (9, 64, 128, 256, 32), (4, 96, 96, 128, 256),
+               (30, 64, 96, 48, 64), (44, 96, 96, 16, 128)}
 
 
 @pytest.mark.parametrize("case", WINO8_CASES)
@@ -330,7 +340,8 @@ def test_conv2d_winograd8_domain_input(L, case):
     p.alpha, p.res_scale = alpha, res_scale
     L.call("aid_conv2d", p)
     torch.cuda.synchronize()
-    assert "wino8r" in L.lib().aid_last_kernel().decode()
+    kern = L.lib().aid_last_kernel().decode()
+    assert "wino8r" in kern and ("wino8r_ks" in kern) == ((B, Cin, Cout, Fd, T) not in WINO8_PLAIN), kern
     err = rel_l2(y.cpu(), ref)
     assert err < 1e-5, err
     # (2b) stream-K instance (scratch given and the launch shape asks for it): same result up to one association per cut tile, deterministic,
@@ -725,7 +736,9 @@ def test_channel_dot(L, shape):
 
 
 @pytest.mark.parametrize("xw", [1, 2])
-@pytest.mark.parametrize("case", [(2, 64, 64, 24, 128, 2), (1, 128, 256, 16, 64, 4), (2, 96, 96, 32, 128, 2), (1, 64, 128, 56, 32, 8)])
+@pytest.mark.parametrize("case", [(2, 64, 64, 24, 128, 2), (1, 128, 256, 16, 64, 4), (2, 96, 96, 32, 128, 2), (1, 64, 128, 56, 32, 8),
+                                  # more than 256 F(8,3) tiles: the plain instances (the small cases run the K-group instances)
+                                  (3, 128, 128, 64, 512, 2), (4, 96, 96, 128, 256, 2)])
 def test_group_stats_from_conv_epilogue(L, case, xw):
     """aid_conv2d(stat_ws) on the row-shared F(4,3) (xw = 1) / F(8,3) (xw = 2) kernel + aid_group_stats(ws_n): the per-tile (sum, sum of squares)
     partials of the conv output replace the read pass; scale and (mean, 1/(std+eps)) agree with the plain two-kernel statistics of the same tensor."""

@@ -204,7 +204,9 @@ def test_full_size_guided_evaluation_vs_oracle_autograd():
                                   (2, 96, 96, 32, 128, 2, 1), (1, 96, 96, 20, 256, 4, 1),
                                   # xw = 2: F(8,3) row-shared tiles (single-class, multi-class, T = 32, 64+32 pair)
                                   (2, 64, 64, 16, 64, 2, 2), (1, 128, 128, 40, 128, 2, 2), (2, 256, 128, 32, 32, 1, 2), (2, 64, 64, 56, 32, 8, 2),
-                                  (2, 96, 96, 32, 128, 2, 2), (1, 96, 96, 16, 256, 4, 2)])
+                                  (2, 96, 96, 32, 128, 2, 2), (1, 96, 96, 16, 256, 4, 2),
+                                  # more than 256 F(8,3) tiles: the plain instances (the small cases above run the K-group instances)
+                                  (3, 128, 128, 64, 512, 2, 2), (4, 96, 96, 128, 256, 2, 2)])
 def test_conv_epilogue_dot_partials(L, case):
     """dgrad conv with the dGELU epilogue + dot_ws: the per-tile partials of <y, aux> per (sample, channel group) that
     replace the aid_group_dot pass, on the in-kernel-transform and the Winograd-domain-input F(4,3) kernels and on the F(8,3) kernel (xw = 2)."""

@@ -463,15 +463,18 @@ def test_f83_matrices_header_and_python_twin_agree():
 
 
 def test_winograd_form_choice_is_a_function_of_the_launch_shape():
-    """aid_conv2d_wino_form / aid_conv2d_wino8_supported (pure host functions of the library): a batch of one keeps F(4,3) on every level of the shipped
-    22.05 kHz network, sub-batches of four take F(8,3) wherever its 512-position tiles quantise, six rows per residue class have no F(8,3) tile, and
-    the answer never depends on anything but the launch shape."""
+    """aid_conv2d_wino_form / aid_conv2d_wino8_supported (pure host functions of the library): a batch of one takes F(8,3) -- the K-group instances --
+    on the levels whose launch is at most one 512-position tile per CU and keeps F(4,3) on the 96-channel levels (384 tiles) and the deepest one (112),
+    sub-batches of four take F(8,3) wherever its 512-position tiles quantise, six rows per residue class have no F(8,3) tile, and the answer never
+    depends on anything but the launch shape."""
     from audio_inpainting_diffusion_amd import _lib
     L = _lib.lib()
     levels = [(64, 64, 2048, 2), (96, 128, 1024, 3), (96, 192, 512, 4), (128, 256, 256, 5), (128, 320, 128, 6), (256, 384, 64, 7), (256, 448, 32, 7)]
     for C, F, T, nd in levels:
         for k in range(nd):
-            assert L.aid_conv2d_wino_form(1, C, C, F, T, 1 << k) == 4
+            f1 = L.aid_conv2d_wino_form(1, C, C, F, T, 1 << k)
+            tiles8 = (C // 64) * F * T // 512
+            assert f1 == (8 if (C != 96 and 128 < tiles8 <= 256 and L.aid_conv2d_wino8_supported(C, C, F, T, 1 << k)) else 4), (C, F, T, k, f1)
             f4 = L.aid_conv2d_wino_form(4, C, C, F, T, 1 << k)
             assert f4 in (4, 8) and f4 == L.aid_conv2d_wino_form(4, C, C, F, T, 1 << k)
             if f4 == 8:

@@ -52,7 +52,9 @@ class Conv2dParams(C.Structure):
                 ("alpha", C.c_float), ("res_scale", C.c_float), ("wp_wino", C.c_void_p), ("wino_taps", C.c_int),
                 ("x_wino", C.c_int), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
                 ("dot_ws", C.c_void_p), ("dot_n", C.c_int), ("stat_ws", C.c_void_p), ("stat_n", C.c_int),
-                ("x2", View), ("Cin1", C.c_int)]
+                ("x2", View), ("Cin1", C.c_int),
+                ("fin_mode", C.c_int), ("fin_count", C.c_void_p), ("fin_gamma", C.c_void_p), ("fin_mod", C.c_void_p), ("fin_mod_ld", C.c_int64),
+                ("fin_eps", C.c_float), ("fin_scale", C.c_void_p), ("fin_stats", C.c_void_p)]
 
 
 class ResampleParams(C.Structure):
@@ -133,7 +135,7 @@ class NormBwdParams(C.Structure):
     _fields_ = [("gd", View), ("x", View), ("gy", View), ("out", View),
                 ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("groups", C.c_int),
                 ("stats", C.c_void_p), ("ws", C.c_void_p), ("eps", C.c_float), ("a", C.c_float), ("accumulate", C.c_int),
-                ("ws_n", C.c_int), ("wout", View), ("wscale", C.c_void_p), ("wscale_ld", C.c_int64), ("wform", C.c_int)]
+                ("ws_n", C.c_int), ("wout", View), ("wscale", C.c_void_p), ("wscale_ld", C.c_int64), ("wform", C.c_int), ("coef_ready", C.c_int)]
 
 
 class AttentionBwdParams(C.Structure):
@@ -249,7 +251,7 @@ EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_st
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_guidance_step", "aid_set_rows", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
-           "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino8_supported", "aid_conv2d_wino_split_ws_bytes", "aid_conv2d_wino8_sk_ws_bytes",
+           "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino8_supported", "aid_conv2d_wino_split_ws_bytes", "aid_conv2d_wino8_sk_ws_bytes", "aid_conv2d_fin_supported",
            "aid_conv2d_wgrad", "aid_wgrad_reduce", "aid_channel_dot", "aid_relpos_bwd", "aid_scale_bwd", "aid_modulation_bwd", "aid_embed_bwd",
            "aid_adam", "aid_ema", "aid_sumsq"]
 
@@ -286,6 +288,8 @@ def lib():
         L.aid_conv2d_wino8_supported.restype = C.c_int
         L.aid_conv2d_wino8_sk_ws_bytes.argtypes = [C.c_int] * 6
         L.aid_conv2d_wino8_sk_ws_bytes.restype = C.c_int64
+        L.aid_conv2d_fin_supported.argtypes = [C.c_int] * 7
+        L.aid_conv2d_fin_supported.restype = C.c_int
         L.aid_conv2d_wino_form.argtypes = [C.c_int] * 6
         L.aid_conv2d_wino_form.restype = C.c_int
         L.aid_conv2d_wino_split_ws_bytes.argtypes = [C.c_int] * 6
@@ -295,11 +299,11 @@ def lib():
         L.aid_conv2d_wgrad_tiles.argtypes = [C.c_int] * 5
         L.aid_conv2d_wgrad_tiles.restype = C.c_int
         for name in EXPORTS[3:]:
-            if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino8_supported", "aid_conv2d_wino_split_ws_bytes", "aid_conv2d_wino8_sk_ws_bytes",
+            if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino8_supported", "aid_conv2d_wino_split_ws_bytes", "aid_conv2d_wino8_sk_ws_bytes", "aid_conv2d_fin_supported",
                             "aid_conv2d_stat_partials", "aid_conv2d_wgrad_tiles"):
                 getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, name).restype = C.c_int
-        if L.aid_abi_version() != 10:
+        if L.aid_abi_version() != 11:
             raise AidError("ABI version mismatch")
         _lib = L
     return _lib

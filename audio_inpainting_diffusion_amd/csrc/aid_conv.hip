@@ -498,6 +498,7 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     AID_REQUIRE(p->epi == 0 || (p->epi == 1 && p->aux.p && p->aux_scale), "aid_conv2d: epi=1 needs aux + aux_scale");
     AID_REQUIRE((int64_t)p->B * p->in_scale_ld < (1LL << 31), "aid_conv2d: in_scale too large");
     AID_REQUIRE(!p->x_wino || (p->KH == 5 && p->KW == 3 && p->wp_wino), "aid_conv2d: x_wino is a 5x3 Winograd-path input layout");
+    AID_REQUIRE(!p->fin_mode || (p->x_wino && p->KH == 5 && p->KW == 3), "aid_conv2d: fin_mode is an option of the row-shared 5x3 Winograd kernels (aid_conv2d_fin_supported)");
     if (p->x2.p) {
         AID_REQUIRE(p->KH == 1 && p->KW == 1 && !p->in_scale && p->act == 0 && p->Cin1 > 0 && p->Cin1 < p->Cin && (p->Cin1 % 16) == 0 && ((p->Cin - p->Cin1) % 16) == 0,
                     "aid_conv2d: x2 is an option of plain 1x1 convolutions with both K segments multiples of 16");

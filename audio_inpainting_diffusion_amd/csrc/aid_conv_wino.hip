@@ -711,8 +711,64 @@ struct ConvWinoRDev {
     W4rGeo g[2];               // [1]: the 32-channel remainder tiles of a 96-channel layer (pair instances)
     int sk_per;                // stream-K instances: (tile, chunk) units per persistent workgroup
     int sk_workers;            // stream-K instances: persistent workgroups (= grid size)
+    int fin_total;             // fin_mode: tiles per sample (both families) -- the tile that finds fin_count[b] == fin_total - 1 folds the sample's partials
 };
 struct W4rSeg { int c0, c1, wid, per; };   // stream-K: one workgroup's share [c0, c1) of a tile's chunks; wid = its worker id (partial / flag slot)
+
+// fin_mode (aid_kernels.h): the last tile of sample b folds the epilogue partials of the whole sample -- the work of group_stats_final / norm_bwd_coef
+// (aid_norm.hip), same summation order (lane l adds partials l, l + 64, ..., then the xor tree), hence the same bits -- so that those two 5-10 us
+// launches per normalisation layer (194 per guided evaluation, a twentieth of a batch-1 evaluation) are not made.  The partials were published with
+// agent-scope stores before the arrival counter was bumped (as the split-K exchange above); they are read back past the XCD's L2 the same way.
+__device__ __forceinline__ double aid_ld_agent(const double* q) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void aid_st_agent(double* q, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(q), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __attribute__((noinline)) void aid_wino_fin(int mode, const double* ws, int nk, int b, int C, double n, const float* gamma, const float* mod, int64_t mod_ld,
+                                                       float eps, float* scale, float* stats, double* sh, int tid, int nthr) {
+    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    if (mode == 1) {
+        for (int g = wave; g < 8; g += nw) {
+            const double* w = ws + ((int64_t)(b * 8 + g) * nk) * 2;
+            double s = 0.0, ss = 0.0;
+            for (int i = lane; i < nk; i += 64) { s += aid_ld_agent(w + 2 * i); ss += aid_ld_agent(w + 2 * i + 1); }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { s += __shfl_xor(s, off, 64); ss += __shfl_xor(ss, off, 64); }
+            if (lane == 0) { sh[2 * g] = s; sh[2 * g + 1] = ss; }
+        }
+        __syncthreads();
+        const int cg = C >> 3;
+        for (int c = tid; c < C; c += nthr) {
+            const int g = c / cg;
+            const double s = sh[2 * g], ss = sh[2 * g + 1];
+            const double mean = s / n;
+            double var = (ss - n * mean * mean) / (n - 1.0);
+            if (var < 0.0) var = 0.0;
+            const double inv = 1.0 / (sqrt(var) + (double)eps);
+            const double m = mod ? (1.0 + (double)mod[(int64_t)b * mod_ld + c]) : 1.0;
+            scale[(int64_t)b * C + c] = (float)((double)gamma[c] * m * inv);
+            if (stats && c == g * cg) {
+                stats[((int64_t)b * 8 + g) * 2 + 0] = (float)mean;
+                stats[((int64_t)b * 8 + g) * 2 + 1] = (float)inv;
+            }
+        }
+    } else {
+        for (int g = wave; g < 8; g += nw) {
+            const int i = b * 8 + g;
+            const double* w = ws + (int64_t)i * nk;
+            double d = 0.0;
+            for (int k = lane; k < nk; k += 64) d += aid_ld_agent(w + k);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
+            if (lane == 0) {
+                const double inv = (double)stats[2 * i + 1];
+                const double sd = 1.0 / inv - (double)eps;
+                scale[i] = (sd > 0.0) ? (float)(d * inv / ((n - 1.0) * sd)) : 0.f;
+            }
+        }
+    }
+}
 
 // Tried for small grids (round 3, profiles/r03_half_tile_probe.txt): two-wave workgroups on half the positions (64 x 128 / 32 x 256 tiles, twice
 // the workgroups, four per CU) when a launch has fewer than 300 ... 1100 full tiles -- B = 1: 24.7 -> 29.4 ... 30.2 ms of 5x3 time per guided
@@ -766,7 +822,7 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
     using S = W4rShape<TT, NC, WGM, NB, WPC, NWV, WM, KS>;
     constexpr int KH = S::KH, NXI = S::NXI, KC = S::KC, KCS = S::KCS;
     constexpr int NW = S::NW, NWQ = S::NWQ, WGN = S::WGN;
-    static_assert(KS == 1 || (KS == 2 && WM == 8 && !SPK && !SK), "K groups: the F(8,3) instances only");
+    static_assert(KS == 1 || (KS == 2 && !SPK && !SK), "K groups: not combined with the split-K / stream-K exchange");
     constexpr int M_BLK = S::M_BLK;
     constexpr int GPR = S::GPR, RA = S::RA, CSLOT = S::CSLOT, CSLOT_USED = S::CSLOT_USED, IL = S::IL, XCI = S::XCI, XSZ = S::XSZ, WROW = S::WROW;
     constexpr int WSZ_RAW = S::WSZ_RAW, WSZ = S::WSZ, BUFSZ = S::BUFSZ, NBUF = S::NBUF;
@@ -1172,13 +1228,13 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
         const int64_t rbase = p.res.p ? ((int64_t)b * p.res.sB + (int64_t)f_o * p.res.sF + t_o) : 0;
         const int64_t abase = p.aux.p ? ((int64_t)b * p.aux.sB + (int64_t)f_o * p.aux.sF + t_o) : 0;
 #pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += 4) {
+        for (int r0 = 0; r0 < 16 / KS; r0 += 4) {
             float4 rv[4], ur[4];
             float sv[4], as[4];
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
                 const int r = r0 + qq;
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                const int m = mbase + (r & 3) + 8 * ((r >> 2) + (KS == 2 ? 2 * ks : 0));
                 const bool ok = m < p.Cout;
                 rv[qq] = (ok && p.res.p) ? *reinterpret_cast<const float4*>(p.res.p + rbase + (int64_t)m * p.res.sC) : make_float4(0.f, 0.f, 0.f, 0.f);
                 sv[qq] = (ok && p.out_scale) ? p.out_scale[(int64_t)b * p.out_scale_ld + m] : 1.f;
@@ -1190,7 +1246,7 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
                 const int r = r0 + qq;
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                const int m = mbase + (r & 3) + 8 * ((r >> 2) + (KS == 2 ? 2 * ks : 0));
                 if (m >= p.Cout) continue;
                 const float M0 = acc[0][r], M1 = acc[1][r], M2 = acc[2][r], M3 = acc[3][r], M4 = acc[4][r], M5 = acc[5][r];
                 const float a12 = M1 + M2, s12 = M1 - M2, a34 = M3 + M4, s34 = M3 - M4;
@@ -1240,9 +1296,26 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
             const int ptile = ge.dot_base + (rg * ge.quads + q) * ge.ttiles + tile_t;
             if (st) {
                 double* o = p.stat_ws + (((int64_t)b * 8 + grp) * p.stat_n + ptile) * 2;
-                o[0] = (double)sacc; o[1] = (double)qacc;
+                if (p.fin_mode) { aid_st_agent(o, (double)sacc); aid_st_agent(o + 1, (double)qacc); }
+                else { o[0] = (double)sacc; o[1] = (double)qacc; }
             } else {
-                p.dot_ws[((int64_t)b * 8 + grp) * p.dot_n + ptile] = (double)sacc;
+                double* o = p.dot_ws + ((int64_t)b * 8 + grp) * p.dot_n + ptile;
+                if (p.fin_mode) aid_st_agent(o, (double)sacc);
+                else *o = (double)sacc;
+            }
+        }
+        if (p.fin_mode) {                                    // (wave-uniform) the last tile of sample b folds the sample's partials: aid_wino_fin
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's partials have reached the coherent level
+            __syncthreads();
+            int* shi = reinterpret_cast<int*>(sbuf0) + 2 * NW * 8;      // (behind `red`)
+            if (tid == 0) shi[0] = (__hip_atomic_fetch_add(p.fin_count + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.fin_total - 1)) ? 1 : 0;
+            __syncthreads();
+            if (shi[0]) {
+                __syncthreads();                               // (everybody has read shi[0]: the scratch below overlaps it)
+                const double n = (double)(p.Cout >> 3) * (double)p.F * (double)p.T;
+                aid_wino_fin(p.fin_mode, st ? p.stat_ws : p.dot_ws, st ? p.stat_n : p.dot_n, b, p.Cout, n, p.fin_gamma, p.fin_mod, p.fin_mod_ld, p.fin_eps,
+                             p.fin_scale, p.fin_stats, reinterpret_cast<double*>(sbuf0), tid, 64 * NW);
+                if (tid == 0) __hip_atomic_store(p.fin_count + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // as found, for the next launch
             }
         }
     }
@@ -1267,6 +1340,16 @@ __global__ __launch_bounds__(64 * NWV, (WPC * NWV + 3) / 4) void conv53_wino4r_k
         if ((int)blockIdx.x < n0) wino4r_tile_body<TT, NC, WGM, NB, WPC, NWV, false>(a, a.g[0], smem, (int)blockIdx.x);
         else wino4r_tile_body<TT, NC1, 1, NB, WPC, NWV, false>(a, a.g[1], smem, (int)blockIdx.x - n0);
     }
+}
+
+// K-group instance of the F(4,3) kernel (see conv53_wino8r_ks_kernel below): one eight-wave workgroup per 64 x 256 tile, two K groups, for launches of at
+// most one tile per CU -- the deepest level of the shipped networks at batch 1 (224 tiles).  Replaces the split-K instances there: the same two waves
+// per SIMD, the partial sums through LDS instead of 98 KB per tile through memory (141-159 -> see DESIGN.md 3.1e).
+template <int TT, int NC>
+__global__ __launch_bounds__(512, 2) void conv53_wino4r_ks_kernel(const ConvWinoRDev a) {
+    using S0 = W4rShape<TT, NC, 2, 3, 1, 8, 4, 2>;
+    __shared__ __attribute__((aligned(16))) float smem[S0::LDS];
+    wino4r_tile_body<TT, NC, 2, 3, 1, 8, false, 4, false, 2>(a, a.g[0], smem, (int)blockIdx.x);
 }
 
 // ---- F(8,3) on the same row-shared body: 10 products per 8 outputs (0.833x the MFMAs of F(4,3), 0.417x of the direct form), Winograd-domain
@@ -1426,10 +1509,28 @@ static int w4r_env(const char* name, int dflt) {
 // 155 -> 147 us (d = 1) ... 169 -> 143 us (d = 64) per launch on [256, 448, 32]; launches with 256 < tiles <= 336 measured neutral to -4 %
 // (profiles/r03_w4r_split_probe.txt); end to end at batch 1: 27.75 -> 28.37 evaluations/s with the threshold at 230, 28.22 at 336
 // (profiles/r03_w4r_ab.txt).  AID_W4R_SPLIT overrides the threshold (0 = never split).
+// K-group instances of the F(4,3) kernel (conv53_wino4r_ks_kernel): at most one tile per CU, the T <= 32 tile shapes (the deep levels).
+// AID_W4R_KS (experiment builds): 0 never (split-K as before), 1 wherever instantiated.
+static bool wino4r_ks_wanted(const aid_conv2d_params* p, int nl, const Wino4rPlan* plan, int64_t ntiles) {
+    static const int force = w4r_env("AID_W4R_KS", -1);
+    if (nl != 1 || plan[0].TT > 32 || (p->Cin % 4)) return false;
+    if (force == 0 || force == 1) return force != 0;
+    return ntiles <= 256;
+}
 static int wino4r_splits(const aid_conv2d_params* p, int nl, int64_t ntiles) {
     static const int thr = w4r_env("AID_W4R_SPLIT", 230);
     if (p->B != 1 || nl != 1 || ntiles > thr || ntiles > AID_W4R_SPLIT_MAX_TILES || (p->Cin % 4)) return 1;
     return 2;
+}
+
+// fin_mode (aid_kernels.h): argument check shared by the two row-shared launchers
+static int wino_fin_check(const aid_conv2d_params* p) {
+    if (!p->fin_mode) return AID_OK;
+    AID_REQUIRE(p->fin_mode == 1 || p->fin_mode == 2, "aid_conv2d: fin_mode is 0, 1 or 2");
+    AID_REQUIRE(p->fin_count && p->fin_scale && (p->Cout % 8) == 0, "aid_conv2d: fin_mode needs fin_count, fin_scale and Cout % 8 == 0");
+    if (p->fin_mode == 1) AID_REQUIRE(p->stat_ws && p->fin_gamma, "aid_conv2d: fin_mode = 1 folds the stat_ws partials and needs fin_gamma");
+    else AID_REQUIRE(p->dot_ws && p->fin_stats, "aid_conv2d: fin_mode = 2 folds the dot_ws partials and needs the forward statistics in fin_stats");
+    return AID_OK;
 }
 
 static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
@@ -1464,7 +1565,12 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
         ge.ntiles = p->B * ge.rgroups * g.quads * g.ttiles * ge.ny;
         ge.per_xcd = (ge.ntiles + 7) / 8;
     }
-    if (wino4r_splits(p, nl, geo[0].ntiles) == 2 && p->ws && p->ws_bytes >= aid_w4r_split_bytes(geo[0].ntiles)) {
+    { const int rc = wino_fin_check(p); if (rc != AID_OK) return rc; }
+    a.fin_total = (geo[0].ntiles + (m96 ? geo[1].ntiles : 0)) / p->B;      // tiles per sample (before a split doubles the workgroups)
+    const bool kg = wino4r_ks_wanted(p, nl, plan, geo[0].ntiles);
+    if (kg) {
+        a.nchunks = p->Cin / 4;
+    } else if (wino4r_splits(p, nl, geo[0].ntiles) == 2 && p->ws && p->ws_bytes >= aid_w4r_split_bytes(geo[0].ntiles)) {
         a.splits = 2;
         a.flags = reinterpret_cast<unsigned*>(p->ws);
         a.part = p->ws + AID_W4R_SPLIT_FLAG_BYTES / 4;
@@ -1495,6 +1601,18 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
         const Wino4rPlan& g = plan[0];
         a.g[0] = geo[0]; a.g[1] = geo[0];
         const dim3 grid((unsigned)(8 * geo[0].per_xcd));
+#define AID_W4R_KS(TTv, NCv) hipLaunchKernelGGL((conv53_wino4r_ks_kernel<TTv, NCv>), grid, dim3(512), 0, st, a)
+        if (kg) switch (g.TT * 16 + g.NC) {
+            case 32 * 16 + 1: AID_W4R_KS(32, 1); break;
+            case 32 * 16 + 2: AID_W4R_KS(32, 2); break;
+            case 32 * 16 + 4: AID_W4R_KS(32, 4); break;
+            case 32 * 16 + 8: AID_W4R_KS(32, 8); break;
+            case 16 * 16 + 1: AID_W4R_KS(16, 1); break;
+            case 16 * 16 + 2: AID_W4R_KS(16, 2); break;
+            case 16 * 16 + 4: AID_W4R_KS(16, 4); break;
+            case 16 * 16 + 8: AID_W4R_KS(16, 8); break;
+            default: aid_set_error("aid_conv2d: row-shared K-group tile shape not instantiated"); return AID_E_BADARG;
+        } else
         switch (g.TT * 16 + g.NC) {
             case 64 * 16 + 1: AID_W4R(64, 1, 2, 0); break;
             case 64 * 16 + 2: AID_W4R(64, 2, 2, 0); break;
@@ -1512,7 +1630,9 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
         AID_CHECK_LAUNCH();
     }
 #undef AID_W4R
-    aid_note_kernel(m96 ? "conv53_wino4r_kernel(64+32)" : (a.splits == 2 ? "conv53_wino4r_kernel(split-K)" : (plan[0].NC == 1 ? "conv53_wino4r_kernel" : "conv53_wino4r_kernel(multi-class)")));
+#undef AID_W4R_KS
+    if (kg) aid_note_kernel("conv53_wino4r_ks_kernel");
+    else aid_note_kernel(m96 ? "conv53_wino4r_kernel(64+32)" : (a.splits == 2 ? "conv53_wino4r_kernel(split-K)" : (plan[0].NC == 1 ? "conv53_wino4r_kernel" : "conv53_wino4r_kernel(multi-class)")));
     return AID_OK;
 }
 
@@ -1597,8 +1717,9 @@ static int wino_form_choice(const aid_conv2d_params* p) {
         for (int l = 0; l < nl; ++l)
             tiles += (int64_t)p->B * (p->dilF / pl[l].NC) * pl[l].quads * pl[l].ttiles * (nl == 2 ? p->Cout_pad / 96 : p->Cout_pad / 64);
         const int64_t per_cu = (tiles + 255) / 256;
-        // (F(8,3) launches of one tile per CU take the K-group instances: two waves per SIMD on the one tile, 1.03 instead of 1.2)
-        return per_cu * per_tile * (per_cu == 1 ? (per_tile == 5 ? 103 : 120) : 100);
+        // (launches of one tile per CU take the K-group instances where there is one: two waves per SIMD on the one tile, 1.03 instead of 1.2)
+        const bool kgroups = per_tile == 5 || (nl == 1 && pl[0].TT <= 32);     // (wino8r_ks_wanted / wino4r_ks_wanted)
+        return per_cu * per_tile * (per_cu == 1 ? (kgroups ? 103 : 120) : 100);
     };
     return cost(p8, n8, 5) < cost(p4, n4, 3) ? 8 : 4;
 }
@@ -1668,8 +1789,10 @@ static int launch_wino8r(const aid_conv2d_params* p, hipStream_t st) {
     // stream-K (scratch `ws` given, i.e. the caller allows it for this launch): when the tiles are not close to a whole number of rounds of the
     // 2 x CUs resident workgroups
     const int64_t ntl = (int64_t)geo[0].ntiles + (m96 ? geo[1].ntiles : 0);
+    { const int rc = wino_fin_check(p); if (rc != AID_OK) return rc; }
+    a.fin_total = (int)(ntl / p->B);                       // tiles per sample
     const int workers = wino8r_sk_workers();
-    const bool sk = p->ws && p->ws_bytes >= aid_w8r_sk_bytes(workers) && wino8r_sk_wanted(ntl, workers);
+    const bool sk = p->ws && p->ws_bytes >= aid_w8r_sk_bytes(workers) && wino8r_sk_wanted(ntl, workers) && !p->fin_mode;
     a.sk_per = 0; a.sk_workers = 0;
     const bool kg = !sk && wino8r_ks_wanted(ntl);
     if (kg) a.nchunks = p->Cin / 4;
@@ -1735,6 +1858,17 @@ extern "C" int aid_conv2d_wino_form(int B, int Cin, int Cout, int F, int T, int 
     return f;
 }
 
+extern "C" int aid_conv2d_fin_supported(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino) {
+    if (B < 1 || (Cout % 8) || !wino_v_shape_ok(Cin, Cout, T)) return 0;
+    if (x_wino == 2) return aid_conv2d_wino8_supported(Cin, Cout, F, T, dilF);
+    if (x_wino != 1) return 0;
+    aid_conv2d_params q = {};
+    q.B = B; q.Cin = Cin; q.Cout = Cout; q.F = F; q.T = T; q.dilF = dilF; q.KH = 5; q.KW = 3;
+    aid_conv2d_pack_dims(Cin, Cout, &q.Cin_pad, &q.Cout_pad);
+    Wino4rPlan plan[2];
+    return wino4r_geometry(&q, plan) ? 1 : 0;
+}
+
 // scratch of the stream-K instances of the F(8,3) kernel (aid_kernels.h: ws with x_wino = 2): 0 when a launch of this shape keeps plain tiles
 extern "C" int64_t aid_conv2d_wino8_sk_ws_bytes(int B, int Cin, int Cout, int F, int T, int dilF) {
     if (!aid_conv2d_wino8_supported(Cin, Cout, F, T, dilF)) return 0;
@@ -1759,6 +1893,7 @@ extern "C" int64_t aid_conv2d_wino_split_ws_bytes(int B, int Cin, int Cout, int 
     const int nl = wino4r_geometry(&q, plan);
     if (nl != 1) return 0;
     const int64_t ntiles = (int64_t)B * (dilF / plan[0].NC) * plan[0].quads * plan[0].ttiles * (q.Cout_pad / 64);
+    if (wino4r_ks_wanted(&q, nl, plan, ntiles)) return 0;       // (the K-group instance takes the launch: no scratch)
     return wino4r_splits(&q, nl, ntiles) == 2 ? aid_w4r_split_bytes(ntiles) : 0;
 }
 
@@ -1855,6 +1990,7 @@ static int conv53_wino_v(const aid_conv2d_params* p, hipStream_t st) {
     int rc;
     rc = launch_wino4r(p, st);                              // row-shared tiles, two workgroups per CU (when the geometry fits)
     if (rc != 1000) return rc;
+    AID_REQUIRE(!p->fin_mode, "aid_conv2d: fin_mode needs the row-shared kernel (aid_conv2d_fin_supported)");
     if (p->Cout_pad % 64 == 0 && wino_tile_n(p->B, p->Cout_pad, p->F, p->T) == 256)
                                rc = launch_wino4v<1, 1, 2, 2, 16, 2, 1>(p, st);     // 64 x 256, 4 waves (one per SIMD: 92 KB of LDS): small grids
     else if (p->Cout_pad % 64 == 0) rc = launch_wino4v<1, 1, 2, 4, 16, 2, 2>(p, st);     // 64 x 512, 8 waves
@@ -1867,6 +2003,7 @@ static int conv53_wino_v(const aid_conv2d_params* p, hipStream_t st) {
 // returns 1 if the Winograd kernel took the launch, 0 if not eligible, <0 on error
 int aid_conv53_wino_try(const aid_conv2d_params* p, hipStream_t st) {
     if (p->x_wino) { const int rc = conv53_wino_v(p, st); return rc == AID_OK ? 1 : rc; }
+    if (p->fin_mode) { aid_set_error("aid_conv2d: fin_mode needs Winograd-domain input on the row-shared kernel (aid_conv2d_fin_supported)"); return AID_E_BADARG; }
     if (!p->wp_wino || !(p->KH == 5 && p->KW == 3) || p->in_scale || p->act != 0) return 0;
     if ((p->Cin % 4) != 0 || p->Cout < 64 || (p->T % 4) != 0) return 0;
     if (aid_pow2ceil(p->T) < 8) return 0;

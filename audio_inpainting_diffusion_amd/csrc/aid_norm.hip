@@ -371,6 +371,7 @@ __global__ __launch_bounds__(256) void norm_bwd_wino8_kernel(const NbDev a) {
 extern "C" int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream) {
     AID_REQUIRE(p && p->gd.p && p->x.p && p->out.p && p->stats && p->ws, "aid_norm_bwd: null pointer");
     AID_REQUIRE(p->groups > 0 && p->C % p->groups == 0 && (p->T % 4) == 0, "aid_norm_bwd: bad shape");
+    AID_REQUIRE(p->coef_ready == 0 || (p->coef_ready == 1 && p->ws_n > 0 && p->groups == 8), "aid_norm_bwd: coef_ready goes with conv-epilogue partials (ws_n > 0, 8 groups)");
     NbDev a;
     a.p = *p;
     a.cg = p->C / p->groups;
@@ -382,8 +383,10 @@ extern "C" int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream) {
     a.nrows = p->B * p->C * p->F;
     a.tiles = aid_cdiv(p->T / 4, lpr);
     const int rpb = 256 / lpr;
-    hipLaunchKernelGGL(norm_bwd_coef, dim3(p->B * p->groups), dim3(64), 0, (hipStream_t)stream, a);
-    AID_CHECK_LAUNCH();
+    if (!p->coef_ready) {                                 // (coef_ready: written by the conv that produced the partials, aid_conv2d fin_mode = 2)
+        hipLaunchKernelGGL(norm_bwd_coef, dim3(p->B * p->groups), dim3(64), 0, (hipStream_t)stream, a);
+        AID_CHECK_LAUNCH();
+    }
     if (p->wout.p && p->wform == 2) {
         AID_REQUIRE((p->T % 16) == 0 && !p->accumulate, "aid_norm_bwd: wout needs T % 16 == 0 and accumulate = 0 (neighbour samples are recomputed)");
         AID_REQUIRE(p->wout.sF >= 10 * (p->T / 8) && (p->wout.sB % 4) == 0 && (p->wout.sC % 4) == 0 && (p->wout.sF % 4) == 0 && (((uintptr_t)p->wout.p) & 15) == 0,

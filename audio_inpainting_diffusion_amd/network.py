@@ -299,10 +299,33 @@ class _Builder:
             self.nbytes += ws.numel() * 8
             cp.stat_ws, cp.stat_n = ws.data_ptr(), ws_n
             src[3].also_writes(ws)                         # (the conv's epilogue now writes the partials this op folds)
+            if self.net.fuse_fin and _lib.lib().aid_conv2d_fin_supported(cp.B, cp.Cin, cp.Cout, cp.F, cp.T, cp.dilF, cp.x_wino):
+                # the last tile of each sample folds the partials itself (aid_kernels.h: fin_mode = 1): no aid_group_stats launch at all
+                cnt = self._fin_count(src[3].lane)
+                cp.fin_mode, cp.fin_count, cp.fin_gamma, cp.fin_eps = 1, cnt.data_ptr(), gamma.data_ptr(), 1e-7
+                cp.fin_mod, cp.fin_mod_ld = _lib.ptr(mod), (0 if mod is None else mod.stride(0))
+                cp.fin_scale, cp.fin_stats = scale.data_ptr(), _lib.ptr(stats)
+                src[3].also_writes(scale, stats, cnt)
+                src[3].also_reads(gamma, mod)
+                self.plan.keep.extend(t for t in (ws, gamma, mod, scale, stats, cnt) if t is not None)
+                self._stats_train_hook(scale, gamma, mod, gname, stats, B, Cc)
+                return
         p = _lib.GroupStatsParams(_lib.view4(x), B, Cc, F, T, 8, gamma.data_ptr(), _lib.ptr(mod),
                                   0 if mod is None else mod.stride(0), 1e-7, scale.data_ptr(), _lib.ptr(stats),
                                   ws.data_ptr(), ws_n)
         self._add("aid_group_stats", p, x, gamma, mod, scale, stats, ws, writes=(scale, stats) + (() if src is not None else (ws,)))
+        self._stats_train_hook(scale, gamma, mod, gname, stats, B, Cc)
+
+    def _fin_count(self, lane):
+        """arrival counters of the fused finalisation (aid_kernels.h: fin_count): one zeroed word per sample and lane (launches of a lane are serial and
+        every launch leaves them zero)"""
+        key = (lane, "fin_count")
+        t = self.scratch.get(key)
+        if t is None:
+            t = self.scratch[key] = torch.zeros(self.B, device=self.device, dtype=torch.int32)
+        return t
+
+    def _stats_train_hook(self, scale, gamma, mod, gname, stats, B, Cc):
         if self.train and gname is not None:
             def bw():                                   # gradient of scale = gamma (1 + affine) / (std + eps) w.r.t. gamma and the affine vector
                 S = self.S_of.pop(scale.data_ptr(), None)
@@ -372,7 +395,7 @@ class _Builder:
             self.S_of[in_scale.data_ptr()] = Sb
 
     def _conv_raw(self, x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha, epi=0,
-                  aux=None, aux_scale=None, wpw=None, x_wino=0, dot=None, x2=None):
+                  aux=None, aux_scale=None, wpw=None, x_wino=0, dot=None, x2=None, fin_stats=None):
         """``x_wino``: 0 plain activations, 4 / 8: ``x`` is the F(4,3) / F(8,3) input transform and ``wpw`` the matching 30- / 50-tap pack."""
         B, _, F, T = y.shape
         x_wino = int(x_wino)
@@ -394,6 +417,11 @@ class _Builder:
         p.x_wino = xw_code
         if dot is not None:                              # (buffer, partials per (b, group)): <y, aux> folded into the epilogue
             p.dot_ws, p.dot_n = dot[0].data_ptr(), dot[1]
+        cnt = None
+        if fin_stats is not None:                        # fin_mode = 2: coefficients of aid_norm_bwd into the floats behind the partials (see _dot_ws)
+            cnt = self._fin_count(self.lane)
+            p.fin_mode, p.fin_count, p.fin_eps, p.fin_stats = 2, cnt.data_ptr(), 1e-7, fin_stats.data_ptr()
+            p.fin_scale = dot[0].data_ptr() + 8 * B * 8 * dot[1]
         if x2 is not None:                               # K axis in two tensors (aid_kernels.h: x2 / Cin1)
             p.x2, p.Cin1 = _lib.view4(x2), x.shape[1]
         ws = None
@@ -418,8 +446,8 @@ class _Builder:
         # algorithmic HBM bytes: x once, residual / aux once, y once, weights once
         nb = 4 * (B * F * T * (cin + cout * (1 + (res is not None) + (aux is not None))) + cin * cout * kh * kw)
         dws = None if dot is None else dot[0]
-        op = self._add("aid_conv2d", p, x, x2, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, ws, dws, flops=2 * B * F * T * cin * cout * kh * kw,
-                       nbytes=nb, writes=(y, ws, dws))
+        op = self._add("aid_conv2d", p, x, x2, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, ws, dws, fin_stats, cnt, flops=2 * B * F * T * cin * cout * kh * kw,
+                       nbytes=nb, writes=(y, ws, dws, cnt))
         self._wrote(y)
         if not self._in_bwd and x_wino and epi == 0 and dot is None and self.net.epilogue_stats:
             n = int(_lib.lib().aid_conv2d_stat_partials(B, cin, cout, F, T, dil, xw_code))
@@ -512,9 +540,12 @@ class _Builder:
                 elif act and kh == 1 and kw == 1 and self.net.fuse_dot_1x1:        # 1x1 steps (init / out blocks): the direct-to-LDS kernel's epilogue
                     nd = int(_lib.lib().aid_conv2d_dot_partials_1x1(B, cout, cin, F, T))
                 dws = self._dot_ws(nd) if nd else self.stats_ws
+                # the last tile of each sample also folds the partials into the normalisation-backward coefficients (aid_kernels.h: fin_mode = 2)
+                fin = bool(nd and kh == 5 and gw and self.net.fuse_fin
+                           and _lib.lib().aid_conv2d_fin_supported(B, cout, cin, F, T, dil, {4: 1, 8: 2}[gw]))
                 self._conv_raw(gin, gd, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, None, 1.0, alpha,
                                epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None, wpw=wpw8T if gw == 8 else wpwT, x_wino=gw,
-                               dot=(dws, nd) if nd else None)
+                               dot=(dws, nd) if nd else None, fin_stats=norm_stats if fin else None)
                 if not nd:
                     dp = _lib.GroupDotParams(_lib.view4(gd), _lib.view4(x), B, cin, F, T, 8, self.stats_ws.data_ptr())
                     self._add("aid_group_dot", dp, gd, x, self.stats_ws, writes=(self.stats_ws,))
@@ -523,6 +554,7 @@ class _Builder:
                 npar = _lib.NormBwdParams(_lib.view4(gd), _lib.view4(x), _lib.view4(gy if fused_res else None), _lib.view4(self.G(x)),
                                           B, cin, F, T, 8, norm_stats.data_ptr(), dws.data_ptr(), 1e-7,
                                           alpha * res_scale, 1 if self._gacc(x) else 0, nd)
+                npar.coef_ready = 1 if fin else 0
                 gxv = self.G(x)
                 nop = self._add("aid_norm_bwd", npar, gd, x, gy, norm_stats, dws, gxv, writes=(gxv,))
                 self._wrote(gxv)
@@ -1154,6 +1186,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
                                # exchanges through memory costs more than the partially filled last round it removes, except on the K = 256 layers
                                # of a batch of one (+2 ... 22 %), where the F(4,3) split-K instances are faster still.
     wgrad_wino = True          # training: F(4,3) form of the 5x3 weight gradients (aid_conv2d_wgrad wino=1)
+    fuse_fin = True            # the last tile of a sample folds the conv epilogue's statistics / dot partials itself (aid_conv2d fin_mode): no aid_group_stats
+                               # launch after such a conv and no coefficient kernel in aid_norm_bwd (A/B: bench.py --no-fin)
     fuse_norm_bwd_wino = True  # reverse sweep: aid_norm_bwd also writes the Winograd-domain, gated copy that the dgrad conv below stages
     epilogue_stats = True      # forward group statistics from the epilogue of the conv that produces the tensor (row-shared F(4,3) kernel)
     GRAPH_MAX_B = 3

@@ -64,6 +64,10 @@ class Op:
         self.fn, self.addr, self.name, self.flops, self.nbytes, self.descr = fn, addr, name, flops, nbytes, descr
         self.lane, self.reads, self.writes, self.params = lane, reads, writes, params
 
+    def also_reads(self, *tensors):
+        """a later emitter patched this op's parameter struct so that it reads one more tensor"""
+        self.reads.extend(_range(t) for t in tensors if t is not None)
+
     def also_writes(self, *tensors):
         """a later emitter patched this op's parameter struct so that it writes one more tensor (epilogue statistics, fused copies)"""
         self.writes.extend(_range(t) for t in tensors if t is not None)

@@ -231,6 +231,7 @@ def main():
     ap.add_argument("--no-pair-merge", action="store_true", help="A/B: separate input-gradient convs for proj_in and res_conv")
     ap.add_argument("--no-lanes", action="store_true", help="A/B: single-stream launch plans at small batches (plan.py lanes off)")
     ap.add_argument("--no-fused-norm-bwd", action="store_true", help="A/B: separate gate / Winograd-transform pre-pass before every dgrad conv")
+    ap.add_argument("--no-fin", action="store_true", help="A/B: separate aid_group_stats / coefficient launches instead of the last tile of a sample folding the epilogue partials")
     ap.add_argument("--no-epilogue-stats", action="store_true", help="A/B: group statistics by their own read pass instead of the conv epilogue")
     ap.add_argument("--wino-forms", default="4,8", help="A/B: Winograd forms the 5x3 layers may use (default 4,8: F(8,3) where the library prefers it; 4: F(4,3) everywhere)")
     ap.add_argument("--stream-k", choices=["off", "whole", "all"], default=None, help="A/B: stream-K instances of the F(8,3) kernel (network.stream_k; default: the network's)")
@@ -273,6 +274,8 @@ def main():
     net = Unet_CQT_oct_with_attention(args, dev)
     if a.no_epilogue_stats:
         net.epilogue_stats = False
+    if a.no_fin:
+        net.fuse_fin = False
     if a.no_fused_norm_bwd:
         net.fuse_norm_bwd_wino = False
     if a.streams:

@@ -28,7 +28,7 @@ extern "C" {
 #define AID_E_BADARG (-1)   /* unsupported shape / null pointer / misaligned stride */
 #define AID_E_LAUNCH (-2)   /* hipLaunchKernel reported an error                    */
 
-#define AID_ABI_VERSION 10
+#define AID_ABI_VERSION 11
 int aid_abi_version(void);
 /* last HIP error string seen by a launcher in this process (never NULL) */
 const char* aid_last_error(void);
@@ -133,6 +133,20 @@ typedef struct {
                                  Cin1 + c); Cin1 and Cin - Cin1 multiples of 16.  One GEMM over a K axis that lives in two tensors: the input
                                  gradients of a ResnetBlock's proj_in and res_conv (unet...py:414-415, :488-491), which both flow into dL/d(block
                                  input), as ONE launch on the stacked transposed weights instead of two read-modify-write passes over it. */
+    int fin_mode;                /* optional, row-shared Winograd kernels only (aid_conv2d_fin_supported(...) != 0): the LAST tile of a sample to finish also folds
+                                 the sample's epilogue partials, in the fixed order of the kernels it replaces (bit-identical results) --
+                                 1 (with stat_ws): what aid_group_stats(ws_n = stat_n) does: fin_scale[b, c] = fin_gamma[c] (1 + fin_mod[b, c]) / (std_g + fin_eps),
+                                    fin_stats[b, g] = (mean, 1 / (std + eps)) when given -- the NEXT layer's aid_group_stats call is then not made at all;
+                                 2 (with dot_ws): what the first kernel of aid_norm_bwd(ws_n = dot_n) does: fin_scale[b*8 + g] = <gd, x>_g inv / ((n - 1) std) from the
+                                    forward statistics fin_stats (input) -- aid_norm_bwd is then called with coef_ready = 1 and fin_scale must be its coefficient
+                                    scratch (the B*8 floats behind the partials in its `ws`).
+                                 0: none. */
+    unsigned* fin_count;         /* [B] arrival counters, ZERO before the first use (the kernel leaves them zero); one array per stream */
+    const float* fin_gamma;      /* mode 1: [Cout] */
+    const float* fin_mod; int64_t fin_mod_ld;   /* mode 1: optional [B, fin_mod_ld] */
+    float fin_eps;
+    float* fin_scale;
+    float* fin_stats;
 } aid_conv2d_params;
 int aid_conv2d(const aid_conv2d_params* p, void* stream);
 /* partials per (sample, group) when dot_ws is asked of a 1x1 layer (epi = 1, no residual; direct-to-LDS kernel); 0: not available */
@@ -157,6 +171,8 @@ int64_t aid_conv2d_wino_split_ws_bytes(int B, int Cin, int Cout, int F, int T, i
    the first AID_CONV2D_SPLIT_FLAG_BYTES bytes zero before the first use, one ws per stream.  Results are deterministic but depend on the launch
    shape (one extra association per cut tile): the caller decides where that is acceptable (network.py: whole batches only). */
 int64_t aid_conv2d_wino8_sk_ws_bytes(int B, int Cin, int Cout, int F, int T, int dilF);
+/* 1 when the kernel that takes a 5x3 layer of this launch shape with this x_wino (1 / 2) honours fin_mode (the row-shared kernels) */
+int aid_conv2d_fin_supported(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino);
 /* number of per-tile partial dots per (sample, group) the F(4,3) / F(8,3) epilogue writes for this shape (x_wino as in aid_conv2d_params); 0 = not supported */
 int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino);
 /* number of per-tile (sum, sum of squares) partials per (sample, group) for stat_ws; 0 = the kernel that takes this shape does not write them */
@@ -364,6 +380,8 @@ typedef struct {
                                      aid_scale_act(wino=1) would write for the dgrad conv of the layer below (its gate pre-pass folded into this pass) */
     const float* wscale; int64_t wscale_ld;   /* [B, wscale_ld] or NULL (-> 1) */
     int wform;                    /* Winograd form of wout: 0 / 1 = F(4,3) as above; 2 = F(8,3), wout rows [10][T/8] (aid_scale_act wino = 2) */
+    int coef_ready;               /* 1: the B*groups coefficients behind the partials in `ws` were already written by the conv that produced the partials
+                                     (aid_conv2d fin_mode = 2): the coefficient kernel is not launched */
 } aid_norm_bwd_params;
 int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream);
 

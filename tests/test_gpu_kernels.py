@@ -4,6 +4,7 @@ the plain torch-CPU fp32 form of the same op, on the same seeded inputs.
 Tolerances (fp32 path, stated per test): 2e-6 rel-L2 for pure data movement / FIR, 1e-5 for reductions and
 GEMM-shaped kernels (summation order differs from oneDNN), well inside BASELINE.json's 1e-4 budget.
 """
+import ctypes
 import math
 
 import numpy as np
@@ -784,6 +785,31 @@ def test_group_stats_from_conv_epilogue(L, case, xw):
     assert rel_l2(out[0][0], out[1][0]) < 1e-6
     assert float((out[0][1][..., 0] - out[1][1][..., 0]).abs().max()) < 1e-6 * float(out[1][1][..., 0].abs().max() + 1)
     assert rel_l2(out[0][1][..., 1], out[1][1][..., 1]) < 1e-6
+    # fin_mode = 1: the last tile of each sample folds the partials itself -- the same bits as aid_group_stats(ws_n = P), run after run, counters back to zero,
+    # with and without the saved statistics / the modulation
+    assert L.lib().aid_conv2d_fin_supported(B, Cin, Cout, Fd, T, dil, xw)
+    cnt = torch.zeros(B + 2, device=DEV, dtype=torch.int32)
+    cnt[B:] = 7
+    for rep in range(3):
+        scale = torch.full((B, Cout), float("nan"), device=DEV)
+        st = torch.full((B, 8, 2), float("nan"), device=DEV)
+        ws.fill_(float("nan"))
+        y2 = torch.full_like(y, float("nan"))
+        p.y = L.view4(y2)
+        p.fin_mode, p.fin_count, p.fin_gamma, p.fin_eps, p.fin_scale = 1, cnt.data_ptr(), gamma.data_ptr(), 1e-7, scale.data_ptr()
+        p.fin_mod, p.fin_mod_ld = (mod.data_ptr(), mod.stride(0)) if rep != 1 else (None, 0)
+        p.fin_stats = st.data_ptr() if rep != 2 else None
+        L.call("aid_conv2d", p)
+        torch.cuda.synchronize()
+        assert torch.equal(y2, y) and cnt[:B].abs().sum().item() == 0 and int(cnt[B]) == 7
+        want = out[0][0] if rep != 1 else out[0][0] / (1.0 + mod.cpu())
+        assert torch.equal(scale.cpu(), out[0][0]) if rep != 1 else rel_l2(scale.cpu(), want) < 1e-6
+        if rep != 2:
+            assert torch.equal(st.cpu(), out[0][1])
+    # the option is refused where no kernel honours it
+    p.x_wino, p.x = 0, L.view4(xd)
+    p.stat_ws, p.stat_n = None, 0
+    assert L.lib().aid_conv2d(ctypes.addressof(p), None) != 0 and b"fin_mode" in L.lib().aid_last_error()
 
 
 @pytest.mark.parametrize("shape", [(64, 64, 5, 3), (96, 128, 5, 3), (2, 96, 5, 3), (256, 40, 1, 1), (192, 96, 1, 3)])

@@ -247,6 +247,27 @@ def test_conv_epilogue_dot_partials(L, case):
     want = (yc * aux.double()).reshape(B, 8, Cout // 8, Fd, T).sum((2, 3, 4))
     assert torch.isfinite(got).all()
     assert float((got - want).abs().max()) < 1e-5 * float((yc.abs() * aux.double().abs()).reshape(B, 8, -1).sum(-1).max())
+    if not (xw and L.lib().aid_conv2d_fin_supported(B, Cin, Cout, Fd, T, dil, xw)):
+        return
+    # fin_mode = 2: the last tile of each sample also writes the coefficients aid_norm_bwd's first kernel would compute from the partials -- same bits
+    stats = torch.stack([_rand(B, 8, seed=44), 0.5 + _rand(B, 8, seed=45).abs()], -1).contiguous().to(DEV)      # (mean, 1 / (std + eps)) of the forward
+    out = torch.empty_like(y)
+    npar = L.NormBwdParams(L.view4(y), L.view4(auxd), L.view4(None), L.view4(out), B, Cout, Fd, T, 8, stats.data_ptr(), ws.data_ptr(), 1e-7, 1.0, 0, P)
+    L.call("aid_norm_bwd", npar)
+    torch.cuda.synchronize()
+    coef_ref = ws[B * 8 * P:].view(torch.float32)[:B * 8].clone()
+    out_ref = out.clone()
+    assert bool(torch.isfinite(coef_ref).all()) and float(coef_ref.abs().max()) > 0
+    cnt = torch.zeros(B, device=DEV, dtype=torch.int32)
+    for _ in range(2):
+        ws.fill_(float("nan"))
+        p.fin_mode, p.fin_count, p.fin_eps, p.fin_stats, p.fin_scale = 2, cnt.data_ptr(), 1e-7, stats.data_ptr(), ws.data_ptr() + 8 * B * 8 * P
+        L.call("aid_conv2d", p)
+        npar.coef_ready = 1
+        out.fill_(float("nan"))
+        L.call("aid_norm_bwd", npar)
+        torch.cuda.synchronize()
+        assert torch.equal(ws[B * 8 * P:].view(torch.float32)[:B * 8], coef_ref) and torch.equal(out, out_ref) and int(cnt.abs().sum()) == 0
 
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 16, 256, True), (1, 96, 96, 8, 128, False), (3, 128, 128, 64, 32, True), (2, 256, 256, 16, 64, True), (1, 64, 128, 4, 512, False)])

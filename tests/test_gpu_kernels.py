@@ -196,7 +196,7 @@ WINO_V_CASES = [
     (2, 64, 96, 48, 64, 2, 0, False),        # remainder tile over two residue classes <64, 2, 1>
     (2, 96, 96, 20, 256, 4, 1, True),        # 5 rows per class: the row-shared kernel declines -> 96 x 512 tiles
     (2, 64, 96, 16, 32, 2, 0, False),        # T = 32: no remainder-tile instance -> 96 x 512 tiles
-    # batch 1, few tiles: the split-K instances (two workgroups per tile) when `ws` is given
+    # batch 1, few tiles: the split-K instances (two workgroups per tile) when `ws` is given (T >= 64 tile shapes; T <= 32: the K-group instances)
     (1, 256, 128, 384, 64, 2, 1, True),      # 192 tiles (the first up-path conv of level 5)
     (1, 128, 128, 160, 128, 32, 0, True),    # 160 tiles, <64, 4>
     (1, 256, 256, 448, 32, 64, 1, False),    # <32, 8>
@@ -249,7 +249,10 @@ def test_conv2d_winograd_domain_input(L, case):
     # (3) split-K (batch 1, few tiles): same result up to the order of one addition, deterministic, flags left zero
     need = int(L.lib().aid_conv2d_wino_split_ws_bytes(B, Cin, Cout, Fd, T, dil))
     tiles = B * Fd * T * (Cout // 64) // 256
-    assert (need > 0) == (B == 1 and Cout % 64 == 0 and tiles <= 230 and "wino4r" in L.lib().aid_last_kernel().decode()), (need, L.lib().aid_last_kernel().decode())
+    kern = L.lib().aid_last_kernel().decode()
+    # (launches of at most 256 tiles on the T <= 32 tile shapes take the K-group instance -- eight waves per tile, the K halves summed through LDS -- and need no scratch)
+    assert ("wino4r_ks" in kern) == (Cout % 64 == 0 and T <= 32 and tiles <= 256 and "wino4r" in kern), (kern, tiles)
+    assert (need > 0) == (B == 1 and Cout % 64 == 0 and tiles <= 230 and "wino4r" in kern and "wino4r_ks" not in kern), (need, kern)
     if need:
         ws = torch.zeros(need // 4 + 8, device=DEV)
         ws[need // 4:] = 7.0

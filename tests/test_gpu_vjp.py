@@ -413,7 +413,9 @@ def test_fused_passes_match_the_unfused_schedule_at_full_size():
         xh, g, nrm = net.denoise_guided(x.to(DEV), v(edm.cnoise(s)), v(edm.cin(s)), v(edm.cskip(s)), v(edm.cout(s)), True,
                                         (y * mask).to(DEV), mask.to(DEV))
         st = net._state(2)
-        n_stat = sum(1 for k in st["plan_body"].keep if isinstance(k, L_mod().GroupStatsParams) and k.ws_n > 0)
+        # (statistics from a conv epilogue: folded by aid_group_stats(ws_n) or, with fin_mode = 1, by the last tile of the conv itself)
+        n_stat = sum(1 for k in st["plan_body"].keep if (isinstance(k, L_mod().GroupStatsParams) and k.ws_n > 0)
+                     or (isinstance(k, L_mod().Conv2dParams) and k.stat_n > 0 and k.fin_mode == 1))
         n_nb = sum(1 for k in st["plan_bwd"].keep if isinstance(k, L_mod().NormBwdParams) and k.wout.p)
         res.append((xh.cpu(), g.cpu(), nrm.cpu(), n_stat, n_nb))
         del net

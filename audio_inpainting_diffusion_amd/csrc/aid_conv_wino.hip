@@ -829,8 +829,13 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
     constexpr int NXP = XSZ / 256, NWP = WSZ / 256, NP = NXP + NWP;
     constexpr int PPW = (NP + NW - 1) / NW;
     constexpr int NSTEP = KH;
-    constexpr int ISTEPS = KS == 2 ? 3 : NSTEP;          // steps of a chunk the next chunk's loads are issued in (K groups: one resident workgroup, nothing
-                                                         //  else covers a load that is still in flight at the end of the chunk -- issue them early)
+    // steps of a chunk the next chunk's direct-to-LDS loads are issued in.  F(8,3) (two buffers: the loads of chunk c + 1 must have landed when chunk c ends):
+    // the first three of the five kh steps -- a load issued in the last step is still in flight at the barrier, and only the other resident workgroup
+    // (none at all for the K-group instances) covers that wait.  Measured (tools/isteps_probe.sh, profiles/r04_isteps_probe.txt): 5 / 3 / 2 / 1 steps ->
+    // 16.78 / 16.38 / 16.20 / 16.64 ms per-layer sum at batch 8, 8.94 / 8.60 / 8.79 / 9.12 at batch 4, dominant kernel 0.677 / 0.680 / 0.677 / 0.662 of the peak.
+    // (Also tried there: s_setprio 1 around every 10-MFMA cluster -- 3 % slower -- and for the whole K loop -- neutral; tools/setprio_probe.sh,
+    //  profiles/r04_setprio_probe.txt.  The two resident workgroups are whole tiles out of phase, not role-split waves: there is nothing to arbitrate.)
+    constexpr int ISTEPS = (KS == 2 || WM == 8) ? 3 : NSTEP;
     static_assert(RA >= 1 && RA * NC * TT == S::N_BLK, "tile shape");
     static_assert(WROW % 4 == 0 && GPR % 4 == 0 && NP > (PPW - 1) * NW, "piece bookkeeping");
 

@@ -484,3 +484,8 @@ def test_winograd_form_choice_is_a_function_of_the_launch_shape():
     assert not L.aid_conv2d_wino8_supported(256, 256, 384, 64, 64) and L.aid_conv2d_wino_form(8, 256, 256, 384, 64, 64) == 4     # 6 rows per class
     assert not L.aid_conv2d_wino8_supported(256, 256, 64, 16, 1) and L.aid_conv2d_wino_form(8, 256, 256, 64, 16, 1) == 4         # T = 16: F(4,3) tiles only
     assert L.aid_conv2d_wino_form(8, 2, 64, 64, 1024, 1) == 0 and L.aid_conv2d_wino_form(8, 64, 2, 64, 1024, 1) == 0              # few-channel layers: no Winograd input
+    # fin_mode (the last tile of a sample folds the epilogue partials) is honoured by the row-shared kernels only
+    assert L.aid_conv2d_fin_supported(4, 128, 128, 256, 256, 2, 2) == 1 and L.aid_conv2d_fin_supported(4, 128, 128, 256, 256, 2, 1) == 1
+    assert L.aid_conv2d_fin_supported(2, 96, 96, 20, 256, 4, 1) == 0          # 5 rows per class: the row-shared kernel declines, the 96 x 512 tiles take the launch
+    assert L.aid_conv2d_fin_supported(8, 256, 256, 384, 64, 64, 2) == 0       # no F(8,3) tile for 6 rows per class
+    assert L.aid_conv2d_fin_supported(4, 128, 128, 256, 256, 2, 0) == 0 and L.aid_conv2d_fin_supported(4, 2, 64, 64, 1024, 1, 1) == 0

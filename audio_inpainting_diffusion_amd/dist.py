@@ -114,7 +114,10 @@ def item_seeds(base_seed: int, lo: int, hi: int) -> List[int]:
 
 
 def _active() -> bool:
-    return dist.is_initialized() and dist.get_world_size() > 1
+    """Collectives run whenever a process group with more than one rank exists -- and also in a ONE-rank group on the RCCL backend, which nothing in
+    this package creates (init_distributed is a no-op at world size 1): a caller that built one gets the same device-memory collectives the
+    8-GPU run uses (tests/test_gpu_dist.py::test_rccl_first_contact_world_size_one, the only RCCL contact a 1-GPU box allows)."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or dist.get_backend() == "nccl")
 
 
 def _host_staged(t: torch.Tensor) -> bool:

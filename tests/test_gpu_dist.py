@@ -397,3 +397,53 @@ def test_bench_self_launches_eight_ranks_rank0_only_json():
     ranks = re.findall(r"\[aid dist\] rank (\d+)/8 \(local \d+\): backend (\w+), device (cuda:\d+)", r.stderr)     # (the ranks' lines may interleave)
     assert sorted(int(k[0]) for k in ranks) == list(range(8)), r.stderr[-2000:]
     print("bench --gpus 8 (self-launched):", j["value"], "evals/s;", j["config"]["parallelism"])
+
+
+_RCCL_SCRIPT = r"""
+import json, os, sys, time
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from audio_inpainting_diffusion_amd import dist as D
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl" and D._active()
+from test_gpu_dist import _setup
+net, args, kw = _setup("cuda:0")
+flat = D.flatten_parameters_(net)
+before = flat.clone()
+ptr = flat.data_ptr()
+nbytes = D.broadcast_parameters(net, src=0)
+torch.cuda.synchronize()
+assert flat.data_ptr() == ptr and torch.equal(flat, before) and not D._host_staged(flat)       # in place, on device memory
+big = torch.empty(745 * 1000 * 1000 // 4, dtype=torch.float32, device="cuda:0").normal_()   # the full-size network's flat buffer, by size
+chk = float(big.double().sum())
+dist.broadcast(big, src=0); torch.cuda.synchronize()
+t0 = time.perf_counter(); dist.broadcast(big, src=0); torch.cuda.synchronize(); t_b = time.perf_counter() - t0
+assert float(big.double().sum()) == chk
+out = torch.arange(3 * 4096, dtype=torch.float32, device="cuda:0").reshape(3, 4096)
+g = D.gather_outputs(out, 3)
+assert g.is_cuda and torch.equal(g, out)
+m = D.max_over_ranks(1.25, torch.device("cuda:0"))
+D.barrier(); torch.cuda.synchronize()
+try:
+    ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+except Exception:
+    ver = "?"
+print(json.dumps({"backend": dist.get_backend(), "bcast_bytes": nbytes, "t_bcast_745MB_s": t_b, "max": m, "rccl": ver}))
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_first_contact_world_size_one():
+    """The only RCCL contact a 1-GPU box allows: a ONE-rank `nccl` (= RCCL) process group on cuda:0 running the SAME dist.py collectives the
+    8-GPU job issues -- the in-place flat-buffer weight broadcast (device memory, not host-staged), a 745 MB broadcast by size, the output
+    all-gather, the max-over-ranks all-reduce and the barrier.  Proves RCCL initialises on the box's driver stack (dmabuf IPC mode) and accepts
+    our tensors; says nothing about xGMI rates (BASELINE configs[2])."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "AID_DIST_BACKEND")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT, ROOT], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["backend"] == "nccl" and j["bcast_bytes"] > 0 and j["max"] == 1.25
+    print(f"RCCL {j['rccl']} one-rank group on cuda:0: flat weight broadcast {j['bcast_bytes'] / 1e6:.2f} MB in place, 745 MB broadcast "
+          f"{j['t_bcast_745MB_s'] * 1e3:.1f} ms, all-gather / all-reduce(MAX) / barrier ok")

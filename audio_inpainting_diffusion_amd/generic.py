@@ -62,9 +62,10 @@ class GenericModelAdapter:
         with torch.enable_grad():
             x_hat = self._eval(x, cnoise, cin, cskip, cout, hpf)
             den = mask * x_hat if degradation is None else _OperatorFn.apply(x_hat, degradation)
+            B = x.shape[0]
             if norm_type == "smoothl1":
-                norm = torch.nn.functional.smooth_l1_loss(y, den, reduction="none", beta=beta).sum(dim=1)
+                norm = torch.nn.functional.smooth_l1_loss(y, den, reduction="none", beta=beta).reshape(B, -1).sum(dim=1)
             else:
-                norm = torch.linalg.norm(y - den, dim=1, ord=norm_type)
+                norm = torch.linalg.norm((y - den).reshape(B, -1), dim=1, ord=norm_type)
             g = torch.autograd.grad(outputs=norm.sum(), inputs=x)[0]
         return x_hat.detach(), g.detach().contiguous(), norm.detach()

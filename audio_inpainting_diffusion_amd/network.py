@@ -1370,8 +1370,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
         B, L = x.shape
         x = x.contiguous()
         cnoise, cin, cskip, cout = self._norm_scalars(B, x.device, (cnoise, cin, cskip, cout))
-        if not (y.is_cuda and y.dtype == torch.float32 and y.is_contiguous() and tuple(y.shape) == (B, L)):
-            raise _lib.AidError("denoise_guided: y must be a contiguous float32 GPU tensor of shape [B, L]")
+        if not (y.is_cuda and y.dtype == torch.float32 and y.is_contiguous() and y.shape[0] == B and (degradation is not None or tuple(y.shape) == (B, L))):
+            raise _lib.AidError("denoise_guided: y must be a contiguous float32 GPU tensor of shape [B, L] ([B, ...] with a degradation operator)")
         if (degradation is not None and not getattr(degradation, "shared_mask", False)) or self._n_split(B) == 1:
             st = self._state(B)                                      # (per-item operator masks: one stream)
             if degradation is None and self._graph_ok(B, st):
@@ -1418,9 +1418,16 @@ class Unet_CQT_oct_with_attention(nn.Module):
             _lib.call("aid_guidance_seed", sp)
         else:                                    # g = -A^T d norm(y - A x_hat) / d r   (no mask: the operator is the degradation)
             den = degradation.apply(x_hat)
-            sp = _lib.GuidanceSeedParams(den.data_ptr(), y.data_ptr(), None, 0, g.data_ptr(), norm.data_ptr(), B, L, nk[0], nk[1])
+            Ld = den.numel() // B                # observations may live in another space than x_hat (Sampler.predict_resample: any per-item shape)
+            if not (den.is_cuda and den.dtype == torch.float32 and den.is_contiguous() and den.shape[0] == B and y.numel() == den.numel()):
+                raise _lib.AidError(f"denoise_guided: degradation(x_hat) {tuple(den.shape)} must be a contiguous float32 GPU tensor of the "
+                                    f"observations' shape {tuple(y.shape)}")
+            gd = g if Ld == L else torch.empty_like(den)
+            sp = _lib.GuidanceSeedParams(den.data_ptr(), y.data_ptr(), None, 0, gd.data_ptr(), norm.data_ptr(), B, Ld, nk[0], nk[1])
             _lib.call("aid_guidance_seed", sp)
-            g = degradation.adjoint(g)
+            g = degradation.adjoint(gd.view(den.shape))
+            if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and tuple(g.shape) == (B, L)):
+                raise _lib.AidError("denoise_guided: degradation.adjoint must return a contiguous float32 GPU tensor [B, L]")
         Gh = tr.rfft(g)
         if hpf:
             Gh = tr.spectrum_scale(Gh, tab["hpf"])                       # the projector is self-adjoint

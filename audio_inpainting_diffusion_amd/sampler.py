@@ -44,6 +44,41 @@ def prepare_smooth_mask(mask: torch.Tensor, size: int) -> torch.Tensor:
     return out
 
 
+class LambdaDegradation:
+    """A degradation given as a torch callable (the ``degradation`` lambda of ``Sampler.predict_resample``, :164-173; the reference
+    differentiates ``norm(y - degradation(x_hat))`` through it with torch.autograd, :65-81).  Here the callable and its VJP at x_hat are the
+    only torch-eager pieces of a guided evaluation: ``apply`` evaluates it on a leaf copy of x_hat, ``adjoint`` pulls the analytic seed
+    d norm / d degradation(x_hat) (aid_guidance_seed) back through it -- for a linear operator that is its adjoint, for any other one exactly
+    the Jacobian-transpose product the reference's autograd forms -- and the network's hand-written input-VJP takes over from there.
+    The reference defines no projection for it (``proj_convex_set`` only exists after predict_inpainting / predict_spectrogram_inpainting)."""
+    shared_mask = False                              # (network.denoise_guided: one stream, no graph replay -- the callable is opaque)
+
+    def __init__(self, fn):
+        self.fn = fn
+        self._leaf = self._den = None
+
+    def apply(self, x_hat):
+        with torch.enable_grad():
+            self._leaf = x_hat.detach().requires_grad_(True)
+            self._den = self.fn(self._leaf)
+        if not torch.is_tensor(self._den) or self._den.shape[0] != x_hat.shape[0]:
+            raise _lib.AidError("predict_resample: degradation(x_hat) must return a tensor with the batch axis first")
+        return self._den.detach().float().contiguous()
+
+    def adjoint(self, g):
+        if self._den is None:
+            raise _lib.AidError("LambdaDegradation.adjoint before apply")
+        den, leaf, self._den, self._leaf = self._den, self._leaf, None, None
+        if not den.requires_grad:                    # a degradation that does not depend on x_hat: the reference's autograd.grad raises as well
+            raise RuntimeError("degradation(x_hat) does not depend on x_hat: reconstruction guidance has no gradient")
+        (gx,) = torch.autograd.grad(den, leaf, g.reshape(den.shape).to(den.dtype))
+        return gx.float().contiguous()
+
+    def project(self, x, y):
+        raise AttributeError("proj_convex_set is undefined for predict_resample (the reference defines it in predict_inpainting / "
+                             "predict_spectrogram_inpainting only): set tester.data_consistency.use = False")
+
+
 class Sampler:
     def __init__(self, model, diff_params, args, rid=False):
         self.model = model
@@ -275,6 +310,17 @@ class Sampler:
         self.mask = self.smask = None
         self.spectral = SpectralMask(mask, y.shape[-1], st.n_fft, st.hop_length, st.win_length, st.window, y.device)
         self.y = self.spectral.apply(y) if observed_is_clean else y
+
+    def predict_resample(self, y, shape, degradation):
+        """y[B, ...] = observations, shape = (B, L) of the signal, degradation = torch callable x[B, L] -> y-shaped tensor   (:164-173): reconstruction
+        guidance through an arbitrary degradation (the reference's generic entry point; its inpainting methods are special cases of it)."""
+        if y.dim() == 3 and self.args.tester.posterior_sampling.norm == 1:
+            raise _lib.AidError("predict_resample: norm = 1 over 3-D observations is the induced matrix 1-norm in the reference (:68-75); "
+                                "only the element-wise norms (2, 'smoothl1', or 1 over [B, N] observations) are implemented")
+        self.y = y.contiguous().float()
+        self.mask = self.smask = None
+        self.spectral = LambdaDegradation(degradation)
+        return self.predict(tuple(shape), self.y.device)
 
     def predict_spectrogram_inpainting(self, y_masked, mask):
         """y_masked[B,L], mask[F,T] (or [B,F,T]) over the STFT of tester.spectrogram_inpainting.stft -> [B,L]

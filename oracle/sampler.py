@@ -88,9 +88,9 @@ class OracleSampler:
             if self.filter_hpf:
                 x_hat = self.model.CQTransform.apply_hpf_DC(x_hat)
             if self.norm == "smoothl1":                                                     # (:72-73; 'sum' over the item)
-                norm = torch.nn.functional.smooth_l1_loss(self.y, self.degradation(x_hat), reduction="none", beta=self.smoothl1_beta).sum(dim=1)
-            else:
-                norm = torch.linalg.norm(self.y - self.degradation(x_hat), dim=1, ord=self.norm)   # [B]  (:65,:75)
+                norm = torch.nn.functional.smooth_l1_loss(self.y, self.degradation(x_hat), reduction="none", beta=self.smoothl1_beta).reshape(B, -1).sum(dim=1)
+            else:                                                                           # (:67-70: dim = 1, or (1, 2) for 3-D observations = per item)
+                norm = torch.linalg.norm((self.y - self.degradation(x_hat)).reshape(B, -1), dim=1, ord=self.norm)   # [B]  (:65,:75)
             g = torch.autograd.grad(norm.sum(), x)[0]                                       # per-item grads
             L = self.audio_len if self.audio_len is not None else x.shape[-1]
             normguide = torch.linalg.norm(g, dim=1, keepdim=True) / L ** 0.5                # (:83) per item
@@ -134,6 +134,16 @@ class OracleSampler:
             self.smask = smooth_mask_rows(mask, self.hann_size) if self.smooth else mask
         return self._predict(seeds, record)
 
+    def predict_resample(self, y, shape, degradation, seeds: Optional[List[int]] = None, record: bool = False):
+        """(:164-173) generic entry point: observations y[B, ...], signal shape (B, L), degradation = any differentiable torch callable.
+        No projection exists for it (proj_convex_set is only defined by the two inpainting entry points)."""
+        self.y, self.degradation, self._shape = y, degradation, tuple(shape)
+
+        def no_projection(x):
+            raise AttributeError("proj_convex_set is undefined for predict_resample")
+        self.project = no_projection
+        return self._predict(seeds, record, shape=tuple(shape))
+
     def predict_spectrogram_inpainting(self, y_masked, mask, stft=(1024, 256, 1024), seeds: Optional[List[int]] = None,
                                        record: bool = False):
         """(:348-364) degradation = STFT-domain mask, projection = y + x - A(x)."""
@@ -143,10 +153,11 @@ class OracleSampler:
         self.project = lambda x: self.y + x - self.degradation(x)
         return self._predict(seeds, record)
 
-    def _predict(self, seeds, record):
+    def _predict(self, seeds, record, shape=None):
         y_masked = self.y
         self.trace = [] if record else None
-        shape = y_masked.shape if y_masked is not None else self._shape
+        if shape is None:
+            shape = y_masked.shape if y_masked is not None else self._shape
         rid = getattr(self, "_want_rid", False)
         self._want_rid = False
         if rid:

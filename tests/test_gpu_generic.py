@@ -105,6 +105,69 @@ def test_hip_sampler_guidance_norm_variants_vs_reference(tag):
     assert rel_l2(out.cpu(), z[tag + ".out"]) < 2e-5
 
 
+@pytest.mark.parametrize("tag", ["lpf_s0", "lpf_s1_l1", "clip_s2", "clip_s3_sl1"])
+def test_hip_sampler_predict_resample_vs_reference(tag):
+    """predict_resample (edm_sampler_inpainting.py:164-173) -- guidance through a generic degradation lambda (low-pass + decimate by 2: observations
+    half as long as the signal; a non-linear soft clipper) -- on the HIP loop kernels against the REFERENCE's own trajectories."""
+    from degradations import resample_degradations
+    z = np.load(os.path.join(GOLDEN, "sampler_resample.npz"))
+    L, T = int(z["L"]), int(z["T"])
+    B, kind, seed, which = z[tag + ".meta"]
+    smp = _sampler(L, T, 0.25, **{"data_consistency.use": False, "posterior_sampling.norm": {2: 2, 1: 1, 3: "smoothl1"}[int(kind)],
+                                  "posterior_sampling.smoothl1_beta": 0.02})
+    torch.manual_seed(int(seed))
+    out = smp.predict_resample(torch.from_numpy(z[tag + ".y"]).to(DEV), (int(B), L), resample_degradations(z["k"])[int(which)])
+    e = rel_l2(out.cpu(), z[tag + ".out"])
+    print(f"HIP sampler loop, predict_resample {tag}: {e:.2e} vs the reference trajectory")
+    assert e < 2e-5
+
+
+@pytest.mark.parametrize("which,norm", [(0, 2), (1, 2), (0, "smoothl1")])
+def test_hip_network_predict_resample_vs_oracle(which, norm):
+    """The same entry point on the HIP NETWORK: aid_guidance_seed on the degraded estimate (its own length), the lambda's torch VJP at x_hat, then the
+    hand-written input-VJP of the whole denoiser -- against the oracle's autograd through network and lambda (B = 2, per-item seeds)."""
+    import ast
+    from audio_inpainting_diffusion_amd.config import small_args
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    from audio_inpainting_diffusion_amd.sampler import Sampler
+    from degradations import resample_degradations
+    from oracle.edm import OracleEDM
+    from oracle.nsgt_cqt import OracleCQT
+    from oracle.sampler import OracleSampler
+    from oracle.unet import OracleUnet
+    z = np.load(os.path.join(GOLDEN, "unet_small_a.npz"))
+    kw = ast.literal_eval(str(z["cfg"]))
+    args = small_args(**kw)
+    args.tester.T, args.tester.posterior_sampling.xi = 3, 0.25
+    args.tester.data_consistency.use = False
+    args.tester.posterior_sampling.norm, args.tester.posterior_sampling.smoothl1_beta = norm, 0.02
+    net = Unet_CQT_oct_with_attention(args, torch.device(DEV))
+    seeded_init_(net, int(z["seed"]), gate_scale=10.0, affine_scale=10.0)
+    Ls = kw["audio_len"]
+    deg = resample_degradations(np.load(os.path.join(GOLDEN, "sampler_resample.npz"))["k"])[which]
+    clean = torch.stack([torch.from_numpy(seeded_normal(41, g, Ls)) for g in range(2)]) * 0.063
+    y = deg(clean)
+    smp = Sampler(model=net, diff_params=EDM(args), args=args)
+    smp.seeds = [7, 8]
+    out = smp.predict_resample(y.to(DEV), (2, Ls), deg)
+    cqt = OracleCQT(kw["num_octs"], kw["bins_per_oct"], "oct", ("kaiser", 1), kw["fs"], Ls)
+    orc = OracleUnet(kw["num_octs"], kw["bins_per_oct"], cqt).load_state_dict(net.state_dict())
+    osmp = OracleSampler(orc, OracleEDM(), T=3, xi=0.25, data_consistency=False, audio_len=Ls, norm=norm, smoothl1_beta=0.02)
+    ref = osmp.predict_resample(y, (2, Ls), deg, seeds=[7, 8])
+    e = rel_l2(out.cpu(), ref)
+    print(f"HIP network, predict_resample (degradation {which}, norm {norm}, y {tuple(y.shape)}): rel-L2 vs oracle = {e:.2e}")
+    assert e < 5e-4
+
+
+def test_predict_resample_has_no_projection_like_the_reference():
+    """data_consistency.use with predict_resample: the reference has no proj_convex_set there (AttributeError at the first evaluation)."""
+    smp = _sampler(2048, 2, 0.25)
+    with pytest.raises(AttributeError):
+        smp.predict_resample(torch.zeros(1, 2048, device=DEV), (1, 2048), lambda x: x)
+
+
 def test_hip_sampler_rid_buffers_vs_reference():
     z = np.load(os.path.join(GOLDEN, "sampler_rid.npz"))
     L, T = int(z["L"]), int(z["T"])

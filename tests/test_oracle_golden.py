@@ -154,6 +154,27 @@ def test_sampler_guidance_norm_variants_match_reference(tag):
     assert rel_l2(out, z[tag + ".out"]) < 1e-5
 
 
+@pytest.mark.parametrize("tag", ["lpf_s0", "lpf_s1_l1", "clip_s2", "clip_s3_sl1"])
+def test_predict_resample_generic_degradation_matches_reference(tag):
+    """predict_resample (edm_sampler_inpainting.py:164-173): guidance through a generic degradation lambda -- a low-pass + decimate-by-2
+    (observations half as long as the signal) and a non-linear soft clipper -- against the reference's own trajectories."""
+    from degradations import resample_degradations
+    z = np.load(os.path.join(GOLDEN, "sampler_resample.npz"))
+    L, T = int(z["L"]), int(z["T"])
+    B, kind, seed, which = z[tag + ".meta"]
+    s = OracleSampler(_Toy(L), OracleEDM(), T=T, xi=0.25, data_consistency=False, audio_len=L, norm={2: 2, 1: 1, 3: "smoothl1"}[int(kind)], smoothl1_beta=0.02)
+    torch.manual_seed(int(seed))
+    out = s.predict_resample(torch.from_numpy(z[tag + ".y"]), (int(B), L), resample_degradations(z["k"])[int(which)])
+    assert rel_l2(out, z[tag + ".out"]) < 1e-5
+
+
+def test_predict_resample_has_no_projection_like_the_reference():
+    L = 2048
+    s = OracleSampler(_Toy(L), OracleEDM(), T=2, xi=0.25, data_consistency=True, audio_len=L)
+    with pytest.raises(AttributeError):
+        s.predict_resample(torch.zeros(1, L), (1, L), lambda x: x)
+
+
 def test_replacement_branch_without_projection_raises_like_the_reference():
     L = 2048
     s = OracleSampler(_Toy(L), OracleEDM(), T=2, xi=0.0, data_consistency=False, audio_len=L)

@@ -96,6 +96,7 @@ class Sampler:
         self.nb_steps = self.args.tester.T
         self.rid = rid                              # True: predict_* return the reference's 8-tuple of per-step buffers (:185-191, :260)
         self.spectral = None
+        self.y = self.mask = self.smask = self.degradation = None      # installed by predict_* / setup_*
         self.seeds: Optional[List[int]] = None      # per-item RNG seeds; None -> global torch CPU generator
         self.trace = None                           # set to [] to record every projected x_hat (tests)
         self.trace_in = None                        # set to [] to record (x, t) handed to every denoiser evaluation (teacher-forced tests)
@@ -214,7 +215,7 @@ class Sampler:
 
     # ---------------------------------------------------------------------------------------------------
     def predict_unconditional(self, shape, device):
-        self.y = None
+        self.y = self.degradation = None
         self.mask = self.smask = self.spectral = None
         return self.predict(shape, device)
 
@@ -293,6 +294,7 @@ class Sampler:
             raise ValueError(f"mask {tuple(mask.shape)} does not match observations {tuple(y_masked.shape)}")
         self.spectral = None
         self.smask = None
+        self.degradation = self.apply_mask                            # (:335)
         if self.data_consistency or self.data_consistency_end:
             sm = prepare_smooth_mask(mask, self.args.tester.data_consistency.hann_size) if self.smooth else mask
             self.smask = sm.to(dev, torch.float32).contiguous()
@@ -310,6 +312,7 @@ class Sampler:
         self.mask = self.smask = None
         self.spectral = SpectralMask(mask, y.shape[-1], st.n_fft, st.hop_length, st.win_length, st.window, y.device)
         self.y = self.spectral.apply(y) if observed_is_clean else y
+        self.degradation = self.apply_spectral_mask                   # (:359)
 
     def predict_resample(self, y, shape, degradation):
         """y[B, ...] = observations, shape = (B, L) of the signal, degradation = torch callable x[B, L] -> y-shaped tensor   (:164-173): reconstruction
@@ -320,7 +323,73 @@ class Sampler:
         self.y = y.contiguous().float()
         self.mask = self.smask = None
         self.spectral = LambdaDegradation(degradation)
+        self.degradation = degradation
         return self.predict(tuple(shape), self.y.device)
+
+    # ---- the remaining public methods of the reference class (its testers never call them; kept so that code written against
+    # ---- testing.edm_sampler_inpainting.Sampler finds every name).  They run outside the sampling loop. ------------------------------
+    def apply_mask(self, x, mask=None):
+        """mask * x   (:264-269)"""
+        m = self.mask if mask is None else mask
+        return m.to(x.device, x.dtype) * x
+
+    def apply_spectral_mask(self, x):
+        """STFT -> mask -> inverse STFT of the installed spectrogram mask (:271-292), on the HIP STFT kernels (stft.SpectralMask)."""
+        if not isinstance(self.spectral, SpectralMask):
+            raise AttributeError("apply_spectral_mask: no spectrogram mask installed (predict_spectrogram_inpainting / setup_spectrogram_inpainting)")
+        return self.spectral.apply(x.contiguous().float())
+
+    def prepare_smooth_mask(self, mask, size=10):
+        """(:302-325) as a method, like the reference's"""
+        return prepare_smooth_mask(mask if mask.dim() > 1 else mask.reshape(1, -1), size)
+
+    def proj_convex_set(self, x):
+        """The data-consistency projection installed by predict_inpainting (:343) / predict_spectrogram_inpainting (:360); AttributeError when
+        none was (the reference's attribute does not exist then)."""
+        if self.y is None or not (self.data_consistency or self.data_consistency_end):
+            raise AttributeError("proj_convex_set is undefined: needs observations and tester.data_consistency.use")
+        x = x.detach().contiguous().float()
+        return self._project(x) if self.spectral is None else self.spectral.project(x, self.y)
+
+    def get_score(self, x, y, t_i, degradation=None):
+        """ONE evaluation of the score (x_hat - x) / t_i^2 exactly as the loop forms it (:115-153): unconditional for y None (DC/Nyquist projector
+        only), reconstruction guidance for xi > 0, replacement + projection for xi == 0.  ``y`` / ``degradation`` other than the installed ones are
+        installed for this call (a callable degradation goes through LambdaDegradation).  With rid=True the guided branch returns the reference's
+        5-tuple (score, denoised estimate, s * rec_grads, estimate after the guidance step, estimate after the projection; :106-108)."""
+        t = torch.as_tensor(t_i, dtype=torch.float32).detach().reshape(()).cpu()
+        x = x.detach().contiguous().float()
+        B, L = x.shape
+        saved = (self.y, self.mask, self.smask, self.spectral, self.degradation)
+        try:
+            if y is None:
+                if degradation is not None:
+                    raise AssertionError("unconditional sampling takes no degradation (:117)")
+                self.y = None
+            else:
+                if y is not saved[0]:
+                    self.y = y.contiguous().float()
+                if callable(degradation) and degradation != saved[4] and degradation is not saved[3]:      # (bound methods compare by ==)
+                    self.mask = self.smask = None
+                    self.spectral, self.degradation = LambdaDegradation(degradation), degradation
+            x_hat = self._denoise(x, t)
+            keep, self.rid = self.rid, bool(self.rid and self.y is not None and self.xi > 0)
+            try:
+                _, d = self._score_step(x, x_hat, t, 0.0, mode=0)          # projection by the loop's rule (raises like the reference when undefined), d = -t * score
+            finally:
+                self.rid = keep
+            score = torch.empty_like(x)
+            _lib.call("aid_axpby", _lib.AxpbyParams(d.data_ptr(), d.data_ptr(), score.data_ptr(), None, None, B, L, -1.0 / float(t), 0.0))
+            if self.rid and self.y is not None and self.xi > 0:
+                return (score,) + tuple(self._rid_last) + (self._rid_pocs,)
+            return score
+        finally:
+            self.y, self.mask, self.smask, self.spectral, self.degradation = saved
+
+    def get_score_rec_guidance(self, x, y, t_i, degradation=None):
+        """(:57-113) the guided evaluation on its own; needs xi > 0 like the branch that calls it in the reference (:129-131)."""
+        if y is None or not self.xi > 0:
+            raise _lib.AidError("get_score_rec_guidance needs observations and xi > 0")
+        return self.get_score(x, y, t_i, degradation)
 
     def predict_spectrogram_inpainting(self, y_masked, mask):
         """y_masked[B,L], mask[F,T] (or [B,F,T]) over the STFT of tester.spectrogram_inpainting.stft -> [B,L]

@@ -168,6 +168,50 @@ def test_predict_resample_has_no_projection_like_the_reference():
         smp.predict_resample(torch.zeros(1, 2048, device=DEV), (1, 2048), lambda x: x)
 
 
+@pytest.mark.parametrize("mode", ["guided", "guided_rid", "replacement", "uncond", "lambda"])
+def test_get_score_single_evaluation_vs_oracle(mode):
+    """Sampler.get_score / get_score_rec_guidance (edm_sampler_inpainting.py:57-153) as stand-alone calls: one evaluation of the score on every branch,
+    against the oracle's get_score (itself pinned by the reference trajectories); rid=True returns the reference's 5-tuple (:106-108)."""
+    from oracle.edm import OracleEDM
+    from oracle.sampler import OracleSampler, smooth_mask_rows
+    from test_oracle_golden import _Toy
+    L, t = 2048, 1.7
+    xi = 0.0 if mode == "replacement" else 0.25
+    smp = _sampler(L, 3, xi, _rid=(mode == "guided_rid"), **({"data_consistency.use": False} if mode == "lambda" else {}))
+    g = torch.Generator().manual_seed(11)
+    y, x = torch.randn(1, L, generator=g) * 0.063, torch.randn(1, L, generator=g) * 1.5
+    mask = torch.ones(1, L)
+    mask[:, 600:900] = 0
+    osmp = OracleSampler(_Toy(L), OracleEDM(), T=3, xi=xi, hann_size=20, audio_len=L, data_consistency=(mode != "lambda"))
+    if mode == "lambda":
+        deg = lambda v: 0.05 * torch.tanh(v / 0.05)
+        out = smp.get_score(x.to(DEV), deg(y).to(DEV), torch.tensor(t), deg)
+        osmp.y, osmp.degradation = deg(y), deg
+        ref = osmp.get_score(x, torch.tensor(t))
+        assert smp.y is None and smp.spectral is None                       # the call installed its operator for its own duration only
+    else:
+        smp.setup_inpainting((y * mask).to(DEV), mask.to(DEV))
+        osmp.y, osmp.mask, osmp.smask = (y * mask if mode != "uncond" else None), mask, smooth_mask_rows(mask, 20)
+        if mode == "uncond":
+            out = smp.get_score(x.to(DEV), None, torch.tensor(t), None)
+        elif mode == "replacement":
+            out = smp.get_score(x.to(DEV), smp.y, torch.tensor(t), smp.degradation)
+        else:
+            out = smp.get_score_rec_guidance(x.to(DEV), smp.y, torch.tensor(t), smp.degradation)
+        ref = osmp.get_score(x, torch.tensor(t))
+        assert smp.y is not None and smp.mask is not None                   # installed state untouched
+    if mode == "guided_rid":
+        assert isinstance(out, tuple) and len(out) == 5
+        for name, a, b in zip(("score", "denoised", "s*grads", "after guidance", "after projection"), out, (ref,) + tuple(osmp._rid_last) + (osmp._rid_pocs,)):
+            assert rel_l2(a.cpu(), b) < 2e-5, name
+        out = out[0]
+    e = rel_l2(out.cpu(), ref)
+    print(f"get_score [{mode}]: rel-L2 vs oracle = {e:.2e}")
+    assert e < 2e-5
+    assert torch.equal(smp.apply_mask(x.to(DEV), mask.to(DEV)).cpu(), mask * x)
+    assert torch.equal(smp.prepare_smooth_mask(mask, 20), smooth_mask_rows(mask, 20))
+
+
 def test_hip_sampler_rid_buffers_vs_reference():
     z = np.load(os.path.join(GOLDEN, "sampler_rid.npz"))
     L, T = int(z["L"]), int(z["T"])

@@ -15,6 +15,41 @@ from __future__ import annotations
 import torch
 
 
+class _FirFn(torch.autograd.Function):
+    """training.FirFilter (aid_resample_poly at ratio 1:1) with its exact adjoint as the backward."""
+
+    @staticmethod
+    def forward(ctx, x, fir):
+        ctx.fir = fir
+        return fir.apply(x.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.fir.adjoint(g.contiguous()), None
+
+
+class AWeighting:
+    """The reference's ``FIRFilter(filter_type="aw")`` (utils/training_utils.py:55-137) as the EDM loss uses it: A-weighting taps
+    (training.a_weighting_taps, golden-pinned against the reference's) applied along time on the HIP FIR kernel, differentiable.
+    GPU rows only -- like every operator of this package it has no CPU path."""
+
+    def __init__(self, fs, ntaps):
+        from .training import a_weighting_taps
+        self.taps = a_weighting_taps(fs, ntaps)
+        self._fir = {}
+
+    def __call__(self, err):
+        from . import _lib
+        from .training import FirFilter
+        if not err.is_cuda:
+            raise _lib.AidError("AWeighting runs on the GPU only (no CPU fallback)")
+        fir = self._fir.get(err.device)
+        if fir is None:
+            fir = self._fir[err.device] = FirFilter(self.taps, err.device)
+        shape = err.shape
+        return _FirFn.apply(err.reshape(-1, shape[-1]).contiguous().float(), fir).reshape(shape)
+
+
 class EDM:
     def __init__(self, args):
         self.args = args
@@ -24,8 +59,9 @@ class EDM:
         self.ro, self.ro_train = dp.ro, dp.ro_train
         self.sigma_data = dp.sigma_data
         self.Schurn, self.Stmin, self.Stmax, self.Snoise = dp.Schurn, dp.Stmin, dp.Stmax, dp.Snoise
-        if dp.aweighting.use_aweighting:
-            raise NotImplementedError("A-weighted training loss is outside the sampling hot path")
+        self.AW = None
+        if dp.aweighting.use_aweighting:              # perceptual error filter (edm.py:33-34, applied at :189-190)
+            self.AW = AWeighting(args.exp.sample_rate, dp.aweighting.ntaps)
 
     def get_gamma(self, t):
         N = t.shape[0]
@@ -63,7 +99,17 @@ class EDM:
             sigma = sigma.unsqueeze(-1)
         return self.cskip(sigma) * xn + self.cout(sigma) * net(self.cin(sigma) * xn, self.cnoise(sigma))
 
-    # ---- training (edm.py:76-85, :150-193) ----------------------------------------------------------------------------------
+    def lambda_w(self, sigma):
+        """Karras et al.'s loss weight 1 / c_out(sigma)^2 (edm.py:130-131; the reference defines it and never calls it)."""
+        return (self.sigma_data ** 2 + sigma ** 2) / (sigma * self.sigma_data) ** 2
+
+    # ---- training (edm.py:67-85, :150-193) ----------------------------------------------------------------------------------
+    def sample_ptrain(self, N):
+        """Log-normal noise levels exp(N(P_mean, P_std^2)) clipped to [sigma_min, sigma_max] (edm.py:67-75, numpy's global generator as there;
+        'not used' by the reference's own training, which draws sample_ptrain_safe)."""
+        import numpy as np
+        return np.clip(np.exp(self.P_mean + self.P_std * np.random.randn(N)), self.sigma_min, self.sigma_max)
+
     def sample_ptrain_safe(self, N):
         a = torch.rand(N)
         return (self.sigma_max ** (1 / self.ro_train) + a * (self.sigma_min ** (1 / self.ro_train) - self.sigma_max ** (1 / self.ro_train))) ** self.ro_train
@@ -84,4 +130,6 @@ class EDM:
                 error = net.CQTransform.apply_hpf_DC(error)
         except Exception:
             pass
+        if self.AW is not None:                # (:189-190)
+            error = self.AW(error)
         return error ** 2, sigma

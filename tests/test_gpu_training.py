@@ -388,3 +388,43 @@ def test_accumulation_rounds_and_a_weighted_loss_vs_oracle_loop():
     den = math.sqrt(sum(float(params[i].detach().norm()) ** 2 for i in range(len(keys))))
     print(f"parameters after 3 iterations x 2 rounds, A-weighted loss: rel-L2 vs oracle loop = {num / den:.2e}")
     assert num / den < 1e-4
+
+
+def test_edm_mirror_a_weighted_loss_vs_reference_filter_golden():
+    """EDM(args) with diff_params.aweighting.use_aweighting (edm.py:33-34, :189-190): the mirror's ``AW`` is the reference's FIRFilter("aw") on the HIP FIR
+    kernel -- output against the reference's own filter output (tests/golden/aweighting.npz), gradient against torch's conv1d, and ``loss_fn`` applies it."""
+    from audio_inpainting_diffusion_amd import _lib
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.edm import EDM
+    z = np.load(os.path.join(GOLDEN, "aweighting.npz"))
+    args = make_args(audio_len=4096, T=2, xi=0.0)
+    args.diff_params.aweighting.use_aweighting, args.diff_params.aweighting.ntaps = True, 101
+    assert args.exp.sample_rate == 22050
+    edm = EDM(args)
+    x = torch.from_numpy(z["x"]).to(DEV).requires_grad_()
+    y = edm.AW(x)
+    assert rel_l2(y.detach().cpu(), z["y22050"]) < 1e-6
+    w = torch.randn(y.shape, generator=torch.Generator().manual_seed(2)).to(DEV)
+    (gx,) = torch.autograd.grad((y * w).sum(), x)
+    xc = torch.from_numpy(z["x"]).requires_grad_()
+    yc = torch.nn.functional.conv1d(xc.unsqueeze(1), torch.from_numpy(z["taps22050"]).view(1, 1, -1), padding=50).squeeze(1)
+    (gc,) = torch.autograd.grad((yc * w.cpu()).sum(), xc)
+    assert rel_l2(gx.cpu(), gc) < 1e-6
+    with pytest.raises(_lib.AidError):
+        edm.AW(torch.zeros(1, 4096))
+
+    class _Net(torch.nn.Module):                       # loss_fn with a trivial net: error = net(inp) - target, filtered, squared
+        def forward(self, inp, cnoise):
+            return 0.5 * inp
+    torch.manual_seed(4)
+    audio = torch.from_numpy(z["x"]).to(DEV) * 0.063
+    err2, sigma = edm.loss_fn(_Net(), audio)
+    torch.manual_seed(4)
+    plain = EDM(make_args(audio_len=4096, T=2, xi=0.0))
+    s2 = plain.sample_ptrain_safe(audio.shape[0]).unsqueeze(-1).to(DEV)
+    inp, target, _ = plain.prepare_train_preconditioning(audio, s2)
+    err = (0.5 * inp - target).cpu()
+    ref = torch.nn.functional.conv1d(err.unsqueeze(1), torch.from_numpy(z["taps22050"]).view(1, 1, -1), padding=50).squeeze(1) ** 2
+    assert torch.equal(sigma, s2) and rel_l2(err2.cpu(), ref) < 1e-5
+    assert abs(float(edm.lambda_w(torch.tensor(0.7))) * float(plain.cout(torch.tensor(0.7)) ** 2) - 1) < 1e-5
+    assert edm.sample_ptrain(5).shape == (5,) and float(edm.sample_ptrain(100).min()) >= edm.sigma_min

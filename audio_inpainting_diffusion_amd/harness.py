@@ -147,13 +147,7 @@ def resample(x: torch.Tensor, orig_freq: int, new_freq: int) -> torch.Tensor:
     return y
 
 
-def resample_batch(audio: torch.Tensor, fs, fs_target: int, length_target: int) -> torch.Tensor:
-    """resample_batch (utils/training_utils.py:140-212) for a batch recorded at one sampling rate ``fs`` (scalar or [B] tensor of
-    equal values; the reference's mixed-rate branches return after their first item and are not reproduced)."""
-    f = fs.reshape(-1) if torch.is_tensor(fs) else torch.tensor([fs])
-    if not bool((f == f[0]).all()):
-        raise NotImplementedError("mixed sampling rates in one batch")
-    f = int(f[0])
+def _resample_one_rate(audio, f: int, fs_target: int, length_target: int) -> torch.Tensor:
     if fs_target == 22050 and f == 44100:
         return resample(audio, 2, 1)[:, :length_target]
     if fs_target == 22050 and f == 48000:
@@ -163,6 +157,23 @@ def resample_batch(audio: torch.Tensor, fs, fs_target: int, length_target: int) 
     if fs_target == 44100 and f == 48000:
         return resample(audio, 160, 147)[:, :length_target]
     return resample(audio, f, fs_target)[:, :length_target]
+
+
+def resample_batch(audio: torch.Tensor, fs, fs_target: int, length_target: int) -> torch.Tensor:
+    """resample_batch (utils/training_utils.py:140-212).  ``fs``: scalar or [B] tensor.  One rate for the whole batch: one batched polyphase launch.
+    Mixed rates (the reference's per-item loops, :156-167 / :177-188 / :199-210): one launch per distinct rate, rows written in place -- the reference's
+    loops ``return`` inside their first iteration, so only ITEM 0 of its result is filled; item 0 here equals it, the other items are resampled too."""
+    f = fs.reshape(-1) if torch.is_tensor(fs) else torch.tensor([fs])
+    if bool((f == f[0]).all()):
+        return _resample_one_rate(audio, int(f[0]), fs_target, length_target)
+    if f.numel() != audio.shape[0]:
+        raise ValueError(f"fs has {f.numel()} entries for a batch of {audio.shape[0]}")
+    out = torch.zeros(audio.shape[0], length_target, device=audio.device, dtype=torch.float32)
+    for rate in sorted(set(int(v) for v in f.tolist())):
+        rows = torch.nonzero(f.cpu() == rate).reshape(-1).to(audio.device)
+        y = _resample_one_rate(audio.index_select(0, rows), rate, fs_target, length_target)
+        out[rows, :y.shape[1]] = y
+    return out
 
 
 def write_audio_file(x: torch.Tensor, sr: int, string: str, path: str = "tmp") -> str:

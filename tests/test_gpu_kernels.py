@@ -653,6 +653,10 @@ def test_polyphase_resampler_vs_oracle(L, ratio):
         assert out.shape == (2, 65536) and rel_l2(out, O.resample_batch(a.double(), 44100, 22050, 65536)) < 2e-6
         out = resample_batch(a.to(DEV), torch.tensor([48000, 48000]), 22050, 65536).cpu()
         assert rel_l2(out, O.resample_batch(a.double(), 48000, 22050, 65536)) < 2e-6
+        # mixed rates in one batch (training_utils.py:156-167): every row at its own rate (the reference fills item 0 only)
+        mix = resample_batch(a.to(DEV), torch.tensor([48000, 44100]), 22050, 65536).cpu()
+        assert rel_l2(mix[0:1], O.resample_batch(a[0:1].double(), 48000, 22050, 65536)) < 2e-6
+        assert rel_l2(mix[1:2], O.resample_batch(a[1:2].double(), 44100, 22050, 65536)) < 2e-6
 
 
 WGRAD_CASES = [

@@ -489,3 +489,32 @@ def test_winograd_form_choice_is_a_function_of_the_launch_shape():
     assert L.aid_conv2d_fin_supported(2, 96, 96, 20, 256, 4, 1) == 0          # 5 rows per class: the row-shared kernel declines, the 96 x 512 tiles take the launch
     assert L.aid_conv2d_fin_supported(8, 256, 256, 384, 64, 64, 2) == 0       # no F(8,3) tile for 6 rows per class
     assert L.aid_conv2d_fin_supported(4, 128, 128, 256, 256, 2, 0) == 0 and L.aid_conv2d_fin_supported(4, 2, 64, 64, 1024, 1, 1) == 0
+
+
+def test_lambda_degradation_is_the_jacobian_transpose_product_at_x_hat():
+    """sampler.LambdaDegradation (Sampler.predict_resample, edm_sampler_inpainting.py:164-173): apply = the callable on a detached copy, adjoint = its VJP at the
+    same point -- what the reference's torch.autograd.grad forms through `degradation(x_hat)` (:65-81) -- for a linear operator that changes the length and for a
+    non-linear one; a second adjoint without an apply is refused, a constant degradation has no gradient."""
+    from audio_inpainting_diffusion_amd._lib import AidError
+    from audio_inpainting_diffusion_amd.sampler import LambdaDegradation
+    from degradations import resample_degradations
+    g0 = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 512, generator=g0)
+    for which in (0, 1):
+        fn = resample_degradations([0.1, 0.2, 0.4, 0.2, 0.1])[which]
+        op = LambdaDegradation(fn)
+        den = op.apply(x)
+        assert not den.requires_grad and torch.equal(den, fn(x))
+        seed = torch.randn(den.shape, generator=g0)
+        got = op.adjoint(seed)
+        xl = x.clone().requires_grad_()
+        (ref,) = torch.autograd.grad(fn(xl), xl, seed)
+        assert got.shape == x.shape and torch.allclose(got, ref, rtol=0, atol=1e-7)
+        with pytest.raises(AidError):
+            op.adjoint(seed)
+    op = LambdaDegradation(lambda v: torch.zeros_like(v))
+    op.apply(x)
+    with pytest.raises(RuntimeError):
+        op.adjoint(torch.ones(2, 512))
+    with pytest.raises(AttributeError):
+        op.project(x, x)

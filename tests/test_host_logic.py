@@ -518,3 +518,24 @@ def test_lambda_degradation_is_the_jacobian_transpose_product_at_x_hat():
         op.adjoint(torch.ones(2, 512))
     with pytest.raises(AttributeError):
         op.project(x, x)
+
+
+def test_sampler_and_edm_expose_the_reference_classes_method_names():
+    """Every method of testing/edm_sampler_inpainting.Sampler (:8-364) and diff_params/edm.EDM (:7-193) exists under the same name with the same
+    positional parameters (the names are the reference's API, listed here; the mirrors' behaviour is pinned by the golden / GPU tests)."""
+    import inspect
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.sampler import Sampler
+    sampler_api = {"__init__": ["model", "diff_params", "args", "rid"], "update_diff_params": [], "get_score_rec_guidance": ["x", "y", "t_i", "degradation"],
+                   "get_score": ["x", "y", "t_i", "degradation"], "predict_unconditional": ["shape", "device"], "predict_resample": ["y", "shape", "degradation"],
+                   "predict": ["shape", "device"], "apply_mask": ["x", "mask"], "apply_spectral_mask": ["x"], "prepare_smooth_mask": ["mask", "size"],
+                   "predict_inpainting": ["y_masked", "mask"], "predict_spectrogram_inpainting": ["y_masked", "mask"]}
+    edm_api = {"__init__": ["args"], "get_gamma": ["t"], "create_schedule": ["nb_steps"], "sample_ptrain": ["N"], "sample_ptrain_safe": ["N"],
+               "sample_prior": ["shape", "sigma"], "cskip": ["sigma"], "cout": ["sigma"], "cin": ["sigma"], "cnoise": ["sigma"], "lambda_w": ["sigma"],
+               "denoiser": ["xn", "net", "sigma"], "prepare_train_preconditioning": ["x", "sigma"], "loss_fn": ["net", "x"]}
+    for cls, api in ((Sampler, sampler_api), (EDM, edm_api)):
+        for name, params in api.items():
+            fn = getattr(cls, name, None)
+            assert callable(fn), f"{cls.__name__}.{name} is missing"
+            got = [p for p in inspect.signature(fn).parameters if p != "self"]
+            assert got[:len(params)] == params, (cls.__name__, name, got)

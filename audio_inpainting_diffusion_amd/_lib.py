@@ -57,6 +57,11 @@ class Conv2dParams(C.Structure):
                 ("fin_eps", C.c_float), ("fin_scale", C.c_void_p), ("fin_stats", C.c_void_p)]
 
 
+class Wino2dGemmParams(C.Structure):
+    _fields_ = [("U", C.c_void_p), ("V", C.c_void_p), ("M", C.c_void_p), ("nxi", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+                ("Cin_pad", C.c_int), ("Cout_pad", C.c_int), ("N", C.c_int64), ("variant", C.c_int)]
+
+
 class ResampleParams(C.Structure):
     _fields_ = [("x", View), ("y", View), ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int),
                 ("up", C.c_int), ("adjoint", C.c_int), ("accumulate", C.c_int)]
@@ -118,7 +123,7 @@ class Add2Params(C.Structure):
 
 class ScaleActParams(C.Structure):
     _fields_ = [("x", View), ("y", View), ("scale", C.c_void_p), ("scale_ld", C.c_int64),
-                ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("act", C.c_int), ("wino", C.c_int)]
+                ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("act", C.c_int), ("wino", C.c_int), ("dilF", C.c_int)]
 
 
 class FftPassParams(C.Structure):
@@ -194,7 +199,7 @@ class PackConvWeightParams(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("wpT", C.c_void_p), ("wpw", C.c_void_p), ("wpwT", C.c_void_p),
                 ("Cout", C.c_int), ("Cin", C.c_int), ("KH", C.c_int), ("KW", C.c_int),
                 ("Cin_pad", C.c_int), ("Cout_pad", C.c_int), ("Cin_padT", C.c_int), ("Cout_padT", C.c_int),
-                ("wpw8", C.c_void_p), ("wpw8T", C.c_void_p)]
+                ("wpw8", C.c_void_p), ("wpw8T", C.c_void_p), ("wpw2", C.c_void_p), ("wpw2T", C.c_void_p)]
 
 
 class WgradReduceParams(C.Structure):
@@ -253,7 +258,7 @@ EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_st
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_guidance_step", "aid_set_rows", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
            "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino8_supported", "aid_conv2d_wino_split_ws_bytes", "aid_conv2d_wino8_sk_ws_bytes", "aid_conv2d_fin_supported",
            "aid_conv2d_wgrad", "aid_wgrad_reduce", "aid_channel_dot", "aid_relpos_bwd", "aid_scale_bwd", "aid_modulation_bwd", "aid_embed_bwd",
-           "aid_adam", "aid_ema", "aid_sumsq"]
+           "aid_adam", "aid_ema", "aid_sumsq", "aid_wino2d_gemm", "aid_conv2d_wino2d_supported", "aid_conv2d_wino2d_positions", "aid_conv2d_wino2d_wanted"]
 
 _lib = None
 
@@ -298,12 +303,18 @@ def lib():
         L.aid_conv2d_stat_partials.restype = C.c_int
         L.aid_conv2d_wgrad_tiles.argtypes = [C.c_int] * 5
         L.aid_conv2d_wgrad_tiles.restype = C.c_int
+        L.aid_conv2d_wino2d_supported.argtypes = [C.c_int] * 5
+        L.aid_conv2d_wino2d_supported.restype = C.c_int
+        L.aid_conv2d_wino2d_wanted.argtypes = [C.c_int] * 6
+        L.aid_conv2d_wino2d_wanted.restype = C.c_int
+        L.aid_conv2d_wino2d_positions.argtypes = [C.c_int] * 4
+        L.aid_conv2d_wino2d_positions.restype = C.c_int64
         for name in EXPORTS[3:]:
             if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino8_supported", "aid_conv2d_wino_split_ws_bytes", "aid_conv2d_wino8_sk_ws_bytes", "aid_conv2d_fin_supported",
-                            "aid_conv2d_stat_partials", "aid_conv2d_wgrad_tiles"):
+                            "aid_conv2d_stat_partials", "aid_conv2d_wgrad_tiles", "aid_conv2d_wino2d_supported", "aid_conv2d_wino2d_positions", "aid_conv2d_wino2d_wanted"):
                 getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, name).restype = C.c_int
-        if L.aid_abi_version() != 11:
+        if L.aid_abi_version() != 12:
             raise AidError("ABI version mismatch")
         _lib = L
     return _lib
@@ -406,6 +417,45 @@ def wino8_matrices():
     BT = BT / sc[:, None]
     BT[np.abs(BT) < 1e-13] = 0.0
     return AT, G * sc[:, None], BT
+
+
+def wino45_matrices():
+    """(AF^T [4,8], GF [8,5], BF^T [8,8], AT^T [4,6], GT [6,3], BT^T [6,6]) of the 2-D form F(4,5) x F(4,3) as the kernels use them (float64; same
+    construction as tools/gen_wino45.py, which writes csrc/aid_wino45.h): row-axis points {0, +-1, +-2, +-1/2, inf}, T-axis {0, +-1, +-2, inf}."""
+    import numpy as np
+
+    def toom(points, m, r):
+        n = m + r - 1
+        pts = np.array([0.0] + [sg * a for a in points for sg in (1, -1)], dtype=np.float64)
+
+        def vander(cols):
+            V = np.zeros((n, cols))
+            for j in range(n - 1):
+                V[j] = pts[j] ** np.arange(cols)
+            V[n - 1, cols - 1] = 1.0
+            return V
+        AT, G, BT = vander(m).T, vander(r), np.linalg.inv(vander(n)).T
+        sc = np.abs(BT).max(axis=1)
+        BT = BT / sc[:, None]
+        BT[np.abs(BT) < 1e-13] = 0.0
+        return AT, G * sc[:, None], BT
+    return toom((1.0, 2.0, 0.5), 4, 5) + toom((1.0, 2.0), 4, 3)
+
+
+def pack_conv_weight_wino2d(w: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+    """[Cout,Cin,5,3] -> 2-D Winograd pack [48, Cin_pad, Cout_pad]: U[xf*6 + xt] = GF w GT^T (float64, stored fp32)."""
+    w = w.detach().double()
+    if transpose:
+        w = w.flip(2, 3).permute(1, 0, 2, 3)
+    co, ci, kh, kw = w.shape
+    assert (kh, kw) == (5, 3)
+    m = wino45_matrices()
+    GF, GT = torch.from_numpy(m[1]).to(w.device), torch.from_numpy(m[4]).to(w.device)
+    U = torch.einsum("fh,tk,oihk->ftio", GF, GT, w).reshape(48, ci, co)
+    cip, cop = pack_dims(ci, co)
+    out = torch.zeros(48, cip, cop, device=w.device, dtype=torch.float32)
+    out[:, :ci, :co] = U.float()
+    return out
 
 
 def pack_conv_weight_wino8(w: torch.Tensor, transpose: bool = False) -> torch.Tensor:

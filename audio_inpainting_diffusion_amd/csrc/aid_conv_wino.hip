@@ -1864,6 +1864,7 @@ extern "C" int aid_conv2d_wino_form(int B, int Cin, int Cout, int F, int T, int 
 }
 
 extern "C" int aid_conv2d_fin_supported(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino) {
+    if (x_wino == 3) return 0;                                         // (the output pass writes plain partials; the fold kernels run)
     if (B < 1 || (Cout % 8) || !wino_v_shape_ok(Cin, Cout, T)) return 0;
     if (x_wino == 2) return aid_conv2d_wino8_supported(Cin, Cout, F, T, dilF);
     if (x_wino != 1) return 0;
@@ -1933,7 +1934,10 @@ extern "C" int aid_conv2d_wino_input_ok(int B, int Cin, int Cout, int F, int T, 
 }
 
 // partials per (sample, group) of the forward (sum, sum of squares) option: the row-shared kernel only
+int aid_w2d_partials(int Cout, int F, int T, int dilF);              // aid_wino2d.hip
+
 extern "C" int aid_conv2d_stat_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino) {
+    if (x_wino == 3) return aid_conv2d_wino2d_supported(Cin, Cout, F, T, dilF) ? aid_w2d_partials(Cout, F, T, dilF) : 0;
     int cip, cop;
     aid_conv2d_pack_dims(Cin, Cout, &cip, &cop);
     if (!x_wino || (Cout % 8) || !wino_v_shape_ok(Cin, Cout, T)) return 0;
@@ -1951,6 +1955,7 @@ extern "C" int aid_conv2d_stat_partials(int B, int Cin, int Cout, int F, int T, 
 
 // tiles per sample of the F(4,3) kernels (64|96 x 512 tiles) when the per-tile <y, aux> partials are well defined
 extern "C" int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino) {
+    if (x_wino == 3) return aid_conv2d_wino2d_supported(Cin, Cout, F, T, dilF) ? aid_w2d_partials(Cout, F, T, dilF) : 0;
     int cip, cop;
     aid_conv2d_pack_dims(Cin, Cout, &cip, &cop);
     if ((Cin % 4) || Cout < 64 || (Cout % 8) || (T % 4) || aid_pow2ceil(T) < 8) return 0;

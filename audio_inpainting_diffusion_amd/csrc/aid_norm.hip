@@ -545,9 +545,12 @@ __global__ __launch_bounds__(256) void scale_act_wino8_kernel(const SaDev a) {
     aid_store_planes<10>(sV, p.y, p.C, p.F, p.T >> 3, a.nrows, (int)(blockIdx.x / a.tiles) * rpb, tile, 2 * lpr, rpb, tid);
 }
 
+int aid_w2d_input(const aid_scale_act_params* p, hipStream_t st);      // aid_wino2d.hip
+
 extern "C" int aid_scale_act(const aid_scale_act_params* p, void* stream) {
     AID_REQUIRE(p && p->x.p && p->y.p, "aid_scale_act: null pointer");
     AID_REQUIRE((p->T % 4) == 0, "aid_scale_act: T must be a multiple of 4");
+    if (p->wino == 3) return aid_w2d_input(p, (hipStream_t)stream);       // 2-D form F(4,5) x F(4,3): V [48][C][N]
     SaDev a;
     a.p = *p;
     if (p->wino == 2) {
@@ -567,7 +570,7 @@ extern "C" int aid_scale_act(const aid_scale_act_params* p, void* stream) {
         return AID_OK;
     }
     if (p->wino) {
-        AID_REQUIRE(p->wino == 1, "aid_scale_act: wino is 0, 1 (F(4,3)) or 2 (F(8,3))");
+        AID_REQUIRE(p->wino == 1, "aid_scale_act: wino is 0, 1 (F(4,3)), 2 (F(8,3)) or 3 (F(4,5) x F(4,3))");
         AID_REQUIRE((p->T % 16) == 0, "aid_scale_act: the Winograd-domain output needs T % 16 == 0");
         AID_REQUIRE((p->y.sB % 4) == 0 && (p->y.sC % 4) == 0 && (p->y.sF % 4) == 0 && (((uintptr_t)p->y.p) & 15) == 0 && p->y.sF >= 6 * (p->T / 4),
                     "aid_scale_act: Winograd-domain output rows are [6][T/4], 16-byte aligned");

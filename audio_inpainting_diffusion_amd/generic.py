@@ -66,6 +66,7 @@ class GenericModelAdapter:
             if norm_type == "smoothl1":
                 norm = torch.nn.functional.smooth_l1_loss(y, den, reduction="none", beta=beta).reshape(B, -1).sum(dim=1)
             else:
-                norm = torch.linalg.norm((y - den).reshape(B, -1), dim=1, ord=norm_type)
+                diff = y - den                                  # (:67-70: 3-D observations take the induced matrix norm over dim = (1, 2), as in the reference)
+                norm = torch.linalg.norm(diff, dim=(1, 2) if diff.dim() == 3 else 1, ord=norm_type)
             g = torch.autograd.grad(outputs=norm.sum(), inputs=x)[0]
         return x_hat.detach(), g.detach().contiguous(), norm.detach()

@@ -399,11 +399,17 @@ class _Builder:
         """``x_wino``: 0 plain activations, 4 / 8: ``x`` is the F(4,3) / F(8,3) input transform and ``wpw`` the matching 30- / 50-tap pack."""
         B, _, F, T = y.shape
         x_wino = int(x_wino)
-        assert x.shape[1] + (0 if x2 is None else x2.shape[1]) == cin and y.shape[1] == cout and x.shape[0] == B and x.shape[2] == F
-        assert x.shape[3] == {0: T, 4: 6 * (T // 4), 8: 10 * (T // 8)}[x_wino]
-        xw_code = {0: 0, 4: 1, 8: 2}[x_wino]                 # aid_conv2d_params::x_wino
+        xw_code = {0: 0, 4: 1, 8: 2, 45: 3}[x_wino]          # aid_conv2d_params::x_wino
         p = _lib.Conv2dParams()
-        p.x, p.y, p.res, p.aux = _lib.view4(x), _lib.view4(y), _lib.view4(res), _lib.view4(aux)
+        if x_wino == 45:                                     # 2-D form: x is the flat V [48][cin][N] of aid_scale_act(wino = 3)
+            npos = int(_lib.lib().aid_conv2d_wino2d_positions(B, F, T, dil))
+            assert x.dim() == 1 and x.numel() == 48 * cin * npos and x2 is None and in_scale is None and not act
+            p.x = _lib.View(x.data_ptr(), 0, 0, 0)
+        else:
+            assert x.shape[1] + (0 if x2 is None else x2.shape[1]) == cin and y.shape[1] == cout and x.shape[0] == B and x.shape[2] == F
+            assert x.shape[3] == {0: T, 4: 6 * (T // 4), 8: 10 * (T // 8)}[x_wino]
+            p.x = _lib.view4(x)
+        p.y, p.res, p.aux = _lib.view4(y), _lib.view4(res), _lib.view4(aux)
         p.wp = wp.data_ptr()
         p.in_scale, p.in_scale_ld = _lib.ptr(in_scale), (0 if in_scale is None else in_scale.stride(0))
         p.out_scale, p.out_scale_ld = _lib.ptr(out_scale), (0 if out_scale is None else out_scale.stride(0))
@@ -428,6 +434,9 @@ class _Builder:
         if F == 1 and kh == 1 and epi == 0:              # qk projections: few columns, long K -> split-K scratch (aid_kernels.h)
             ws = self._scratch(("ws", 8 * B * cout * T))
             p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        elif x_wino == 45:                               # the GEMM's output M [48][cout][N], read back by the output-transform pass of the same call
+            ws = self._scratch(("m45", 48 * cout * npos))
+            p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
         elif x_wino == 4 and B == 1 and self.whole_batch:     # a WHOLE batch of one (never a sub-batch: a segment's bits must not depend on the split):
                                                          # launches with few tiles share the K axis of a tile between two workgroups
             need = int(_lib.lib().aid_conv2d_wino_split_ws_bytes(B, cin, cout, F, T, dil))
@@ -442,7 +451,7 @@ class _Builder:
             if need:
                 ws = self._split_ws(need)
                 p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
-        assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] == (50 if x_wino == 8 else 30) and wpw.shape[1:] == wp.shape[1:]))
+        assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] == {8: 50, 45: 48}.get(x_wino, 30) and wpw.shape[1:] == wp.shape[1:]))
         # algorithmic HBM bytes: x once, residual / aux once, y once, weights once
         nb = 4 * (B * F * T * (cin + cout * (1 + (res is not None) + (aux is not None))) + cin * cout * kh * kw)
         dws = None if dot is None else dot[0]
@@ -464,18 +473,23 @@ class _Builder:
             self.nbytes += t.numel() * 8
         return t
 
-    def _wino_input(self, cin, cout, T, wp, wpw, F=0, dil=1, wpw8=None):
+    def _wino_input(self, cin, cout, T, wp, wpw, F=0, dil=1, wpw8=None, wpw2=None):
         """The Winograd form the pre-pass should write for this 5x3 layer (aid_scale_act wino = 1 / 2 -> aid_conv2d x_wino = 1 / 2): 8 = F(8,3)
         (10 MFMAs per 8 outputs; needs the 50-tap pack), 4 = F(4,3), 0 = plain activations.  The library answers from the launch shape
         (aid_conv2d_wino_form); ``net.wino_forms`` restricts the choice (A/B measurements, tests of the F(4,3) kernels)."""
         if wpw is None or wpw.shape[0] != 30:
             return 0
+        if wpw2 is not None and 45 in self.net.wino_forms and _lib.lib().aid_conv2d_wino2d_supported(cin, cout, F, T, dil):
+            # the non-fused 2-D form F(4,5) x F(4,3) (csrc/aid_wino2d.hip: 3.0 products per output) where the library predicts it faster than the fused
+            # 1-D kernels (aid_conv2d_wino2d_wanted, a function of the launch shape); wino_forms = (45,): wherever it is supported (tests, A/B)
+            if tuple(self.net.wino_forms) == (45,) or _lib.lib().aid_conv2d_wino2d_wanted(self.B, cin, cout, F, T, dil):
+                return 45
         form = int(_lib.lib().aid_conv2d_wino_form(self.B, cin, cout, F, T, dil))
         if form == 8 and (wpw8 is None or 8 not in self.net.wino_forms):
             form = 4
         elif form == 4 and 4 not in self.net.wino_forms and wpw8 is not None and _lib.lib().aid_conv2d_wino8_supported(cin, cout, F, T, dil):
             form = 8                                          # wino_forms = (8,): F(8,3) wherever its tiles fit (tests, A/B)
-        if form == 4 and not (4 in self.net.wino_forms and bool(_lib.lib().aid_conv2d_wino_input_ok(self.B, cin, cout, F, T, dil))):
+        if form == 4 and not ((4 in self.net.wino_forms or tuple(self.net.wino_forms) == (45,)) and bool(_lib.lib().aid_conv2d_wino_input_ok(self.B, cin, cout, F, T, dil))):
             form = 0
         return form
 
@@ -483,19 +497,30 @@ class _Builder:
     def _wino_cols(form, T):
         return {0: T, 4: 6 * (T // 4), 8: 10 * (T // 8)}[form]
 
+    def _wino_scratch(self, tag, form, B, C, F, T, dil):
+        """scratch for the conv input the pre-pass writes: [B, C, F, cols] (plain / 1-D Winograd domain) or the flat V [48][C][N] of the 2-D form"""
+        if form == 45:
+            return self._scratch((tag + "45", 48 * C * int(_lib.lib().aid_conv2d_wino2d_positions(B, F, T, dil))))
+        return self._scratch((tag, B, C, F, self._wino_cols(form, T)))
+
+    @staticmethod
+    def _sa_out(t):
+        """aid_scale_act's output view: 4-D scratch, or the flat V of the 2-D form (strides unused)"""
+        return _lib.View(t.data_ptr(), 0, 0, 0) if t.dim() == 1 else _lib.view4(t)
+
     def conv(self, x, y, wp, cin, cout, kh=1, kw=1, dil=1, in_scale=None, act=0, out_scale=None, res=None,
-             res_scale=1.0, alpha=1.0, wpT=None, norm_stats=None, wpw=None, wpwT=None, res_nograd=False, wname=None, wpw8=None, wpw8T=None):
+             res_scale=1.0, alpha=1.0, wpT=None, norm_stats=None, wpw=None, wpwT=None, res_nograd=False, wname=None, wpw8=None, wpw8T=None,
+             wpw2=None, wpw2T=None):
         """Forward conv + registration of its input-VJP.  ``norm_stats``: the (mean, 1/(std+eps)) buffer when
         ``in_scale`` was produced by ``stats`` from this same ``x`` (the scale then depends on x)."""
         if act and kh > 1:
             # evaluate norm*mod -> GELU once per element into a scratch tensor; the conv stages plain copies
-            xw = self._wino_input(cin, cout, x.shape[3], wp, wpw, x.shape[2], dil, wpw8)
-            hshape = (x.shape[0], cin, x.shape[2], self._wino_cols(xw, x.shape[3]))
-            hbuf = self._scratch(("h",) + hshape)
-            sp = _lib.ScaleActParams(_lib.view4(x), _lib.view4(hbuf), in_scale.data_ptr(), in_scale.stride(0), x.shape[0], cin,
-                                     x.shape[2], x.shape[3], 1, {0: 0, 4: 1, 8: 2}[xw])
+            xw = self._wino_input(cin, cout, x.shape[3], wp, wpw, x.shape[2], dil, wpw8, wpw2)
+            hbuf = self._wino_scratch("h", xw, x.shape[0], cin, x.shape[2], x.shape[3], dil)
+            sp = _lib.ScaleActParams(_lib.view4(x), self._sa_out(hbuf), in_scale.data_ptr(), in_scale.stride(0), x.shape[0], cin,
+                                     x.shape[2], x.shape[3], 1, {0: 0, 4: 1, 8: 2, 45: 3}[xw], dil)
             self._add("aid_scale_act", sp, x, hbuf, in_scale, writes=(hbuf,))
-            self._conv_raw(hbuf, y, wp, cin, cout, kh, kw, dil, None, 0, out_scale, res, res_scale, alpha, wpw=wpw8 if xw == 8 else wpw, x_wino=xw)
+            self._conv_raw(hbuf, y, wp, cin, cout, kh, kw, dil, None, 0, out_scale, res, res_scale, alpha, wpw={8: wpw8, 45: wpw2}.get(xw, wpw), x_wino=xw)
         else:
             self._conv_raw(x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha)
         if wpT is None:
@@ -515,10 +540,9 @@ class _Builder:
             if kh > 1 and out_scale is not None:
                 # 5x3 dgrad: apply the gate in a copy pass so the conv input needs no in-kernel prologue
                 # (keeps it on the direct-to-LDS kernel)
-                gw = self._wino_input(cout, cin, gy.shape[3], wpT, wpwT, gy.shape[2], dil, wpw8T) if norm_stats is not None else 0
-                gshape = (gy.shape[0], cout, gy.shape[2], self._wino_cols(gw, gy.shape[3]))
-                gin = self._scratch(("g",) + gshape)
-                nb = self._nb_src.pop(self._vkey(gy), None) if (gw and self.net.fuse_norm_bwd_wino) else None
+                gw = self._wino_input(cout, cin, gy.shape[3], wpT, wpwT, gy.shape[2], dil, wpw8T, wpw2T) if norm_stats is not None else 0
+                gin = self._wino_scratch("g", gw, gy.shape[0], cout, gy.shape[2], gy.shape[3], dil)
+                nb = self._nb_src.pop(self._vkey(gy), None) if (gw in (4, 8) and self.net.fuse_norm_bwd_wino) else None
                 if nb is not None and nb[1] > self._g_last.get(gin.data_ptr(), -1) and nb[3].lane == self.lane:
                     # gy was written last by an aid_norm_bwd and nothing used this scratch since: that pass also writes gin
                     nb[0].wout, nb[0].wscale, nb[0].wscale_ld = _lib.view4(gin), out_scale.data_ptr(), out_scale.stride(0)
@@ -526,8 +550,8 @@ class _Builder:
                     self.plan.keep.extend((gin, out_scale))
                     nb[3].also_writes(gin)
                 else:
-                    sp = _lib.ScaleActParams(_lib.view4(gy), _lib.view4(gin), out_scale.data_ptr(), out_scale.stride(0), gy.shape[0],
-                                             cout, gy.shape[2], gy.shape[3], 0, {0: 0, 4: 1, 8: 2}[gw])
+                    sp = _lib.ScaleActParams(_lib.view4(gy), self._sa_out(gin), out_scale.data_ptr(), out_scale.stride(0), gy.shape[0],
+                                             cout, gy.shape[2], gy.shape[3], 0, {0: 0, 4: 1, 8: 2, 45: 3}[gw], dil)
                     self._add("aid_scale_act", sp, gy, gin, out_scale, writes=(gin,))
                 self._g_last[gin.data_ptr()] = len(self.plan.ops)      # (the dgrad conv below reads it)
                 gsc = None
@@ -536,15 +560,15 @@ class _Builder:
                 # <gd, x> per (sample, group): folded into the dgrad conv's epilogue when it runs on the F(4,3) kernels
                 nd = 0
                 if act and kh == 5 and gsc is None and wpwT is not None and wpwT.shape[0] == 30:
-                    nd = int(_lib.lib().aid_conv2d_dot_partials(B, cout, cin, F, T, dil, {0: 0, 4: 1, 8: 2}[gw]))
+                    nd = int(_lib.lib().aid_conv2d_dot_partials(B, cout, cin, F, T, dil, {0: 0, 4: 1, 8: 2, 45: 3}[gw]))
                 elif act and kh == 1 and kw == 1 and self.net.fuse_dot_1x1:        # 1x1 steps (init / out blocks): the direct-to-LDS kernel's epilogue
                     nd = int(_lib.lib().aid_conv2d_dot_partials_1x1(B, cout, cin, F, T))
                 dws = self._dot_ws(nd) if nd else self.stats_ws
                 # the last tile of each sample also folds the partials into the normalisation-backward coefficients (aid_kernels.h: fin_mode = 2)
-                fin = bool(nd and kh == 5 and gw and self.net.fuse_fin
+                fin = bool(nd and kh == 5 and gw in (4, 8) and self.net.fuse_fin
                            and _lib.lib().aid_conv2d_fin_supported(B, cout, cin, F, T, dil, {4: 1, 8: 2}[gw]))
                 self._conv_raw(gin, gd, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, None, 1.0, alpha,
-                               epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None, wpw=wpw8T if gw == 8 else wpwT, x_wino=gw,
+                               epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None, wpw={8: wpw8T, 45: wpw2T}.get(gw, wpwT), x_wino=gw,
                                dot=(dws, nd) if nd else None, fin_stats=norm_stats if fin else None)
                 if not nd:
                     dp = _lib.GroupDotParams(_lib.view4(gd), _lib.view4(x), B, cin, F, T, 8, self.stats_ws.data_ptr())
@@ -796,11 +820,13 @@ class Unet_CQT_oct_with_attention(nn.Module):
                     wd = wd.float().contiguous()
                 (cip, cop), (cipT, copT) = _lib.pack_dims(ci, co), _lib.pack_dims(co, ci)
                 w8 = wino and 8 in self.wino_forms                                            # F(8,3) packs (50 taps)
+                w2 = wino and 45 in self.wino_forms and co % 128 == 0 and ci % 128 == 0       # 2-D F(4,5) x F(4,3) packs (48 planes; C >= 128 layers)
                 bufs = [ensure(name, (kh * kw, cip, cop)), ensure(name + "#T", (kh * kw, cipT, copT)),
                         ensure(name + "#W", (30, cip, cop)) if wino else None, ensure(name + "#WT", (30, cipT, copT)) if wino else None,
-                        ensure(name + "#W8", (50, cip, cop)) if w8 else None, ensure(name + "#W8T", (50, cipT, copT)) if w8 else None]
+                        ensure(name + "#W8", (50, cip, cop)) if w8 else None, ensure(name + "#W8T", (50, cipT, copT)) if w8 else None,
+                        ensure(name + "#W2", (48, cip, cop)) if w2 else None, ensure(name + "#W2T", (48, cipT, copT)) if w2 else None]
                 pp = _lib.PackConvWeightParams(wd.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr(), _lib.ptr(bufs[2]), _lib.ptr(bufs[3]),
-                                               co, ci, kh, kw, cip, cop, cipT, copT, _lib.ptr(bufs[4]), _lib.ptr(bufs[5]))
+                                               co, ci, kh, kw, cip, cop, cipT, copT, _lib.ptr(bufs[4]), _lib.ptr(bufs[5]), _lib.ptr(bufs[6]), _lib.ptr(bufs[7]))
                 _lib.call("aid_pack_conv_weight", pp)       # all layouts of this weight in one launch (same values as _lib.pack_conv_weight*)
             elif leaf == "gamma":
                 put(name, w.detach().reshape(-1).float())
@@ -909,7 +935,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
             bd.conv(x, xn, W[pfx + f"H.{k}.weight"], N, N, kh, kw, dil=(2 ** k if kh > 1 else 1), in_scale=sc, act=1,
                     out_scale=self._mod(st, pfx + f"gate.{k}"), res=x, alpha=RSQRT2, wpT=W[pfx + f"H.{k}.weight#T"],
                     norm_stats=stb, wpw=W.get(pfx + f"H.{k}.weight#W"), wpwT=W.get(pfx + f"H.{k}.weight#WT"), wname=pfx + f"H.{k}.weight",
-                    wpw8=W.get(pfx + f"H.{k}.weight#W8"), wpw8T=W.get(pfx + f"H.{k}.weight#W8T"))
+                    wpw8=W.get(pfx + f"H.{k}.weight#W8"), wpw8T=W.get(pfx + f"H.{k}.weight#W8T"),
+                    wpw2=W.get(pfx + f"H.{k}.weight#W2"), wpw2T=W.get(pfx + f"H.{k}.weight#W2T"))
             x = xn
         if blk.proj_place == "after":
             assert hasattr(blk, "proj_out") and hasattr(blk, "res_conv")
@@ -1178,8 +1205,10 @@ class Unet_CQT_oct_with_attention(nn.Module):
                                # sub-batch streams; a second lane INSIDE each sub-batch stream measured -19 % at batch 8 (six streams competing)
     param_grads_in_train_mode = False   # True: a train()-mode call whose INPUT requires grad also yields parameter gradients (TrainFn) instead of
                                         # the input-only VJP; off by default because the reference's tester samples with the network in train() mode
-    wino_forms = (4, 8)        # Winograd forms the 5x3 layers may use: F(8,3) where the library prefers it (aid_conv2d_wino_form), F(4,3) otherwise;
-                               # (4,) keeps every layer on the F(4,3) kernels (A/B measurements; set before the first forward)
+    wino_forms = (4, 8, 45)    # Winograd forms the 5x3 layers may use: 45 = the non-fused 2-D form F(4,5) x F(4,3) (csrc/aid_wino2d.hip) on the C >= 128 layers
+                               # where the library predicts it faster (aid_conv2d_wino2d_wanted), F(8,3) where the library prefers it (aid_conv2d_wino_form),
+                               # F(4,3) otherwise; (4,) keeps every layer on the F(4,3) kernels, (45,) forces the 2-D form wherever it is supported
+                               # (A/B measurements, tests; set before the first forward)
     stream_k = "off"           # stream-K instances of the F(8,3) kernel: "whole" = launches of whole batches (a batch that is not split into sub-batch
                                # streams), "all" = sub-batch launches too (their bits then depend on the split), "off" = plain tiles everywhere.
                                # Off by default: measured per layer at batch 1 ... 8 (profiles/r04_streamk_probe.txt) the 164 KB partial every cut tile

@@ -317,9 +317,12 @@ class Sampler:
     def predict_resample(self, y, shape, degradation):
         """y[B, ...] = observations, shape = (B, L) of the signal, degradation = torch callable x[B, L] -> y-shaped tensor   (:164-173): reconstruction
         guidance through an arbitrary degradation (the reference's generic entry point; its inpainting methods are special cases of it)."""
-        if y.dim() == 3 and self.args.tester.posterior_sampling.norm == 1:
-            raise _lib.AidError("predict_resample: norm = 1 over 3-D observations is the induced matrix 1-norm in the reference (:68-75); "
-                                "only the element-wise norms (2, 'smoothl1', or 1 over [B, N] observations) are implemented")
+        if y.dim() == 3 and self.args.tester.posterior_sampling.norm != "smoothl1" and type(self.model).__name__ != "GenericModelAdapter":
+            # (:67-70: torch.linalg.norm(y - den, dim=(1, 2), ord=norm) over 3-D observations is the INDUCED matrix norm -- ord = 2 the largest singular
+            #  value, ord = 1 the largest column sum -- not the element-wise norm aid_guidance_seed computes over the flattened item)
+            raise _lib.AidError("predict_resample: norm = 2 / 1 over 3-D observations is the induced matrix norm (spectral / max column sum) in the reference "
+                                "(edm_sampler_inpainting.py:67-75); the HIP guidance seed implements the element-wise norms only: use norm = 'smoothl1', "
+                                "flatten the observations to [B, N], or wrap the model in generic.GenericModelAdapter (torch autograd, reference semantics)")
         self.y = y.contiguous().float()
         self.mask = self.smask = None
         self.spectral = LambdaDegradation(degradation)

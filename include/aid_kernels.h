@@ -28,7 +28,7 @@ extern "C" {
 #define AID_E_BADARG (-1)   /* unsupported shape / null pointer / misaligned stride */
 #define AID_E_LAUNCH (-2)   /* hipLaunchKernel reported an error                    */
 
-#define AID_ABI_VERSION 11
+#define AID_ABI_VERSION 12
 int aid_abi_version(void);
 /* last HIP error string seen by a launcher in this process (never NULL) */
 const char* aid_last_error(void);
@@ -110,7 +110,12 @@ typedef struct {
                                  and aid_conv2d_wino_input_supported(...) != 0.  The kernel then stages and multiplies only.
                                  2: `x` is the F(8,3) input transform [B, Cin, F, 10, T/8] (aid_scale_act wino = 2): 10 MFMAs per 8 outputs
                                  (0.417x the direct form); needs the 50-tap pack and aid_conv2d_wino_form(...) == 8.  fp32 error about 2x that of
-                                 F(4,3) (3e-6 rel-L2 per layer at Cin = 128; profiles/r04_wino_fm3_error.txt). */
+                                 F(4,3) (3e-6 rel-L2 per layer at Cin = 128; profiles/r04_wino_fm3_error.txt).
+                                 3: the NON-FUSED 2-D form F(4,5) x F(4,3) (3.0 products per output; csrc/aid_wino2d.hip): x.p is V [48][Cin][N] written by
+                                 aid_scale_act(wino = 3) (x's strides are not used), wp_wino the 48-plane pack U = GF w GT^T (aid_pack_conv_weight wpw2),
+                                 wino_taps = 48, and `ws` MUST hold 48 * Cout * N floats for M = U V: aid_wino2d_gemm, then the output-transform pass with the
+                                 epilogue below; needs aid_conv2d_wino2d_supported(...) != 0 (Cout % 128 == 0, Cin % 16 == 0, F % dilF == 0, T % 16 == 0).
+                                 fp32 error 2-4e-6 rel-L2 per layer (profiles/r04_wino2d_fm5_error.txt). */
     float* ws; int64_t ws_bytes; /* optional scratch (the library never allocates): lets grid-starved 1x1 GEMMs (the qk projections:
                                  B*T columns only, K of several thousand) split K over up to 8 workgroups per tile; partial sums
                                  go to ws[S][B][Cout][F][T] and a second kernel reduces them in a FIXED order (deterministic) and
@@ -177,8 +182,29 @@ int aid_conv2d_fin_supported(int B, int Cin, int Cout, int F, int T, int dilF, i
 int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino);
 /* number of per-tile (sum, sum of squares) partials per (sample, group) for stat_ws; 0 = the kernel that takes this shape does not write them */
 int aid_conv2d_stat_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino);
+/* x_wino = 3 (2-D Winograd form): 1 when the layer shape is supported; positions per transform plane N for a launch of B samples (0: unsupported) */
+int aid_conv2d_wino2d_supported(int Cin, int Cout, int F, int T, int dilF);
+int64_t aid_conv2d_wino2d_positions(int B, int F, int T, int dilF);
+/* 1 when a launch of this shape SHOULD take the 2-D form (measured per layer against the fused 1-D kernels; a function of the launch shape) */
+int aid_conv2d_wino2d_wanted(int B, int Cin, int Cout, int F, int T, int dilF);
 /* padded dims the packed weight buffer must have for a given (Cin, Cout) */
 void aid_conv2d_pack_dims(int Cin, int Cout, int* Cin_pad, int* Cout_pad);
+
+/* ---------------------------------------------------------------------------------------------------
+ * aid_wino2d_gemm -- the batched fp32-MFMA GEMM at the centre of the 2-D Winograd form F(4,5) x F(4,3) of the dilated 5x3 convolution
+ *   (aid_conv2d x_wino = 3 runs it followed by the output-transform pass; exposed on its own for tests and measurements).
+ *   replaces: the multiply-accumulate work of Conv2d.forward / F.conv2d(dilation=(d,1)) (unet...py:79-88, :433-436, :472-482) on the C >= 128 layers.
+ *   For every transform index xi < nxi (48):   M[xi][co][n] = sum_ci U[xi][ci][co] * V[xi][ci][n]
+ *   U [nxi][Cin_pad][Cout_pad] (aid_pack_conv_weight wpw2 / wpw2T), V [nxi][Cin][N] (aid_scale_act wino = 3), M [nxi][Cout][N]; N % 4 == 0,
+ *   Cin a multiple of 16, Cout_pad a multiple of 128, every plane below 4 GiB.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* U; const float* V; float* M;
+    int nxi, Cin, Cout, Cin_pad, Cout_pad;
+    int64_t N;
+    int variant;               /* 0: the product instance; > 0: tile-shape experiments (tools/w2d_probe.py) */
+} aid_wino2d_gemm_params;
+int aid_wino2d_gemm(const aid_wino2d_gemm_params* p, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * aid_resample -- 8-tap cubic FIR 2:1 resampling along T with reflect padding.
@@ -480,7 +506,12 @@ typedef struct {
     int wino;                 /* 1: write the F(4,3) input transform of h along T instead of h itself: y is [B,C,F,6,T/4],
                                  y[..,xi,g] = (B^T d)[xi], d = h[4g-1 .. 4g+4] (zero outside the row); T % 16 == 0.
                                  2: the F(8,3) input transform: y is [B,C,F,10,T/8], d = h[8g-1 .. 8g+8]; interpolation points
-                                 {0, +-0.4, +-0.8, +-1.25, +-2.5, inf}, matrices in csrc/aid_wino8.h (tools/gen_wino8.py) */
+                                 {0, +-0.4, +-0.8, +-1.25, +-2.5, inf}, matrices in csrc/aid_wino8.h (tools/gen_wino8.py)
+                                 3: the 2-D input transform F(4,5) x F(4,3) for aid_conv2d x_wino = 3 (matrices: csrc/aid_wino45.h, tools/gen_wino45.py):
+                                 y.p is V [48][C][N] (y's strides are not used), N = aid_conv2d_wino2d_positions(B, F, T, dilF),
+                                 V[xf*6 + xt][c][b*NB + (j*dilF + r)*(T/4) + g] = (BF^T h BT)[xf][xt] of the 8 x 6 patch of rows r + dilF*(4j-2 .. 4j+5),
+                                 samples 4g-1 .. 4g+4 (zero outside the tensor); F % dilF == 0, T % 16 == 0 */
+    int dilF;                 /* wino = 3 only: the dilation of the 5x3 layer that will read V */
 } aid_scale_act_params;
 int aid_scale_act(const aid_scale_act_params* p, void* stream);
 
@@ -544,13 +575,15 @@ int aid_wino_gy(const aid_wino_gy_params* p, void* stream);
  *   wp  [KH*KW][Cin_pad][Cout_pad]         wp[t][ci][co] = w[co][ci][kh][kw], t = kh*KW + kw, zero padded
  *   wpT [KH*KW][Cin_padT][Cout_padT]       the input-gradient operator: taps flipped, channel roles swapped (pack dims of (Cout, Cin)); NULL: skip
  *   wpw / wpwT [30][...]                   F(4,3) packs U = G w of both (5x3 only; fp64 arithmetic, rounded once); NULL: skip
- *   wpw8 / wpw8T [50][...]                 F(8,3) packs of both (5x3 only; G of csrc/aid_wino8.h); NULL: skip */
+ *   wpw8 / wpw8T [50][...]                 F(8,3) packs of both (5x3 only; G of csrc/aid_wino8.h); NULL: skip
+ *   wpw2 / wpw2T [48][...]                 F(4,5) x F(4,3) packs of both (5x3 only; csrc/aid_wino45.h); NULL: skip */
 typedef struct {
     const float* w;
     float* wp; float* wpT; float* wpw; float* wpwT;
     int Cout, Cin, KH, KW;
     int Cin_pad, Cout_pad, Cin_padT, Cout_padT;
     float* wpw8; float* wpw8T;
+    float* wpw2; float* wpw2T;   /* 2-D packs U[xf*6 + xt] = GF w GT^T of both operators, [48][...] (5x3 only; G of csrc/aid_wino45.h); NULL: skip */
 } aid_pack_conv_weight_params;
 int aid_pack_conv_weight(const aid_pack_conv_weight_params* p, void* stream);
 

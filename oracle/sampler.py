@@ -89,8 +89,9 @@ class OracleSampler:
                 x_hat = self.model.CQTransform.apply_hpf_DC(x_hat)
             if self.norm == "smoothl1":                                                     # (:72-73; 'sum' over the item)
                 norm = torch.nn.functional.smooth_l1_loss(self.y, self.degradation(x_hat), reduction="none", beta=self.smoothl1_beta).reshape(B, -1).sum(dim=1)
-            else:                                                                           # (:67-70: dim = 1, or (1, 2) for 3-D observations = per item)
-                norm = torch.linalg.norm((self.y - self.degradation(x_hat)).reshape(B, -1), dim=1, ord=self.norm)   # [B]  (:65,:75)
+            else:                                                                           # (:67-70: dim = 1 for [B, N] observations; dim = (1, 2) for 3-D ones,
+                diff = self.y - self.degradation(x_hat)                                     #  where ord = 2 / 1 is the INDUCED matrix norm: spectral / max column sum)
+                norm = torch.linalg.norm(diff, dim=(1, 2) if diff.dim() == 3 else 1, ord=self.norm)   # [B]  (:65,:75)
             g = torch.autograd.grad(norm.sum(), x)[0]                                       # per-item grads
             L = self.audio_len if self.audio_len is not None else x.shape[-1]
             normguide = torch.linalg.norm(g, dim=1, keepdim=True) / L ** 0.5                # (:83) per item

@@ -1,0 +1,191 @@
+"""GPU parity of the non-fused 2-D Winograd path F(4,5) x F(4,3) of the dilated 5x3 convolution (csrc/aid_wino2d.hip), through the C ABI:
+aid_scale_act(wino=3) -> aid_conv2d(x_wino=3) = aid_wino2d_gemm + output pass, against the torch-CPU form of the plain convolution
+(reference: Conv2d.forward / ResnetBlock.forward, networks/unet_cqt_oct_with_projattention_adaLN_2.py:79-88, :472-482).
+
+fp32 error budget of the form: 1e-5 rel-L2 per layer (tools/wino2d_fm5_error.py: 2.2e-6 ... 4.3e-6).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def L():
+    from audio_inpainting_diffusion_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("shape", [(128, 128, 256), (64, 128, 1000), (256, 256, 2052), (32, 128, 4)])
+def test_wino2d_gemm_vs_torch(L, shape):
+    """M[xi] = U[xi]^T V[xi] for 48 planes; ragged last column tile, K of 2 .. 16 chunks"""
+    cin, cout, N = shape
+    cip, cop = L.pack_dims(cin, cout)
+    U = torch.zeros(48, cip, cop)
+    U[:, :cin, :cout] = _rand(48, cin, cout, seed=1, scale=1 / math.sqrt(cin))
+    V = _rand(48, cin, N, seed=2)
+    Ud, Vd = U.to(DEV), V.to(DEV)
+    M = torch.full((48, cout, N + 8), 7.0, device=DEV)[:, :, :N].contiguous()
+    tail = torch.full((64,), 7.0, device=DEV)
+    p = L.Wino2dGemmParams(Ud.data_ptr(), Vd.data_ptr(), M.data_ptr(), 48, cin, cout, cip, cop, N, 0)
+    L.call("aid_wino2d_gemm", p)
+    torch.cuda.synchronize()
+    ref = torch.bmm(U[:, :cin, :cout].transpose(1, 2).double(), V.double())
+    assert rel_l2(M.cpu(), ref) < 2e-6
+    assert float(tail.min()) == 7.0
+
+
+def _conv_ref(x, w, dil, in_scale, act, out_scale, res, res_scale, alpha):
+    h = x * in_scale[:, :, None, None]
+    if act:
+        h = F.gelu(h)
+    y = F.conv2d(h, w, padding="same", dilation=(dil, 1))
+    if out_scale is not None:
+        y = y * out_scale[:, :, None, None]
+    if res is not None:
+        y = y + res_scale * res
+    return alpha * y
+
+
+W2D_CASES = [
+    # B, C, F, T, dil
+    (2, 128, 16, 32, 1),         # R = 16: 4 row tiles
+    (1, 128, 24, 64, 2),         # R = 12, two residue classes
+    (2, 128, 20, 16, 4),         # R = 5: ragged (second tile holds one real row), T = 16
+    (1, 128, 28, 32, 1),         # R = 28
+    (2, 128, 24, 32, 8),         # R = 3: a single ragged tile per class
+    (1, 256, 12, 48, 2),         # two Cout tiles, T = 48 (TG = 12)
+    (3, 128, 8, 528, 1),         # TG = 132 > 64 lanes: neighbour samples across wave boundaries
+]
+
+
+def _input_ref(h, dil):
+    """V[xf*6+xt][c][b*NB + (j*dil + r)*TG + g] from its definition, float64 on the CPU"""
+    from audio_inpainting_diffusion_amd._lib import wino45_matrices
+    m = wino45_matrices()
+    BF, BT = torch.from_numpy(m[2]), torch.from_numpy(m[5])
+    B, C, Fd, T = h.shape
+    R, TG = Fd // dil, T // 4
+    J = (R + 3) // 4
+    hs = h.double().reshape(B, C, R, dil, T)                              # row f = jj * dil + r
+    hp = F.pad(hs, (1, 4, 0, 0, 2, 4 * J + 4 - R))                           # jj: 2 before, up to 4J+5 after; t: 1 before, 4 after
+    pt = hp.unfold(-1, 6, 4)[..., :TG, :]                                   # [B, C, JJ, dil, TG, 6]
+    pf = pt.unfold(2, 8, 4)[:, :, :J]                                       # [B, C, J, dil, TG, 6, 8]
+    V = torch.einsum("xi,yk,bcjrgki->xybjrgc", BF, BT, pf)                  # [8, 6, B, J, dil, TG, C]
+    return V.reshape(48, B * J * dil * TG, C).permute(0, 2, 1).contiguous()  # [48, C, N]
+
+
+@pytest.mark.parametrize("case", W2D_CASES)
+def test_conv2d_wino2d(L, case):
+    B, C, Fd, T, dil = case
+    assert L.lib().aid_conv2d_wino2d_supported(C, C, Fd, T, dil)
+    N = int(L.lib().aid_conv2d_wino2d_positions(B, Fd, T, dil))
+    R = Fd // dil
+    assert N == B * ((R + 3) // 4) * dil * (T // 4)
+    x = _rand(B, C, Fd, T, seed=40)
+    w = _rand(C, C, 5, 3, seed=41, scale=1.0 / math.sqrt(C * 15))
+    in_scale = 1.0 + 0.5 * _rand(B, C, seed=42)
+    out_scale = _rand(B, C, seed=43)
+    res = _rand(B, C, Fd, T, seed=44)
+    alpha, res_scale = 1 / math.sqrt(2), 1.5
+    xd, wd, isd, osd, resd = x.to(DEV), w.to(DEV), in_scale.to(DEV), out_scale.to(DEV), res.to(DEV)
+    # (1) the input transform against its definition (GELU prologue)
+    V = torch.full((48 * C * N + 16,), 7.0, device=DEV)
+    sp = L.ScaleActParams(L.view4(xd), L.View(V.data_ptr(), 0, 0, 0), isd.data_ptr(), isd.stride(0), B, C, Fd, T, 1, 3, dil)
+    L.call("aid_scale_act", sp)
+    torch.cuda.synchronize()
+    assert float(V[48 * C * N:].min()) == 7.0
+    Vref = _input_ref(F.gelu(x * in_scale[:, :, None, None]), dil)
+    assert rel_l2(V[:48 * C * N].cpu().reshape(48, C, N), Vref) < 1e-6
+    # (2) forward: the convolution on it, gate + residual epilogue, (sum, sum of squares) partials
+    wp, wpw = L.pack_conv_weight(wd), L.pack_conv_weight_wino2d(wd)
+    y = torch.full((B, C, Fd, T), float("nan"), device=DEV)
+    ws = torch.full((48 * C * N + 16,), 7.0, device=DEV)
+    nst = int(L.lib().aid_conv2d_stat_partials(B, C, C, Fd, T, dil, 3))
+    assert nst > 0 and nst == int(L.lib().aid_conv2d_dot_partials(B, C, C, Fd, T, dil, 3))
+    assert L.lib().aid_conv2d_fin_supported(B, C, C, Fd, T, dil, 3) == 0
+    sws = torch.zeros(B * 8 * nst * 2, device=DEV, dtype=torch.float64)
+    p = L.Conv2dParams()
+    p.x, p.y, p.res, p.aux = L.View(V.data_ptr(), 0, 0, 0), L.view4(y), L.view4(resd), L.view4(None)
+    p.wp, p.wp_wino, p.wino_taps, p.x_wino = wp.data_ptr(), wpw.data_ptr(), 48, 3
+    p.out_scale, p.out_scale_ld = osd.data_ptr(), osd.stride(0)
+    p.B, p.Cin, p.Cout, p.F, p.T = B, C, C, Fd, T
+    p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
+    p.KH, p.KW, p.dilF, p.act, p.epi = 5, 3, dil, 0, 0
+    p.alpha, p.res_scale = alpha, res_scale
+    p.ws, p.ws_bytes = ws.data_ptr(), 48 * C * N * 4
+    p.stat_ws, p.stat_n = sws.data_ptr(), nst
+    L.call("aid_conv2d", p)
+    torch.cuda.synchronize()
+    assert "w2d_gemm" in L.lib().aid_last_kernel().decode()
+    ref = _conv_ref(x, w, dil, in_scale, 1, out_scale, res, res_scale, alpha)
+    err = rel_l2(y.cpu(), ref)
+    assert err < 1e-5, err
+    assert float(ws[48 * C * N:].min()) == 7.0
+    part = sws.cpu().reshape(B, 8, nst, 2).sum(2)
+    yg = y.cpu().double().reshape(B, 8, -1)
+    assert rel_l2(part[..., 0], yg.sum(-1)) < 1e-5 and rel_l2(part[..., 1], (yg * yg).sum(-1)) < 1e-6
+    # aid_group_stats folds these partials like those of the fused kernels
+    gamma = (1.0 + 0.3 * _rand(C, seed=45)).to(DEV)
+    sc1, sc2 = torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+    st1, st2 = torch.empty(B, 8, 2, device=DEV), torch.empty(B, 8, 2, device=DEV)
+    gws = torch.empty(B * 8 * L.AID_STATS_SPLIT * 2, device=DEV, dtype=torch.float64)
+    L.call("aid_group_stats", L.GroupStatsParams(L.view4(y), B, C, Fd, T, 8, gamma.data_ptr(), None, 0, 1e-7, sc1.data_ptr(), st1.data_ptr(), gws.data_ptr(), 0))
+    L.call("aid_group_stats", L.GroupStatsParams(L.view4(y), B, C, Fd, T, 8, gamma.data_ptr(), None, 0, 1e-7, sc2.data_ptr(), st2.data_ptr(), sws.data_ptr(), nst))
+    assert rel_l2(sc2.cpu(), sc1.cpu()) < 1e-6 and rel_l2(st2.cpu(), st1.cpu()) < 1e-5
+    # three runs bit-identical
+    y2 = torch.empty_like(y)
+    p.y = L.view4(y2)
+    L.call("aid_conv2d", p)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    # (3) reverse sweep: the transposed operator on the gated gradient (no activation), dGELU epilogue, <y, aux> partials
+    gy = _rand(B, C, Fd, T, seed=46)
+    gyd = gy.to(DEV)
+    sp = L.ScaleActParams(L.view4(gyd), L.View(V.data_ptr(), 0, 0, 0), osd.data_ptr(), osd.stride(0), B, C, Fd, T, 0, 3, dil)
+    L.call("aid_scale_act", sp)
+    wpT, wpwT = L.pack_conv_weight(wd, transpose=True), L.pack_conv_weight_wino2d(wd, transpose=True)
+    gd = torch.full((B, C, Fd, T), float("nan"), device=DEV)
+    dws = torch.zeros(B * 8 * nst, device=DEV, dtype=torch.float64)
+    q = L.Conv2dParams()
+    q.x, q.y, q.res, q.aux = L.View(V.data_ptr(), 0, 0, 0), L.view4(gd), L.view4(None), L.view4(xd)
+    q.wp, q.wp_wino, q.wino_taps, q.x_wino = wpT.data_ptr(), wpwT.data_ptr(), 48, 3
+    q.out_scale, q.out_scale_ld = isd.data_ptr(), isd.stride(0)
+    q.aux_scale, q.aux_scale_ld = isd.data_ptr(), isd.stride(0)
+    q.B, q.Cin, q.Cout, q.F, q.T = B, C, C, Fd, T
+    q.Cin_pad, q.Cout_pad = wpT.shape[1], wpT.shape[2]
+    q.KH, q.KW, q.dilF, q.act, q.epi = 5, 3, dil, 0, 1
+    q.alpha, q.res_scale = alpha, 1.0
+    q.ws, q.ws_bytes = ws.data_ptr(), 48 * C * N * 4
+    q.dot_ws, q.dot_n = dws.data_ptr(), nst
+    L.call("aid_conv2d", q)
+    torch.cuda.synchronize()
+    xr = x.clone().requires_grad_(True)
+    hr = F.gelu(xr * in_scale[:, :, None, None])
+    yr = alpha * F.conv2d(hr, w, padding="same", dilation=(dil, 1)) * out_scale[:, :, None, None]
+    gref, = torch.autograd.grad(yr, xr, gy)                              # = alpha * in_scale * gelu'(x in_scale) * conv^T(gy * out_scale)
+    assert rel_l2(gd.cpu(), gref) < 1e-5
+    dref = (gd.cpu().double() * x.double()).reshape(B, 8, -1).sum(-1)
+    assert rel_l2(dws.cpu().reshape(B, 8, nst).sum(-1), dref) < 1e-5
+    # (4) the pack kernel writes the same 2-D packs as the torch helper
+    outs = [torch.empty_like(wp), torch.empty_like(wpT), torch.empty_like(wpw), torch.empty_like(wpwT)]
+    pp = L.PackConvWeightParams(wd.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), None, None, C, C, 5, 3, wp.shape[1], wp.shape[2],
+                                wpT.shape[1], wpT.shape[2], None, None, outs[2].data_ptr(), outs[3].data_ptr())
+    L.call("aid_pack_conv_weight", pp)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], wp) and torch.equal(outs[1], wpT)
+    assert rel_l2(outs[2].cpu(), wpw.cpu()) < 1e-7 and rel_l2(outs[3].cpu(), wpwT.cpu()) < 1e-7

@@ -33,7 +33,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in aid_kernels.h but not exported"
     lib.aid_abi_version.restype = ctypes.c_int
-    assert lib.aid_abi_version() == int(re.search(r"#define AID_ABI_VERSION (\d+)", hdr).group(1)) == 11
+    assert lib.aid_abi_version() == int(re.search(r"#define AID_ABI_VERSION (\d+)", hdr).group(1)) == 12
     from audio_inpainting_diffusion_amd import _lib
     assert set(_lib.EXPORTS) == declared
     a, b = _lib.pack_dims(2, 96)
@@ -366,7 +366,7 @@ def test_header_compiles_as_c_and_struct_sizes_match_the_binding(tmp_path):
              "aid_scale_act_params": "ScaleActParams", "aid_add2_params": "Add2Params", "aid_conv2d_wgrad_params": "WgradParams",
              "aid_wino_gy_params": "WinoGyParams", "aid_pack_conv_weight_params": "PackConvWeightParams", "aid_wgrad_reduce_params": "WgradReduceParams",
              "aid_channel_dot_params": "ChannelDotParams", "aid_relpos_bwd_params": "RelposBwdParams", "aid_scale_bwd_params": "ScaleBwdParams", "aid_modulation_bwd_params": "ModulationBwdParams",
-             "aid_embed_bwd_params": "EmbedBwdParams", "aid_adam_params": "AdamParams", "aid_ema_params": "EmaParams", "aid_sumsq_params": "SumsqParams"}
+             "aid_embed_bwd_params": "EmbedBwdParams", "aid_wino2d_gemm_params": "Wino2dGemmParams", "aid_adam_params": "AdamParams", "aid_ema_params": "EmaParams", "aid_sumsq_params": "SumsqParams"}
     hdr = open(os.path.join(ROOT, "include", "aid_kernels.h")).read()
     declared = set(re.findall(r"\}\s*(aid_\w+)\s*;", hdr))
     assert declared == set(pairs), declared ^ set(pairs)
@@ -539,3 +539,34 @@ def test_sampler_and_edm_expose_the_reference_classes_method_names():
             assert callable(fn), f"{cls.__name__}.{name} is missing"
             got = [p for p in inspect.signature(fn).parameters if p != "self"]
             assert got[:len(params)] == params, (cls.__name__, name, got)
+
+
+def test_three_dimensional_observations_take_the_induced_matrix_norm_or_are_rejected():
+    """torch.linalg.norm(y - den, dim=(1, 2), ord=2) over 3-D observations (edm_sampler_inpainting.py:67-75) is the SPECTRAL norm, not the
+    Frobenius norm of the flattened item.  The oracle keeps the reference's semantics; the HIP sampler (whose guidance seed is element-wise)
+    refuses such a call instead of silently computing another norm."""
+    from audio_inpainting_diffusion_amd import _lib
+    from audio_inpainting_diffusion_amd.config import small_args
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.sampler import Sampler
+    from oracle.edm import OracleEDM
+    from oracle.sampler import OracleSampler
+    from test_oracle_golden import _Toy
+    L = 2048
+    deg = lambda v: v.reshape(v.shape[0], 4, L // 4)[:, :3, ::2]                # noqa: E731  (a linear map onto [B, 3, L/8] observations)
+    torch.manual_seed(3)
+    y = deg(0.063 * torch.randn(1, L))
+    runs = {}
+    for norm in (2, "fro"):
+        s = OracleSampler(_Toy(L), OracleEDM(), T=2, xi=0.25, data_consistency=False, audio_len=L, norm=norm)
+        torch.manual_seed(4)
+        runs[norm] = s.predict_resample(y, (1, L), deg)
+    assert torch.isfinite(runs[2]).all() and rel_l2(runs[2], runs["fro"]) > 1e-3        # ord = 2 is NOT the flattened (Frobenius) norm
+    args = small_args()
+    args.tester.posterior_sampling.norm = 2
+
+    class _Fused:                                                                   # (stands for the MI355X network: never evaluated here)
+        denoise = denoise_guided = None
+    smp = Sampler(model=_Fused(), diff_params=EDM(args), args=args)
+    with pytest.raises(_lib.AidError, match="induced matrix norm"):
+        smp.predict_resample(y, (1, L), deg)

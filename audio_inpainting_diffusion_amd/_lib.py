@@ -256,7 +256,7 @@ EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_st
            "aid_time_attention", "aid_embed", "aid_modulation", "aid_cqt_analysis", "aid_cqt_synthesis",
            "aid_cqt_gather", "aid_axpby", "aid_score_step", "aid_add2", "aid_group_dot", "aid_norm_bwd",
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_guidance_step", "aid_set_rows", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
-           "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino8_supported", "aid_conv2d_wino_split_ws_bytes", "aid_conv2d_wino8_sk_ws_bytes", "aid_conv2d_fin_supported",
+           "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino8_supported", "aid_conv2d_wino_split_ws_bytes", "aid_conv2d_fin_supported",
            "aid_conv2d_wgrad", "aid_wgrad_reduce", "aid_channel_dot", "aid_relpos_bwd", "aid_scale_bwd", "aid_modulation_bwd", "aid_embed_bwd",
            "aid_adam", "aid_ema", "aid_sumsq", "aid_wino2d_gemm", "aid_conv2d_wino2d_supported", "aid_conv2d_wino2d_positions", "aid_conv2d_wino2d_wanted"]
 
@@ -291,8 +291,6 @@ def lib():
         L.aid_conv2d_wino_input_ok.restype = C.c_int
         L.aid_conv2d_wino8_supported.argtypes = [C.c_int] * 5
         L.aid_conv2d_wino8_supported.restype = C.c_int
-        L.aid_conv2d_wino8_sk_ws_bytes.argtypes = [C.c_int] * 6
-        L.aid_conv2d_wino8_sk_ws_bytes.restype = C.c_int64
         L.aid_conv2d_fin_supported.argtypes = [C.c_int] * 7
         L.aid_conv2d_fin_supported.restype = C.c_int
         L.aid_conv2d_wino_form.argtypes = [C.c_int] * 6
@@ -310,11 +308,11 @@ def lib():
         L.aid_conv2d_wino2d_positions.argtypes = [C.c_int] * 4
         L.aid_conv2d_wino2d_positions.restype = C.c_int64
         for name in EXPORTS[3:]:
-            if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino8_supported", "aid_conv2d_wino_split_ws_bytes", "aid_conv2d_wino8_sk_ws_bytes", "aid_conv2d_fin_supported",
+            if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino8_supported", "aid_conv2d_wino_split_ws_bytes", "aid_conv2d_fin_supported",
                             "aid_conv2d_stat_partials", "aid_conv2d_wgrad_tiles", "aid_conv2d_wino2d_supported", "aid_conv2d_wino2d_positions", "aid_conv2d_wino2d_wanted"):
                 getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, name).restype = C.c_int
-        if L.aid_abi_version() != 12:
+        if L.aid_abi_version() != 13:
             raise AidError("ABI version mismatch")
         _lib = L
     return _lib

@@ -9,7 +9,6 @@
 //   conv53_wino4v_kernel : F(4,3), Winograd-domain input written by the producer pass (aid_scale_act wino=1), 64|96 x 512 tiles (fallback geometries)
 //   conv53_wino4r_kernel : F(4,3), Winograd-domain input, ROW-SHARED staging on dilation sub-lattices, 2-3 workgroups per CU (+ pair and split-K instances)
 //   conv53_wino8r_kernel : F(8,3) on the same row-shared body (wino4r_tile_body<..., WM = 8>): 64 x 512 tiles, 160 accumulators per lane -- the dominant kernel
-//   conv53_wino8r_sk_kernel : its stream-K instance (persistent grid; off by default)
 //   conv53_wino8r_ks_kernel : its K-group instance for launches of at most one tile per CU (small batches): eight waves on one tile, two K groups, sum through LDS
 // Which form takes a launch: wino_form_choice() / aid_conv2d_wino_form().
 #include "aid_common.h"
@@ -709,11 +708,8 @@ struct ConvWinoRDev {
     float* part;               // splits == 2: [tile][96][256] Winograd-domain partial accumulators of the workgroup that finishes first
     unsigned* flags;           // splits == 2: [tile][2] (arrival counter, partial published); zero before and after every launch
     W4rGeo g[2];               // [1]: the 32-channel remainder tiles of a 96-channel layer (pair instances)
-    int sk_per;                // stream-K instances: (tile, chunk) units per persistent workgroup
-    int sk_workers;            // stream-K instances: persistent workgroups (= grid size)
     int fin_total;             // fin_mode: tiles per sample (both families) -- the tile that finds fin_count[b] == fin_total - 1 folds the sample's partials
 };
-struct W4rSeg { int c0, c1, wid, per; };   // stream-K: one workgroup's share [c0, c1) of a tile's chunks; wid = its worker id (partial / flag slot)
 
 // fin_mode (aid_kernels.h): the last tile of sample b folds the epilogue partials of the whole sample -- the work of group_stats_final / norm_bwd_coef
 // (aid_norm.hip), same summation order (lane l adds partials l, l + 64, ..., then the xor tree), hence the same bits -- so that those two 5-10 us
@@ -815,14 +811,12 @@ struct W4rShape {
 
 // One tile.  `smem`: W4rShape::LDS floats of LDS (declared by the kernel, so that the two tile families of a pair instance share it);
 // `bid`: workgroup index within this tile family's part of the grid.
-// SK (stream-K instances): `bid` is the LOGICAL tile index and `seg` this workgroup's share of the tile's K chunks; the tile is finished by the
-// workgroup that holds its first chunks (see conv53_wino8r_sk_kernel).
-template <int TT, int NC, int WGM, int NB, int WPC, int NWV, bool SPK, int WM = 4, bool SK = false, int KS = 1>
-__device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4rGeo& ge, float* smem, const int bid, const W4rSeg seg = W4rSeg{}) {
+template <int TT, int NC, int WGM, int NB, int WPC, int NWV, bool SPK, int WM = 4, int KS = 1>
+__device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4rGeo& ge, float* smem, const int bid) {
     using S = W4rShape<TT, NC, WGM, NB, WPC, NWV, WM, KS>;
     constexpr int KH = S::KH, NXI = S::NXI, KC = S::KC, KCS = S::KCS;
     constexpr int NW = S::NW, NWQ = S::NWQ, WGN = S::WGN;
-    static_assert(KS == 1 || (KS == 2 && !SPK && !SK), "K groups: not combined with the split-K / stream-K exchange");
+    static_assert(KS == 1 || (KS == 2 && !SPK), "K groups: not combined with the split-K exchange");
     constexpr int M_BLK = S::M_BLK;
     constexpr int GPR = S::GPR, RA = S::RA, CSLOT = S::CSLOT, CSLOT_USED = S::CSLOT_USED, IL = S::IL, XCI = S::XCI, XSZ = S::XSZ, WROW = S::WROW;
     constexpr int WSZ_RAW = S::WSZ_RAW, WSZ = S::WSZ, BUFSZ = S::BUFSZ, NBUF = S::NBUF;
@@ -844,10 +838,7 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
     float* const sbuf1 = smem + BUFSZ;
     float* const sbuf2 = smem + (NBUF == 3 ? 2 * BUFSZ : 0);
 
-    int tid_ = threadIdx.x;
-    if (SK) asm volatile("" : "+v"(tid_));               // (persistent loop: keeps the per-lane address arithmetic below from being hoisted out of the tile loop,
-                                                         //  where it would stay live -- some 300 spilled registers -- across every K loop)
-    const int tid = tid_;
+    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ks = KS == 2 ? wave / NWQ : 0;             // K group of this wave
@@ -856,9 +847,9 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
     const int half = lane >> 5;
 
     // XCD-aware logical tile (see conv53_wino4v_kernel); order: Cout tile fastest, then t tile, quad, residue-class group, sample
-    const int Lt = SK ? bid : (bid & 7) * ge.per_xcd + (bid >> 3);
+    const int Lt = (bid & 7) * ge.per_xcd + (bid >> 3);
     if (Lt >= ge.ntiles) return;
-    const int nch = SK ? (seg.c1 - seg.c0) : a.nchunks;   // chunks this workgroup multiplies
+    const int nch = a.nchunks;                           // chunks this workgroup multiplies
     int rest = Lt;
     const int sp = SPK ? (rest & 1) : 0;                 // split-K: the two halves of a tile are neighbours in the same XCD's share
     if (SPK) rest >>= 1;
@@ -915,7 +906,7 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
         if (ok) pvalid |= 1u << i;
         if (__ballot(ok) != 0ull) pany |= 1u << i;
     }
-    const int cbase = SK ? seg.c0 : ((SPK && sp) ? a.nchunks : 0);        // first chunk of this workgroup's share of the K axis
+    const int cbase = (SPK && sp) ? a.nchunks : 0;        // first chunk of this workgroup's share of the K axis
     const int64_t xstep = (int64_t)KCS * p.x.sC * 4, wstep = (int64_t)KCS * p.Cout_pad * 4;   // bytes per chunk (wave-uniform)
     const char* const xbase = reinterpret_cast<const char*>(p.x.p + (int64_t)b * p.x.sB) + cbase * xstep;
     const char* const wbase = reinterpret_cast<const char*>(p.wp_wino) + cbase * wstep;
@@ -1012,58 +1003,6 @@ __device__ __forceinline__ void wino4r_tile_body(const ConvWinoRDev& a, const W4
         for (int ch = 0; ch < nch; ch += 2) {
             chunk(std::integral_constant<int, 0>{}, ch);
             if (ch + 1 < nch) chunk(std::integral_constant<int, 1>{}, ch + 1);
-        }
-    }
-
-    // ---- stream-K: a workgroup whose share does not start at chunk 0 publishes its accumulators (slot `wid`) and moves on; the workgroup that holds the
-    // tile's FIRST chunks -- it reaches them at the END of its span, after everybody else's share of this tile is long done -- adds the partials of
-    // the following workers in worker order (a fixed order: deterministic) and runs the epilogue.  Every worker writes its partial BEFORE it can ever
-    // wait, so a waiting workgroup only waits for one that is resident or will be dispatched as soon as any slot frees.  Same agent-scope exchange as
-    // the split-K instances above.
-    if constexpr (SK) {
-        constexpr int PSZ = NXI * 16 * 64 * NW;                                        // floats per partial
-        int* sh = reinterpret_cast<int*>(smem);
-        if (seg.c0 > 0) {
-            unsigned long long* part = reinterpret_cast<unsigned long long*>(a.part + (int64_t)seg.wid * PSZ) + tid;
-#pragma unroll
-            for (int x = 0; x < NXI; ++x)
-#pragma unroll
-                for (int r2 = 0; r2 < 8; ++r2) {
-                    const unsigned long long v = (unsigned long long)__float_as_uint(acc[x][2 * r2]) | ((unsigned long long)__float_as_uint(acc[x][2 * r2 + 1]) << 32);
-                    __hip_atomic_store(part + (x * 8 + r2) * (64 * NW), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(a.flags + seg.wid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        if (seg.c1 < a.nchunks) {
-            const int nparts = (a.nchunks - seg.c1 + seg.per - 1) / seg.per;
-            for (int k = 1; k <= nparts; ++k) {
-                unsigned* fl = a.flags + seg.wid + k;
-                __syncthreads();
-                if (tid == 0) {
-                    unsigned* sticky = a.flags + (AID_W4R_SPLIT_FLAG_BYTES / 4 - 1);
-                    int it = 0;                                                            // (bounded, ~1 s; sticky error word: see the split-K instances)
-                    for (; it < (1 << 22) && __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u; ++it) __builtin_amdgcn_s_sleep(4);
-                    if (it >= (1 << 22)) __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    sh[1] = it < (1 << 22) && __hip_atomic_load(sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
-                }
-                __syncthreads();
-                const float poison = sh[1] ? 0.f : __uint_as_float(0x7fc00000u);
-                const unsigned long long* part = reinterpret_cast<const unsigned long long*>(a.part + (int64_t)(seg.wid + k) * PSZ) + tid;
-#pragma unroll
-                for (int x = 0; x < NXI; ++x) {                // one plane (16 registers) of the partial in flight at a time: all ten would not fit beside the 160 accumulators
-                    unsigned long long v[8];
-#pragma unroll
-                    for (int r2 = 0; r2 < 8; ++r2) v[r2] = __hip_atomic_load(part + (x * 8 + r2) * (64 * NW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int r2 = 0; r2 < 8; ++r2) { acc[x][2 * r2] += __uint_as_float((unsigned)v[r2]) + poison; acc[x][2 * r2 + 1] += __uint_as_float((unsigned)(v[r2] >> 32)) + poison; }
-                    asm volatile("" ::: "memory");
-                }
-                if (tid == 0 && sh[1]) __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // consumed: zero for the next launch
-            }
-            __syncthreads();                                  // sh lives in the buffer the partial-sum reduction below reuses
         }
     }
 
@@ -1354,7 +1293,7 @@ template <int TT, int NC>
 __global__ __launch_bounds__(512, 2) void conv53_wino4r_ks_kernel(const ConvWinoRDev a) {
     using S0 = W4rShape<TT, NC, 2, 3, 1, 8, 4, 2>;
     __shared__ __attribute__((aligned(16))) float smem[S0::LDS];
-    wino4r_tile_body<TT, NC, 2, 3, 1, 8, false, 4, false, 2>(a, a.g[0], smem, (int)blockIdx.x);
+    wino4r_tile_body<TT, NC, 2, 3, 1, 8, false, 4, 2>(a, a.g[0], smem, (int)blockIdx.x);
 }
 
 // ---- F(8,3) on the same row-shared body: 10 products per 8 outputs (0.833x the MFMAs of F(4,3), 0.417x of the direct form), Winograd-domain
@@ -1387,13 +1326,13 @@ __global__ __launch_bounds__(512, 2) void conv53_wino8r_ks_kernel(const ConvWino
     using S0 = W4rShape<TT, NC, WGM, 2, 1, 8, 8, 2>;
     if constexpr (NC1 == 0) {
         __shared__ __attribute__((aligned(16))) float smem[S0::LDS];
-        wino4r_tile_body<TT, NC, WGM, 2, 1, 8, false, 8, false, 2>(a, a.g[0], smem, (int)blockIdx.x);
+        wino4r_tile_body<TT, NC, WGM, 2, 1, 8, false, 8, 2>(a, a.g[0], smem, (int)blockIdx.x);
     } else {
         using S1 = W4rShape<TT, NC1, 1, 2, 1, 8, 8, 2>;
         __shared__ __attribute__((aligned(16))) float smem[S0::LDS > S1::LDS ? S0::LDS : S1::LDS];
         const int n0 = 8 * a.g[0].per_xcd;
-        if ((int)blockIdx.x < n0) wino4r_tile_body<TT, NC, WGM, 2, 1, 8, false, 8, false, 2>(a, a.g[0], smem, (int)blockIdx.x);
-        else wino4r_tile_body<TT, NC1, 1, 2, 1, 8, false, 8, false, 2>(a, a.g[1], smem, (int)blockIdx.x - n0);
+        if ((int)blockIdx.x < n0) wino4r_tile_body<TT, NC, WGM, 2, 1, 8, false, 8, 2>(a, a.g[0], smem, (int)blockIdx.x);
+        else wino4r_tile_body<TT, NC1, 1, 2, 1, 8, false, 8, 2>(a, a.g[1], smem, (int)blockIdx.x - n0);
     }
 }
 
@@ -1641,39 +1580,6 @@ static int launch_wino4r(const aid_conv2d_params* p, hipStream_t st) {
     return AID_OK;
 }
 
-// ---- stream-K instance of the F(8,3) kernel: a PERSISTENT grid of `sk_workers` workgroups (two per CU); the launch's (tile, chunk) units -- tiles in
-// the same XCD-aware order, the Cin / 2 chunks of a tile consecutive -- are cut into equal contiguous spans, one per workgroup.  A launch whose tile
-// count is not a whole number of rounds (1.75 rounds of 512-position tiles on the deepest level at batch 8; 0.2 ... 0.9 at batch 1) is then bound by
-// its MFMAs, not by ceil(rounds) tiles per CU.  Cost: at most one partial (160 accumulators per lane, 164 KB) written and read per workgroup.
-template <int TT, int NC, int WGM, int NC1 = 0>
-__global__ __launch_bounds__(256, 2) void conv53_wino8r_sk_kernel(const ConvWinoRDev a) {
-    using S0 = W4rShape<TT, NC, WGM, 2, 2, 4, 8>;
-    using S1 = W4rShape<TT, NC1 == 0 ? NC : NC1, NC1 == 0 ? WGM : 1, 2, 2, 4, 8>;
-    __shared__ __attribute__((aligned(16))) float smem[S0::LDS > S1::LDS ? S0::LDS : S1::LDS];
-    const int wid = ((int)blockIdx.x & 7) * (a.sk_workers >> 3) + ((int)blockIdx.x >> 3);        // consecutive workers (= consecutive tiles) share an XCD
-    const int n0 = a.g[0].ntiles;
-    const int64_t total = (int64_t)(n0 + (NC1 == 0 ? 0 : a.g[1].ntiles)) * a.nchunks;
-    int64_t u0 = (int64_t)wid * a.sk_per;
-    const int64_t u1 = u0 + a.sk_per < total ? u0 + a.sk_per : total;
-    bool first = true;
-    while (u0 < u1) {
-        const int tile = (int)(u0 / a.nchunks);
-        W4rSeg seg;
-        seg.c0 = (int)(u0 - (int64_t)tile * a.nchunks);
-        seg.c1 = (int64_t)a.nchunks - seg.c0 < u1 - u0 ? a.nchunks : seg.c0 + (int)(u1 - u0);
-        seg.wid = wid; seg.per = a.sk_per;
-        if (!first) __syncthreads();                      // the previous tile's epilogue scratch lives in the staging buffers
-        first = false;
-        if constexpr (NC1 == 0) {
-            wino4r_tile_body<TT, NC, WGM, 2, 2, 4, false, 8, true>(a, a.g[0], smem, tile, seg);
-        } else {
-            if (tile < n0) wino4r_tile_body<TT, NC, WGM, 2, 2, 4, false, 8, true>(a, a.g[0], smem, tile, seg);
-            else wino4r_tile_body<TT, NC1, 1, 2, 2, 4, false, 8, true>(a, a.g[1], smem, tile - n0, seg);
-        }
-        u0 += seg.c1 - seg.c0;
-    }
-}
-
 // ---- F(8,3) row-shared tiles: geometry, eligibility, launch ---------------------------------------------------------------------------------------
 // ng: groups per tile (64 for the 64-channel tile = 512 positions, 128 for the 32-channel remainder tile of 96-channel layers).  Instantiated:
 // 64 groups -- TT = 64: NC 1, 2 (RA = 8, 4); TT = 32: NC 1, 2, 4 (RA = 16, 8, 4); 128 groups -- TT = 64: NC 1, 2, 4 (RA = 16, 8, 4).  More classes per tile would not
@@ -1729,21 +1635,6 @@ static int wino_form_choice(const aid_conv2d_params* p) {
     return cost(p8, n8, 5) < cost(p4, n4, 3) ? 8 : 4;
 }
 
-// stream-K: persistent workgroups = 2 per CU (what the register / LDS budget of the kernel keeps resident), a multiple of 8 (XCDs)
-static int wino8r_sk_workers() {
-    static int w = 0;
-    if (!w) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
-        w = 2 * cus / 8 * 8;
-        if (w > AID_W4R_SPLIT_FLAG_BYTES / 4 - 8) w = AID_W4R_SPLIT_FLAG_BYTES / 4 - 8;      // (flag words; the last one is the sticky error word)
-    }
-    return w;
-}
-static inline int64_t aid_w8r_sk_bytes(int workers) { return AID_W4R_SPLIT_FLAG_BYTES + (int64_t)workers * (160 * 256 * 4); }
-// Plain tiles lose [ceil(rounds) - rounds] / ceil(rounds) of the launch to the partially filled last round (rounds = tiles / resident workgroups);
-// stream-K pays one partial per workgroup and gives up the hardware's dynamic tile dispatch.  Taken when the loss exceeds 8 % (measured threshold,
-// profiles/r04_streamk_probe.txt) -- launches of fewer tiles than resident workgroups included.
 // K-group instances (conv53_wino8r_ks_kernel): a launch none of whose CUs would hold two tiles.  Per-layer A/B against the plain F(8,3) tiles and
 // F(4,3) (profiles/r04_ks_probe.txt): -12 ... -18 % on the <= 256-tile launches (batch 1: levels 0, 3, 4, 5; batch 2: level 6), within +-2 % of the
 // plain tiles elsewhere (where they are not used: the hardware's dynamic dispatch of two independent workgroups per CU is the safer schedule).
@@ -1754,10 +1645,7 @@ static bool wino8r_ks_wanted(int64_t ntiles) {
     if (force == 2 && ntiles > 512 && ntiles <= 768) return true;
     return ntiles <= 256;
 }
-static bool wino8r_sk_wanted(int64_t ntiles, int workers) {
-    const int64_t rounds_up = (ntiles + workers - 1) / workers;
-    return ntiles * 100 < rounds_up * workers * 92;
-}
+
 
 static int launch_wino8r(const aid_conv2d_params* p, hipStream_t st) {
     static const float* zero = nullptr;
@@ -1791,25 +1679,13 @@ static int launch_wino8r(const aid_conv2d_params* p, hipStream_t st) {
         ge.ntiles = p->B * ge.rgroups * g.quads * g.ttiles * ge.ny;
         ge.per_xcd = (ge.ntiles + 7) / 8;
     }
-    // stream-K (scratch `ws` given, i.e. the caller allows it for this launch): when the tiles are not close to a whole number of rounds of the
-    // 2 x CUs resident workgroups
     const int64_t ntl = (int64_t)geo[0].ntiles + (m96 ? geo[1].ntiles : 0);
     { const int rc = wino_fin_check(p); if (rc != AID_OK) return rc; }
     a.fin_total = (int)(ntl / p->B);                       // tiles per sample
-    const int workers = wino8r_sk_workers();
-    const bool sk = p->ws && p->ws_bytes >= aid_w8r_sk_bytes(workers) && wino8r_sk_wanted(ntl, workers) && !p->fin_mode;
-    a.sk_per = 0; a.sk_workers = 0;
-    const bool kg = !sk && wino8r_ks_wanted(ntl);
+    const bool kg = wino8r_ks_wanted(ntl);
     if (kg) a.nchunks = p->Cin / 4;
-    if (sk) {
-        a.flags = reinterpret_cast<unsigned*>(p->ws);
-        a.part = p->ws + AID_W4R_SPLIT_FLAG_BYTES / 4;
-        a.sk_workers = workers;
-        a.sk_per = (int)((ntl * a.nchunks + workers - 1) / workers);
-    }
 #define AID_W8R(TTv, NCv, WGMv, NC1v) do { \
-        if (sk) hipLaunchKernelGGL((conv53_wino8r_sk_kernel<TTv, NCv, WGMv, NC1v>), dim3((unsigned)workers), dim3(256), 0, st, a); \
-        else if (kg) hipLaunchKernelGGL((conv53_wino8r_ks_kernel<TTv, NCv, WGMv, NC1v>), grid, dim3(512), 0, st, a); \
+        if (kg) hipLaunchKernelGGL((conv53_wino8r_ks_kernel<TTv, NCv, WGMv, NC1v>), grid, dim3(512), 0, st, a); \
         else hipLaunchKernelGGL((conv53_wino8r_kernel<TTv, NCv, WGMv, NC1v>), grid, dim3(256), 0, st, a); } while (0)
     if (m96) {
         a.g[0] = geo[0]; a.g[1] = geo[1];
@@ -1839,8 +1715,7 @@ static int launch_wino8r(const aid_conv2d_params* p, hipStream_t st) {
         AID_CHECK_LAUNCH();
     }
 #undef AID_W8R
-    if (sk) aid_note_kernel(m96 ? "conv53_wino8r_sk_kernel(64+32)" : "conv53_wino8r_sk_kernel");
-    else if (kg) aid_note_kernel(m96 ? "conv53_wino8r_ks_kernel(64+32)" : "conv53_wino8r_ks_kernel");
+    if (kg) aid_note_kernel(m96 ? "conv53_wino8r_ks_kernel(64+32)" : "conv53_wino8r_ks_kernel");
     else aid_note_kernel(m96 ? "conv53_wino8r_kernel(64+32)" : (plan[0].NC == 1 ? "conv53_wino8r_kernel" : "conv53_wino8r_kernel(multi-class)"));
     return AID_OK;
 }
@@ -1873,20 +1748,6 @@ extern "C" int aid_conv2d_fin_supported(int B, int Cin, int Cout, int F, int T, 
     aid_conv2d_pack_dims(Cin, Cout, &q.Cin_pad, &q.Cout_pad);
     Wino4rPlan plan[2];
     return wino4r_geometry(&q, plan) ? 1 : 0;
-}
-
-// scratch of the stream-K instances of the F(8,3) kernel (aid_kernels.h: ws with x_wino = 2): 0 when a launch of this shape keeps plain tiles
-extern "C" int64_t aid_conv2d_wino8_sk_ws_bytes(int B, int Cin, int Cout, int F, int T, int dilF) {
-    if (!aid_conv2d_wino8_supported(Cin, Cout, F, T, dilF)) return 0;
-    aid_conv2d_params q = {};
-    q.B = B; q.Cin = Cin; q.Cout = Cout; q.F = F; q.T = T; q.dilF = dilF; q.KH = 5; q.KW = 3;
-    aid_conv2d_pack_dims(Cin, Cout, &q.Cin_pad, &q.Cout_pad);
-    Wino4rPlan plan[2];
-    const int nl = wino8r_geometry(&q, plan);
-    int64_t ntl = 0;
-    for (int l = 0; l < nl; ++l) ntl += (int64_t)B * (dilF / plan[l].NC) * plan[l].quads * plan[l].ttiles * (nl == 2 ? q.Cout_pad / 96 : q.Cout_pad / 64);
-    const int workers = wino8r_sk_workers();
-    return (nl && wino8r_sk_wanted(ntl, workers)) ? aid_w8r_sk_bytes(workers) : 0;
 }
 
 // scratch of the split-K instances (aid_kernels.h: ws): 0 when a launch of this shape is not split

@@ -443,14 +443,6 @@ class _Builder:
             if need:
                 ws = self._split_ws(need)
                 p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
-        elif x_wino == 8 and self.net.stream_k != "off" and (self.whole_batch or self.net.stream_k == "all"):
-            # F(8,3) launches whose tiles are not close to a whole number of rounds of resident workgroups run the STREAM-K instance (a persistent
-            # grid sharing the (tile, K-chunk) units evenly).  Its cuts depend on the launch shape, so by default only WHOLE batches get the scratch:
-            # the sub-batches of a split batch keep plain tiles and stay bit-identical to the unsplit schedule and to each other.
-            need = int(_lib.lib().aid_conv2d_wino8_sk_ws_bytes(B, cin, cout, F, T, dil))
-            if need:
-                ws = self._split_ws(need)
-                p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
         assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] == {8: 50, 45: 48}.get(x_wino, 30) and wpw.shape[1:] == wp.shape[1:]))
         # algorithmic HBM bytes: x once, residual / aux once, y once, weights once
         nb = 4 * (B * F * T * (cin + cout * (1 + (res is not None) + (aux is not None))) + cin * cout * kh * kw)
@@ -1209,11 +1201,6 @@ class Unet_CQT_oct_with_attention(nn.Module):
                                # where the library predicts it faster (aid_conv2d_wino2d_wanted), F(8,3) where the library prefers it (aid_conv2d_wino_form),
                                # F(4,3) otherwise; (4,) keeps every layer on the F(4,3) kernels, (45,) forces the 2-D form wherever it is supported
                                # (A/B measurements, tests; set before the first forward)
-    stream_k = "off"           # stream-K instances of the F(8,3) kernel: "whole" = launches of whole batches (a batch that is not split into sub-batch
-                               # streams), "all" = sub-batch launches too (their bits then depend on the split), "off" = plain tiles everywhere.
-                               # Off by default: measured per layer at batch 1 ... 8 (profiles/r04_streamk_probe.txt) the 164 KB partial every cut tile
-                               # exchanges through memory costs more than the partially filled last round it removes, except on the K = 256 layers
-                               # of a batch of one (+2 ... 22 %), where the F(4,3) split-K instances are faster still.
     wgrad_wino = True          # training: F(4,3) form of the 5x3 weight gradients (aid_conv2d_wgrad wino=1)
     fuse_fin = True            # the last tile of a sample folds the conv epilogue's statistics / dot partials itself (aid_conv2d fin_mode): no aid_group_stats
                                # launch after such a conv and no coefficient kernel in aid_norm_bwd (A/B: bench.py --no-fin)

@@ -234,7 +234,6 @@ def main():
     ap.add_argument("--no-fin", action="store_true", help="A/B: separate aid_group_stats / coefficient launches instead of the last tile of a sample folding the epilogue partials")
     ap.add_argument("--no-epilogue-stats", action="store_true", help="A/B: group statistics by their own read pass instead of the conv epilogue")
     ap.add_argument("--wino-forms", default="4,8,45", help="A/B: Winograd forms the 5x3 layers may use (default 4,8,45: the 2-D form F(4,5) x F(4,3) and F(8,3) where the library prefers them; 4,8: the fused 1-D kernels only; 4: F(4,3) everywhere)")
-    ap.add_argument("--stream-k", choices=["off", "whole", "all"], default=None, help="A/B: stream-K instances of the F(8,3) kernel (network.stream_k; default: the network's)")
     ap.add_argument("--split", default="", help="A/B: explicit sub-batch sizes, e.g. 5,3 (network.split_sizes; implies --streams = their count)")
     ap.add_argument("--conv-table", action="store_true", help="print per-shape conv kernel times (stderr)")
     a = ap.parse_args()
@@ -281,8 +280,6 @@ def main():
     if a.streams:
         net.split_streams = a.streams
     net.wino_forms = tuple(int(v) for v in a.wino_forms.split(","))
-    if a.stream_k:
-        net.stream_k = a.stream_k
     if a.split:
         net.split_sizes = tuple(int(v) for v in a.split.split(","))
         a.streams = net.split_streams = len(net.split_sizes)

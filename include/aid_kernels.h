@@ -28,7 +28,7 @@ extern "C" {
 #define AID_E_BADARG (-1)   /* unsupported shape / null pointer / misaligned stride */
 #define AID_E_LAUNCH (-2)   /* hipLaunchKernel reported an error                    */
 
-#define AID_ABI_VERSION 12
+#define AID_ABI_VERSION 13
 int aid_abi_version(void);
 /* last HIP error string seen by a launcher in this process (never NULL) */
 const char* aid_last_error(void);
@@ -171,11 +171,6 @@ int aid_conv2d_wino8_supported(int Cin, int Cout, int F, int T, int dilF);
 /* bytes of `ws` a 5x3 x_wino layer of this shape wants for its split-K instance (B = 1 launches with few tiles); 0: the shape is not split */
 #define AID_CONV2D_SPLIT_FLAG_BYTES 4096
 int64_t aid_conv2d_wino_split_ws_bytes(int B, int Cin, int Cout, int F, int T, int dilF);
-/* bytes of `ws` a 5x3 x_wino = 2 (F(8,3)) layer of this launch shape wants for its STREAM-K instance (a persistent grid of 2 x CUs workgroups that share
-   the launch's (tile, K-chunk) units evenly; taken when the tiles are not close to a whole number of rounds); 0: plain tiles.  Same rules as above:
-   the first AID_CONV2D_SPLIT_FLAG_BYTES bytes zero before the first use, one ws per stream.  Results are deterministic but depend on the launch
-   shape (one extra association per cut tile): the caller decides where that is acceptable (network.py: whole batches only). */
-int64_t aid_conv2d_wino8_sk_ws_bytes(int B, int Cin, int Cout, int F, int T, int dilF);
 /* 1 when the kernel that takes a 5x3 layer of this launch shape with this x_wino (1 / 2) honours fin_mode (the row-shared kernels) */
 int aid_conv2d_fin_supported(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino);
 /* number of per-tile partial dots per (sample, group) the F(4,3) / F(8,3) epilogue writes for this shape (x_wino as in aid_conv2d_params); 0 = not supported */

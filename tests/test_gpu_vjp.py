@@ -467,6 +467,53 @@ def test_guided_chain_vs_reference_sampler_and_unet_fixture(tag):
     assert worst[0] < 1e-4 and worst[1] < 1e-4 and worst[2] < 1e-4
 
 
+def test_guided_whole_trajectory_vs_reference_fixture():
+    """sampler_guided_traj.npz = a WHOLE T = 10 trajectory of the REFERENCE's Sampler + EDM + U-Net (make_golden.py --only guided_traj): churn only
+    inside a window (deterministic head, five stochastic steps, deterministic tail: both branches of edm_sampler_inpainting.py:204), nine Heun steps
+    and the final Euler step onto t = 0 (:236-251).  The HIP sampler over the HIP network, free-running from the same global-generator seed: the
+    state after EVERY step and the output; and all 19 evaluations teacher-forced on the recorded input states."""
+    from audio_inpainting_diffusion_amd.edm import EDM
+    from audio_inpainting_diffusion_amd.sampler import Sampler
+    from oracle.edm import OracleEDM
+    net, _, zu, kw, args = _setup("a")
+    z = np.load(os.path.join(GOLDEN, "sampler_guided_traj.npz"))
+    assert ast.literal_eval(str(z["cfg"])) == kw and int(z["seed"]) == int(zu["seed"])
+    T = int(z["T"])
+    g = z["gamma"][:T]
+    assert g[0] == 0 and g[T - 1] == 0 and (g > 0).sum() >= 3 and (g == 0).sum() >= 3 and z["t"][-1] == 0 and int(z["n_eval"]) == 2 * T - 1
+    y, mask = torch.from_numpy(z["y"]), torch.from_numpy(z["mask"])
+    edm = OracleEDM()
+    v = lambda t: t.reshape(-1).to(DEV).contiguous()
+    worst = [0.0, 0.0, 0.0]
+    for e in range(int(z["n_eval"])):
+        x = torch.from_numpy(z[f"e{e}.x"])
+        s = torch.full((1, 1), float(z[f"e{e}.t"]))
+        xh, gr, nrm = net.denoise_guided(x.to(DEV), v(edm.cnoise(s)), v(edm.cin(s)), v(edm.cskip(s)), v(edm.cout(s)), True, y.to(DEV), mask.to(DEV))
+        e1, e2 = rel_l2(xh.cpu(), z[f"e{e}.x_hat"]), rel_l2(gr.cpu(), z[f"e{e}.rec_grads"])
+        e3 = abs(float(nrm.cpu()) - float(z[f"e{e}.norm"][0])) / float(z[f"e{e}.norm"][0])
+        worst = [max(a, b) for a, b in zip(worst, (e1, e2, e3))]
+    print(f"whole trajectory, 19 evaluations teacher-forced vs the reference: worst x_hat {worst[0]:.2e}, rec_grads {worst[1]:.2e}, norm {worst[2]:.2e}")
+    assert worst[0] < 1e-4 and worst[1] < 1e-4 and worst[2] < 1e-4
+    args.tester.T, args.tester.posterior_sampling.xi = T, 0.25
+    args.tester.data_consistency.hann_size = 20
+    dp = args.tester.diff_params
+    dp.Stmin, dp.Stmax, dp.Schurn = float(z["Stmin"]), float(z["Stmax"]), float(z["Schurn"])
+    smp = Sampler(model=net, diff_params=EDM(args), args=args, rid=True)
+    torch.manual_seed(int(z["noise_seed"]))
+    res = smp.predict_inpainting(y.to(DEV), mask.to(DEV))
+    assert np.array_equal(res[7].cpu().numpy(), z["t"])
+    errs = [rel_l2(res[6][i].cpu(), z["xt2"][i]) for i in range(T)]
+    errs_in = [rel_l2(res[5][i].cpu(), z["xt"][i]) for i in range(T)]
+    print("HIP free-running trajectory vs the reference, state after every step:", " ".join(f"{e:.1e}" for e in errs), "| out", f"{rel_l2(res[0].cpu(), z['out']):.1e}")
+    assert max(errs) < 2e-3 and max(errs_in) < 2e-3 and rel_l2(res[0].cpu(), z["out"]) < 2e-3      # (19 chained evaluations of an O(1)-gate random network amplify rounding)
+    # the same run without the debug buffers returns the same output
+    smp2 = Sampler(model=net, diff_params=EDM(args), args=args)
+    torch.manual_seed(int(z["noise_seed"]))
+    out2 = smp2.predict_inpainting(y.to(DEV), mask.to(DEV))
+    assert torch.equal(out2, res[0])
+
+
+
 def test_full_size_guided_evaluation_vs_reference_fixture():
     """unet_full_cfgA_guided.npz = ONE guided evaluation of the reference's Sampler + EDM + full-size cfg-A U-Net (make_golden.py --only full_guided):
     norm, every 97th sample and eight seeded projections (+ squared norm) of x_hat and rec_grads."""

@@ -323,6 +323,48 @@ def test_guided_chain_matches_reference_sampler_and_unet(tag):
         assert rel_l2(out, z[k + ".out"]) < 2e-3          # (five chained evaluations of an O(1)-gate random network amplify rounding)
 
 
+def test_guided_whole_trajectory_matches_reference():
+    """sampler_guided_traj.npz: a WHOLE T = 10 trajectory of the reference's Sampler + EDM + U-Net (make_golden.py --only guided_traj) with churn
+    inside a window only -- deterministic head, stochastic middle, deterministic tail, Heun steps and the final Euler step onto t = 0
+    (edm_sampler_inpainting.py:204, :236-251).  The oracle reproduces the schedule / gamma bit for bit, every evaluation teacher-forced, and the
+    free-running trajectory state by state."""
+    from audio_inpainting_diffusion_amd.init import seeded_state_dict
+    from oracle.edm import OracleEDM
+    from oracle.sampler import OracleSampler
+    z = np.load(os.path.join(GOLDEN, "sampler_guided_traj.npz"))
+    zu = np.load(os.path.join(GOLDEN, "unet_small_a.npz"))
+    kw = ast.literal_eval(str(z["cfg"]))
+    assert kw == ast.literal_eval(str(zu["cfg"]))
+    shapes = [(k, ast.literal_eval(s)) for k, s in zip(zu["keys"], zu["shapes"])]
+    sd = seeded_state_dict(shapes, int(z["seed"]), gate_scale=10.0, affine_scale=10.0)
+    cqt = OracleCQT(kw["num_octs"], kw["bins_per_oct"], "oct", ("kaiser", 1), kw["fs"], kw["audio_len"])
+    net = OU.OracleUnet(kw["num_octs"], kw["bins_per_oct"], cqt).load_state_dict(sd)
+    T = int(z["T"])
+    edm = OracleEDM(Schurn=float(z["Schurn"]), Stmin=float(z["Stmin"]), Stmax=float(z["Stmax"]))
+    t = edm.create_schedule(T)
+    gamma = edm.get_gamma(t)
+    assert np.array_equal(t.numpy(), z["t"]) and np.array_equal(gamma.numpy(), z["gamma"])
+    g = z["gamma"][:T]
+    assert g[0] == 0 and g[T - 1] == 0 and (g > 0).sum() >= 3 and (g == 0).sum() >= 3 and z["t"][-1] == 0 and int(z["n_eval"]) == 2 * T - 1
+    y, mask = torch.from_numpy(z["y"]), torch.from_numpy(z["mask"])
+    for e in range(int(z["n_eval"])):
+        x = torch.from_numpy(z[f"e{e}.x"]).clone().requires_grad_()
+        sig = torch.full((1, 1), float(z[f"e{e}.t"]))
+        xh = cqt.apply_hpf_DC(edm.denoiser(x, net, sig))
+        norm = torch.linalg.norm(y - mask * xh, dim=1, ord=2)
+        gr = torch.autograd.grad(norm.sum(), x)[0]
+        assert rel_l2(xh.detach(), z[f"e{e}.x_hat"]) < 2e-5, e
+        assert rel_l2(gr, z[f"e{e}.rec_grads"]) < 1e-4, e
+        assert abs(float(norm) - float(z[f"e{e}.norm"][0])) < 2e-5 * float(norm), e
+    smp = OracleSampler(net, edm, T=T, xi=0.25, hann_size=20, audio_len=kw["audio_len"])
+    torch.manual_seed(int(z["noise_seed"]))
+    res = smp.predict_inpainting(y, mask, rid=True)
+    errs = [rel_l2(res[6][i], z["xt2"][i]) for i in range(T)]
+    print("oracle free-running trajectory vs reference, state after every step:", " ".join(f"{e:.1e}" for e in errs))
+    assert max(errs) < 1e-5 and rel_l2(res[0], z["out"]) < 1e-5       # (same torch CPU kernels as the reference: 3e-7 measured)
+
+
+
 def test_full_size_guided_evaluation_oracle_vs_reference_fixture():
     """unet_full_cfgA_guided.npz (one guided evaluation of the reference's Sampler + EDM + full-size cfg-A U-Net): the oracle chain at FULL size
     (186 M parameters; ~1.5 min and ~18 GB of host RAM) reproduces norm, the strided samples and the seeded projections of x_hat and rec_grads."""

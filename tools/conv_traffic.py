@@ -3,7 +3,7 @@
 runs, as MI355X_MICROARCH.md prescribes).   usage: conv_traffic.py <dir with fetch pass> <dir with write pass> <out.json>"""
 import collections, csv, glob, json, sys
 
-CONV = ("conv53_wino8r_sk_kernel", "conv53_wino8r_kernel", "conv53_wino4r_kernel", "conv53_wino4v_kernel", "conv53_wino4_kernel", "conv_mfma_kernel", "conv1x1_stream_kernel", "conv11_dma_kernel", "conv11_rs_kernel", "conv_small_cout_kernel",
+CONV = ("conv53_wino8r_kernel", "conv53_wino4r_kernel", "conv53_wino4v_kernel", "conv53_wino4_kernel", "conv_mfma_kernel", "conv1x1_stream_kernel", "conv11_dma_kernel", "conv11_rs_kernel", "conv_small_cout_kernel",
         "conv_small_cin_kernel", "conv53_dma_kernel")
 
 def avg(d, counter):

@@ -258,7 +258,7 @@ EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_st
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_guidance_step", "aid_set_rows", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
            "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino8_supported", "aid_conv2d_wino_split_ws_bytes", "aid_conv2d_fin_supported",
            "aid_conv2d_wgrad", "aid_wgrad_reduce", "aid_channel_dot", "aid_relpos_bwd", "aid_scale_bwd", "aid_modulation_bwd", "aid_embed_bwd",
-           "aid_adam", "aid_ema", "aid_sumsq", "aid_wino2d_gemm", "aid_conv2d_wino2d_supported", "aid_conv2d_wino2d_positions", "aid_conv2d_wino2d_wanted"]
+           "aid_adam", "aid_ema", "aid_sumsq", "aid_wino2d_gemm", "aid_conv2d_wino2d_gemm", "aid_conv2d_wino2d_output", "aid_conv2d_wino2d_supported", "aid_conv2d_wino2d_positions", "aid_conv2d_wino2d_wanted"]
 
 _lib = None
 

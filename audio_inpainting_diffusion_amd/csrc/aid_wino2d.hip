@@ -265,104 +265,93 @@ static inline W2dGeo w2d_geo(int B, int F, int T, int dil) {
     return g;
 }
 static inline bool w2d_shape_ok(int Cin, int Cout, int F, int T, int dil) {
-    return dil >= 1 && (F % dil) == 0 && (T % 16) == 0 && T >= 16 && (Cin % 16) == 0 && (Cout % 128) == 0 && Cin >= 64;
+    return dil >= 1 && (F % dil) == 0 && (T % 16) == 0 && T >= 16 && T <= 2048 && (Cin % 16) == 0 && (Cout % 128) == 0 && Cin >= 64;
 }
 
 // =====================================================================================================================================
-// 1. input pass: V[xi][c][n] = BF^T act(x * scale[b,c]) BT.  One thread walks SEG consecutive row tiles of ONE (sample, channel, residue class,
-// sample group): every new tile loads its four new sub-lattice rows (float4 + the two neighbour samples from the adjacent lanes), activates and
-// T-transforms them once, and keeps the last four of the previous tile in registers (a window of 8 rows x 6 values); then the row transform per
-// T plane and 48 stores.  Lanes run along g, then r: a wave reads whole contiguous rows and writes 256-byte runs of every plane.
+// 1. input pass: V[xi][c][n] = BF^T act(x * scale[b,c]) BT.  A workgroup owns, for one (sample, channel), RB residue classes x JB row tiles x all
+// sample groups.  Phase 1: the 4 JB + 4 sub-lattice rows of those classes (RB adjacent rows of T samples per sub-lattice index: contiguous in
+// memory) are loaded as float4, scaled and activated ONCE per element and parked in LDS (36 KB: four workgroups per CU).  Phase 2: one tile per
+// thread and turn -- 8 rows x 6 samples out of LDS, the T transform per row, the row transform per T plane, 48 stores.  Threads run along the
+// position index n' = (j dil + r) TG + g, the memory order of every plane of V: a wave stores 256 contiguous bytes per plane (RB TG = 64 positions),
+// whatever T is -- the first version of this pass (one thread walking row tiles, lanes along g then r) wrote 32-byte runs at T = 32 and ran at 3.4 TB/s.
+// Activations per element: (4 JB + 4) / (4 JB) = 1.125 at JB = 8.  ~90 registers: its waves fit beside the two resident GEMM workgroups of another stream.
 // =====================================================================================================================================
 struct W2dInDev {
     aid_view x; const float* scale; int64_t scale_ld;
     float* V;
     int B, C, F, T, act, dil;
-    int R, J, TG, NB, nseg, seg;
-    int64_t N, total;
+    int R, J, TG, NB;
+    int RB, JB, nrb, njb;      // residue classes / row tiles per workgroup, workgroups along each
+    int rowf;                  // floats per LDS row group = RB * T
+    int64_t N;
 };
 
 __global__ __launch_bounds__(256) void w2d_input_kernel(const W2dInDev a) {
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = gid < a.total;
-    int64_t rest = live ? gid : a.total - 1;
-    const int g = (int)(rest % a.TG); rest /= a.TG;
-    const int r = (int)(rest % a.dil); rest /= a.dil;
-    const int sg = (int)(rest % a.nseg); rest /= a.nseg;
-    const int c = (int)(rest % a.C);
-    const int b = (int)(rest / a.C);
-    const int lane = threadIdx.x & 63;
+    extern __shared__ __attribute__((aligned(16))) float w2d_slab[];
+    int rest = blockIdx.x;
+    const int jbk = rest % a.njb; rest /= a.njb;
+    const int rbk = rest % a.nrb; rest /= a.nrb;
+    const int c = rest % a.C;
+    const int b = rest / a.C;
+    const int tid = threadIdx.x;
+    const int j0 = jbk * a.JB, r0 = rbk * a.RB;
+    const int jbe = min(a.JB, a.J - j0);                  // row tiles of this workgroup
+    const int nrows = 4 * jbe + 4;                        // sub-lattice indices 4 j0 - 2 .. 4 (j0 + jbe) + 1
     const float sc = a.scale ? a.scale[(int64_t)b * a.scale_ld + c] : 1.f;
-    const float* const xb = a.x.p + (int64_t)b * a.x.sB + (int64_t)c * a.x.sC + (int64_t)r * a.x.sF + 4 * g;
-    const int64_t rstep = (int64_t)a.dil * a.x.sF;
-    const bool first_g = g == 0, last_g = g == a.TG - 1;
-
-    float W[8][6];
-    float4 raw[4];
-    float hl[4], hr[4];                                   // neighbour samples of the wave's first / last lane (only when a row has more than 64 groups)
-    auto fetch = [&](int jbase) {                         // raw rows jbase .. jbase + 3 of this thread's residue class (zeros outside [0, R))
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int jj = jbase + i;
-            const bool in = jj >= 0 && jj < a.R;
-            const float* xr = xb + (int64_t)jj * rstep;
-            raw[i] = in ? *reinterpret_cast<const float4*>(xr) : make_float4(0.f, 0.f, 0.f, 0.f);
-            hl[i] = (in && lane == 0 && !first_g) ? xr[-1] : 0.f;
-            hr[i] = (in && lane == 63 && !last_g) ? xr[4] : 0.f;
+    const float* const xb = a.x.p + (int64_t)b * a.x.sB + (int64_t)c * a.x.sC;
+    const int T4 = a.T >> 2, per_row = a.RB * T4;         // float4s per row group
+    // ---- phase 1: HBM -> activation -> LDS -------------------------------------------------------------------------------------------
+    const int n4 = nrows * per_row;
+#pragma unroll 4
+    for (int e = tid; e < n4; e += 256) {
+        const int jl = e / per_row, rem = e - jl * per_row;
+        const int rl = rem / T4, t4 = rem - rl * T4;
+        const int jj = 4 * j0 - 2 + jl;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (jj >= 0 && jj < a.R) {
+            v = *reinterpret_cast<const float4*>(xb + (int64_t)(r0 + rl + jj * a.dil) * a.x.sF + 4 * t4);
+            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+            if (a.act == 1) { v.x = aid_gelu(v.x); v.y = aid_gelu(v.y); v.z = aid_gelu(v.z); v.w = aid_gelu(v.w); }      // (gelu(0) = 0: the padding stays zero)
         }
-    };
-    auto process = [&](int i, float* w) {                 // activate and T-transform fetched row i
-        float d[6];
-        float4 v = raw[i];
-        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
-        float lf0 = hl[i] * sc, rt0 = hr[i] * sc;
-        if (a.act == 1) {                                 // (gelu(0) = 0: the padding stays zero)
-            v.x = aid_gelu(v.x); v.y = aid_gelu(v.y); v.z = aid_gelu(v.z); v.w = aid_gelu(v.w);
-            if (lane == 0) lf0 = aid_gelu(lf0);
-            if (lane == 63) rt0 = aid_gelu(rt0);
-        }
-        d[1] = v.x; d[2] = v.y; d[3] = v.z; d[4] = v.w;
-        float lf = __shfl_up(v.w, 1), rt = __shfl_down(v.x, 1);             // lane - 1 / lane + 1: groups g - 1 / g + 1 of the same row (g runs fastest)
-        if (lane == 0) lf = lf0;
-        if (lane == 63) rt = rt0;
-        d[0] = first_g ? 0.f : lf;
-        d[5] = last_g ? 0.f : rt;
-        aid_w45_input_t(d, w);
-    };
-    const int j0 = sg * a.seg;
-    const int j1 = min(a.J, j0 + a.seg);
-    fetch(4 * j0 - 2);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) process(i, W[4 + i]);
-    fetch(4 * j0 + 2);
-    float* const vb = a.V + (int64_t)c * a.N + (int64_t)b * a.NB + (int64_t)r * a.TG + g;
+        *reinterpret_cast<float4*>(w2d_slab + 4 * e) = v;
+    }
+    __syncthreads();
+    // ---- phase 2: tiles ----------------------------------------------------------------------------------------------------------------
+    const int per_j = a.RB * a.TG;
+    const int ntile = jbe * per_j;
     const int64_t pstride = (int64_t)a.C * a.N;
-    for (int j = j0; j < j1; ++j) {
+    for (int tl = tid; tl < ntile; tl += 256) {
+        const int jl = tl / per_j, rem = tl - jl * per_j;
+        const int rl = rem / a.TG, g = rem - rl * a.TG;
+        const float* sp = w2d_slab + (4 * jl) * a.rowf + rl * a.T + 4 * g;
+        float W[8][6];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int t = 0; t < 6; ++t) W[i][t] = W[4 + i][t];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) process(i, W[4 + i]);
-        if (j + 1 < j1) fetch(4 * j + 6);                 // the next tile's rows are in flight while this one is transformed and stored
-        float* vp = vb + (int64_t)j * a.dil * a.TG;
+        for (int i = 0; i < 8; ++i) {
+            const float* row = sp + i * a.rowf;
+            const float4 v = *reinterpret_cast<const float4*>(row);
+            float d[6];
+            d[0] = g > 0 ? row[-1] : 0.f;
+            d[1] = v.x; d[2] = v.y; d[3] = v.z; d[4] = v.w;
+            d[5] = g < a.TG - 1 ? row[4] : 0.f;
+            aid_w45_input_t(d, W[i]);
+        }
+        float* vp = a.V + (int64_t)c * a.N + (int64_t)b * a.NB + (int64_t)((j0 + jl) * a.dil + r0 + rl) * a.TG + g;
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
-            float d[8], V[8];
+            float d[8], Vo[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) d[i] = W[i][t];
-            aid_w45_input_f(d, V);
-            if (live) {
+            aid_w45_input_f(d, Vo);
 #pragma unroll
-                for (int f = 0; f < 8; ++f) vp[(int64_t)(f * 6 + t) * pstride] = V[f];
-            }
+            for (int f = 0; f < 8; ++f) vp[(int64_t)(f * 6 + t) * pstride] = Vo[f];
         }
     }
 }
 
 // called by aid_scale_act (aid_norm.hip) for wino == 3
 int aid_w2d_input(const aid_scale_act_params* p, hipStream_t st) {
-    AID_REQUIRE(p->dilF >= 1 && (p->F % p->dilF) == 0 && (p->T % 16) == 0, "aid_scale_act(wino=3): F % dilF == 0 and T % 16 == 0");
+    AID_REQUIRE(p->dilF >= 1 && (p->F % p->dilF) == 0 && (p->T % 16) == 0 && p->T <= 2048, "aid_scale_act(wino=3): F % dilF == 0, T % 16 == 0, T <= 2048");
     AID_REQUIRE((p->x.sB % 4) == 0 && (p->x.sC % 4) == 0 && (p->x.sF % 4) == 0 && (((uintptr_t)p->x.p) & 15) == 0, "aid_scale_act(wino=3): 16-byte aligned input rows");
     const W2dGeo ge = w2d_geo(p->B, p->F, p->T, p->dilF);
     AID_REQUIRE(ge.N < (1LL << 31), "aid_scale_act(wino=3): too many positions");
@@ -370,12 +359,22 @@ int aid_w2d_input(const aid_scale_act_params* p, hipStream_t st) {
     a.x = p->x; a.scale = p->scale; a.scale_ld = p->scale_ld; a.V = p->y.p;
     a.B = p->B; a.C = p->C; a.F = p->F; a.T = p->T; a.act = p->act; a.dil = p->dilF;
     a.R = ge.R; a.J = ge.J; a.TG = ge.TG; a.NB = ge.NB; a.N = ge.N;
-    // tiles per thread: long walks amortise the four warm-up rows, short ones give the chip enough threads (>= ~4 waves per SIMD)
-    int seg = 8;
-    while (seg > 1 && (int64_t)p->B * p->C * p->dilF * ge.TG * aid_cdiv(ge.J, seg) < 256 * 1024) seg >>= 1;
-    a.seg = seg; a.nseg = aid_cdiv(ge.J, seg);
-    a.total = (int64_t)p->B * p->C * a.nseg * p->dilF * ge.TG;
-    hipLaunchKernelGGL(w2d_input_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, st, a);
+    // RB classes per workgroup: 64 positions (256 bytes) per row tile where the dilation has that many classes; the largest divisor of dil below that otherwise
+    int RB = ge.TG >= 64 ? 1 : 64 / ge.TG;
+    if (RB > p->dilF) RB = p->dilF;
+    while (p->dilF % RB) --RB;
+    a.RB = RB; a.nrb = p->dilF / RB; a.rowf = RB * p->T;
+    // JB row tiles per workgroup: 8 (activations 1.125 x), fewer when the slab would pass 64 KB or the launch would have too few workgroups
+    int JB = 16384 / a.rowf / 4 - 1;
+    if (JB > 8) JB = 8;
+    if (JB > ge.J) JB = ge.J;
+    while (JB > 2 && (int64_t)p->B * p->C * a.nrb * aid_cdiv(ge.J, JB) < 2048) JB >>= 1;
+    AID_REQUIRE(JB >= 1, "aid_scale_act(wino=3): T too long for the LDS slab");
+    a.JB = JB; a.njb = aid_cdiv(ge.J, JB);
+    const int64_t nblk = (int64_t)p->B * p->C * a.nrb * a.njb;
+    AID_REQUIRE(nblk < (1LL << 31), "aid_scale_act(wino=3): grid too large");
+    const size_t lds = (size_t)(4 * JB + 4) * a.rowf * 4;
+    hipLaunchKernelGGL(w2d_input_kernel, dim3((unsigned)nblk), dim3(256), lds, st, a);
     AID_CHECK_LAUNCH();
     return AID_OK;
 }
@@ -396,41 +395,55 @@ struct W2dOutDev {
     int64_t N;
 };
 
-__global__ __launch_bounds__(128) void w2d_output_kernel(const W2dOutDev a) {
+// One thread owns TWO consecutive sample groups of one row tile and output channel (one float2 of every plane): per row-axis index xf it loads the six
+// T planes and applies the T transform first (6 -> 4 samples per group), then accumulates the four output rows with the row-axis coefficients
+// (the +- pairs of AF^T: s = a + b, t = a - b) -- 32 accumulators instead of the 96 of a row-transform-first order, ~90 registers, so that eight
+// waves per SIMD keep loads in flight and the pass's waves fit beside the two resident GEMM workgroups of another stream.
+__global__ __launch_bounds__(256) void w2d_output_kernel(const W2dOutDev a) {
     const aid_conv2d_params& p = a.p;
     int rest = blockIdx.x;
     const int blk = rest % a.nblk; rest /= a.nblk;
     const int co = rest % p.Cout;
     const int b = rest / p.Cout;
     const int tid = threadIdx.x;
-    const int np = (blk * 128 + tid) * 4;                 // first of this thread's 4 positions within the sample
+    const int np = (blk * 256 + tid) * 2;                 // first of this thread's 2 positions within the sample
     const bool live = np < a.NB;
     float s1 = 0.f, s2 = 0.f, sd = 0.f;
     if (live) {
-        const int q = np / a.TG, g0 = np - q * a.TG;       // row tile index q = j * dil + r; groups g0 .. g0+3 (TG % 4 == 0)
+        const int q = np / a.TG, g0 = np - q * a.TG;       // row tile index q = j * dil + r; groups g0, g0 + 1 (TG is even)
         const int j = q / p.dilF, r = q - j * p.dilF;
         const float* mp = a.M + ((int64_t)co * a.N + (int64_t)b * a.NB + np);
         const int64_t pstride = (int64_t)p.Cout * a.N;
-        constexpr float AF[4][8] = AID_W45_ATF;
-        float4 P[4][6];
+        float Y[4][8];
+        auto plane = [&](int f, float* o) {                // T transform of row-axis plane f: 2 groups x 4 samples
+            float2 m[6];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int t = 0; t < 6; ++t) m[t] = *reinterpret_cast<const float2*>(mp + (int64_t)(f * 6 + t) * pstride);
+            float Mt[6];
 #pragma unroll
-            for (int t = 0; t < 6; ++t) P[i][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = 0; t < 6; ++t) Mt[t] = m[t].x;
+            aid_w45_output_t(Mt, o);
 #pragma unroll
-        for (int f = 0; f < 8; ++f) {
-            float4 m[6];
+            for (int t = 0; t < 6; ++t) Mt[t] = m[t].y;
+            aid_w45_output_t(Mt, o + 4);
+        };
+        {
+            float a0[8], a1[8], a2[8];
+            plane(0, a0); plane(1, a1); plane(2, a2);
 #pragma unroll
-            for (int t = 0; t < 6; ++t) m[t] = *reinterpret_cast<const float4*>(mp + (int64_t)(f * 6 + t) * pstride);
+            for (int e = 0; e < 8; ++e) { const float s = a1[e] + a2[e], t = a1[e] - a2[e]; Y[0][e] = a0[e] + s; Y[1][e] = t; Y[2][e] = s; Y[3][e] = t; }
+        }
+        {
+            float a1[8], a2[8];
+            plane(3, a1); plane(4, a2);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float cf = AF[i][f];
-                if (cf == 0.f) continue;
+            for (int e = 0; e < 8; ++e) { const float s = a1[e] + a2[e], t = a1[e] - a2[e]; Y[0][e] += s; Y[1][e] += 2.0f * t; Y[2][e] += 4.0f * s; Y[3][e] += 8.0f * t; }
+        }
+        {
+            float a1[8], a2[8], a7[8];
+            plane(5, a1); plane(6, a2); plane(7, a7);
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    P[i][t].x += cf * m[t].x; P[i][t].y += cf * m[t].y; P[i][t].z += cf * m[t].z; P[i][t].w += cf * m[t].w;
-                }
-            }
+            for (int e = 0; e < 8; ++e) { const float s = a1[e] + a2[e], t = a1[e] - a2[e]; Y[0][e] += s; Y[1][e] += 0.5f * t; Y[2][e] += 0.25f * s; Y[3][e] += 0.125f * t + a7[e]; }
         }
         const float sv = p.out_scale ? p.out_scale[(int64_t)b * p.out_scale_ld + co] : 1.f;
         const float as = p.epi == 1 ? p.aux_scale[(int64_t)b * p.aux_scale_ld + co] : 0.f;
@@ -441,41 +454,43 @@ __global__ __launch_bounds__(128) void w2d_output_kernel(const W2dOutDev a) {
             const int f = r + jj * p.dilF;
             const int t0 = 4 * g0;
             float* yp = p.y.p + (int64_t)b * p.y.sB + (int64_t)co * p.y.sC + (int64_t)f * p.y.sF + t0;
-            const float* rp = p.res.p ? p.res.p + (int64_t)b * p.res.sB + (int64_t)co * p.res.sC + (int64_t)f * p.res.sF + t0 : nullptr;
-            const float* up = p.aux.p ? p.aux.p + (int64_t)b * p.aux.sB + (int64_t)co * p.aux.sC + (int64_t)f * p.aux.sF + t0 : nullptr;
-            float4 rv[4], uv[4];
+            float rr[8], uu[8];
+            if (p.res.p) {
+                const float* rp = p.res.p + (int64_t)b * p.res.sB + (int64_t)co * p.res.sC + (int64_t)f * p.res.sF + t0;
+                const float4 v0 = *reinterpret_cast<const float4*>(rp), v1 = *reinterpret_cast<const float4*>(rp + 4);
+                rr[0] = v0.x; rr[1] = v0.y; rr[2] = v0.z; rr[3] = v0.w; rr[4] = v1.x; rr[5] = v1.y; rr[6] = v1.z; rr[7] = v1.w;
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                rv[k] = rp ? *reinterpret_cast<const float4*>(rp + 4 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
-                uv[k] = up ? *reinterpret_cast<const float4*>(up + 4 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int e = 0; e < 8; ++e) rr[e] = 0.f;
             }
+            if (p.aux.p) {
+                const float* up = p.aux.p + (int64_t)b * p.aux.sB + (int64_t)co * p.aux.sC + (int64_t)f * p.aux.sF + t0;
+                const float4 v0 = *reinterpret_cast<const float4*>(up), v1 = *reinterpret_cast<const float4*>(up + 4);
+                uu[0] = v0.x; uu[1] = v0.y; uu[2] = v0.z; uu[3] = v0.w; uu[4] = v1.x; uu[5] = v1.y; uu[6] = v1.z; uu[7] = v1.w;
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {                  // group g0 + k: component k of the float4s
-                float Mt[6], y[4];
-#pragma unroll
-                for (int t = 0; t < 6; ++t) Mt[t] = w2d_get(P[i][t], k);
-                aid_w45_output_t(Mt, y);
-                const float rr[4] = {rv[k].x, rv[k].y, rv[k].z, rv[k].w};
-                const float uu[4] = {uv[k].x, uv[k].y, uv[k].z, uv[k].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = y[e] * sv;
-                    if (p.epi == 1) v *= aid_dgelu(uu[e] * as);
-                    v += p.res_scale * rr[e];
-                    v *= p.alpha;
-                    y[e] = v;
-                    s1 += v; s2 += v * v; sd += v * uu[e];
-                }
-                *reinterpret_cast<float4*>(yp + 4 * k) = make_float4(y[0], y[1], y[2], y[3]);
+                for (int e = 0; e < 8; ++e) uu[e] = 0.f;
             }
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = Y[i][e] * sv;
+                if (p.epi == 1) v *= aid_dgelu(uu[e] * as);
+                v += p.res_scale * rr[e];
+                v *= p.alpha;
+                y[e] = v;
+                s1 += v; s2 += v * v; sd += v * uu[e];
+            }
+            *reinterpret_cast<float4*>(yp) = make_float4(y[0], y[1], y[2], y[3]);
+            *reinterpret_cast<float4*>(yp + 4) = make_float4(y[4], y[5], y[6], y[7]);
         }
     }
     if (!p.stat_ws && !p.dot_ws) return;
-    // block partials (fixed order: lanes by xor tree, then the two waves)
+    // block partials (fixed order: lanes by xor tree, then the four waves)
     double d1 = (double)s1, d2 = (double)s2, d3 = (double)sd;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { d1 += __shfl_xor(d1, off, 64); d2 += __shfl_xor(d2, off, 64); d3 += __shfl_xor(d3, off, 64); }
-    __shared__ double red[2][3];
+    __shared__ double red[4][3];
     if ((tid & 63) == 0) { red[tid >> 6][0] = d1; red[tid >> 6][1] = d2; red[tid >> 6][2] = d3; }
     __syncthreads();
     if (tid == 0) {
@@ -485,33 +500,39 @@ __global__ __launch_bounds__(128) void w2d_output_kernel(const W2dOutDev a) {
         const int nslot = cpg * a.nblk;
         if (p.stat_ws) {
             double* w = p.stat_ws + (((int64_t)b * 8 + grp) * nslot + slot) * 2;
-            w[0] = red[0][0] + red[1][0];
-            w[1] = red[0][1] + red[1][1];
+            w[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+            w[1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
         }
-        if (p.dot_ws) p.dot_ws[((int64_t)b * 8 + grp) * nslot + slot] = red[0][2] + red[1][2];
+        if (p.dot_ws) p.dot_ws[((int64_t)b * 8 + grp) * nslot + slot] = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
     }
 }
 
 static inline int w2d_nblk(int NB) { return (NB / 4 + 127) / 128; }
 
 extern "C" int aid_conv2d_wino2d_supported(int Cin, int Cout, int F, int T, int dilF) { return w2d_shape_ok(Cin, Cout, F, T, dilF) ? 1 : 0; }
-// Which launches take the 2-D form instead of the fused 1-D kernels.  Measured per layer (tools/w2d_probe.py layer, profiles/r05_w2d_layer_probe*.txt):
-// at K = Cout = 256 the three passes together take 0.67-0.81 of the fused F(8,3) / F(4,3) kernel with its pre-pass (the GEMM runs at 0.80-0.85 of
-// the fp32 MFMA peak on 2.08x fewer products; the two transform passes move 9 x the activation at 3.5-6 TB/s); at K = 128 the GEMM sits at the
-// HBM ridge (32 FLOP/B) and the sum is 0.87-1.1 of the fused kernel.  Ragged row tiles (F / dil not a multiple of 4) pad the GEMM: up to 4/3.
+// Which launches take the 2-D form instead of the fused 1-D kernels.  Measured per layer (tools/w2d_probe.py layer, profiles/r05_w2d_passes_ab.txt,
+// the three passes together against the fused F(8,3) / F(4,3) kernel with its pre-pass):
+//   K = Cout = 256 (levels 5, 6): 0.61-0.74 at batch 4 (the GEMM runs at 0.77-0.85 of the fp32 MFMA peak on 2.08x fewer products; the two transform
+//     passes move 9 x the activation at 4.4-7 TB/s), 0.55-0.58 at batch 1 (48 x more tiles than the fused kernel has to fill the chip with);
+//   K = 128: the GEMM sits at the HBM ridge (32 FLOP/B).  T <= 128 (level 4, the 128-channel step of level 5): 0.82-0.94 at batch 4, 0.58-0.63 at
+//     batch 1; T = 256 (level 3): 1.02 at batch 4, 0.87 at batch 1 -- taken only for launches of at most 2 x 65536 positions.
+// Ragged row tiles (F / dil not a multiple of 4) pad the GEMM by up to 4/3: K = 256 still wins at 1.33 (0.84), K = 128 only up to 1.2.
+// A function of the launch shape, B included: equal launches (the same sub-batch size) take equal kernels.
 extern "C" int aid_conv2d_wino2d_wanted(int B, int Cin, int Cout, int F, int T, int dilF) {
     if (!w2d_shape_ok(Cin, Cout, F, T, dilF)) return 0;
     const W2dGeo ge = w2d_geo(B, F, T, dilF);
     const double pad = (double)ge.J * 4.0 / (double)ge.R;
     if (Cin >= 256 && Cout >= 256) return pad <= 1.34 ? 1 : 0;
-    return 0;
+    if (Cin < 128 || Cout < 128 || pad > 1.21) return 0;
+    if (T <= 128) return 1;
+    return (int64_t)B * F * T <= 2 * 65536 ? 1 : 0;
 }
 extern "C" int64_t aid_conv2d_wino2d_positions(int B, int F, int T, int dilF) { return (dilF >= 1 && F % dilF == 0 && T % 4 == 0) ? w2d_geo(B, F, T, dilF).N : 0; }
 // per-(sample, group) partial count of stat_ws / dot_ws for x_wino = 3
 int aid_w2d_partials(int Cout, int F, int T, int dilF) { return (Cout >> 3) * w2d_nblk(w2d_geo(1, F, T, dilF).NB); }
 
 // aid_conv2d with x_wino = 3: x.p = V [48][Cin][N], wp_wino = U [48][Cin_pad][Cout_pad], ws = scratch for M [48][Cout][N]
-int aid_conv53_wino2d(const aid_conv2d_params* p, hipStream_t st) {
+static int w2d_check(const aid_conv2d_params* p) {
     AID_REQUIRE(p->KH == 5 && p->KW == 3 && p->wp_wino && p->wino_taps == 48, "aid_conv2d(x_wino=3): needs the 48-plane pack (aid_pack_conv_weight wpw2)");
     AID_REQUIRE(w2d_shape_ok(p->Cin, p->Cout, p->F, p->T, p->dilF), "aid_conv2d(x_wino=3): shape not supported (aid_conv2d_wino2d_supported)");
     AID_REQUIRE(!p->in_scale && p->act == 0 && !p->x2.p && !p->fin_mode, "aid_conv2d(x_wino=3): no in-kernel prologue, no x2, no fin_mode");
@@ -525,15 +546,42 @@ int aid_conv53_wino2d(const aid_conv2d_params* p, hipStream_t st) {
     const int npart = aid_w2d_partials(p->Cout, p->F, p->T, p->dilF);
     AID_REQUIRE(!p->stat_ws || p->stat_n == npart, "aid_conv2d(x_wino=3): stat_n != aid_conv2d_stat_partials()");
     AID_REQUIRE(!p->dot_ws || p->dot_n == npart, "aid_conv2d(x_wino=3): dot_n != aid_conv2d_dot_partials()");
+    return AID_OK;
+}
+static int w2d_gemm_of(const aid_conv2d_params* p, hipStream_t st) {
+    const W2dGeo ge = w2d_geo(p->B, p->F, p->T, p->dilF);
     aid_wino2d_gemm_params gp;
     gp.U = p->wp_wino; gp.V = p->x.p; gp.M = p->ws;
     gp.nxi = 48; gp.Cin = p->Cin; gp.Cout = p->Cout; gp.Cin_pad = p->Cin_pad; gp.Cout_pad = p->Cout_pad; gp.N = ge.N; gp.variant = 0;
-    const int rc = aid_wino2d_gemm(&gp, st);
-    if (rc != AID_OK) return rc;
+    return aid_wino2d_gemm(&gp, st);
+}
+static int w2d_output_of(const aid_conv2d_params* p, hipStream_t st) {
+    const W2dGeo ge = w2d_geo(p->B, p->F, p->T, p->dilF);
     W2dOutDev a;
     a.p = *p; a.M = p->ws;
     a.R = ge.R; a.J = ge.J; a.TG = ge.TG; a.NB = ge.NB; a.N = ge.N; a.nblk = w2d_nblk(ge.NB);
-    hipLaunchKernelGGL(w2d_output_kernel, dim3((unsigned)((int64_t)p->B * p->Cout * a.nblk)), dim3(128), 0, st, a);
+    hipLaunchKernelGGL(w2d_output_kernel, dim3((unsigned)((int64_t)p->B * p->Cout * a.nblk)), dim3(256), 0, st, a);
     AID_CHECK_LAUNCH();
     return AID_OK;
+}
+int aid_conv53_wino2d(const aid_conv2d_params* p, hipStream_t st) {
+    int rc = w2d_check(p);
+    if (rc != AID_OK) return rc;
+    rc = w2d_gemm_of(p, st);
+    if (rc != AID_OK) return rc;
+    return w2d_output_of(p, st);
+}
+// The two launches of aid_conv2d(x_wino = 3) as separate calls on the same parameter block (a launch plan that wants the MFMA-bound GEMM and the
+// HBM-bound output pass as separate nodes: per-kernel timing, different streams).  _gemm then _output on one stream == aid_conv2d(p).
+extern "C" int aid_conv2d_wino2d_gemm(const aid_conv2d_params* p, void* stream) {
+    AID_REQUIRE(p && p->x.p && p->y.p && p->x_wino == 3, "aid_conv2d_wino2d_gemm: x_wino = 3 parameters");
+    const int rc = w2d_check(p);
+    return rc != AID_OK ? rc : w2d_gemm_of(p, (hipStream_t)stream);
+}
+extern "C" int aid_conv2d_wino2d_output(const aid_conv2d_params* p, void* stream) {
+    AID_REQUIRE(p && p->x.p && p->y.p && p->x_wino == 3, "aid_conv2d_wino2d_output: x_wino = 3 parameters");
+    const int rc = w2d_check(p);
+    if (rc != AID_OK) return rc;
+    aid_note_kernel("w2d_output_kernel");
+    return w2d_output_of(p, (hipStream_t)stream);
 }

@@ -59,46 +59,112 @@ def _cpulist(text: str) -> List[int]:
     return out
 
 
-def gpu_numa_node(device_index: int) -> Optional[int]:
-    """NUMA node of a GPU from sysfs (/sys/bus/pci/devices/<domain:bus:dev.fn>/numa_node), or None when it cannot be read / is -1."""
+def gpu_pci_bdf(device_index: int) -> Optional[str]:
+    """PCI address "dddd:bb:dd.f" of a visible GPU (torch device properties), or None."""
     try:
         pr = torch.cuda.get_device_properties(device_index)
-        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
-        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        return "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        return None
+
+
+def gpu_numa_node(device_index: int, sysfs: str = "/sys", bdf_of=gpu_pci_bdf) -> Optional[int]:
+    """NUMA node of a GPU from sysfs (<sysfs>/bus/pci/devices/<domain:bus:dev.fn>/numa_node), or None when it cannot be read / is -1.
+    ``sysfs`` / ``bdf_of`` are injectable so that the lookup can be tested against a faked tree (tests/test_dist_gloo.py)."""
+    try:
+        bdf = bdf_of(device_index)
+        node = int(open(os.path.join(sysfs, "bus/pci/devices", bdf, "numa_node")).read())
         return node if node >= 0 else None
     except Exception:
         return None
 
 
+def plan_rank_binding(local: int, ranks_on_node: int, ndev: int, avail: List[int], sysfs: str = "/sys", bdf_of=gpu_pci_bdf) -> dict:
+    """Which CPUs local rank ``local`` should run on: the cores of its GPU's NUMA node, shared evenly between the ranks whose GPUs sit on the same
+    node; an even split of ``avail`` when sysfs does not say.  Pure function of its arguments (no affinity call): returns
+    {"gpu", "pci", "numa_node", "cpus", "peers", "fallback"}; ``fallback`` names why the NUMA path was not taken (None when it was)."""
+    avail = sorted(avail)
+    gpu = local % ndev if ndev else None
+    out = {"gpu": gpu, "pci": bdf_of(gpu) if ndev else None, "numa_node": None, "peers": list(range(ranks_on_node)), "fallback": None}
+    mine = avail
+    node = gpu_numa_node(gpu, sysfs, bdf_of) if ndev else None
+    if node is None:
+        out["fallback"] = "no GPU" if not ndev else "numa_node of the GPU not readable (or -1)"
+    else:
+        out["numa_node"] = node
+        try:
+            cpus = [c for c in _cpulist(open(os.path.join(sysfs, f"devices/system/node/node{node}/cpulist")).read()) if c in set(avail)]
+            same = [r for r in range(ranks_on_node) if gpu_numa_node(r % ndev, sysfs, bdf_of) == node]
+            if cpus and local in same:
+                mine, out["peers"] = cpus, same
+            else:
+                out["fallback"] = "none of the node's CPUs is in this process's affinity mask"
+        except OSError:
+            out["fallback"] = "cpulist of the node not readable"
+    peers = out["peers"]
+    k, n = peers.index(local) if local in peers else 0, max(1, len(peers))
+    out["cpus"] = mine[k * len(mine) // n:(k + 1) * len(mine) // n] or mine
+    return out
+
+
+_BINDING: dict = {}
+
+
 def bind_rank_to_gpu_numa(local: int, ranks_on_node: int, log=None) -> Optional[int]:
-    """Pin this rank's CPU threads (noise generation, launch loop) to the cores of its GPU's NUMA node, shared evenly between the ranks whose
-    GPUs sit on the same node; falls back to an even split of the visible cores when sysfs does not say.  Returns the thread count set."""
+    """Pin this rank's CPU threads (noise generation, launch loop) to the cores of its GPU's NUMA node (plan_rank_binding).  Returns the thread
+    count set; the plan that was applied is kept for rank_report()."""
     try:
         avail = sorted(os.sched_getaffinity(0))
     except AttributeError:
         return None
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    mine, peers = avail, list(range(ranks_on_node))
-    node = gpu_numa_node(local % ndev) if ndev else None
-    if node is not None:
-        try:
-            cpus = [c for c in _cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()) if c in set(avail)]
-            same = [r for r in range(ranks_on_node) if gpu_numa_node(r % ndev) == node]
-            if cpus and local in same:
-                mine, peers = cpus, same
-        except OSError:
-            pass
-    k, n = peers.index(local) if local in peers else 0, max(1, len(peers))
-    share = mine[k * len(mine) // n:(k + 1) * len(mine) // n] or mine
+    plan = plan_rank_binding(local, ranks_on_node, ndev, avail)
+    share = plan["cpus"]
     try:
         os.sched_setaffinity(0, share)
     except OSError:
         return None
     torch.set_num_threads(max(1, len(share)))
+    _BINDING.clear()
+    _BINDING.update(plan)
     if log is not None:
-        print(f"[aid dist] local rank {local}: GPU NUMA node {node}, {len(share)} CPU threads "
-              f"({share[0]}..{share[-1]})", file=log, flush=True)
+        print(f"[aid dist] local rank {local}: GPU {plan['gpu']} ({plan['pci']}) NUMA node {plan['numa_node']}, {len(share)} CPU threads "
+              f"({share[0]}..{share[-1]})" + (f" -- FALLBACK: {plan['fallback']}" if plan["fallback"] else ""), file=log, flush=True)
     return len(share)
+
+
+def rccl_version() -> Optional[str]:
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:
+        return None
+
+
+def rank_report(rank: int, local: int, **timings) -> dict:
+    """One rank's line of the bench JSON's ``ranks`` table: where it ran (GPU, PCI address, NUMA node, CPU threads, binding fallback if any) and
+    its own wall-clock numbers -- enough to tell a mis-bound or slow rank from a slow collective without a rerun."""
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    gpu = torch.cuda.current_device() if ndev else None
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count()
+    r = {"rank": rank, "local_rank": local, "host": socket.gethostname(), "gpu": gpu, "pci": gpu_pci_bdf(gpu) if ndev else None,
+         "gpu_name": torch.cuda.get_device_properties(gpu).name if ndev else None,
+         "numa_node": _BINDING.get("numa_node", gpu_numa_node(gpu) if ndev else None), "cpu_threads": ncpu,
+         "numa_peers": _BINDING.get("peers"), "binding_fallback": _BINDING.get("fallback", "bind_rank_to_gpu_numa not called")}
+    r.update({k: (round(v, 4) if isinstance(v, float) else v) for k, v in timings.items()})
+    return r
+
+
+def gather_objects(obj, dst: int = 0):
+    """Python objects of every rank on rank ``dst`` (list in rank order; None elsewhere); [obj] in a single-process world."""
+    if not _active():
+        return [obj]
+    out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object(obj, out, dst=dst)
+    return out
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:

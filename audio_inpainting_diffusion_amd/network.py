@@ -222,6 +222,8 @@ class _Builder:
                 self._keep.append(t)                      # launches already recorded point into it
             t = self.scratch[key] = torch.zeros(max(nbytes, 4096 + 336 * 98304) // 4, device=self.device, dtype=torch.float32)
             self.nbytes += t.numel() * 4
+        if not any(t is z for z in self.plan.zero_on_fail):
+            self.plan.zero_on_fail.append(t)               # (its first 4096 bytes are the flags)
         return t
 
     @property
@@ -323,6 +325,8 @@ class _Builder:
         t = self.scratch.get(key)
         if t is None:
             t = self.scratch[key] = torch.zeros(self.B, device=self.device, dtype=torch.int32)
+        if not any(t is z for z in self.plan.zero_on_fail):
+            self.plan.zero_on_fail.append(t)               # (a launch that fails must not leave a counter half-way for the next run)
         return t
 
     def _stats_train_hook(self, scale, gamma, mod, gname, stats, B, Cc):
@@ -447,8 +451,15 @@ class _Builder:
         # algorithmic HBM bytes: x once, residual / aux once, y once, weights once
         nb = 4 * (B * F * T * (cin + cout * (1 + (res is not None) + (aux is not None))) + cin * cout * kh * kw)
         dws = None if dot is None else dot[0]
-        op = self._add("aid_conv2d", p, x, x2, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, ws, dws, fin_stats, cnt, flops=2 * B * F * T * cin * cout * kh * kw,
-                       nbytes=nb, writes=(y, ws, dws, cnt))
+        if x_wino == 45:
+            # two plan nodes on one parameter block: the MFMA-bound batched GEMM M = U V (its FLOPs and the bytes of V + M are booked here) and the
+            # HBM-bound output-transform pass with the epilogue (reads M, residual / aux; writes y and the partials)
+            self._add("aid_conv2d_wino2d_gemm", p, x, wpw, ws, flops=2 * B * F * T * cin * cout * kh * kw, nbytes=4 * 48 * npos * (cin + cout), writes=(ws,))
+            op = self._add("aid_conv2d_wino2d_output", p, ws, y, res, out_scale, aux, aux_scale, dws, nbytes=4 * (48 * npos * cout + B * F * T * cout * (1 + (res is not None) + (aux is not None))),
+                           writes=(y, dws))
+        else:
+            op = self._add("aid_conv2d", p, x, x2, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, ws, dws, fin_stats, cnt, flops=2 * B * F * T * cin * cout * kh * kw,
+                           nbytes=nb, writes=(y, ws, dws, cnt))
         self._wrote(y)
         if not self._in_bwd and x_wino and epi == 0 and dot is None and self.net.epilogue_stats:
             n = int(_lib.lib().aid_conv2d_stat_partials(B, cin, cout, F, T, dil, xw_code))

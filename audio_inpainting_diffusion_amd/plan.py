@@ -57,6 +57,10 @@ def _disjoint(a, b) -> bool:
     return any(ia[d] + sa[1][d] <= ib[d] or ib[d] + sb[1][d] <= ia[d] for d in order)
 
 
+# entry points that take an aid_conv2d_params block (the two launches of the 2-D Winograd form are separate plan nodes)
+CONV_OPS = ("aid_conv2d", "aid_conv2d_wino2d_gemm", "aid_conv2d_wino2d_output")
+
+
 class Op:
     __slots__ = ("fn", "addr", "name", "flops", "nbytes", "descr", "lane", "reads", "writes", "params")
 
@@ -86,12 +90,13 @@ class Plan:
         self.trace = None          # set to a list to bracket EVERY launch with HIP events (tools/plan_trace.py)
         self._sched = None
         self.side_stream = None    # stream of lane 1 (the owner may share one between plans that never run at the same time)
+        self.zero_on_fail = []     # scratch whose contract is "zero before a launch, left zero by it" (arrival counters, split-K flags): re-zeroed when a launch fails
 
     # ---- construction ------------------------------------------------------------------------------------------------------
     def add(self, name, params, *tensors, flops=0, nbytes=0, writes: Sequence[torch.Tensor] = ()):
         """tensors: everything the launch touches through raw pointers (kept alive); writes: the subset it writes (the rest is read)."""
         fn = getattr(_lib.lib(), name)
-        if name == "aid_conv2d":
+        if name in CONV_OPS:
             q = params
             descr = "conv %dx%d d%-3d Cin%-4d Cout%-4d F%-3d T%-4d act%d epi%d" % (q.KH, q.KW, q.dilF, q.Cin, q.Cout, q.F, q.T, q.act, q.epi)
         else:
@@ -192,7 +197,18 @@ class Plan:
 
     # ---- execution -----------------------------------------------------------------------------------------------------------
     def _fail(self, op, rc):
-        raise _lib.AidError(f"{op.name} failed rc={rc}: {_lib.lib().aid_last_error().decode()}")
+        msg = _lib.lib().aid_last_error().decode()
+        try:                       # a failed launch may have left counters / flags half-way: the next run must not find them non-zero
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except Exception:
+            pass
+        for t in self.zero_on_fail:
+            try:
+                t.zero_() if t.dtype != torch.float32 else t[:1024].zero_()      # (fp32 scratch: AID_CONV2D_SPLIT_FLAG_BYTES of flags lead it)
+            except Exception:
+                pass
+        raise _lib.AidError(f"{op.name} failed rc={rc}: {msg}")
 
     def run(self):
         cur = torch.cuda.current_stream()
@@ -206,8 +222,8 @@ class Plan:
                     e0.record()
                     rc = op.fn(op.addr, stream)
                     e1.record()
-                    trace.append((e0, e1, op.name, op.descr, op.addr, _lib.lib().aid_last_kernel().decode() if op.name == "aid_conv2d" else "", op.lane))
-                elif timing is not None and op.flops > 0 and op.name == "aid_conv2d":
+                    trace.append((e0, e1, op.name, op.descr, op.addr, _lib.lib().aid_last_kernel().decode() if op.name in CONV_OPS else "", op.lane))
+                elif timing is not None and op.flops > 0 and op.name in CONV_OPS:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     rc = op.fn(op.addr, stream)

@@ -49,8 +49,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA = 157.3          # TFLOP/s, dense fp32 matrix (MI355X_MICROARCH.md)
 # executed MFMA FLOPs as a fraction of the direct form: F(4,3) issues 6 products per 4 outputs x 3 taps = 1/2, F(8,3) 10 per 8 x 3 = 5/12
-WINO_EXEC = {"conv53_wino4r_kernel": 0.5, "conv53_wino4v_kernel": 0.5, "conv53_wino4_kernel": 0.5, "conv53_wino8r_kernel": 10.0 / 24.0, "conv53_wino8r_sk_kernel": 10.0 / 24.0,
-             "conv53_wino8r_ks_kernel": 10.0 / 24.0}
+# the 2-D form F(4,5) x F(4,3) 48 per 16 x 15 = 1/5 (its GEMM is a plan node of its own: w2d_gemm_kernel; the output pass carries no FLOPs)
+WINO_EXEC = {"conv53_wino4r_kernel": 0.5, "conv53_wino4v_kernel": 0.5, "conv53_wino4_kernel": 0.5, "conv53_wino8r_kernel": 10.0 / 24.0,
+             "conv53_wino8r_ks_kernel": 10.0 / 24.0, "w2d_gemm_kernel": 48.0 / 240.0}
 
 
 def ensure_built() -> None:
@@ -189,7 +190,7 @@ def family_table(timing, by_kernel=False):
     by_kernel: aggregate by the device kernel's name (what rocprofv3 lists) instead of name + tile kind."""
     fam = {}
     for e0, e1, fl, _d, nb, kn in timing:
-        base = kn.split("(")[0].split("+")[0]
+        base = kn.split("(")[0].split("+")[0].split("<")[0]
         r = fam.setdefault(base if by_kernel else kn, dict(launches=0, ms=0.0, alg=0.0, exe=0.0, bytes=0.0))
         r["launches"] += 1
         r["ms"] += e0.elapsed_time(e1)
@@ -338,7 +339,7 @@ def main():
         jlast = do_step(i)
     torch.cuda.synchronize()
     D.barrier()
-    wall = time.perf_counter() - t0
+    wall_rank = wall = time.perf_counter() - t0
     wall = D.max_over_ranks(wall, dev)
     assert torch.isfinite(state["x"]).all()
     # Kernel speeds are measured right after the timed region: the SAME sampler continues for one warm-up and ROOF_STEPS measured
@@ -373,7 +374,13 @@ def main():
         for d, (n, ms, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             print("%-100s n=%3d  %8.3f ms/launch  %6.1f TF/s  %5.1f%% of conv time" % (d, n, ms / n, f / ms / 1e9, 100 * ms / conv_ms), file=sys.stderr)
     evals = world * B * 2 * a.steps
+    # every rank's own line (where it ran, its own wall clock, broadcast time, single-stream step): a slow SCALE line can be read without a rerun
+    ranks = D.gather_objects(D.rank_report(rank, local, wall_s=wall_rank, bcast_s=t_bcast, ms_per_step=1e3 * wall_rank / a.steps,
+                                           single_stream_ms_per_step=1e3 * wall_serial, segments=[lo, hi]))
     if rank == 0:
+        if world > 1 and world <= torch.cuda.device_count():
+            assert not shared, "ranks share a GPU although the node has one per rank (AID_SHARED_GPU / AID_DIST_BACKEND left set?)"
+            assert len({r["gpu"] for r in ranks}) == world, "two ranks report the same GPU: %r" % [(r["rank"], r["gpu"]) for r in ranks]
         fams = family_table(timing)
         kerns = family_table(timing, by_kernel=True)
         dom_name = next(iter(kerns)) if kerns else None
@@ -397,15 +404,20 @@ def main():
                        "network": "unet_cqt_oct_with_attention %s, %.1f M params, random-init (seeded)" % ("44.1 kHz 8-octave" if a.workload == "musicnet44k" else "7-octave", sum(p.numel() for p in net.parameters()) / 1e6),
                        "parallelism": "segments sharded %d-way, one process per GPU, weights broadcast once in place (%.0f MB in %.3f s, %s), no collective in the loop"
                                       % (world, nbytes / 1e6, t_bcast, (torch.distributed.get_backend() if world > 1 else "single process")),
-                       "sub_batch_streams": n_split, "hip_graph_replay": graphs, "functional_shared_gpu": bool(shared)},
+                       "sub_batch_streams": n_split, "hip_graph_replay": graphs, "functional_shared_gpu": bool(shared),
+                       "backend": (torch.distributed.get_backend() if world > 1 else "single process"), "rccl_version": D.rccl_version(),
+                       "visible_gpus": torch.cuda.device_count()},
+            "ranks": ranks,
             "roofline": {"bound": "mfma", "kernel": dom_name, "measured_in": roofline_pass,
                          "definition": "achieved = MFMA FLOPs issued by ALL launches of the dominant kernel (by device-kernel name, every template instance / tile kind) "
-                                       "/ their summed duration (HIP events around each launch); Winograd F(4,3) issues 1/2 and F(8,3) 5/12 of the direct-form FLOPs; "
+                                       "/ their summed duration (HIP events around each launch); Winograd F(4,3) issues 1/2, F(8,3) 5/12 and the 2-D form F(4,5) x F(4,3) (w2d_gemm_kernel, the K = 256 layers) 1/5 of the direct-form FLOPs; "
                                        "algorithmic_tflops = direct-form FLOPs / the same time; step_executed_frac = issued MFMA FLOPs of all conv / GEMM launches "
-                                       "of one step / ms_per_step of the timed region / peak",
+                                       "of one step / ms_per_step of the timed region / peak; non_winograd_conv_time_fraction_single_stream = 1 - (time of ALL 5x3 Winograd MFMA kernels: "
+                                       "the fused 1-D kernels and the 2-D form's GEMM) / single-stream step time",
                          "step_executed_frac": round(exe / ROOF_STEPS / (wall / a.steps) / 1e12 / PEAK_F32_MFMA, 4),
                          "step_executed_tflops": round(exe / ROOF_STEPS / (wall / a.steps) / 1e12, 2),
-                         "non_winograd_conv_time_fraction_single_stream": round(1.0 - dom.get("time_ms", 0.0) / ROOF_STEPS / (1e3 * wall_serial), 3),
+                         "non_winograd_conv_time_fraction_single_stream": round(1.0 - sum(v["time_ms"] for k, v in kerns.items() if k in WINO_EXEC) / ROOF_STEPS / (1e3 * wall_serial), 3),
+                         "non_dominant_kernel_time_fraction_single_stream": round(1.0 - dom.get("time_ms", 0.0) / ROOF_STEPS / (1e3 * wall_serial), 3),
                          "achieved": dom.get("executed_mfma_tflops"), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s", "frac": dom.get("frac_of_fp32_mfma_peak"),
                          "algorithmic_tflops": dom.get("algorithmic_tflops"), "launches": dom.get("launches"), "avg_launch_us": dom.get("avg_launch_us"),
                          "algorithmic_gflop_per_launch": dom.get("algorithmic_gflop_per_launch"),

@@ -200,6 +200,12 @@ typedef struct {
     int variant;               /* 0: the product instance; > 0: tile-shape experiments (tools/w2d_probe.py) */
 } aid_wino2d_gemm_params;
 int aid_wino2d_gemm(const aid_wino2d_gemm_params* p, void* stream);
+/* The two launches of aid_conv2d(x_wino = 3) as separate calls on the SAME parameter block (a launch plan that wants the MFMA-bound GEMM and the
+ * HBM-bound output pass as separate nodes: per-kernel timing, different streams): _gemm = M = U V into p->ws (aid_wino2d_gemm),
+ * _output = the output transform y = AF^T M AT with the epilogue (gate, residual, dGELU, statistics / dot partials) from p->ws.
+ * _gemm followed by _output on one stream is exactly aid_conv2d(p).   replaces: the same F.conv2d call sites as aid_conv2d (unet...py:433-436, :472-482). */
+int aid_conv2d_wino2d_gemm(const aid_conv2d_params* p, void* stream);
+int aid_conv2d_wino2d_output(const aid_conv2d_params* p, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * aid_resample -- 8-tap cubic FIR 2:1 resampling along T with reflect padding.

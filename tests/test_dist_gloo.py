@@ -37,6 +37,8 @@ def _worker(rank, world, port, q):
     local = torch.stack([torch.full((L,), float(s)) for s in seeds]) if seeds else torch.zeros(0, L)
     allout = D.gather_outputs(local, n_items)
     t = D.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    reps = D.gather_objects(D.rank_report(rank, rank, wall_s=1.0 + rank, segments=[lo, hi]))      # bench.py's per-rank table: rank order on rank 0, None elsewhere
+    assert (reps is None) if rank else ([x["rank"] for x in reps] == [0, 1] and [x["wall_s"] for x in reps] == [1.0, 2.0] and reps[1]["segments"] == [3, 5])
     D.barrier()
     q.put((rank, same, nbytes, (lo, hi), allout[:, 0].tolist(), t))
     dist.destroy_process_group()
@@ -69,3 +71,53 @@ def test_shard_ranges_cover_and_are_world_size_independent():
             assert rs[0][0] == 0 and rs[-1][1] == n and all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
             seeds = sum((item_seeds(5, lo, hi) for lo, hi in rs), [])
             assert seeds == list(range(5, 5 + n))
+
+
+def _fake_sysfs(root, gpus, nodes):
+    """gpus: [(bdf, numa_node)]; nodes: {node: cpulist text}"""
+    for bdf, node in gpus:
+        d = os.path.join(root, "bus/pci/devices", bdf)
+        os.makedirs(d)
+        with open(os.path.join(d, "numa_node"), "w") as f:
+            f.write(f"{node}\n")
+    for node, cpulist in nodes.items():
+        d = os.path.join(root, f"devices/system/node/node{node}")
+        os.makedirs(d)
+        with open(os.path.join(d, "cpulist"), "w") as f:
+            f.write(cpulist + "\n")
+
+
+def test_rank_binding_on_a_faked_8_gpu_2_node_tree(tmp_path):
+    """gpu_numa_node / plan_rank_binding against a faked sysfs tree shaped like an 8 x MI355X host (2 sockets x 64 cores with SMT, 4 GPUs per socket):
+    every rank lands on its own GPU's node, the four ranks of a node split its CPUs evenly and disjointly; the fallbacks say why they were taken."""
+    from audio_inpainting_diffusion_amd import dist as D
+    bdfs = ["0000:%02x:00.0" % b for b in (0x05, 0x15, 0x65, 0x75, 0x85, 0x95, 0xe5, 0xf5)]
+    _fake_sysfs(str(tmp_path), [(bdfs[i], 0 if i < 4 else 1) for i in range(8)], {0: "0-63,128-191", 1: "64-127,192-255"})
+    bdf_of = lambda i: bdfs[i]
+    assert [D.gpu_numa_node(i, str(tmp_path), bdf_of) for i in range(8)] == [0] * 4 + [1] * 4
+    assert D._cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11]
+    avail = list(range(256))
+    plans = [D.plan_rank_binding(r, 8, 8, avail, str(tmp_path), bdf_of) for r in range(8)]
+    node_cpus = {0: set(range(0, 64)) | set(range(128, 192)), 1: set(range(64, 128)) | set(range(192, 256))}
+    for r, pl in enumerate(plans):
+        assert pl["gpu"] == r and pl["pci"] == bdfs[r] and pl["numa_node"] == (0 if r < 4 else 1) and pl["fallback"] is None
+        assert pl["peers"] == ([0, 1, 2, 3] if r < 4 else [4, 5, 6, 7])
+        assert len(pl["cpus"]) == 32 and set(pl["cpus"]) <= node_cpus[pl["numa_node"]]
+    for node in (0, 1):
+        got = [c for pl in plans if pl["numa_node"] == node for c in pl["cpus"]]
+        assert len(got) == len(set(got)) == 128 and set(got) == node_cpus[node]           # disjoint, and together the whole node
+    # an affinity mask that excludes node 1's CPUs (a container pinned to socket 0): ranks 4-7 fall back to an even split and say so
+    half = sorted(node_cpus[0])
+    pl = D.plan_rank_binding(5, 8, 8, half, str(tmp_path), bdf_of)
+    assert pl["numa_node"] == 1 and pl["fallback"] and len(pl["cpus"]) == 16 and set(pl["cpus"]) <= node_cpus[0]
+    # numa_node = -1 (not reported) and an unknown device: even split of what is visible
+    _fake_sysfs(str(tmp_path / "b"), [("0000:01:00.0", -1)], {})
+    pl = D.plan_rank_binding(1, 2, 1, list(range(16)), str(tmp_path / "b"), lambda i: "0000:01:00.0")
+    assert pl["numa_node"] is None and pl["fallback"] and pl["cpus"] == list(range(8, 16)) and pl["gpu"] == 0
+    pl = D.plan_rank_binding(0, 2, 0, list(range(16)), str(tmp_path / "b"), bdf_of)
+    assert pl["gpu"] is None and pl["fallback"] == "no GPU" and pl["cpus"] == list(range(8))
+    # more ranks than GPUs (functional shared-GPU run): ranks wrap around the devices
+    assert D.plan_rank_binding(9, 16, 8, avail, str(tmp_path), bdf_of)["gpu"] == 1
+    rep = D.rank_report(0, 0, wall_s=1.23456789, bcast_s=0.5)
+    assert rep["rank"] == 0 and rep["wall_s"] == 1.2346 and "binding_fallback" in rep and "cpu_threads" in rep
+    assert D.gather_objects({"a": 1}) == [{"a": 1}]

@@ -138,7 +138,11 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
     assert j["config"]["functional_shared_gpu"] == (torch.cuda.device_count() < 2)
     assert j["roofline"]["frac"] is not None and 0 < j["roofline"]["frac"] < 1.0
-    print("bench --gpus 2 (self-launched):", j["value"], "evals/s;", j["config"]["parallelism"])
+    # the per-rank table a bad SCALE line is read from: one row per rank in rank order, where it ran and its own clocks
+    assert [x["rank"] for x in j["ranks"]] == [0, 1] and all(x["wall_s"] > 0 and x["bcast_s"] >= 0 and x["cpu_threads"] >= 1 and x["pci"] for x in j["ranks"])
+    assert [x["segments"] for x in j["ranks"]] == [[0, 1], [1, 2]] and j["config"]["backend"] in ("gloo", "nccl") and j["config"]["visible_gpus"] == torch.cuda.device_count()
+    assert max(x["wall_s"] for x in j["ranks"]) * 1e3 <= j["ms_per_step"] * j["steps"] * 1.001 + 1e-6
+    print("bench --gpus 2 (self-launched):", j["value"], "evals/s;", j["config"]["parallelism"], "| ranks:", [(x["rank"], x["gpu"], x["numa_node"], x["cpu_threads"], x["wall_s"]) for x in j["ranks"]])
 
 
 @pytest.mark.parametrize("xi,dctype", [(0.25, "end"), (0.0, "end"), (0.25, "always")])
@@ -396,6 +400,8 @@ def test_bench_self_launches_eight_ranks_rank0_only_json():
     import re
     ranks = re.findall(r"\[aid dist\] rank (\d+)/8 \(local \d+\): backend (\w+), device (cuda:\d+)", r.stderr)     # (the ranks' lines may interleave)
     assert sorted(int(k[0]) for k in ranks) == list(range(8)), r.stderr[-2000:]
+    assert [x["rank"] for x in j["ranks"]] == list(range(8)) and [x["segments"] for x in j["ranks"]] == [[i, i + 1] for i in range(8)]
+    assert all(x["wall_s"] > 0 and x["cpu_threads"] >= 1 for x in j["ranks"])
     print("bench --gpus 8 (self-launched):", j["value"], "evals/s;", j["config"]["parallelism"])
 
 

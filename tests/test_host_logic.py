@@ -491,6 +491,44 @@ def test_winograd_form_choice_is_a_function_of_the_launch_shape():
     assert L.aid_conv2d_fin_supported(4, 128, 128, 256, 256, 2, 0) == 0 and L.aid_conv2d_fin_supported(4, 2, 64, 64, 1024, 1, 1) == 0
 
 
+def test_two_dimensional_winograd_choice_is_a_function_of_the_launch_shape():
+    """aid_conv2d_wino2d_supported / _wanted / _positions (pure host functions): K = 256 levels always (padding up to 4/3), K = 128 levels with T <= 128 up to
+    1.2 padding, the T = 256 level only for launches of at most two samples, nothing below 128 channels; positions = B * ceil(F / (4 dil)) * dil * T / 4."""
+    from audio_inpainting_diffusion_amd import _lib
+    L = _lib.lib()
+    for B in (1, 2, 4, 8):
+        for d in (1, 2, 4, 8, 16, 32, 64):
+            assert L.aid_conv2d_wino2d_wanted(B, 256, 256, 448, 32, d) == 1 and L.aid_conv2d_wino2d_wanted(B, 256, 256, 384, 64, d) == 1
+        for d in (1, 2, 4, 8, 16, 32):
+            assert L.aid_conv2d_wino2d_wanted(B, 128, 128, 320, 128, d) == 1                 # (d = 32: 10 rows per class -> 12, padding 1.2)
+        assert L.aid_conv2d_wino2d_wanted(B, 128, 128, 384, 64, 64) == 0                    # 6 rows per class -> 8: 1.33 does not pay at K = 128
+        assert L.aid_conv2d_wino2d_wanted(B, 128, 128, 256, 256, 2) == (1 if B <= 2 else 0)
+        assert L.aid_conv2d_wino2d_wanted(B, 96, 96, 192, 512, 2) == 0 and L.aid_conv2d_wino2d_wanted(B, 64, 64, 64, 2048, 1) == 0
+        assert L.aid_conv2d_wino2d_wanted(B, 128, 128, 320, 128, 4) == L.aid_conv2d_wino2d_wanted(B, 128, 128, 320, 128, 4)
+        assert L.aid_conv2d_wino2d_positions(B, 448, 32, 64) == B * 2 * 64 * 8 and L.aid_conv2d_wino2d_positions(B, 384, 64, 1) == B * 96 * 16
+    assert L.aid_conv2d_wino2d_supported(256, 256, 448, 32, 1) == 1 and L.aid_conv2d_wino2d_supported(128, 128, 256, 256, 16) == 1
+    assert L.aid_conv2d_wino2d_supported(96, 96, 192, 512, 2) == 0 and L.aid_conv2d_wino2d_supported(256, 256, 448, 24, 1) == 0      # Cout % 128, T % 16
+    assert L.aid_conv2d_wino2d_supported(256, 256, 450, 32, 4) == 0 and L.aid_conv2d_wino2d_supported(128, 128, 64, 4096, 1) == 0    # F % dil, T <= 2048
+
+
+def test_failed_launch_re_zeroes_the_scratch_that_must_be_found_zero():
+    """Plan._fail: arrival counters / split-K flags have the contract "zero before a launch, left zero by it"; a launch that fails must not leave them
+    half-way for the next run."""
+    import ctypes as C
+    from audio_inpainting_diffusion_amd import _lib
+    from audio_inpainting_diffusion_amd.plan import Op, Plan
+    pl = Plan()
+    cnt = torch.ones(4, dtype=torch.int32)
+    flags = torch.ones(4096, dtype=torch.float32)
+    pl.zero_on_fail.extend([cnt, flags])
+    holder = C.c_int(0)
+    pl.ops.append(Op(lambda addr, stream: 2, C.addressof(holder), "aid_conv2d", 0, 0, "fake", 0, [], [], holder))
+    pl.run = Plan.run.__get__(pl)
+    with pytest.raises(_lib.AidError, match="aid_conv2d failed rc=2"):
+        pl._fail(pl.ops[0], 2)
+    assert int(cnt.abs().sum()) == 0 and float(flags[:1024].abs().sum()) == 0.0 and float(flags[1024:].sum()) == 3072.0
+
+
 def test_lambda_degradation_is_the_jacobian_transpose_product_at_x_hat():
     """sampler.LambdaDegradation (Sampler.predict_resample, edm_sampler_inpainting.py:164-173): apply = the callable on a detached copy, adjoint = its VJP at the
     same point -- what the reference's torch.autograd.grad forms through `degradation(x_hat)` (:65-81) -- for a linear operator that changes the length and for a

@@ -9,6 +9,7 @@ from audio_inpainting_diffusion_amd import _lib
 from audio_inpainting_diffusion_amd.config import make_args
 from audio_inpainting_diffusion_amd.init import seeded_init_
 from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+from audio_inpainting_diffusion_amd.plan import CONV_OPS
 
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 B = int(argv[0]) if argv else 8
@@ -59,7 +60,7 @@ for nm in ("fwd", "bwd"):
     for (a0, a1, name, descr, addr, kn, lane) in tr[nm]:
         us = 1e3 * a0.elapsed_time(a1)
         k = structs.get(addr)
-        sh = shape_of(k) if (k is not None and name != "aid_conv2d") else ""
+        sh = shape_of(k) if (k is not None and name not in CONV_OPS) else ""
         extra = ""
         if k is not None:
             t = type(k).__name__
@@ -69,7 +70,7 @@ for nm in ("fwd", "bwd"):
             if t == "ResampleParams": extra = "up%d adj%d acc%d" % (k.up, k.adjoint, k.accumulate)
             if t == "GroupStatsParams": extra = "ws_n%d" % k.ws_n
         key = name.replace("aid_", "")
-        if name == "aid_conv2d":
+        if name in CONV_OPS:
             q = k
             if kn.startswith("conv53_wino"): key = "conv5x3 winograd"
             elif q.KH == 5: key = "conv5x3 few-channel (%s)" % kn.split("(")[0]
@@ -80,7 +81,7 @@ for nm in ("fwd", "bwd"):
         elif extra and name in ("aid_norm_bwd", "aid_scale_act"):
             key += " " + ("wino" if "wino" in extra else "plain")
         r = cat.setdefault(key, [0, 0.0]); r[0] += 1; r[1] += us
-        rows.append((nm + str(lane), name, descr if name == "aid_conv2d" else sh + " " + extra, kn, us))
+        rows.append((nm + str(lane), name, descr if name in CONV_OPS else sh + " " + extra, kn, us))
         lane_us[lane] = lane_us.get(lane, 0.0) + us
 if "--list" in sys.argv:
     for nm, name, d, kn, us in rows:

@@ -171,8 +171,16 @@ def resample_batch(audio: torch.Tensor, fs, fs_target: int, length_target: int) 
     out = torch.zeros(audio.shape[0], length_target, device=audio.device, dtype=torch.float32)
     for rate in sorted(set(int(v) for v in f.tolist())):
         rows = torch.nonzero(f.cpu() == rate).reshape(-1).to(audio.device)
-        y = _resample_one_rate(audio.index_select(0, rows), rate, fs_target, length_target)
-        out[rows, :y.shape[1]] = y
+        sub = audio.index_select(0, rows)
+        if rate in (44100, 48000):
+            y = _resample_one_rate(sub, rate, fs_target, length_target)
+        else:                                                  # the reference's loops print a warning and pass such a row through unchanged (:165, :186, :207)
+            import warnings
+            warnings.warn(f"resample_batch: strange fs {rate} in a mixed-rate batch: rows passed through unresampled, as the reference does")
+            y = sub[:, :length_target].float()
+        if y.shape[1] < length_target:                         # the reference's ``proc_batch[i] = a[0:length_target]`` raises on a short row: no silent zero padding
+            raise ValueError(f"resample_batch: rows at {rate} Hz give {y.shape[1]} samples at {fs_target} Hz, fewer than length_target = {length_target}")
+        out[rows] = y
     return out
 
 

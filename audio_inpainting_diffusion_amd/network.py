@@ -1117,8 +1117,10 @@ class Unet_CQT_oct_with_attention(nn.Module):
 
     # ---------------------------------------------------------------------------------------------------
     # sub-batch streams: the fused sampler entry points (denoise / denoise_guided) cut a batch into 2-3 sub-batches and
-    # run them on separate HIP streams.  Segments are independent, so results are bit-identical; what changes is the
-    # schedule: while one sub-batch is in an MFMA-bound conv, the HBM-bound passes (statistics, activation / transform
+    # run them on separate HIP streams.  Segments are independent and every kernel's per-sample arithmetic is independent of the batch; the
+    # Winograd form / tile instance of a 5x3 layer, however, is chosen from the LAUNCH shape (batch included), so a split agrees with the unsplit
+    # schedule to the bit only where both take the same instances (small networks) and to rounding (<= 5e-6, tests/test_gpu_dist.py) at full size.
+    # What changes is the schedule: while one sub-batch is in an MFMA-bound conv, the HBM-bound passes (statistics, activation / transform
     # pre-passes, normalisation backward) and the partially filled last round of workgroups of another sub-batch's conv use
     # the idle wave slots and CUs (measured at B=8, guided: +6.3 % with 2 sub-batches, +7.6 % with 3, -1.7 % with 4).
     # ---------------------------------------------------------------------------------------------------

@@ -185,12 +185,17 @@ def cpu_baseline(net, args, guided: bool, spectral: bool = False, n_timed: int =
                       f"on the fastest ({best[1]}, {cores} threads; median {dt:.2f} s, min {min(times):.2f} s; value = 1 / median), torch {torch.__version__} CPU fp32"}
 
 
+def kernel_base(kn: str) -> str:
+    """device-kernel name as rocprofv3 lists it, without the tile kind / template instance aid_last_kernel appends"""
+    return kn.split("(")[0].split("+")[0].split("<")[0]
+
+
 def family_table(timing, by_kernel=False):
     """timing: (event0, event1, algorithmic_flops, description, algorithmic_bytes, kernel_name) per conv launch.
     by_kernel: aggregate by the device kernel's name (what rocprofv3 lists) instead of name + tile kind."""
     fam = {}
     for e0, e1, fl, _d, nb, kn in timing:
-        base = kn.split("(")[0].split("+")[0].split("<")[0]
+        base = kernel_base(kn)
         r = fam.setdefault(base if by_kernel else kn, dict(launches=0, ms=0.0, alg=0.0, exe=0.0, bytes=0.0))
         r["launches"] += 1
         r["ms"] += e0.elapsed_time(e1)
@@ -387,7 +392,7 @@ def main():
         dom = kerns.get(dom_name, {})
         conv_ms = sum(v["time_ms"] for v in fams.values())
         alg = sum(t[2] for t in timing)
-        exe = sum(t[2] * WINO_EXEC.get(t[5].split("(")[0], 1.0) for t in timing)
+        exe = sum(t[2] * WINO_EXEC.get(kernel_base(t[5]), 1.0) for t in timing)
         sec = max(conv_ms * 1e-3, 1e-12)
         out = {
             "metric": "denoiser-steps/sec", "value": round(evals / wall, 3), "unit": "denoiser evaluations (one segment each) per second, whole job",
@@ -437,26 +442,41 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+def _kernel_sources_sha16():
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "audio_inpainting_diffusion_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "audio_inpainting_diffusion_amd", "csrc", "*.h"))
+                    + [os.path.join(ROOT, "include", "aid_kernels.h")]):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _traffic_fields(dom_name, dom):
     """roofline.traffic = HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE in
     separate rocprofv3 runs of this command with --streams 1, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) -- counters cannot be read
-    from inside this process; traffic_over_algorithmic compares it with this run's algorithmic bytes per launch of the same kernel."""
+    from inside this process.  Reported ONLY when that profile was taken on THIS build (it records the hash of the kernel sources, tools/conv_traffic.py);
+    otherwise traffic is null and traffic_from_profile says which profile exists and why it was not used (no stale numbers)."""
     tp = _profile_traffic()
-    per = ((tp or {}).get("per_kernel_bytes") or {})
+    same = bool(tp and tp.get("kernel_sources_sha16") and tp["kernel_sources_sha16"] == _kernel_sources_sha16())
+    per = ((tp or {}).get("per_kernel_bytes") or {}) if same else {}
     t = per.get(dom_name) if dom_name else None
     alg = dom.get("algorithmic_mb_per_launch")
-    return {"traffic": t, "traffic_unit": "HBM bytes per launch (PMC, committed profile)", "traffic_source": (tp or {}).get("file"),
+    if tp is not None:
+        tp = dict(tp, used=same, note=("same kernel sources as this run" if same else "profile of ANOTHER build (kernel sources differ): not reported as this run's traffic"))
+    return {"traffic": t, "traffic_unit": "HBM bytes per launch (PMC passes of this build, committed profile)", "traffic_source": (tp or {}).get("file") if same else None,
             "traffic_over_algorithmic": (round(t / (alg * 1e6), 3) if (t and alg) else None), "traffic_from_profile": tp}
 
 
 def _profile_traffic():
-    """HBM bytes per launch of the conv kernels from the committed PMC passes of this command (profiles/), or null."""
-    for name in ("r04_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json"):
+    """HBM bytes per launch of the conv kernels from the newest committed PMC passes of this command (profiles/), or null."""
+    for name in ("r05_conv_traffic.json", "r04_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json"):
         tr = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tr):
             try:
                 j = json.load(open(tr))
-                return {"file": "profiles/" + name, "hbm_bytes_per_conv_launch_corrected": j.get("hbm_bytes_per_conv_launch_corrected"),
+                return {"file": "profiles/" + name, "kernel_sources_sha16": j.get("kernel_sources_sha16"), "command": j.get("command"),
+                        "hbm_bytes_per_conv_launch_corrected": j.get("hbm_bytes_per_conv_launch_corrected"),
                         "per_kernel_bytes": j.get("per_kernel_hbm_bytes_corrected")}
             except Exception:
                 return None

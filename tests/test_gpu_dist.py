@@ -187,7 +187,10 @@ def test_replacement_branch_without_projection_raises():
 
 
 def test_sub_batch_streams_are_bit_identical_to_one_stream():
-    """network.denoise / denoise_guided cut a batch into sub-batches on concurrent HIP streams: same bits as one stream."""
+    """network.denoise / denoise_guided cut a batch into sub-batches on concurrent HIP streams: same bits as one stream WHEN every sub-batch launch
+    takes the kernel instance the whole-batch launch takes -- true for this small network, whose launches all stay under one tile per CU.  (Every
+    kernel's per-sample arithmetic is independent of the batch, but the Winograd form / tile instance of a 5x3 layer is a function of the LAUNCH shape,
+    batch included: at full size a split can move a layer to another form.  test_full_size_split_vs_unsplit_agree_to_rounding states that tolerance.)"""
     from oracle.edm import OracleEDM
     net, args, kw = _setup(DEV)
     B, Ls = 7, kw["audio_len"]
@@ -214,6 +217,35 @@ def test_sub_batch_streams_are_bit_identical_to_one_stream():
             assert torch.equal(a_, b_)
     net.split_streams = None
     assert net._n_split(8) == 2 and net._n_split(4) == 2 and net._n_split(2) == 1
+
+def test_full_size_split_vs_unsplit_agree_to_rounding():
+    """Full-size network, batch 4, one guided evaluation: two sub-batches of two on concurrent streams against the unsplit batch.  The Winograd form and
+    tile instance of a 5x3 layer are chosen from the launch shape (aid_conv2d_wino_form / aid_conv2d_wino2d_wanted: batch 2 and batch 4 launches of the
+    same layer may differ -- 2-D form, F(8,3), F(4,3), K-group instances), so the two schedules agree to rounding, not to the bit: <= 5e-6."""
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
+    from audio_inpainting_diffusion_amd.masks import long_gap_mask
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    from oracle.edm import OracleEDM
+    args = make_args("maestro22k")
+    Ls, B = args.exp.audio_len, 4
+    net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(DEV)), 0, gate_scale=10.0, affine_scale=10.0)
+    edm = OracleEDM()
+    x = (torch.from_numpy(seeded_normal(31, 0, B * Ls)).reshape(B, Ls) * 0.3).to(DEV)
+    y = torch.from_numpy(seeded_normal(32, 0, B * Ls)).reshape(B, Ls) * 0.063
+    mask = long_gap_mask(Ls, 22050, 300)
+    s = torch.tensor([[0.2], [0.6], [1.5], [4.0]])
+    v = lambda t: t.reshape(-1).to(DEV).contiguous()
+    co = (v(edm.cnoise(s)), v(edm.cin(s)), v(edm.cskip(s)), v(edm.cout(s)))
+    res = {}
+    for n in (1, 2):
+        net.split_streams = n
+        assert len(net.states_of(B)) == n
+        res[n] = tuple(t.clone() for t in net.denoise_guided(x, *co, True, (y * mask).to(DEV), mask.to(DEV)))
+    torch.cuda.synchronize()
+    e = [rel_l2(a_.cpu(), b_.cpu()) for a_, b_ in zip(res[1][:2], res[2][:2])]
+    print(f"full size, batch 4: 2 sub-batches of 2 vs unsplit: x_hat rel-L2 {e[0]:.2e}, rec_grads rel-L2 {e[1]:.2e}")
+    assert e[0] < 5e-6 and e[1] < 5e-5
 
 
 @pytest.mark.parametrize("B", [1, 2])

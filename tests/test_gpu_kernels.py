@@ -645,6 +645,12 @@ def test_polyphase_resampler_vs_oracle(L, ratio):
         mix = resample_batch(a.to(DEV), torch.tensor([48000, 44100]), 22050, 65536).cpu()
         assert rel_l2(mix[0:1], O.resample_batch(a[0:1].double(), 48000, 22050, 65536)) < 2e-6
         assert rel_l2(mix[1:2], O.resample_batch(a[1:2].double(), 44100, 22050, 65536)) < 2e-6
+        # a row shorter than length_target raises (the reference's row assignment would), a strange rate is passed through with a warning (:165)
+        with pytest.raises(ValueError, match="fewer than length_target"):
+            resample_batch(a.to(DEV), torch.tensor([48000, 44100]), 22050, 10 ** 6)
+        with pytest.warns(UserWarning, match="strange fs"):
+            odd = resample_batch(a.to(DEV), torch.tensor([32000, 44100]), 22050, 65536).cpu()
+        assert torch.equal(odd[0], a[0, :65536]) and torch.equal(odd[1], mix[1])
 
 
 WGRAD_CASES = [

@@ -76,10 +76,11 @@ def test_unet_full_cfgA_vs_reference_golden(forms):
     st = net._state(1)
     n8 = sum(1 for k in st["plan_body"].keep if isinstance(k, _lib.Conv2dParams) and k.x_wino == 2)
     n4 = sum(1 for k in st["plan_body"].keep if isinstance(k, _lib.Conv2dParams) and k.x_wino == 1)
-    n2 = sum(1 for k in st["plan_body"].keep if isinstance(k, _lib.Conv2dParams) and k.x_wino == 3)
+    n2 = sum(1 for o in st["plan_body"].ops if o.name == "aid_conv2d_wino2d_gemm")          # (GEMM and output pass are two plan nodes on one parameter block)
+    assert n2 == sum(1 for o in st["plan_body"].ops if o.name == "aid_conv2d_wino2d_output") == sum(1 for k in st["plan_body"].keep if isinstance(k, _lib.Conv2dParams) and k.x_wino == 3) // 2
     print(f"unet_full_cfgA (wino_forms {forms}: {n2} F(4,5)xF(4,3) + {n8} F(8,3) + {n4} F(4,3) layers): rel-L2 vs reference golden = {e:.3e}; algorithmic GFLOP/eval = {net.flops_per_eval(1) / 1e9:.1f}")
     # (6 rows per residue class -- dil 64 on level 5, dil 32 on level 4 -- have no F(8,3) tile: with F(4,3) input excluded those four layers transform in the kernel)
-    if 45 in forms:      # (45,): the 2-D form on every C >= 128 layer (52 of the 75); the default: where the library predicts it faster (the K = 256 layers)
+    if 45 in forms:      # (45,): the 2-D form on every C >= 128 layer (52 of the 75); the default: where the library predicts it faster (a batch of one: every C >= 128 layer but the 4/3-padded one)
         assert n2 + n8 + n4 == 75 and (n2 == 52 if forms == (45,) else n2 >= 20)
     else:
         assert n2 == 0 and ((n8 >= 60 and n4 == 0) if forms == (8,) else ((n8 == 0 and n4 == 75) if forms == (4,) else (n8 >= 20 and n8 + n4 == 75)))

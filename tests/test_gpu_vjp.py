@@ -420,8 +420,9 @@ def test_fused_passes_match_the_unfused_schedule_at_full_size():
         res.append((xh.cpu(), g.cpu(), nrm.cpu(), n_stat, n_nb))
         del net
         torch.cuda.empty_cache()
-    # (the layers that take the 2-D Winograd form have their own gate / transform pass: aid_norm_bwd writes no Winograd-domain copy for them)
-    assert res[0][3] >= 40 and res[0][4] >= 20 and res[1][3] == 0 and res[1][4] == 0, (res[0][3:], res[1][3:])
+    # (the layers that take the 2-D Winograd form -- at this batch of two every C >= 128 level -- have their own gate / transform pass: aid_norm_bwd
+    #  writes its Winograd-domain copy only for the F(4,3) / F(8,3) layers: 16 of them here)
+    assert res[0][3] >= 40 and res[0][4] >= 10 and res[1][3] == 0 and res[1][4] == 0, (res[0][3:], res[1][3:])
     e1, e2 = rel_l2(res[0][0], res[1][0]), rel_l2(res[0][1], res[1][1])
     print(f"fused vs unfused passes: x_hat rel-L2 = {e1:.2e}, rec_grads rel-L2 = {e2:.2e}; statistics from epilogues: {res[0][3]}, fused norm_bwd: {res[0][4]}")
     assert e1 < 2e-6 and e2 < 2e-5

@@ -13,6 +13,7 @@
 // Which form takes a launch: wino_form_choice() / aid_conv2d_wino_form().
 #include "aid_common.h"
 #include "aid_wino8.h"
+#include "aid_fin.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -715,57 +716,6 @@ struct ConvWinoRDev {
 // (aid_norm.hip), same summation order (lane l adds partials l, l + 64, ..., then the xor tree), hence the same bits -- so that those two 5-10 us
 // launches per normalisation layer (194 per guided evaluation, a twentieth of a batch-1 evaluation) are not made.  The partials were published with
 // agent-scope stores before the arrival counter was bumped (as the split-K exchange above); they are read back past the XCD's L2 the same way.
-__device__ __forceinline__ double aid_ld_agent(const double* q) {
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void aid_st_agent(double* q, double v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(q), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __attribute__((noinline)) void aid_wino_fin(int mode, const double* ws, int nk, int b, int C, double n, const float* gamma, const float* mod, int64_t mod_ld,
-                                                       float eps, float* scale, float* stats, double* sh, int tid, int nthr) {
-    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
-    if (mode == 1) {
-        for (int g = wave; g < 8; g += nw) {
-            const double* w = ws + ((int64_t)(b * 8 + g) * nk) * 2;
-            double s = 0.0, ss = 0.0;
-            for (int i = lane; i < nk; i += 64) { s += aid_ld_agent(w + 2 * i); ss += aid_ld_agent(w + 2 * i + 1); }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) { s += __shfl_xor(s, off, 64); ss += __shfl_xor(ss, off, 64); }
-            if (lane == 0) { sh[2 * g] = s; sh[2 * g + 1] = ss; }
-        }
-        __syncthreads();
-        const int cg = C >> 3;
-        for (int c = tid; c < C; c += nthr) {
-            const int g = c / cg;
-            const double s = sh[2 * g], ss = sh[2 * g + 1];
-            const double mean = s / n;
-            double var = (ss - n * mean * mean) / (n - 1.0);
-            if (var < 0.0) var = 0.0;
-            const double inv = 1.0 / (sqrt(var) + (double)eps);
-            const double m = mod ? (1.0 + (double)mod[(int64_t)b * mod_ld + c]) : 1.0;
-            scale[(int64_t)b * C + c] = (float)((double)gamma[c] * m * inv);
-            if (stats && c == g * cg) {
-                stats[((int64_t)b * 8 + g) * 2 + 0] = (float)mean;
-                stats[((int64_t)b * 8 + g) * 2 + 1] = (float)inv;
-            }
-        }
-    } else {
-        for (int g = wave; g < 8; g += nw) {
-            const int i = b * 8 + g;
-            const double* w = ws + (int64_t)i * nk;
-            double d = 0.0;
-            for (int k = lane; k < nk; k += 64) d += aid_ld_agent(w + k);
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
-            if (lane == 0) {
-                const double inv = (double)stats[2 * i + 1];
-                const double sd = 1.0 / inv - (double)eps;
-                scale[i] = (sd > 0.0) ? (float)(d * inv / ((n - 1.0) * sd)) : 0.f;
-            }
-        }
-    }
-}
-
 // Tried for small grids (round 3, profiles/r03_half_tile_probe.txt): two-wave workgroups on half the positions (64 x 128 / 32 x 256 tiles, twice
 // the workgroups, four per CU) when a launch has fewer than 300 ... 1100 full tiles -- B = 1: 24.7 -> 29.4 ... 30.2 ms of 5x3 time per guided
 // evaluation, B = 2 / 3 neutral to -12 %: the weight slice every tile re-stages is amortised over half the MFMAs.  Not kept.
@@ -1739,7 +1689,7 @@ extern "C" int aid_conv2d_wino_form(int B, int Cin, int Cout, int F, int T, int 
 }
 
 extern "C" int aid_conv2d_fin_supported(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino) {
-    if (x_wino == 3) return 0;                                         // (the output pass writes plain partials; the fold kernels run)
+    if (x_wino == 3) return (B >= 1 && (Cout % 8) == 0 && aid_conv2d_wino2d_supported(Cin, Cout, F, T, dilF)) ? 1 : 0;      // (the LAST block of the output pass folds)
     if (B < 1 || (Cout % 8) || !wino_v_shape_ok(Cin, Cout, T)) return 0;
     if (x_wino == 2) return aid_conv2d_wino8_supported(Cin, Cout, F, T, dilF);
     if (x_wino != 1) return 0;

@@ -12,6 +12,7 @@
 // Matrices: tools/gen_wino45.py -> aid_wino45.h.
 #include "aid_common.h"
 #include "aid_wino45.h"
+#include "aid_fin.h"
 #include <type_traits>
 #include <utility>
 #include <stdlib.h>
@@ -393,6 +394,7 @@ struct W2dOutDev {
     const float* M;
     int R, J, TG, NB, nblk;
     int64_t N;
+    int fin_total;             // fin_mode: blocks per sample = Cout * nblk -- the block that finds fin_count[b] == fin_total - 1 folds the sample's partials
 };
 
 // One thread owns TWO consecutive sample groups of one row tile and output channel (one float2 of every plane): per row-axis index xf it loads the six
@@ -500,10 +502,30 @@ __global__ __launch_bounds__(256) void w2d_output_kernel(const W2dOutDev a) {
         const int nslot = cpg * a.nblk;
         if (p.stat_ws) {
             double* w = p.stat_ws + (((int64_t)b * 8 + grp) * nslot + slot) * 2;
-            w[0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-            w[1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+            const double v0 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]), v1 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+            if (p.fin_mode) { aid_st_agent(w, v0); aid_st_agent(w + 1, v1); }
+            else { w[0] = v0; w[1] = v1; }
         }
-        if (p.dot_ws) p.dot_ws[((int64_t)b * 8 + grp) * nslot + slot] = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
+        if (p.dot_ws) {
+            double* w = p.dot_ws + ((int64_t)b * 8 + grp) * nslot + slot;
+            const double v = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
+            if (p.fin_mode) aid_st_agent(w, v);
+            else *w = v;
+        }
+    }
+    if (p.fin_mode) {                                        // (block-uniform) the last block of sample b folds the sample's partials (aid_fin.h), as the
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // row-shared kernels do: this block's partials have reached the coherent level,
+        __syncthreads();                                      // then ONE arrival per block
+        __shared__ int last;
+        __shared__ double fsh[16];
+        if (tid == 0) last = (__hip_atomic_fetch_add(p.fin_count + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.fin_total - 1)) ? 1 : 0;
+        __syncthreads();
+        if (last) {
+            const double n = (double)(p.Cout >> 3) * (double)p.F * (double)p.T;
+            aid_wino_fin(p.fin_mode, p.stat_ws ? p.stat_ws : p.dot_ws, (p.Cout >> 3) * a.nblk, b, p.Cout, n, p.fin_gamma, p.fin_mod, p.fin_mod_ld, p.fin_eps,
+                         p.fin_scale, p.fin_stats, fsh, tid, 256);
+            if (tid == 0) __hip_atomic_store(p.fin_count + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // as found, for the next launch
+        }
     }
 }
 
@@ -535,7 +557,13 @@ int aid_w2d_partials(int Cout, int F, int T, int dilF) { return (Cout >> 3) * w2
 static int w2d_check(const aid_conv2d_params* p) {
     AID_REQUIRE(p->KH == 5 && p->KW == 3 && p->wp_wino && p->wino_taps == 48, "aid_conv2d(x_wino=3): needs the 48-plane pack (aid_pack_conv_weight wpw2)");
     AID_REQUIRE(w2d_shape_ok(p->Cin, p->Cout, p->F, p->T, p->dilF), "aid_conv2d(x_wino=3): shape not supported (aid_conv2d_wino2d_supported)");
-    AID_REQUIRE(!p->in_scale && p->act == 0 && !p->x2.p && !p->fin_mode, "aid_conv2d(x_wino=3): no in-kernel prologue, no x2, no fin_mode");
+    AID_REQUIRE(!p->in_scale && p->act == 0 && !p->x2.p, "aid_conv2d(x_wino=3): no in-kernel prologue, no x2");
+    if (p->fin_mode) {                                       // the last block of a sample folds the partials (aid_conv2d_fin_supported(.., 3) == 1)
+        AID_REQUIRE(p->fin_mode == 1 || p->fin_mode == 2, "aid_conv2d: fin_mode is 0, 1 or 2");
+        AID_REQUIRE(p->fin_count && p->fin_scale && (p->Cout % 8) == 0, "aid_conv2d: fin_mode needs fin_count, fin_scale and Cout % 8 == 0");
+        if (p->fin_mode == 1) AID_REQUIRE(p->stat_ws && p->fin_gamma, "aid_conv2d: fin_mode = 1 folds the stat_ws partials and needs fin_gamma");
+        else AID_REQUIRE(p->dot_ws && p->fin_stats, "aid_conv2d: fin_mode = 2 folds the dot_ws partials and needs the forward statistics in fin_stats");
+    }
     AID_REQUIRE(!(p->stat_ws && p->dot_ws), "aid_conv2d(x_wino=3): stat_ws and dot_ws are exclusive");
     AID_REQUIRE(!p->dot_ws || p->epi == 1, "aid_conv2d(x_wino=3): dot_ws goes with the dGELU epilogue");
     const W2dGeo ge = w2d_geo(p->B, p->F, p->T, p->dilF);
@@ -560,6 +588,7 @@ static int w2d_output_of(const aid_conv2d_params* p, hipStream_t st) {
     W2dOutDev a;
     a.p = *p; a.M = p->ws;
     a.R = ge.R; a.J = ge.J; a.TG = ge.TG; a.NB = ge.NB; a.N = ge.N; a.nblk = w2d_nblk(ge.NB);
+    a.fin_total = p->Cout * a.nblk;
     hipLaunchKernelGGL(w2d_output_kernel, dim3((unsigned)((int64_t)p->B * p->Cout * a.nblk)), dim3(256), 0, st, a);
     AID_CHECK_LAUNCH();
     return AID_OK;

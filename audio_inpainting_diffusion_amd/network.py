@@ -301,7 +301,7 @@ class _Builder:
             self.nbytes += ws.numel() * 8
             cp.stat_ws, cp.stat_n = ws.data_ptr(), ws_n
             src[3].also_writes(ws)                         # (the conv's epilogue now writes the partials this op folds)
-            if self.net.fuse_fin and _lib.lib().aid_conv2d_fin_supported(cp.B, cp.Cin, cp.Cout, cp.F, cp.T, cp.dilF, cp.x_wino):
+            if self.net.fuse_fin and self._fin_wanted(cp.B, cp.x_wino) and _lib.lib().aid_conv2d_fin_supported(cp.B, cp.Cin, cp.Cout, cp.F, cp.T, cp.dilF, cp.x_wino):
                 # the last tile of each sample folds the partials itself (aid_kernels.h: fin_mode = 1): no aid_group_stats launch at all
                 cnt = self._fin_count(src[3].lane)
                 cp.fin_mode, cp.fin_count, cp.fin_gamma, cp.fin_eps = 1, cnt.data_ptr(), gamma.data_ptr(), 1e-7
@@ -317,6 +317,13 @@ class _Builder:
                                   ws.data_ptr(), ws_n)
         self._add("aid_group_stats", p, x, gamma, mod, scale, stats, ws, writes=(scale, stats) + (() if src is not None else (ws,)))
         self._stats_train_hook(scale, gamma, mod, gname, stats, B, Cc)
+
+    @staticmethod
+    def _fin_wanted(B, x_wino):
+        """The output pass of the 2-D form has thousands of short blocks per sample, each of which would publish its partial past the L2 and bump the
+        sample's arrival counter: measured neutral at batch 1 and -0.4 % at batch 8 (profiles/r05_fin2d_ab.txt) -- taken for launches of at most two
+        samples, where the fold launch it removes is a larger share of the evaluation; the row-shared kernels (few large tiles) always take it."""
+        return x_wino != 3 or B <= 2
 
     def _fin_count(self, lane):
         """arrival counters of the fused finalisation (aid_kernels.h: fin_count): one zeroed word per sample and lane (launches of a lane are serial and
@@ -455,8 +462,8 @@ class _Builder:
             # two plan nodes on one parameter block: the MFMA-bound batched GEMM M = U V (its FLOPs and the bytes of V + M are booked here) and the
             # HBM-bound output-transform pass with the epilogue (reads M, residual / aux; writes y and the partials)
             self._add("aid_conv2d_wino2d_gemm", p, x, wpw, ws, flops=2 * B * F * T * cin * cout * kh * kw, nbytes=4 * 48 * npos * (cin + cout), writes=(ws,))
-            op = self._add("aid_conv2d_wino2d_output", p, ws, y, res, out_scale, aux, aux_scale, dws, nbytes=4 * (48 * npos * cout + B * F * T * cout * (1 + (res is not None) + (aux is not None))),
-                           writes=(y, dws))
+            op = self._add("aid_conv2d_wino2d_output", p, ws, y, res, out_scale, aux, aux_scale, dws, fin_stats, cnt,
+                           nbytes=4 * (48 * npos * cout + B * F * T * cout * (1 + (res is not None) + (aux is not None))), writes=(y, dws, cnt))
         else:
             op = self._add("aid_conv2d", p, x, x2, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, ws, dws, fin_stats, cnt, flops=2 * B * F * T * cin * cout * kh * kw,
                            nbytes=nb, writes=(y, ws, dws, cnt))
@@ -568,8 +575,8 @@ class _Builder:
                     nd = int(_lib.lib().aid_conv2d_dot_partials_1x1(B, cout, cin, F, T))
                 dws = self._dot_ws(nd) if nd else self.stats_ws
                 # the last tile of each sample also folds the partials into the normalisation-backward coefficients (aid_kernels.h: fin_mode = 2)
-                fin = bool(nd and kh == 5 and gw in (4, 8) and self.net.fuse_fin
-                           and _lib.lib().aid_conv2d_fin_supported(B, cout, cin, F, T, dil, {4: 1, 8: 2}[gw]))
+                fin = bool(nd and kh == 5 and gw in (4, 8, 45) and self.net.fuse_fin and self._fin_wanted(B, {4: 1, 8: 2, 45: 3}[gw])
+                           and _lib.lib().aid_conv2d_fin_supported(B, cout, cin, F, T, dil, {4: 1, 8: 2, 45: 3}[gw]))
                 self._conv_raw(gin, gd, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, None, 1.0, alpha,
                                epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None, wpw={8: wpw8T, 45: wpw2T}.get(gw, wpwT), x_wino=gw,
                                dot=(dws, nd) if nd else None, fin_stats=norm_stats if fin else None)

@@ -138,7 +138,7 @@ typedef struct {
                                  Cin1 + c); Cin1 and Cin - Cin1 multiples of 16.  One GEMM over a K axis that lives in two tensors: the input
                                  gradients of a ResnetBlock's proj_in and res_conv (unet...py:414-415, :488-491), which both flow into dL/d(block
                                  input), as ONE launch on the stacked transposed weights instead of two read-modify-write passes over it. */
-    int fin_mode;                /* optional, row-shared Winograd kernels only (aid_conv2d_fin_supported(...) != 0): the LAST tile of a sample to finish also folds
+    int fin_mode;                /* optional, row-shared Winograd kernels and the output pass of the 2-D form (aid_conv2d_fin_supported(...) != 0): the LAST tile / block of a sample to finish also folds
                                  the sample's epilogue partials, in the fixed order of the kernels it replaces (bit-identical results) --
                                  1 (with stat_ws): what aid_group_stats(ws_n = stat_n) does: fin_scale[b, c] = fin_gamma[c] (1 + fin_mod[b, c]) / (std_g + fin_eps),
                                     fin_stats[b, g] = (mean, 1 / (std + eps)) when given -- the NEXT layer's aid_group_stats call is then not made at all;
@@ -171,7 +171,7 @@ int aid_conv2d_wino8_supported(int Cin, int Cout, int F, int T, int dilF);
 /* bytes of `ws` a 5x3 x_wino layer of this shape wants for its split-K instance (B = 1 launches with few tiles); 0: the shape is not split */
 #define AID_CONV2D_SPLIT_FLAG_BYTES 4096
 int64_t aid_conv2d_wino_split_ws_bytes(int B, int Cin, int Cout, int F, int T, int dilF);
-/* 1 when the kernel that takes a 5x3 layer of this launch shape with this x_wino (1 / 2) honours fin_mode (the row-shared kernels) */
+/* 1 when the kernel that takes a 5x3 layer of this launch shape with this x_wino (1 / 2 / 3) honours fin_mode (the row-shared kernels; the 2-D form's output pass) */
 int aid_conv2d_fin_supported(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino);
 /* number of per-tile partial dots per (sample, group) the F(4,3) / F(8,3) epilogue writes for this shape (x_wino as in aid_conv2d_params); 0 = not supported */
 int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino);

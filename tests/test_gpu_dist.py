@@ -330,6 +330,19 @@ def _worker_full8(rank, world, port, q):
     nbytes = D.broadcast_parameters(net, src=0)
     torch.cuda.synchronize()
     t_bcast = time.time() - t0
+    per = int(os.environ.get("AID_TEST_SEGMENTS_PER_RANK", "1"))
+    if per > 1:                                                    # configs[2]: 8 segments per rank -- the rank's own items only (64 full-length rows are rebuilt from seeds)
+        from audio_inpainting_diffusion_amd.init import seeded_normal
+        lo, hi = D.shard_range(world * per, r, w)
+        y = torch.stack([torch.from_numpy(seeded_normal(41, g, args.exp.audio_len)) for g in range(lo, hi)]) * 0.063
+        out = _full_step(net, args, y, mask, D.item_seeds(700, lo, hi), "cuda:0")
+        peak = torch.cuda.max_memory_allocated() / 2 ** 30
+        allout = D.gather_outputs(out, world * per)
+        D.barrier()
+        keep = np.concatenate([allout[:per].cpu().numpy(), allout[-per:].cpu().numpy()])         # (the first and the last rank's shards: what the test compares)
+        q.put((rank, nbytes, (lo, hi), keep, t_bcast, nthr, torch.distributed.get_backend(), float(allout.double().pow(2).sum()), peak))
+        torch.distributed.destroy_process_group()
+        return
     lo, hi = D.shard_range(world, r, w)
     out = _full_step(net, args, y[lo:hi], mask, D.item_seeds(700, lo, hi), "cuda:0")
     allout = D.gather_outputs(out, world)
@@ -415,6 +428,50 @@ def test_full_size_eight_ranks_on_one_gpu_equal_one_process():
         assert allout.shape == tuple(ref.shape) and nbytes > 700e6 and e < 5e-6
         assert np.array_equal(allout, res[0][3])                   # every rank holds the same gathered result, in global segment order
     assert sum(r[5] or 0 for r in res) <= (os.cpu_count() or 8) or all(r[5] is None for r in res)     # the ranks' CPU shares do not overlap
+
+def test_config2_eight_ranks_eight_segments_each_on_one_gpu():
+    """BASELINE configs[2] at its FULL job shape on one GPU: 64 gap segments, 8 ranks x 8 segments each (eight processes sharing cuda:0 over gloo, the
+    full-size network in each, one 745 MB broadcast per rank, global-index seeds, one guided Heun step = two evaluations with the input-VJP per
+    segment, ONE all-gather of the 64 outputs).  A rank's batch of eight is the same launch sequence as a single process's batch of eight with the
+    same seeds: the first and the last rank's shards of the gathered result equal those single-process runs to the BIT; every rank holds the same 64 rows.
+    Skipped when the device has less free memory than 8 x the measured peak of one batch-8 step needs."""
+    from audio_inpainting_diffusion_amd import dist as D
+    from audio_inpainting_diffusion_amd.init import seeded_normal
+    world, per = 8, 8
+    net, args, _, mask = _full_setup(DEV, seed=0, n_items=1)
+    Ls = args.exp.audio_len
+    refs = {}
+    torch.cuda.reset_peak_memory_stats()
+    for r in (0, world - 1):
+        lo, hi = D.shard_range(world * per, r, world)
+        y = torch.stack([torch.from_numpy(seeded_normal(41, g, Ls)) for g in range(lo, hi)]) * 0.063
+        refs[r] = _full_step(net, args, y, mask, D.item_seeds(700, lo, hi), DEV).cpu().numpy()
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    del net
+    torch.cuda.empty_cache()
+    free = torch.cuda.mem_get_info()[0] / 2 ** 30
+    if free < world * (peak + 3.0) + 8.0:
+        pytest.skip(f"8 ranks x {peak:.1f} GiB (one batch-8 step) do not fit the {free:.0f} GiB free on this device")
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    os.environ["AID_TEST_SEGMENTS_PER_RANK"] = str(per)
+    try:
+        procs = [ctx.Process(target=_worker_full8, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted((q.get(timeout=2400) for _ in range(world)), key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=600)
+            assert p.exitcode == 0
+    finally:
+        os.environ.pop("AID_TEST_SEGMENTS_PER_RANK", None)
+    assert [r[2] for r in res] == [(per * i, per * (i + 1)) for i in range(world)]
+    for rank, nbytes, _, keep, t_bcast, nthr, backend, ssq, rpeak in res:
+        assert keep.shape == (2 * per, Ls) and nbytes > 700e6 and np.isfinite(keep).all()
+        assert np.array_equal(keep[:per], refs[0]) and np.array_equal(keep[per:], refs[world - 1])      # bit-identical to the single-process batch-8 runs of those shards
+        assert ssq == res[0][7]                                                                          # every rank gathered the same 64 rows
+        print(f"configs[2] shape, rank {rank}/8 ({backend}, {nthr} CPU threads, broadcast {t_bcast:.2f} s, peak {rpeak:.1f} GiB): 8 segments, shards of ranks 0 and 7 == single-process B = 8 runs")
 
 
 def test_bench_self_launches_eight_ranks_rank0_only_json():

@@ -117,7 +117,7 @@ def test_conv2d_wino2d(L, case):
     ws = torch.full((48 * C * N + 16,), 7.0, device=DEV)
     nst = int(L.lib().aid_conv2d_stat_partials(B, C, C, Fd, T, dil, 3))
     assert nst > 0 and nst == int(L.lib().aid_conv2d_dot_partials(B, C, C, Fd, T, dil, 3))
-    assert L.lib().aid_conv2d_fin_supported(B, C, C, Fd, T, dil, 3) == 0
+    assert L.lib().aid_conv2d_fin_supported(B, C, C, Fd, T, dil, 3) == 1
     sws = torch.zeros(B * 8 * nst * 2, device=DEV, dtype=torch.float64)
     p = L.Conv2dParams()
     p.x, p.y, p.res, p.aux = L.View(V.data_ptr(), 0, 0, 0), L.view4(y), L.view4(resd), L.view4(None)
@@ -153,6 +153,26 @@ def test_conv2d_wino2d(L, case):
     L.call("aid_conv2d", p)
     torch.cuda.synchronize()
     assert torch.equal(y, y2)
+    # fin_mode = 1: the LAST block of each sample's output pass folds the partials itself -- the same bits as aid_group_stats(ws_n = nst), counters back to zero;
+    # also through the two separate entry points (GEMM, then output pass)
+    cnt = torch.zeros(B + 2, device=DEV, dtype=torch.int32)
+    cnt[B:] = 7
+    for rep in range(2):
+        scf, stf = torch.full((B, C), float("nan"), device=DEV), torch.full((B, 8, 2), float("nan"), device=DEV)
+        sws.fill_(float("nan"))
+        y2.fill_(float("nan"))
+        p.fin_mode, p.fin_count, p.fin_gamma, p.fin_eps, p.fin_scale, p.fin_stats = 1, cnt.data_ptr(), gamma.data_ptr(), 1e-7, scf.data_ptr(), stf.data_ptr()
+        if rep == 0:
+            L.call("aid_conv2d", p)
+        else:
+            L.call("aid_conv2d_wino2d_gemm", p)
+            assert "w2d_gemm" in L.lib().aid_last_kernel().decode()
+            L.call("aid_conv2d_wino2d_output", p)
+            assert L.lib().aid_last_kernel().decode() == "w2d_output_kernel"
+        torch.cuda.synchronize()
+        assert torch.equal(y2, y) and int(cnt[:B].abs().sum()) == 0 and int(cnt[B]) == 7
+        assert torch.equal(scf, sc2) and torch.equal(stf, st2)
+    p.fin_mode = 0
     # (3) reverse sweep: the transposed operator on the gated gradient (no activation), dGELU epilogue, <y, aux> partials
     gy = _rand(B, C, Fd, T, seed=46)
     gyd = gy.to(DEV)
@@ -181,6 +201,27 @@ def test_conv2d_wino2d(L, case):
     assert rel_l2(gd.cpu(), gref) < 1e-5
     dref = (gd.cpu().double() * x.double()).reshape(B, 8, -1).sum(-1)
     assert rel_l2(dws.cpu().reshape(B, 8, nst).sum(-1), dref) < 1e-5
+    # fin_mode = 2: the last block also writes the coefficients aid_norm_bwd's first kernel would compute from the partials -- same bits
+    dwsf = torch.full((B * 8 * (nst + 1),), float("nan"), device=DEV, dtype=torch.float64)
+    dwsf[:B * 8 * nst] = dws
+    out = torch.empty_like(gd)
+    npar = L.NormBwdParams(L.view4(gd), L.view4(xd), L.view4(None), L.view4(out), B, C, Fd, T, 8, st2.data_ptr(), dwsf.data_ptr(), 1e-7, 1.0, 0, nst)
+    L.call("aid_norm_bwd", npar)
+    torch.cuda.synchronize()
+    coef_ref, out_ref = dwsf[B * 8 * nst:].view(torch.float32)[:B * 8].clone(), out.clone()
+    assert bool(torch.isfinite(coef_ref).all()) and float(coef_ref.abs().max()) > 0
+    gd2 = torch.empty_like(gd)
+    q.y = L.view4(gd2)
+    for _ in range(2):
+        dwsf.fill_(float("nan"))
+        q.dot_ws = dwsf.data_ptr()
+        q.fin_mode, q.fin_count, q.fin_eps, q.fin_stats, q.fin_scale = 2, cnt.data_ptr(), 1e-7, st2.data_ptr(), dwsf.data_ptr() + 8 * B * 8 * nst
+        L.call("aid_conv2d", q)
+        npar.coef_ready = 1
+        out.fill_(float("nan"))
+        L.call("aid_norm_bwd", npar)
+        torch.cuda.synchronize()
+        assert torch.equal(gd2, gd) and torch.equal(dwsf[B * 8 * nst:].view(torch.float32)[:B * 8], coef_ref) and torch.equal(out, out_ref) and int(cnt[:B].abs().sum()) == 0
     # (4) the pack kernel writes the same 2-D packs as the torch helper
     outs = [torch.empty_like(wp), torch.empty_like(wpT), torch.empty_like(wpw), torch.empty_like(wpwT)]
     pp = L.PackConvWeightParams(wd.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), None, None, C, C, 5, 3, wp.shape[1], wp.shape[2],

@@ -40,7 +40,8 @@ pmc)
     timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python bench.py --steps 1 --warmup 0 --roof-steps 1 --no-cpu-baseline --streams 1 > /dev/null 2>&1
   done
   python tools/conv_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/r05_conv_traffic.json > /dev/null
-  rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+  rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE ;;
+pmcshapes)
   for shape in "8 256 256 384 64 5 3 4" "8 256 256 448 32 5 3 4" "8 128 128 320 128 5 3 4" "8 64 64 64 2048 5 3 1" "8 96 96 192 512 5 3 4"; do tools/pmc_conv.sh "$shape" 2; tools/pmc_conv.sh "$shape" 1; done > $O/r05_wino_pmc.txt 2>&1 ;;
 probe)
   python tools/w2d_probe.py layer 4 > $O/r05_w2d_layer_probe.txt 2>&1 ;;
@@ -51,6 +52,8 @@ traces)
   python tools/plan_trace.py 1 maestro22k --list > $O/r05_trace_b1.txt 2>/dev/null
   python tools/plan_trace.py 4 musicnet44k > $O/r05_trace_cfgB_b4.txt 2>/dev/null
   python bench.py --no-cpu-baseline --streams 1 --conv-table > /dev/null 2> $O/r05_conv_table.txt ;;
+streams)
+  { for rep in 1 2 3; do for st in 2 3; do echo "== rep $rep --streams $st"; run --streams $st | cut -c1-200; done; done; } > $O/r05_streams_2_vs_3.txt ;;
 e2e)
   { python tools/e2e_run.py maestro22k 8; python tools/e2e_run.py maestro22k 1; python tools/e2e_run.py musicnet44k 4; python tools/e2e_run.py librispeech16k 16; } > $O/r05_e2e_full_runs.txt 2>/dev/null ;;
 c11)

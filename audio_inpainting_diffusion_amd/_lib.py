@@ -258,7 +258,7 @@ EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_st
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_guidance_step", "aid_set_rows", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
            "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino8_supported", "aid_conv2d_wino_split_ws_bytes", "aid_conv2d_fin_supported",
            "aid_conv2d_wgrad", "aid_wgrad_reduce", "aid_channel_dot", "aid_relpos_bwd", "aid_scale_bwd", "aid_modulation_bwd", "aid_embed_bwd",
-           "aid_adam", "aid_ema", "aid_sumsq", "aid_wino2d_gemm", "aid_conv2d_wino2d_gemm", "aid_conv2d_wino2d_output", "aid_conv2d_wino2d_supported", "aid_conv2d_wino2d_positions", "aid_conv2d_wino2d_wanted"]
+           "aid_adam", "aid_ema", "aid_sumsq", "aid_wino2d_gemm", "aid_wino2d_set_split", "aid_conv2d_wino2d_gemm", "aid_conv2d_wino2d_output", "aid_conv2d_wino2d_supported", "aid_conv2d_wino2d_positions", "aid_conv2d_wino2d_wanted"]
 
 _lib = None
 
@@ -307,9 +307,11 @@ def lib():
         L.aid_conv2d_wino2d_wanted.restype = C.c_int
         L.aid_conv2d_wino2d_positions.argtypes = [C.c_int] * 4
         L.aid_conv2d_wino2d_positions.restype = C.c_int64
+        L.aid_wino2d_set_split.argtypes = [C.c_int]
+        L.aid_wino2d_set_split.restype = C.c_int
         for name in EXPORTS[3:]:
             if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino8_supported", "aid_conv2d_wino_split_ws_bytes", "aid_conv2d_fin_supported",
-                            "aid_conv2d_stat_partials", "aid_conv2d_wgrad_tiles", "aid_conv2d_wino2d_supported", "aid_conv2d_wino2d_positions", "aid_conv2d_wino2d_wanted"):
+                            "aid_conv2d_stat_partials", "aid_conv2d_wgrad_tiles", "aid_conv2d_wino2d_supported", "aid_conv2d_wino2d_positions", "aid_conv2d_wino2d_wanted", "aid_wino2d_set_split"):
                 getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, name).restype = C.c_int
         if L.aid_abi_version() != 13:

@@ -202,6 +202,193 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WPC * WGM * WGN + 3) / 4) void w2d
         }
 }
 
+// ---- LABELLED VARIANT (never the default, never the headline): the same batched GEMM with both fp32 operands SPLIT into three bf16
+// pieces each (truncation: 8 + 8 + 8 significand bits, x = p0 + p1 + p2 EXACTLY) and the six largest cross products on the bf16 matrix pipe
+// (v_mfma_f32_32x32x16_bf16: a bf16 x bf16 product is exact in fp32, accumulation in fp32) -- p2 q0 + p0 q2 + p1 q1 + p1 q0 + p0 q1 + p0 q0, smallest first;
+// the dropped terms are below 2^-32 of the product.  Error study BEFORE the kernel (tools/bf16split_error.py, profiles/r05_bf16split_error.txt): 1.8e-6
+// per layer at K = 256 against 4.3e-6 of the fp32-MFMA form (the fp32 MFMA rounds every product; this form does not); the 3-product split is 6e-5: not built.
+// 6 MFMAs of 32 cycles per 16 k against 8 of 64: 0.375x the matrix-pipe time; the split is VALU work on the fragments (4 ops + 1.5 packs per value).
+// Same LDS images, same direct-to-LDS staging, one k-step of 16 per chunk: lane half h holds k = 8 h .. 8 h + 7 of BOTH fragments.
+typedef __bf16 w2d_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned w2d_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void w2d_split3(const float (&x)[8], w2d_u32x4 (&p)[3]) {
+    unsigned a[3][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned b0 = __float_as_uint(x[k]) & 0xffff0000u;
+        const float r1 = x[k] - __uint_as_float(b0);                 // exact
+        const unsigned b1 = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(b1);                   // exact, at most 8 significant bits: its bf16 truncation is itself
+        a[0][k] = b0; a[1][k] = b1; a[2][k] = __float_as_uint(r2);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[q][k] = __builtin_amdgcn_perm(a[q][2 * k + 1], a[q][2 * k], 0x07060302u);     // (hi16 of k+1) << 16 | hi16 of k
+}
+
+template <int MT, int NT, int WGM, int WGN, int NBUF, int WPC>
+__global__ __launch_bounds__(64 * WGM * WGN, (WPC * WGM * WGN + 3) / 4) void w2d_gemm_s6_kernel(const W2dGemmDev a) {
+    constexpr int KC = 16;
+    using S = W2dGemmShape<MT, NT, WGM, WGN, KC, NBUF>;
+    constexpr int NW = S::NW, M_BLK = S::M_BLK, N_BLK = S::N_BLK, XSZ = S::XSZ, BUFSZ = S::BUFSZ;
+    constexpr int NXP = S::NXP, PPW = S::PPW;
+    typedef typename W2dVec<MT>::type avec;
+    typedef typename W2dVec<NT>::type bvec;
+    __shared__ __attribute__((aligned(16))) float smem[S::LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int half = lane >> 5;
+    const int Lt = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+    if (Lt >= a.ntiles) return;
+    int rest = Lt;
+    const int by = rest % a.ntm; rest /= a.ntm;
+    const int bn = rest % a.ntn;
+    const int xi = rest / a.ntn;
+    const int m0 = by * M_BLK, n0 = bn * N_BLK;
+
+    unsigned poff[PPW];
+    int plds[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int pc = wave + i * NW;
+        plds[i] = pc * 256;
+        if (pc < NXP) {
+            const int e = pc * 256 + 4 * lane;
+            const int k = e / N_BLK, nl = e % N_BLK;
+            poff[i] = (unsigned)(4 * ((int64_t)k * a.N + min(n0 + nl, a.N - 4)));
+        } else {
+            const int e = (pc - NXP) * 256 + 4 * lane;
+            const int k = e / M_BLK, col = e % M_BLK;
+            poff[i] = (unsigned)(4 * ((int64_t)k * a.Cout_pad + m0 + col));
+        }
+    }
+    const int64_t xstep = (int64_t)KC * a.N * 4, wstep = (int64_t)KC * a.Cout_pad * 4;
+    const char* const xbase = reinterpret_cast<const char*>(a.V + (int64_t)xi * a.Cin * a.N);
+    const char* const wbase = reinterpret_cast<const char*>(a.U + (int64_t)xi * a.Cin_pad * a.Cout_pad);
+    const int vB = (8 * half) * N_BLK + wn * (32 * NT) + NT * (lane & 31);
+    const int vA = XSZ + (8 * half) * M_BLK + wm * (32 * MT) + MT * (lane & 31);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto issue_all = [&](int ch, float* buf) {
+        w2d_static_for<PPW>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const char* base = (wave + i * NW < NXP) ? xbase + ch * xstep : wbase + ch * wstep;
+            const unsigned la = W2D_LDS_ADDR(buf + plds[i]);
+            const unsigned off = poff[i];
+            W2D_DMA16_SBASE(off, base, la);
+        });
+    };
+    const int nch = a.nchunks;
+    constexpr int AHEAD = NBUF - 1;
+    w2d_static_for<AHEAD>([&](auto qc) { if (decltype(qc)::value < nch) issue_all(decltype(qc)::value, smem + decltype(qc)::value * BUFSZ); });
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+
+    auto chunk = [&](auto curc, int ch) {
+        constexpr int cur = decltype(curc)::value;
+        const float* Bf = smem + cur * BUFSZ;
+        float* Nx = smem + ((cur + AHEAD) % NBUF) * BUFSZ;
+        const bool more = (ch + AHEAD) < nch;
+        if (more) issue_all(ch + AHEAD, Nx);
+        avec av[8];
+        bvec bv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            av[k] = *reinterpret_cast<const avec*>(Bf + vA + k * M_BLK);
+            bv[k] = *reinterpret_cast<const bvec*>(Bf + vB + k * N_BLK);
+        }
+        w2d_u32x4 pa[MT][3];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            float x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = w2d_get(av[k], i);
+            w2d_split3(x, pa[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = w2d_get(bv[k], j);
+            w2d_u32x4 pb[3];
+            w2d_split3(x, pb);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                f32x16 c = acc[i][j];
+#define W2D_S6(qa, qb) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(w2d_bf16x8, pa[i][qa]), __builtin_bit_cast(w2d_bf16x8, pb[qb]), c, 0, 0, 0)
+                W2D_S6(2, 0); W2D_S6(0, 2); W2D_S6(1, 1); W2D_S6(1, 0); W2D_S6(0, 1); W2D_S6(0, 0);
+#undef W2D_S6
+                acc[i][j] = c;
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (NBUF >= 3 && more) __builtin_amdgcn_s_waitcnt(W2D_VMCNT(PPW * (AHEAD - 1)));
+        else if (NBUF >= 4 && (ch + AHEAD - 1) < nch) __builtin_amdgcn_s_waitcnt(W2D_VMCNT(PPW * (AHEAD - 2)));
+        else __builtin_amdgcn_s_waitcnt(W2D_VMCNT(0));
+        __builtin_amdgcn_s_waitcnt(W2D_LGKMCNT0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    for (int ch = 0; ch < nch; ch += NBUF)
+        w2d_static_for<NBUF>([&](auto qc) { if (ch + decltype(qc)::value < nch) chunk(qc, ch + decltype(qc)::value); });
+
+    const int n = n0 + wn * (32 * NT) + NT * (lane & 31);
+    if (n >= a.N) return;
+    float* const cb = a.Mo + (int64_t)xi * a.Cout * a.N + n;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * (32 * MT) + MT * (4 * half + (r & 3) + 8 * (r >> 2)) + i;
+            if (m >= a.Cout) continue;
+            float* q = cb + (int64_t)m * a.N;
+            if constexpr (NT == 4) *reinterpret_cast<float4*>(q) = make_float4(acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]);
+            else if constexpr (NT == 2) *reinterpret_cast<float2*>(q) = make_float2(acc[i][0][r], acc[i][1][r]);
+            else *q = acc[i][0][r];
+        }
+}
+
+template <int MT, int NT, int WGM, int WGN, int NBUF, int WPC>
+static int w2d_launch_gemm_s6(const aid_wino2d_gemm_params* p, hipStream_t st, const char* name) {
+    using S = W2dGemmShape<MT, NT, WGM, WGN, 16, NBUF>;
+    AID_REQUIRE(p->Cin % 16 == 0, "aid_wino2d_gemm: Cin must be a multiple of the K chunk");
+    AID_REQUIRE(p->Cout_pad % S::M_BLK == 0, "aid_wino2d_gemm: Cout_pad must be a multiple of the M tile");
+    AID_REQUIRE((int64_t)p->Cin * p->N * 4 < (1LL << 32) && (int64_t)p->Cin_pad * p->Cout_pad * 4 < (1LL << 32), "aid_wino2d_gemm: one plane must stay below 4 GiB");
+    W2dGemmDev a;
+    a.U = p->U; a.V = p->V; a.Mo = p->M;
+    a.Cin = p->Cin; a.Cout = p->Cout; a.Cin_pad = p->Cin_pad; a.Cout_pad = p->Cout_pad; a.N = (int)p->N;
+    a.nchunks = p->Cin / 16;
+    a.ntn = aid_cdiv(p->N, S::N_BLK);
+    a.ntm = aid_cdiv(p->Cout, S::M_BLK);
+    a.ntiles = p->nxi * a.ntn * a.ntm;
+    a.per_xcd = aid_cdiv(a.ntiles, 8);
+    hipLaunchKernelGGL((w2d_gemm_s6_kernel<MT, NT, WGM, WGN, NBUF, WPC>), dim3((unsigned)(8 * a.per_xcd)), dim3(64 * S::NW), 0, st, a);
+    AID_CHECK_LAUNCH();
+    aid_note_kernel(name);
+    return AID_OK;
+}
+
+// the split-precision variant as a process-wide switch of aid_conv2d(x_wino = 3) (0: the fp32-MFMA product kernel; 6: the six-product bf16 split): set
+// by bench.py --mfma-split 6 and the variant's tests only
+static int g_w2d_split = 0;
+extern "C" int aid_wino2d_set_split(int pieces) {
+    AID_REQUIRE(pieces == 0 || pieces == 6, "aid_wino2d_set_split: 0 (fp32 MFMA) or 6 (six bf16 products per fp32 product)");
+    g_w2d_split = pieces;
+    return AID_OK;
+}
+
 template <int MT, int NT, int WGM, int WGN, int KC, int NBUF, int WPC>
 static int w2d_launch_gemm(const aid_wino2d_gemm_params* p, hipStream_t st, const char* name) {
     using S = W2dGemmShape<MT, NT, WGM, WGN, KC, NBUF>;
@@ -229,6 +416,7 @@ extern "C" int aid_wino2d_gemm(const aid_wino2d_gemm_params* p, void* stream) {
     AID_REQUIRE(((uintptr_t)p->U & 15) == 0 && ((uintptr_t)p->V & 15) == 0 && ((uintptr_t)p->M & 15) == 0 && (p->Cout_pad % 4) == 0, "aid_wino2d_gemm: 16-byte alignment");
     AID_REQUIRE(p->Cin_pad >= p->Cin && p->Cout_pad >= p->Cout, "aid_wino2d_gemm: padded dims");
     int variant = p->variant;
+    if (variant == 0 && g_w2d_split == 6) variant = ((int64_t)p->nxi * aid_cdiv(p->N, 256) * aid_cdiv(p->Cout, 128) < 1600) ? 101 : 100;
     if (variant == 0) {
         // 128 x 256 tiles (two workgroups per CU) while the launch has a few rounds of them; 128 x 128 tiles at four workgroups per CU for the short ones
         // (batch 1-2, the deepest level): 15-20 % faster there (profiles/r05_w2d_layer_probe2_b1.txt).  Every output element sums its K products in
@@ -249,6 +437,9 @@ extern "C" int aid_wino2d_gemm(const aid_wino2d_gemm_params* p, void* stream) {
         case 9: return w2d_launch_gemm<2, 4, 2, 2, 8, 6, 2>(p, st, "w2d_gemm_kernel<128x256,kc8,nb6>");
         case 10: return w2d_launch_gemm<4, 2, 2, 2, 8, 4, 2>(p, st, "w2d_gemm_kernel<256x128,kc8,nb4>");
         case 11: return w2d_launch_gemm<2, 2, 2, 2, 16, 2, 4>(p, st, "w2d_gemm_kernel<128x128,kc16,nb2,wpc4>");
+        case 100: return w2d_launch_gemm_s6<2, 4, 2, 2, 3, 2>(p, st, "w2d_gemm_s6_kernel<128x256,nb3>");
+        case 101: return w2d_launch_gemm_s6<2, 2, 2, 2, 3, 3>(p, st, "w2d_gemm_s6_kernel<128x128,nb3,wpc3>");
+        case 102: return w2d_launch_gemm_s6<2, 4, 2, 2, 2, 2>(p, st, "w2d_gemm_s6_kernel<128x256,nb2>");
         default: break;
     }
     aid_set_error("aid_wino2d_gemm: unknown variant");

@@ -51,7 +51,8 @@ PEAK_F32_MFMA = 157.3          # TFLOP/s, dense fp32 matrix (MI355X_MICROARCH.md
 # executed MFMA FLOPs as a fraction of the direct form: F(4,3) issues 6 products per 4 outputs x 3 taps = 1/2, F(8,3) 10 per 8 x 3 = 5/12
 # the 2-D form F(4,5) x F(4,3) 48 per 16 x 15 = 1/5 (its GEMM is a plan node of its own: w2d_gemm_kernel; the output pass carries no FLOPs)
 WINO_EXEC = {"conv53_wino4r_kernel": 0.5, "conv53_wino4v_kernel": 0.5, "conv53_wino4_kernel": 0.5, "conv53_wino8r_kernel": 10.0 / 24.0,
-             "conv53_wino8r_ks_kernel": 10.0 / 24.0, "w2d_gemm_kernel": 48.0 / 240.0}
+             "conv53_wino8r_ks_kernel": 10.0 / 24.0, "w2d_gemm_kernel": 48.0 / 240.0,
+             "w2d_gemm_s6_kernel": 48.0 / 240.0}       # (variant: fp32-equivalent products; they run on the bf16 pipe, so its frac_of_fp32_mfma_peak may pass 1)
 
 
 def ensure_built() -> None:
@@ -240,6 +241,8 @@ def main():
     ap.add_argument("--no-fin", action="store_true", help="A/B: separate aid_group_stats / coefficient launches instead of the last tile of a sample folding the epilogue partials")
     ap.add_argument("--no-epilogue-stats", action="store_true", help="A/B: group statistics by their own read pass instead of the conv epilogue")
     ap.add_argument("--wino-forms", default="4,8,45", help="A/B: Winograd forms the 5x3 layers may use (default 4,8,45: the 2-D form F(4,5) x F(4,3) and F(8,3) where the library prefers them; 4,8: the fused 1-D kernels only; 4: F(4,3) everywhere)")
+    ap.add_argument("--mfma-split", type=int, default=0, choices=[0, 6], help="LABELLED VARIANT (never the default): 6 = the 2-D Winograd form's GEMMs on three bf16 pieces per fp32 operand, "
+                    "six bf16 MFMA products, fp32 accumulation (aid_wino2d_set_split); the JSON's dtype says so")
     ap.add_argument("--split", default="", help="A/B: explicit sub-batch sizes, e.g. 5,3 (network.split_sizes; implies --streams = their count)")
     ap.add_argument("--conv-table", action="store_true", help="print per-shape conv kernel times (stderr)")
     a = ap.parse_args()
@@ -277,6 +280,8 @@ def main():
     L, B = args.exp.audio_len, (a.batch or B_def)
 
     net = Unet_CQT_oct_with_attention(args, dev)
+    if a.mfma_split:
+        assert _lib.lib().aid_wino2d_set_split(a.mfma_split) == 0
     if a.no_epilogue_stats:
         net.epilogue_stats = False
     if a.no_fin:
@@ -397,7 +402,8 @@ def main():
         out = {
             "metric": "denoiser-steps/sec", "value": round(evals / wall, 3), "unit": "denoiser evaluations (one segment each) per second, whole job",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * wall / a.steps, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+            "dtype": "f32" if not a.mfma_split else "VARIANT: f32 storage and accumulation; the GEMMs of the 2-D Winograd layers multiply three bf16 pieces per f32 operand (exact split), six bf16-MFMA products each; all other kernels f32",
             "config": {"workload": {"maestro22k": "BASELINE.json configs[1]: batch %d x 22.05 kHz MAESTRO-shape segments (L=184184) per GPU, %g ms gap, ",
                                     "librispeech16k": "BASELINE.json configs[3]: batch %d x 16 kHz LibriSpeech-shape segments (L=184184) per GPU, 4 gaps of %g ms, ",
                                     "musicnet44k": "BASELINE.json configs[4]: batch %d x 44.1 kHz segments (L=184184) per GPU, 8-octave network, %g ms gap, "}[a.workload] % (B, gap_ms)

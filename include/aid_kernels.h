@@ -206,6 +206,10 @@ int aid_wino2d_gemm(const aid_wino2d_gemm_params* p, void* stream);
  * _gemm followed by _output on one stream is exactly aid_conv2d(p).   replaces: the same F.conv2d call sites as aid_conv2d (unet...py:433-436, :472-482). */
 int aid_conv2d_wino2d_gemm(const aid_conv2d_params* p, void* stream);
 int aid_conv2d_wino2d_output(const aid_conv2d_params* p, void* stream);
+/* LABELLED VARIANT, off by default (never the measured headline): pieces = 6 makes the GEMM of the 2-D form split both fp32 operands into three bf16
+ * pieces (exactly) and issue the six largest cross products on the bf16 matrix pipe with fp32 accumulation (aid_wino2d_gemm variants 100 / 101);
+ * pieces = 0 restores the fp32-MFMA kernel.  Process-wide.  Error study: profiles/r05_bf16split_error.txt (1.8e-6 per layer at K = 256; fp32 MFMA 4.3e-6). */
+int aid_wino2d_set_split(int pieces);
 
 /* ---------------------------------------------------------------------------------------------------
  * aid_resample -- 8-tap cubic FIR 2:1 resampling along T with reflect padding.

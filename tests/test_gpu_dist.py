@@ -434,24 +434,32 @@ def test_config2_eight_ranks_eight_segments_each_on_one_gpu():
     full-size network in each, one 745 MB broadcast per rank, global-index seeds, one guided Heun step = two evaluations with the input-VJP per
     segment, ONE all-gather of the 64 outputs).  A rank's batch of eight is the same launch sequence as a single process's batch of eight with the
     same seeds: the first and the last rank's shards of the gathered result equal those single-process runs to the BIT; every rank holds the same 64 rows.
-    Skipped when the device has less free memory than 8 x the measured peak of one batch-8 step needs."""
+    Eight batch-8 processes need 8 x the measured peak of one batch-8 step: where that does not fit the device the test falls back to 4 (then 2) segments
+    per rank and says so (MI355X, 288 GB: a batch-8 guided step peaks at ~73 GiB -- its saved activations for the input-VJP -- so eight of them do not fit)."""
     from audio_inpainting_diffusion_amd import dist as D
     from audio_inpainting_diffusion_amd.init import seeded_normal
-    world, per = 8, 8
-    net, args, _, mask = _full_setup(DEV, seed=0, n_items=1)
-    Ls = args.exp.audio_len
-    refs = {}
-    torch.cuda.reset_peak_memory_stats()
-    for r in (0, world - 1):
-        lo, hi = D.shard_range(world * per, r, world)
-        y = torch.stack([torch.from_numpy(seeded_normal(41, g, Ls)) for g in range(lo, hi)]) * 0.063
-        refs[r] = _full_step(net, args, y, mask, D.item_seeds(700, lo, hi), DEV).cpu().numpy()
-    peak = torch.cuda.max_memory_allocated() / 2 ** 30
-    del net
-    torch.cuda.empty_cache()
-    free = torch.cuda.mem_get_info()[0] / 2 ** 30
-    if free < world * (peak + 3.0) + 8.0:
-        pytest.skip(f"8 ranks x {peak:.1f} GiB (one batch-8 step) do not fit the {free:.0f} GiB free on this device")
+    world = 8
+    total = torch.cuda.mem_get_info()[1] / 2 ** 30
+    for per in (8, 4, 2):                               # 8 = configs[2]; fewer only when eight such processes do not fit this device's memory
+        net, args, _, mask = _full_setup(DEV, seed=0, n_items=1)                                # (a fresh network per attempt: cached launch plans pin their buffers)
+        Ls = args.exp.audio_len
+        refs = {}
+        torch.cuda.reset_peak_memory_stats()
+        for r in (0, world - 1):
+            lo, hi = D.shard_range(world * per, r, world)
+            y = torch.stack([torch.from_numpy(seeded_normal(41, g, Ls)) for g in range(lo, hi)]) * 0.063
+            refs[r] = _full_step(net, args, y, mask, D.item_seeds(700, lo, hi), DEV).cpu().numpy()
+        peak = torch.cuda.max_memory_allocated() / 2 ** 30
+        del net
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        free = torch.cuda.mem_get_info()[0] / 2 ** 30
+        print(f"configs[2] rehearsal: one batch-{per} guided step peaks at {peak:.1f} GiB; eight ranks need {world * (peak + 2.0):.0f} of the {free:.0f} GiB free ({total:.0f} GiB device)")
+        if free >= world * (peak + 2.0) + 8.0:
+            break
+    else:
+        pytest.skip(f"8 ranks x {peak:.1f} GiB (one batch-2 step) do not fit the {free:.0f} GiB free on this device")
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -471,7 +479,7 @@ def test_config2_eight_ranks_eight_segments_each_on_one_gpu():
         assert keep.shape == (2 * per, Ls) and nbytes > 700e6 and np.isfinite(keep).all()
         assert np.array_equal(keep[:per], refs[0]) and np.array_equal(keep[per:], refs[world - 1])      # bit-identical to the single-process batch-8 runs of those shards
         assert ssq == res[0][7]                                                                          # every rank gathered the same 64 rows
-        print(f"configs[2] shape, rank {rank}/8 ({backend}, {nthr} CPU threads, broadcast {t_bcast:.2f} s, peak {rpeak:.1f} GiB): 8 segments, shards of ranks 0 and 7 == single-process B = 8 runs")
+        print(f"configs[2] shape, rank {rank}/8 ({backend}, {nthr} CPU threads, broadcast {t_bcast:.2f} s, peak {rpeak:.1f} GiB): {per} segments, shards of ranks 0 and 7 == single-process B = {per} runs")
 
 
 def test_bench_self_launches_eight_ranks_rank0_only_json():

@@ -88,6 +88,35 @@ def test_unet_full_cfgA_vs_reference_golden(forms):
     assert abs(net.flops_per_eval(1) / 2.035e12 - 1) < 0.02    # 2.035 TFLOP per evaluation
 
 
+def test_unet_full_cfgA_split_precision_variant_vs_reference_golden():
+    """The LABELLED VARIANT of VERDICT r4 next-8 (aid_wino2d_set_split(6): the 2-D form's GEMM on three bf16 pieces per fp32 operand, six bf16 MFMA products,
+    fp32 accumulation) on the full-size network against the REFERENCE's output: it must stay inside the product path's tolerance, and the switch must be
+    process-wide and reversible."""
+    from audio_inpainting_diffusion_amd import _lib
+    from audio_inpainting_diffusion_amd.config import make_args
+    from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    z = np.load(os.path.join(GOLDEN, "unet_full_cfgA.npz"))
+    args = make_args("maestro22k")
+    net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(DEV)), 0, gate_scale=10.0, affine_scale=10.0)
+    Ls = args.exp.audio_len
+    x = torch.from_numpy(seeded_normal(2024, 0, Ls)).reshape(1, Ls) * 0.5
+    cn = torch.from_numpy(z["cnoise"]).to(DEV)
+    try:
+        assert _lib.lib().aid_wino2d_set_split(6) == 0
+        with torch.no_grad():
+            ys = net(x.to(DEV), cn).clone()
+        kn = [o for o in net._state(1)["plan_body"].ops if o.name == "aid_conv2d_wino2d_gemm"]
+        assert len(kn) >= 20
+    finally:
+        assert _lib.lib().aid_wino2d_set_split(0) == 0
+    with torch.no_grad():
+        y0 = net(x.to(DEV), cn)
+    es, e0 = rel_l2(ys.cpu(), z["y"]), rel_l2(y0.cpu(), z["y"])
+    print(f"unet_full_cfgA, split-precision variant (bf16 x 6 on the 2-D form's GEMMs): rel-L2 vs reference golden = {es:.3e} (fp32 MFMA: {e0:.3e}); variant vs product path {rel_l2(ys.cpu(), y0.cpu()):.2e}")
+    assert es < TOL and e0 < TOL and _lib.lib().aid_wino2d_set_split(3) != 0
+
+
 def _oracle_for(net, kw):
     from oracle.nsgt_cqt import OracleCQT
     from oracle.unet import OracleUnet

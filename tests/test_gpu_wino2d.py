@@ -47,6 +47,19 @@ def test_wino2d_gemm_vs_torch(L, shape):
     ref = torch.bmm(U[:, :cin, :cout].transpose(1, 2).double(), V.double())
     assert rel_l2(M.cpu(), ref) < 2e-6
     assert float(tail.min()) == 7.0
+    # the labelled split-precision variant (three bf16 pieces per fp32 operand, six products on the bf16 matrix pipe, fp32 accumulation): the pieces are an
+    # exact decomposition and the dropped cross terms are below 2^-32 -- it must be at least as close to the fp64 product as the fp32-MFMA kernel
+    e32 = rel_l2(M.cpu(), ref)
+    if cout % 128 == 0:
+        for variant in (100, 101):
+            M.fill_(7.0)
+            p.variant = variant
+            L.call("aid_wino2d_gemm", p)
+            torch.cuda.synchronize()
+            assert "w2d_gemm_s6" in L.lib().aid_last_kernel().decode()
+            es = rel_l2(M.cpu(), ref)
+            print(f"GEMM {shape}: fp32 MFMA {e32:.2e}, bf16 x 6 split (variant {variant}) {es:.2e}")
+            assert es < 2e-6 and es < 1.5 * e32 + 1e-8 and float(tail.min()) == 7.0
 
 
 def _conv_ref(x, w, dil, in_scale, act, out_scale, res, res_scale, alpha):

@@ -24,6 +24,9 @@ variants)
     run --wino-forms 4,8 --streams 1
     run --wino-forms 4
     run --no-pair-merge
+    run --mfma-split 6
+    run --mfma-split 6 --batch 1 --steps 4 --warmup 2
+    run --mfma-split 6 --workload musicnet44k
   } > $O/r05_bench_variants.jsonl ;;
 small)
   { for b in 1 2 3 4; do run --batch $b --steps 4 --warmup 2; done
@@ -61,6 +64,9 @@ c11)
     # (the ablation block of profiles/r05_c11_probe.txt came from an experimental build with an AID_C11_MODE switch; the product kernel has none)
     for rs in 0 1; do echo "== batch 1, AID_C11_RS=$rs"; AID_C11_RS=$rs timeout 300 python tools/c11_probe.py 1; done
   } 2>&1 | grep -v amdgpu.ids > $O/r05_c11_probe.txt ;;
+suite)
+  timeout 2400 python -m pytest tests -m gpu -q -rs --durations=12 > $O/r05_gpu_suite.txt 2>&1
+  python -c "import __graft_entry__ as g; g.smoke()" >> $O/r05_gpu_suite.txt 2>&1 ;;
 train)
   { python tools/train_bench.py 4 3; python tools/train_bench.py 8 3; } > $O/r05_train_bench.txt 2>/dev/null ;;
 esac; done

@@ -529,6 +529,23 @@ def test_failed_launch_re_zeroes_the_scratch_that_must_be_found_zero():
     assert int(cnt.abs().sum()) == 0 and float(flags[:1024].abs().sum()) == 0.0 and float(flags[1024:].sum()) == 3072.0
 
 
+def test_bench_reports_pmc_traffic_only_for_the_same_build_and_names_kernels_as_rocprof_does():
+    """bench.py: roofline.traffic comes from a committed PMC profile ONLY when that profile was taken on the same kernel sources (no stale
+    numbers); the per-kernel tables aggregate by the device kernel's name as rocprofv3 lists it; executed-FLOP fractions per Winograd form."""
+    import bench
+    assert bench.kernel_base("w2d_gemm_kernel<128x256,kc16,nb3>") == "w2d_gemm_kernel" and bench.kernel_base("conv53_wino8r_kernel(64+32)") == "conv53_wino8r_kernel"
+    assert bench.kernel_base("conv11_dma_kernel+splitk") == "conv11_dma_kernel" and bench.kernel_base("w2d_gemm_s6_kernel<128x128,nb3,wpc3>") == "w2d_gemm_s6_kernel"
+    assert bench.WINO_EXEC["w2d_gemm_kernel"] == 0.2 and abs(bench.WINO_EXEC["conv53_wino8r_kernel"] - 5 / 12) < 1e-12 and bench.WINO_EXEC["conv53_wino4r_kernel"] == 0.5
+    f = bench._traffic_fields("conv53_wino8r_kernel", {"algorithmic_mb_per_launch": 500.0})
+    tp = f["traffic_from_profile"]
+    if tp is None:
+        assert f["traffic"] is None and f["traffic_over_algorithmic"] is None
+    else:
+        same = tp.get("kernel_sources_sha16") == bench._kernel_sources_sha16()
+        assert tp["used"] == same and (f["traffic"] is None or same) and (f["traffic_source"] is None) == (not same)
+    assert len(bench._kernel_sources_sha16()) == 16
+
+
 def test_lambda_degradation_is_the_jacobian_transpose_product_at_x_hat():
     """sampler.LambdaDegradation (Sampler.predict_resample, edm_sampler_inpainting.py:164-173): apply = the callable on a detached copy, adjoint = its VJP at the
     same point -- what the reference's torch.autograd.grad forms through `degradation(x_hat)` (:65-81) -- for a linear operator that changes the length and for a

@@ -87,8 +87,11 @@ def layer(batches):
     lib = _lib.lib()
     g = torch.Generator(device="cpu").manual_seed(0)
     print("layer, dil, B | 2-D: input us (TB/s)  gemm us (frac)  output us (TB/s)  total | 1-D form: pre us  conv us  total | ratio")
+    only = os.environ.get("PROBE_ONLY", "")                  # e.g. "L5 C256": restrict to the layer shapes whose label starts with it (PMC runs)
     for B in batches:
         for label, C, Fd, T, dils in LAYER_SHAPES:
+            if only and not label.startswith(only):
+                continue
             x = torch.randn(B, C, Fd, T, generator=g).to(dev)
             res = torch.randn(B, C, Fd, T, generator=g).to(dev)
             y = torch.empty_like(x)

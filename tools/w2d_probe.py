@@ -24,6 +24,11 @@ GEMM_SHAPES = [
     ("L5 C256 B1", 256, 256, 96 * 16),
     ("L6 C256 B1", 256, 256, 112 * 8),
     ("L6 C256 B2", 256, 256, 2 * 112 * 8),
+    ("L5 C256 B2", 256, 256, 2 * 96 * 16),
+    ("L4 C128 B1", 128, 128, 80 * 32),
+    ("L4 C128 B2", 128, 128, 2 * 80 * 32),
+    ("L3 C128 B1", 128, 128, 64 * 64),
+    ("L5d C128 B1", 128, 128, 96 * 16),
 ]
 
 

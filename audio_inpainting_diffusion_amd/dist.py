@@ -162,9 +162,9 @@ def gather_objects(obj, dst: int = 0):
     """Python objects of every rank on rank ``dst`` (list in rank order; None elsewhere); [obj] in a single-process world."""
     if not _active():
         return [obj]
-    out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
-    dist.gather_object(obj, out, dst=dst)
-    return out
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)                     # (all_gather_object: the object collective every backend implements; RCCL stages through the current device)
+    return out if dist.get_rank() == dst else None
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:

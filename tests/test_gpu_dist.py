@@ -429,7 +429,7 @@ def test_full_size_eight_ranks_on_one_gpu_equal_one_process():
         assert np.array_equal(allout, res[0][3])                   # every rank holds the same gathered result, in global segment order
     assert sum(r[5] or 0 for r in res) <= (os.cpu_count() or 8) or all(r[5] is None for r in res)     # the ranks' CPU shares do not overlap
 
-def test_config2_eight_ranks_eight_segments_each_on_one_gpu():
+def test_config2_job_shape_eight_ranks_several_segments_each_on_one_gpu():
     """BASELINE configs[2] at its FULL job shape on one GPU: 64 gap segments, 8 ranks x 8 segments each (eight processes sharing cuda:0 over gloo, the
     full-size network in each, one 745 MB broadcast per rank, global-index seeds, one guided Heun step = two evaluations with the input-VJP per
     segment, ONE all-gather of the 64 outputs).  A rank's batch of eight is the same launch sequence as a single process's batch of eight with the
@@ -527,6 +527,8 @@ out = torch.arange(3 * 4096, dtype=torch.float32, device="cuda:0").reshape(3, 40
 g = D.gather_outputs(out, 3)
 assert g.is_cuda and torch.equal(g, out)
 m = D.max_over_ranks(1.25, torch.device("cuda:0"))
+reps = D.gather_objects(D.rank_report(0, 0, wall_s=0.5, segments=[0, 3]))        # bench.py's per-rank table over RCCL (object collective staged through cuda:0)
+assert isinstance(reps, list) and len(reps) == 1 and reps[0]["rank"] == 0 and reps[0]["pci"] and reps[0]["segments"] == [0, 3] and D.rccl_version()
 D.barrier(); torch.cuda.synchronize()
 try:
     ver = ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -540,7 +542,7 @@ dist.destroy_process_group()
 def test_rccl_first_contact_world_size_one():
     """The only RCCL contact a 1-GPU box allows: a ONE-rank `nccl` (= RCCL) process group on cuda:0 running the SAME dist.py collectives the
     8-GPU job issues -- the in-place flat-buffer weight broadcast (device memory, not host-staged), a 745 MB broadcast by size, the output
-    all-gather, the max-over-ranks all-reduce and the barrier.  Proves RCCL initialises on the box's driver stack (dmabuf IPC mode) and accepts
+    all-gather, the max-over-ranks all-reduce, the per-rank report table of the bench JSON (an object collective) and the barrier.  Proves RCCL initialises on the box's driver stack (dmabuf IPC mode) and accepts
     our tensors; says nothing about xGMI rates (BASELINE configs[2])."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "AID_DIST_BACKEND")}
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")

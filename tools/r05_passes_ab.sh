@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of the 2-D Winograd transform passes (round 5): first version (AID_W2D_LEGACY=3) against the LDS-staged input pass / T-transform-first output pass.
+# (historical: AID_W2D_LEGACY existed only in the intermediate build that carried both versions of the passes; the first versions were removed after this A/B)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out
 for B in 4 1; do

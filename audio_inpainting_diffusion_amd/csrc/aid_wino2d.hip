@@ -728,7 +728,9 @@ extern "C" int aid_conv2d_wino2d_supported(int Cin, int Cout, int F, int T, int 
 //   K = Cout = 256 (levels 5, 6): 0.61-0.74 at batch 4 (the GEMM runs at 0.77-0.85 of the fp32 MFMA peak on 2.08x fewer products; the two transform
 //     passes move 9 x the activation at 4.4-7 TB/s), 0.55-0.58 at batch 1 (48 x more tiles than the fused kernel has to fill the chip with);
 //   K = 128: the GEMM sits at the HBM ridge (32 FLOP/B).  T <= 128 (level 4, the 128-channel step of level 5): 0.82-0.94 at batch 4, 0.58-0.63 at
-//     batch 1; T = 256 (level 3): 1.02 at batch 4, 0.87 at batch 1 -- taken only for launches of at most 2 x 65536 positions.
+//     batch 1; T = 256 (level 3): 1.02 at batch 4 per layer ALONE, 0.87 at batch 1 -- and +1 % END TO END at batch 8 (three alternating runs: 55.49 ->
+//     55.9 evaluations/s, profiles/r05_w2d_force_ab.txt; with the K = 128 levels altogether 53.6 -> 55.3, r05_w2d_k128_ab.txt): beside the other
+//     sub-batch stream the form with fewer MFMAs wins where the isolated A/B ties.  Taken up to T = 256.
 // Ragged row tiles (F / dil not a multiple of 4) pad the GEMM by up to 4/3: K = 256 still wins at 1.33 (0.84), K = 128 only up to 1.2.
 // A function of the launch shape, B included: equal launches (the same sub-batch size) take equal kernels.
 extern "C" int aid_conv2d_wino2d_wanted(int B, int Cin, int Cout, int F, int T, int dilF) {
@@ -737,7 +739,7 @@ extern "C" int aid_conv2d_wino2d_wanted(int B, int Cin, int Cout, int F, int T, 
     const double pad = (double)ge.J * 4.0 / (double)ge.R;
     if (Cin >= 256 && Cout >= 256) return pad <= 1.34 ? 1 : 0;
     if (Cin < 128 || Cout < 128 || pad > 1.21) return 0;
-    if (T <= 128) return 1;
+    if (T <= 256) return 1;
     return (int64_t)B * F * T <= 2 * 65536 ? 1 : 0;
 }
 extern "C" int64_t aid_conv2d_wino2d_positions(int B, int F, int T, int dilF) { return (dilF >= 1 && F % dilF == 0 && T % 4 == 0) ? w2d_geo(B, F, T, dilF).N : 0; }

@@ -492,7 +492,7 @@ class _Builder:
         if wpw2 is not None and 45 in self.net.wino_forms and _lib.lib().aid_conv2d_wino2d_supported(cin, cout, F, T, dil):
             # the non-fused 2-D form F(4,5) x F(4,3) (csrc/aid_wino2d.hip: 3.0 products per output) where the library predicts it faster than the fused
             # 1-D kernels (aid_conv2d_wino2d_wanted, a function of the launch shape); wino_forms = (45,): wherever it is supported (tests, A/B)
-            if tuple(self.net.wino_forms) == (45,) or _lib.lib().aid_conv2d_wino2d_wanted(self.B, cin, cout, F, T, dil):
+            if tuple(self.net.wino_forms) == (45,) or (min(cin, cout) >= self.net.w2d_min_channels and (T <= self.net.w2d_force_max_T or _lib.lib().aid_conv2d_wino2d_wanted(self.B, cin, cout, F, T, dil))):
                 return 45
         form = int(_lib.lib().aid_conv2d_wino_form(self.B, cin, cout, F, T, dil))
         if form == 8 and (wpw8 is None or 8 not in self.net.wino_forms):
@@ -1221,6 +1221,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
                                # where the library predicts it faster (aid_conv2d_wino2d_wanted), F(8,3) where the library prefers it (aid_conv2d_wino_form),
                                # F(4,3) otherwise; (4,) keeps every layer on the F(4,3) kernels, (45,) forces the 2-D form wherever it is supported
                                # (A/B measurements, tests; set before the first forward)
+    w2d_force_max_T = 0        # A/B: layers with T up to this take the 2-D form wherever it is SUPPORTED, whatever the library's per-layer prediction says (bench.py --w2d-force-max-t)
+    w2d_min_channels = 128     # A/B: 256 keeps the 2-D form off the K = 128 levels the library would give it (bench.py --w2d-min-channels)
     wgrad_wino = True          # training: F(4,3) form of the 5x3 weight gradients (aid_conv2d_wgrad wino=1)
     fuse_fin = True            # the last tile of a sample folds the conv epilogue's statistics / dot partials itself (aid_conv2d fin_mode): no aid_group_stats
                                # launch after such a conv and no coefficient kernel in aid_norm_bwd (A/B: bench.py --no-fin)

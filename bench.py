@@ -243,6 +243,8 @@ def main():
     ap.add_argument("--wino-forms", default="4,8,45", help="A/B: Winograd forms the 5x3 layers may use (default 4,8,45: the 2-D form F(4,5) x F(4,3) and F(8,3) where the library prefers them; 4,8: the fused 1-D kernels only; 4: F(4,3) everywhere)")
     ap.add_argument("--mfma-split", type=int, default=0, choices=[0, 6], help="LABELLED VARIANT (never the default): 6 = the 2-D Winograd form's GEMMs on three bf16 pieces per fp32 operand, "
                     "six bf16 MFMA products, fp32 accumulation (aid_wino2d_set_split); the JSON's dtype says so")
+    ap.add_argument("--w2d-min-channels", type=int, default=0, help="A/B: 256 keeps the 2-D Winograd form off the K = 128 levels (network.w2d_min_channels)")
+    ap.add_argument("--w2d-force-max-t", type=int, default=0, help="A/B: the 2-D Winograd form on every SUPPORTED layer with T up to this (network.w2d_force_max_T)")
     ap.add_argument("--split", default="", help="A/B: explicit sub-batch sizes, e.g. 5,3 (network.split_sizes; implies --streams = their count)")
     ap.add_argument("--conv-table", action="store_true", help="print per-shape conv kernel times (stderr)")
     a = ap.parse_args()
@@ -282,6 +284,10 @@ def main():
     net = Unet_CQT_oct_with_attention(args, dev)
     if a.mfma_split:
         assert _lib.lib().aid_wino2d_set_split(a.mfma_split) == 0
+    if a.w2d_min_channels:
+        net.w2d_min_channels = a.w2d_min_channels
+    if a.w2d_force_max_t:
+        net.w2d_force_max_T = a.w2d_force_max_t
     if a.no_epilogue_stats:
         net.epilogue_stats = False
     if a.no_fin:

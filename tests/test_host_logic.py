@@ -492,8 +492,8 @@ def test_winograd_form_choice_is_a_function_of_the_launch_shape():
 
 
 def test_two_dimensional_winograd_choice_is_a_function_of_the_launch_shape():
-    """aid_conv2d_wino2d_supported / _wanted / _positions (pure host functions): K = 256 levels always (padding up to 4/3), K = 128 levels with T <= 128 up to
-    1.2 padding, the T = 256 level only for launches of at most two samples, nothing below 128 channels; positions = B * ceil(F / (4 dil)) * dil * T / 4."""
+    """aid_conv2d_wino2d_supported / _wanted / _positions (pure host functions): K = 256 levels always (padding up to 4/3), K = 128 levels with T <= 256 up to
+    1.2 padding (longer rows only for launches of at most two samples), nothing below 128 channels; positions = B * ceil(F / (4 dil)) * dil * T / 4."""
     from audio_inpainting_diffusion_amd import _lib
     L = _lib.lib()
     for B in (1, 2, 4, 8):
@@ -502,7 +502,7 @@ def test_two_dimensional_winograd_choice_is_a_function_of_the_launch_shape():
         for d in (1, 2, 4, 8, 16, 32):
             assert L.aid_conv2d_wino2d_wanted(B, 128, 128, 320, 128, d) == 1                 # (d = 32: 10 rows per class -> 12, padding 1.2)
         assert L.aid_conv2d_wino2d_wanted(B, 128, 128, 384, 64, 64) == 0                    # 6 rows per class -> 8: 1.33 does not pay at K = 128
-        assert L.aid_conv2d_wino2d_wanted(B, 128, 128, 256, 256, 2) == (1 if B <= 2 else 0)
+        assert L.aid_conv2d_wino2d_wanted(B, 128, 128, 256, 256, 2) == 1 and L.aid_conv2d_wino2d_wanted(B, 128, 128, 128, 512, 2) == (1 if B <= 2 else 0)
         assert L.aid_conv2d_wino2d_wanted(B, 96, 96, 192, 512, 2) == 0 and L.aid_conv2d_wino2d_wanted(B, 64, 64, 64, 2048, 1) == 0
         assert L.aid_conv2d_wino2d_wanted(B, 128, 128, 320, 128, 4) == L.aid_conv2d_wino2d_wanted(B, 128, 128, 320, 128, 4)
         assert L.aid_conv2d_wino2d_positions(B, 448, 32, 64) == B * 2 * 64 * 8 and L.aid_conv2d_wino2d_positions(B, 384, 64, 1) == B * 96 * 16

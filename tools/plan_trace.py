@@ -65,21 +65,23 @@ for nm in ("fwd", "bwd"):
         if k is not None:
             t = type(k).__name__
             if t == "NormBwdParams": extra = ("wino " if k.wout.p else "") + ("acc" if k.accumulate else "")
-            if t == "ScaleActParams": extra = ("act " if k.act else "") + ("wino" if k.wino else "")
+            if t == "ScaleActParams": extra = ("act " if k.act else "") + ("wino2d" if k.wino == 3 else ("wino" if k.wino else ""))
             if t == "Add2Params": extra = "2in" if k.v.p else "1in"
             if t == "ResampleParams": extra = "up%d adj%d acc%d" % (k.up, k.adjoint, k.accumulate)
             if t == "GroupStatsParams": extra = "ws_n%d" % k.ws_n
         key = name.replace("aid_", "")
         if name in CONV_OPS:
             q = k
-            if kn.startswith("conv53_wino"): key = "conv5x3 winograd"
+            if kn.startswith("conv53_wino"): key = "conv5x3 winograd (fused 1-D kernels)"
+            elif kn.startswith("w2d_gemm"): key = "conv5x3 2-D winograd: batched GEMM"
+            elif kn.startswith("w2d_output"): key = "conv5x3 2-D winograd: output pass"
             elif q.KH == 5: key = "conv5x3 few-channel (%s)" % kn.split("(")[0]
             elif q.F == 1: key = "conv1x1 qk GEMM"
             elif min(q.Cin, q.Cout) <= 8: key = "conv1x1 few-channel (2/8 <-> C)"
             elif q.act or q.epi: key = "conv1x1 CxC step (act/epi)"
             else: key = "conv1x1 proj/res (C<->C')"
         elif extra and name in ("aid_norm_bwd", "aid_scale_act"):
-            key += " " + ("wino" if "wino" in extra else "plain")
+            key += " " + ("2-D winograd input pass" if "wino2d" in extra else ("wino" if "wino" in extra else "plain"))
         r = cat.setdefault(key, [0, 0.0]); r[0] += 1; r[1] += us
         rows.append((nm + str(lane), name, descr if name in CONV_OPS else sh + " " + extra, kn, us))
         lane_us[lane] = lane_us.get(lane, 0.0) + us

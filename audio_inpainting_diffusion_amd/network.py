@@ -1209,7 +1209,10 @@ class Unet_CQT_oct_with_attention(nn.Module):
     # uploads, hipFuncSetAttribute), the second captures the same call sequence on torch's capture stream with static
     # input / output buffers, later calls copy the inputs in and replay.  Sub-batch streams (B >= 4) stay eager.
     # ---------------------------------------------------------------------------------------------------
-    use_graphs = True
+    use_graphs = False         # OFF by default since round 5: with three launches per 2-D Winograd layer, most of them long, eager launches on the two lanes beat the
+                               # replay at every small batch -- batch 1 / 2 / 3: 36.9 / 44.9 / 47.9 with replay, 37.5 / 45.5 / 48.5 without (two alternating runs each,
+                               # profiles/r05_graphs_ab.txt; round 3, when an evaluation was ~1900 short launches: +8 %).  `net.use_graphs = True` (bench.py --graphs)
+                               # turns it back on, e.g. for hosts that cannot issue ~30 000 launches per second per rank.
     fuse_dot_1x1 = True        # reverse sweep: <gd, x> partials of the 1x1 steps from the dgrad conv's epilogue instead of an aid_group_dot pass
     merge_pair_dgrad = True    # reverse sweep: input gradients of a block's proj_in and res_conv as ONE 1x1 conv over a K axis in two tensors
     plan_lanes = True          # tag the init blocks / pyramid / out blocks as lane 1 of the launch plans (plan.py)

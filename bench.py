@@ -234,7 +234,8 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="sub-batch HIP streams per evaluation (default: automatic, network._n_split; 1 = plain single-stream schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roof-steps", type=int, default=3, help="Heun steps of the single-stream roofline pass after the timed region (>= 1; 3 by default)")
-    ap.add_argument("--no-graphs", action="store_true", help="A/B: eager launches instead of HIP-graph replay at small batches")
+    ap.add_argument("--no-graphs", action="store_true", help="(the default since round 5) eager launches at small batches")
+    ap.add_argument("--graphs", action="store_true", help="A/B: HIP-graph replay of the evaluation at small batches (network.use_graphs; the default until round 4)")
     ap.add_argument("--no-pair-merge", action="store_true", help="A/B: separate input-gradient convs for proj_in and res_conv")
     ap.add_argument("--no-lanes", action="store_true", help="A/B: single-stream launch plans at small batches (plan.py lanes off)")
     ap.add_argument("--no-fused-norm-bwd", action="store_true", help="A/B: separate gate / Winograd-transform pre-pass before every dgrad conv")
@@ -302,6 +303,8 @@ def main():
         a.streams = net.split_streams = len(net.split_sizes)
     if a.no_graphs:
         net.use_graphs = False
+    if a.graphs:
+        net.use_graphs = True
     if a.no_pair_merge:
         net.merge_pair_dgrad = False
     if a.no_lanes:

@@ -32,7 +32,7 @@ small)
   { for b in 1 2 3 4; do run --batch $b --steps 4 --warmup 2; done
     for b in 1 2 4; do run --batch $b --steps 4 --warmup 2 --wino-forms 4,8; done
     run --batch 1 --steps 4 --warmup 2 --no-lanes
-    run --batch 1 --steps 4 --warmup 2 --no-graphs
+    run --batch 1 --steps 4 --warmup 2 --graphs
     run --batch 2 --steps 4 --warmup 2 --no-lanes
   } > $O/r05_small_batch.jsonl ;;
 prof)

@@ -968,7 +968,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
         else:
             bd.add2(x, xin, yout, RSQRT2, RSQRT2)
 
-    def _build_state(self, B: int, train: bool = False, lanes: bool = True):
+    def _build_state(self, B: int, train: bool = False, lanes: bool = True, sub: bool = False):
         self.prepare()
         dev = next(self.parameters()).device
         n, bpo, Ns = self.num_octs, self.bins_per_oct, self.Ns
@@ -987,7 +987,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
                 raise NotImplementedError(f"{nm}.kernel differs from the reference's cubic FIR (unet...py:514-515), which aid_resample hard-wires")
         st = dict(B=B)
         bd = _Builder(self, B, dev, train=train)
-        bd.whole_batch = bool(lanes)                     # (sub-batch states are built with lanes=False, see _state)
+        bd.whole_batch = bool(lanes) and not sub         # (sub-batch states are built with lanes=False -- or sub=True in the lanes_in_sub_batches A/B -- see _state)
         st["sigma"] = bd.buf(B)
         st["emb"] = bd.buf(B, self.emb_dim)
         st["mod"] = bd.buf(B, self._mod_total)
@@ -1096,7 +1096,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
         if st["lanes"] > 1:                              # ONE side stream for every two-lane plan of this network (they never run concurrently)
             if getattr(self, "_lane_stream", None) is None:
                 self._lane_stream = torch.cuda.Stream(device=dev)
-            bd.plan.side_stream = self._lane_stream
+            bd.plan.side_stream = torch.cuda.Stream(device=dev) if sub else self._lane_stream      # (concurrent sub-batch plans: one side stream each)
         st["plan_body"] = bd.plan
         st["nbytes"] = bd.nbytes
         st["flops"] = bd.plan.flops
@@ -1119,7 +1119,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
         self._states[group] = grp                                       # (re)insert as most recently used
         st = grp.get((B, slot))
         if st is None:
-            st = grp[(B, slot)] = self._build_state(B, train=(group[1] == "train"), lanes=(group[1] == 1))   # (sub-batches already share the GPU)
+            st = grp[(B, slot)] = self._build_state(B, train=(group[1] == "train"), lanes=(group[1] == 1 or self.lanes_in_sub_batches), sub=(group[1] != 1 and group[1] != "train"))   # (sub-batches already share the GPU)
         return st
 
     # ---------------------------------------------------------------------------------------------------
@@ -1216,6 +1216,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
     fuse_dot_1x1 = True        # reverse sweep: <gd, x> partials of the 1x1 steps from the dgrad conv's epilogue instead of an aid_group_dot pass
     merge_pair_dgrad = True    # reverse sweep: input gradients of a block's proj_in and res_conv as ONE 1x1 conv over a K axis in two tensors
     plan_lanes = True          # tag the init blocks / pyramid / out blocks as lane 1 of the launch plans (plan.py)
+    lanes_in_sub_batches = False   # A/B: two-lane plans inside sub-batch streams too (bench.py --lanes-in-sub-batches --lanes-max-batch 4): 56.4 -> 55.8 at batch 8
+                                   # (profiles/r05_lanes_ab.txt); one unsplit batch of 8 on two lanes: 54.4
     lanes_max_batch = 3        # ... and run the two lanes on two streams for whole batches up to this size.  Larger batches fill the GPU and run as
                                # sub-batch streams; a second lane INSIDE each sub-batch stream measured -19 % at batch 8 (six streams competing)
     param_grads_in_train_mode = False   # True: a train()-mode call whose INPUT requires grad also yields parameter gradients (TrainFn) instead of

@@ -246,6 +246,8 @@ def main():
                     "six bf16 MFMA products, fp32 accumulation (aid_wino2d_set_split); the JSON's dtype says so")
     ap.add_argument("--w2d-min-channels", type=int, default=0, help="A/B: 256 keeps the 2-D Winograd form off the K = 128 levels (network.w2d_min_channels)")
     ap.add_argument("--w2d-force-max-t", type=int, default=0, help="A/B: the 2-D Winograd form on every SUPPORTED layer with T up to this (network.w2d_force_max_T)")
+    ap.add_argument("--lanes-max-batch", type=int, default=-1, help="A/B: run the two lanes of the launch plans on two streams for (sub-)batches up to this size (network.lanes_max_batch; default 3)")
+    ap.add_argument("--lanes-in-sub-batches", action="store_true", help="A/B: two-lane launch plans inside the sub-batch streams too (network.lanes_in_sub_batches)")
     ap.add_argument("--split", default="", help="A/B: explicit sub-batch sizes, e.g. 5,3 (network.split_sizes; implies --streams = their count)")
     ap.add_argument("--conv-table", action="store_true", help="print per-shape conv kernel times (stderr)")
     a = ap.parse_args()
@@ -309,6 +311,10 @@ def main():
         net.merge_pair_dgrad = False
     if a.no_lanes:
         net.lanes_max_batch = 0
+    if a.lanes_max_batch >= 0:
+        net.lanes_max_batch = a.lanes_max_batch
+    if a.lanes_in_sub_batches:
+        net.lanes_in_sub_batches = True
     if rank == 0:
         seeded_init_(net, 0)                       # reference-scale gates (1e-7), like a fresh reference network
     D.barrier()

@@ -507,7 +507,7 @@ def test_guided_whole_trajectory_vs_reference_fixture():
     errs = [rel_l2(res[6][i].cpu(), z["xt2"][i]) for i in range(T)]
     errs_in = [rel_l2(res[5][i].cpu(), z["xt"][i]) for i in range(T)]
     print("HIP free-running trajectory vs the reference, state after every step:", " ".join(f"{e:.1e}" for e in errs), "| out", f"{rel_l2(res[0].cpu(), z['out']):.1e}")
-    assert max(errs) < 2e-3 and max(errs_in) < 2e-3 and rel_l2(res[0].cpu(), z["out"]) < 2e-3      # (19 chained evaluations of an O(1)-gate random network amplify rounding)
+    assert max(errs) < 2e-5 and max(errs_in) < 2e-5 and rel_l2(res[0].cpu(), z["out"]) < 2e-5      # (measured 7e-8 growing to 4e-7 over the ten steps)
     # the same run without the debug buffers returns the same output
     smp2 = Sampler(model=net, diff_params=EDM(args), args=args)
     torch.manual_seed(int(z["noise_seed"]))

@@ -205,8 +205,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WPC * WGM * WGN + 3) / 4) void w2d
 // ---- LABELLED VARIANT (never the default, never the headline): the same batched GEMM with both fp32 operands SPLIT into three bf16
 // pieces each (truncation: 8 + 8 + 8 significand bits, x = p0 + p1 + p2 EXACTLY) and the six largest cross products on the bf16 matrix pipe
 // (v_mfma_f32_32x32x16_bf16: a bf16 x bf16 product is exact in fp32, accumulation in fp32) -- p2 q0 + p0 q2 + p1 q1 + p1 q0 + p0 q1 + p0 q0, smallest first;
-// the dropped terms are below 2^-32 of the product.  Error study BEFORE the kernel (tools/bf16split_error.py, profiles/r05_bf16split_error.txt): 1.8e-6
-// per layer at K = 256 against 4.3e-6 of the fp32-MFMA form (the fp32 MFMA rounds every product; this form does not); the 3-product split is 6e-5: not built.
+// the dropped terms p1 q2 + p2 q1 (+ p2 q2) are NOT negligible per product: each is ~2^-24 of it (measured, tools/bf16split_error.py --per-product,
+// profiles/r06_bf16split_per_product.txt: max 2^-21.3, median 2^-25.2 -- up to 6x one fp32 rounding; only p2 q2 is below 2^-32).  Error study BEFORE the kernel
+// (tools/bf16split_error.py, profiles/r05_bf16split_error.txt): 1.8e-6 per layer at K = 256 against 4.3e-6 of the fp32-MFMA form -- that comes from the bf16 MFMA
+// accumulating 16 exact products per instruction (fewer fp32 roundings of the running sum), not from exact products; the 3-product split is 6e-5: not built.
 // 6 MFMAs of 32 cycles per 16 k against 8 of 64: 0.375x the matrix-pipe time; the split is VALU work on the fragments (4 ops + 1.5 packs per value).
 // Same LDS images, same direct-to-LDS staging, one k-step of 16 per chunk: lane half h holds k = 8 h .. 8 h + 7 of BOTH fragments.
 typedef __bf16 w2d_bf16x8 __attribute__((ext_vector_type(8)));

@@ -66,6 +66,8 @@ class OracleSampler:
         self.filter_hpf = filter_out_cqt_DC_Nyq
         self.audio_len = audio_len
         self.trace = None
+        self.stop_after = None                          # tests: leave the loop after this many steps (the state is returned as it is)
+        self.states = None                              # tests: set to [] to record the state after every step
         self.rid = None                                 # set by predict_*(rid=True): per-step debug buffers (:185-191, :217-226, :255)
         self.degradation = lambda x: self.mask * x                                          # apply_mask (:264-269)
         self.project = lambda x: self.smask * self.y + (1 - self.smask) * x                 # (:343)
@@ -192,6 +194,10 @@ class OracleSampler:
                 x = x + h * d
             if rid:
                 R["xt2"][i] = x
+            if self.states is not None:
+                self.states.append(x.detach().clone())
+            if self.stop_after is not None and i + 1 >= self.stop_after:
+                return x.detach()
         if self.data_consistency_end and self.y is not None:                                # (:252)
             x = self.project(x)
         if rid:                                                                             # (:260)

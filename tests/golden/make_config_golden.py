@@ -62,5 +62,56 @@ def main():
     print("wrote", path, len(d), "arrays")
 
 
+TRAJ_ITEM, TRAJ_STEPS, TRAJ_SEED0, TRAJ_FULL = 5, 8, 100, (3, 6)
+
+
+def main_traj():
+    """--traj: BASELINE.json configs[1], ONE item (index TRAJ_ITEM of the batch of 8, the second sub-batch stream), the first TRAJ_STEPS Heun
+    steps (2 * TRAJ_STEPS guided evaluations) of the FREE-RUNNING oracle sampler from the real prior draw with the churn noise of the tester's
+    schedule (per-item generator seeded TRAJ_SEED0 + item: prior, then one draw per churned step, edm_sampler_inpainting.py:201-251) ->
+    tests/golden/config1_traj.npz: after every step the state x_{i+1} (8 projections + squared norm + every 97th sample), the projected x_hat of
+    both evaluations of the step, and the FULL fp32 state entering steps TRAJ_FULL (restart points of the teacher-forced GPU test: states on a
+    chaotic trajectory cannot be rebuilt from seeds).  ~12-20 min on 8 cores."""
+    from audio_inpainting_diffusion_amd.init import seeded_state_dict
+    from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
+    from oracle.edm import OracleEDM
+    from oracle.nsgt_cqt import OracleCQT
+    from oracle.sampler import OracleSampler
+    from oracle.unet import OracleUnet
+    c = build("config1")
+    args, L, b = c["args"], c["L"], TRAJ_ITEM
+    n, bpo, fs = args.network.cqt.num_octs, args.network.cqt.bins_per_oct, args.exp.sample_rate
+    shapes = [(k, tuple(v.shape)) for k, v in Unet_CQT_oct_with_attention(args, torch.device("meta")).state_dict().items()]
+    sd = seeded_state_dict(shapes, c["net_seed"], gate_scale=10.0, affine_scale=10.0)
+    net = OracleUnet(n, bpo, OracleCQT(n, bpo, "oct", ("kaiser", 1), fs, L)).load_state_dict(sd)
+    hann = int(args.tester.data_consistency.hann_size)
+    osmp = OracleSampler(net, OracleEDM(), T=int(args.tester.T), xi=0.25, hann_size=hann, audio_len=L)
+    osmp.stop_after, osmp.states = TRAJ_STEPS, []
+    t0 = time.time()
+    orig = osmp.get_score
+
+    def timed(x, t_i):
+        r = orig(x, t_i)
+        print(f"  evaluation {len(osmp.trace)} (t = {float(t_i):.4f}) done   [{time.time() - t0:.0f} s]", flush=True)
+        return r
+    osmp.get_score = timed
+    mrow = c["mask"][b:b + 1] if c["mask"].shape[0] > 1 else c["mask"]
+    osmp.predict_inpainting(c["y"][b:b + 1], mrow, seeds=[TRAJ_SEED0 + b], record=True)
+    assert len(osmp.states) == TRAJ_STEPS and len(osmp.trace) == 2 * TRAJ_STEPS
+    d = {"item": np.array(b), "steps": np.array(TRAJ_STEPS), "seed": np.array(TRAJ_SEED0 + b)}
+    for i, x in enumerate(osmp.states):
+        d[f"x{i + 1}.proj"], d[f"x{i + 1}.s"] = summarise(x[0], 300 + i)
+        if i + 1 in TRAJ_FULL:
+            d[f"x{i + 1}.full"] = x[0].numpy().astype(np.float32)
+    for k, xh in enumerate(osmp.trace):
+        d[f"xhat{k}.proj"], d[f"xhat{k}.s"] = summarise(xh[0], 400 + k)
+    path = os.path.join(HERE, "config1_traj.npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if "--traj" in sys.argv:
+        main_traj()
+    else:
+        main()

@@ -32,6 +32,29 @@ def _attr(obj, *names):
     return None
 
 
+PINNED_VERSION = "0.0.8"     # the version the reference's own notebook output records: /root/reference/notebooks/demo_inpainting_spectrogram.ipynb
+                             # cell 4: "Downloading cqt-nsgt-pytorch-0.0.8.tar.gz (12 kB)" (wheel built there: cqt_nsgt_pytorch-0.0.8-py3-none-any.whl)
+
+
+def _package_version(mod):
+    try:
+        from importlib.metadata import version
+        return version("cqt_nsgt_pytorch")
+    except Exception:
+        return str(getattr(mod, "__version__", "unknown"))
+
+
+def _package_sha256(mod):
+    """sha256 over the package's .py files in sorted order (identifies the exact source the dump was made with)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(mod.__file__), "**", "*.py"), recursive=True)):
+        h.update(os.path.relpath(f, os.path.dirname(mod.__file__)).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _arr(v):
     if v is None:
         return np.zeros(0)
@@ -46,6 +69,13 @@ def main():
     except ImportError:
         sys.exit("cqt_nsgt_pytorch is not installed here: run this script on a machine that has it (pip install cqt_nsgt_pytorch)")
     import cqt_nsgt_pytorch
+    version = _package_version(cqt_nsgt_pytorch)
+    if version != PINNED_VERSION:
+        msg = (f"cqt_nsgt_pytorch {version} is installed, the reference author ran {PINNED_VERSION} "
+               f"(notebooks/demo_inpainting_spectrogram.ipynb cell 4 output): pip install cqt_nsgt_pytorch=={PINNED_VERSION}")
+        if "--any-version" not in sys.argv:
+            sys.exit(msg + "   (or pass --any-version: the dump then records the version it was made with and the conformance test says so)")
+        print("WARNING:", msg)
     for tag, numocts, binsoct, fs, L in CONFIGS:
         cqt = CQT_nsgt(numocts, binsoct, mode="oct", window=("kaiser", 1), fs=fs, audio_len=L, dtype=torch.float32, device="cpu")
         rng = np.random.Generator(np.random.PCG64(1234))
@@ -58,7 +88,7 @@ def main():
                                 torch.from_numpy(rng.standard_normal(tuple(c.shape)).astype(np.float32))) for c in C]
             yr = cqt.bwd(Cr)
         d = {"cfg": np.array([numocts, binsoct, fs, L], dtype=np.float64), "seed": np.array(1234),
-             "package_version": np.array(str(getattr(cqt_nsgt_pytorch, "__version__", "unknown"))),
+             "package_version": np.array(version), "package_file_sha256": np.array(_package_sha256(cqt_nsgt_pytorch)),
              "n_oct": np.array(len(C)), "roundtrip": _arr(rt), "hpf": _arr(hp), "bwd_random": _arr(yr)}
         for o, c in enumerate(C):
             d[f"fwd_{o}"] = _arr(c).astype(np.complex64)

@@ -20,6 +20,7 @@ import torch
 from conftest import GOLDEN, rel_l2
 
 FIXTURES = sorted(glob.glob(os.path.join(GOLDEN, "cqt_ref_*.npz")))
+PINNED_CQT_VERSION = "0.0.8"
 NO_FIXTURE = ("no tests/golden/cqt_ref_*.npz: CQT parity vs cqt_nsgt_pytorch is UNPINNED -- run tests/golden/make_cqt_golden.py "
               "on a machine that has the package")
 
@@ -141,6 +142,11 @@ def test_oracle_reproduces_the_real_package(path):
     from oracle.nsgt_cqt import OracleCQT
     from audio_inpainting_diffusion_amd.cqt import RULES_DEFAULT, RULE_PRESETS
     z = np.load(path)
+    # the version the reference author ran is on record (notebooks/demo_inpainting_spectrogram.ipynb cell 4 output: cqt-nsgt-pytorch-0.0.8.tar.gz):
+    # a dump made with another version pins "some version", not "the version" -- refuse it
+    assert "package_version" in z.files and str(z["package_version"]) == PINNED_CQT_VERSION, \
+        f"{os.path.basename(path)} was dumped from cqt_nsgt_pytorch {z['package_version'] if 'package_version' in z.files else '?'}; " \
+        f"the reference's notebook records {PINNED_CQT_VERSION}: pip install cqt_nsgt_pytorch=={PINNED_CQT_VERSION} and re-run tests/golden/make_cqt_golden.py"
     match, report = _matching_preset(z)
     assert match, f"no rule preset reproduces the frame of cqt_nsgt_pytorch for {os.path.basename(path)}: {report}; extend CQTRules"
     assert RULE_PRESETS[match[0]] == RULES_DEFAULT or any(RULE_PRESETS[m] == RULES_DEFAULT for m in match), \

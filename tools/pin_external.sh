@@ -3,7 +3,11 @@
 #   * cqt_nsgt_pytorch  (the reference's constant-Q transform; call sites networks/unet_cqt_oct_with_projattention_adaLN_2.py:620,743,841,
 #                        testing/edm_sampler_inpainting.py:63,123)
 #   * torchaudio        (torchaudio.functional.resample behind utils/training_utils.py:140-212 resample_batch)
-# Run it from the repository root on ANY machine where `pip install cqt_nsgt_pytorch torchaudio` works (CPU is enough):
+# The VERSION the reference author ran is on record: /root/reference/notebooks/demo_inpainting_spectrogram.ipynb, cell 4 output,
+#   "Downloading cqt-nsgt-pytorch-0.0.8.tar.gz (12 kB)" next to torch 1.13.0+cu116 (so torchaudio 0.13.0 is the matching resampler).
+# SURVEY.md section 8c calls the package "un-pinned" -- by that evidence it is pinned to 0.0.8; make_cqt_golden.py refuses any other
+# version (unless --any-version) and records version + source sha256 in the dump, test_cqt_conformance.py asserts 0.0.8.
+# Run it from the repository root on ANY machine where `pip install cqt_nsgt_pytorch==0.0.8 torchaudio` works (CPU is enough):
 #
 #     tools/pin_external.sh
 #
@@ -18,7 +22,7 @@
 set -u
 cd "$(dirname "$0")/.."
 rc=0
-python tests/golden/make_cqt_golden.py || { echo "pin_external: cqt_nsgt_pytorch is not importable here (pip install cqt_nsgt_pytorch)"; rc=1; }
+python tests/golden/make_cqt_golden.py || { echo "pin_external: cqt_nsgt_pytorch is not importable here (pip install cqt_nsgt_pytorch==0.0.8)"; rc=1; }
 python tests/golden/make_resample_golden.py || { echo "pin_external: torchaudio is not importable here (pip install torchaudio)"; rc=1; }
 python -m pytest tests/test_cqt_conformance.py tests/test_resample_conformance.py -q -m "not gpu" -rs || rc=1
 python - <<'PY'

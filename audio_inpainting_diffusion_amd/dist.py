@@ -42,11 +42,56 @@ def init_distributed(backend: str = None) -> Tuple[int, int, int]:
                 raise RuntimeError(f"RCCL needs one GPU per rank ({torch.cuda.device_count()} visible for "
                                    f"{world} ranks); set AID_DIST_BACKEND=gloo for a functional shared-GPU run")
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            if backend == "nccl":
+                _rccl_first_contact(local)
+        except Exception as e:
+            # never a silent switch to another backend: a node that has one GPU per rank and cannot bring RCCL up is a broken node, and a gloo
+            # number from it would be read as an xGMI number
+            raise RuntimeError(f"[aid dist] rank {rank}/{world} (local {local}): backend '{backend}' failed to initialise "
+                               f"({type(e).__name__}: {e}); {torch.cuda.device_count() if torch.cuda.is_available() else 0} GPUs visible, "
+                               f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}, rendezvous "
+                               f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}.  NOT falling back to gloo: set AID_DIST_BACKEND=gloo "
+                               f"explicitly for a functional (host-staged) run") from e
         dev = f"cuda:{local % max(1, torch.cuda.device_count())}" if torch.cuda.is_available() else "cpu"
         print(f"[aid dist] rank {rank}/{world} (local {local}): backend {dist.get_backend()}, device {dev}, "
               f"rendezvous {os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']}", file=sys.stderr, flush=True)
     return rank, local, world
+
+
+def _rccl_first_contact(local: int) -> None:
+    """RCCL builds its communicator lazily: make the FIRST collective happen here (one 4-byte all-reduce on the rank's device + synchronize) so that a
+    broken xGMI / IPC setup fails at start-up with this rank's name on it, not somewhere inside the weight broadcast."""
+    t = torch.ones(1, device=torch.device("cuda", local))
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    if int(t.item()) != dist.get_world_size():
+        raise RuntimeError(f"first RCCL all-reduce returned {float(t.item())} for world size {dist.get_world_size()}")
+
+
+def placement_problems(ranks: List[dict], shared: bool, shared_requested: bool, visible_gpus: int) -> dict:
+    """Sanity of a finished multi-rank run from its per-rank reports (rank_report): {"errors": [...], "warnings": [...]}.  Pure function.
+    A physical GPU is identified by (host, PCI address) -- local device indices repeat across hosts -- and compared per host:
+    two ranks of one host on one GPU is an error when that host had a GPU for each of them and nobody asked for sharing (AID_SHARED_GPU);
+    a requested shared-GPU functional run on a box that could have given every rank its own GPU is a warning, not an abort."""
+    out = {"errors": [], "warnings": []}
+    if len(ranks) < 2:
+        return out
+    by_host: dict = {}
+    for r in ranks:
+        by_host.setdefault(r.get("host"), []).append(r)
+    for host, rs in by_host.items():
+        ids = [(r.get("pci") or r.get("gpu")) for r in rs]
+        dup = len(set(ids)) < len(rs)
+        enough = len(rs) <= visible_gpus
+        if shared and enough:
+            (out["warnings"] if shared_requested else out["errors"]).append(
+                f"host {host}: ranks share GPUs although {visible_gpus} are visible for {len(rs)} ranks"
+                + (" (AID_SHARED_GPU set: functional run)" if shared_requested else " (AID_DIST_BACKEND=gloo left set?)"))
+        elif dup and enough and not shared:
+            out["errors"].append(f"host {host}: two ranks report the same GPU: %r" % [(r["rank"], r.get("gpu"), r.get("pci")) for r in rs])
+    return out
 
 
 def _cpulist(text: str) -> List[int]:

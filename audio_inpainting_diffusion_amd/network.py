@@ -1135,6 +1135,38 @@ class Unet_CQT_oct_with_attention(nn.Module):
                                # kernel two sub-batches of four beat three of 3 / 3 / 2 -- 46.8 vs 44.9 evaluations/s at batch 8, profiles/r04_bench_after_form_model.txt;
                                # with F(4,3) alone it was 43.5 either way.)
 
+    cu_partition = 0           # EXPERIMENT (round 6, VERDICT r5 next-1a; bench.py --cu-partition N): > 0 = spatial partition of the chip for the sub-batch
+                               # streams -- inside every sub-batch the launch plans run on TWO CU-masked streams (streams.py), lane 0 = the MFMA-bound kernels
+                               # (5x3 / 1x1 convs above the fp32 ridge, the 2-D form's GEMM, attention) on 256 - N CUs, lane 1 = the HBM-bound passes on the
+                               # last N / 8 CUs of every XCD; the cross-lane dependencies are the plan's derived ones (plan.py).  0 = free-running streams.
+    cu_partition_ridge = 30.0  # FLOP per algorithmic byte above which a conv launch counts as MFMA-bound (fp32 ridge ~ 20-26 FLOP/B)
+
+    def _type_lane(self, op) -> int:
+        if op.name in ("aid_conv2d_wino2d_gemm", "aid_time_attention", "aid_time_attention_bwd"):
+            return 0
+        if op.name == "aid_conv2d" and op.flops > 0 and op.nbytes > 0 and op.flops / op.nbytes >= self.cu_partition_ridge:
+            return 0
+        return 1
+
+    def _partition_streams(self, n: int):
+        """[(MFMA stream, pass stream)] per sub-batch, CU-masked (created once per partition size)"""
+        key = (int(self.cu_partition), n)
+        if getattr(self, "_part_key", None) != key:
+            from .streams import cu_masked_stream, partition_masks
+            mw, pw = partition_masks(int(self.cu_partition))
+            self._part_streams = [(cu_masked_stream(mw), cu_masked_stream(pw)) for _ in range(n)]
+            self._part_key = key
+        return self._part_streams
+
+    def _retag_by_type(self, plan, side):
+        """lanes of a launch plan by kernel type (see cu_partition); dependencies are re-derived by plan.schedule()"""
+        if getattr(plan, "_typed", False) is False:
+            for op in plan.ops:
+                op.lane = self._type_lane(op)
+            plan._sched = None
+            plan._typed = True
+        plan.lanes, plan.side_stream = 2, side
+
     def _n_split(self, B: int) -> int:
         n = self.split_streams
         if n is None:
@@ -1150,6 +1182,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
             bounds = [0]
             for k in self.split_sizes:
                 bounds.append(bounds[-1] + int(k))
+        if self.cu_partition:
+            return n, bounds, [m for m, _ in self._partition_streams(n)]
         if getattr(self, "_side_streams", None) is None or len(self._side_streams) < n:
             # (equal priorities: raising one or two of the three sub-batch streams measured 43.7 -> 41.6 ... 42.7 evaluations/s)
             self._side_streams = [torch.cuda.Stream() for _ in range(n)]
@@ -1173,6 +1207,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
         B = st["B"]
         st["sigma"].copy_(sigma.reshape(-1).to(torch.float32).expand(B) if sigma.numel() == 1 else sigma.reshape(B).to(torch.float32))
         st["plan_mod"].run()
+        if self.cu_partition and st.get("part_slot") is not None:
+            self._retag_by_type(st["plan_body"], self._part_streams[st["part_slot"]][1])
         st["plan_body"].run()
 
     def forward(self, inputs: torch.Tensor, sigma: torch.Tensor) -> torch.Tensor:
@@ -1348,8 +1384,9 @@ class Unet_CQT_oct_with_attention(nn.Module):
             lo, hi = bounds[i], bounds[i + 1]
             streams[i].wait_stream(cur)
             with torch.cuda.stream(streams[i]):
-                self._denoise_one(x[lo:hi], cnoise[lo:hi], cin[lo:hi], cskip[lo:hi], cout[lo:hi], hpf,
-                                  self._state(hi - lo, i, (B, n)), out=out[lo:hi])
+                sti = self._state(hi - lo, i, (B, n))
+                sti["part_slot"] = i if self.cu_partition else None
+                self._denoise_one(x[lo:hi], cnoise[lo:hi], cin[lo:hi], cskip[lo:hi], cout[lo:hi], hpf, sti, out=out[lo:hi])
         for st_ in streams:
             cur.wait_stream(st_)
         return out
@@ -1380,6 +1417,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
         """gYsum[B,Lh] complex: gradient w.r.t. the synthesis band-sum spectrum of the LAST forward of this batch
         size -> fills the gradients of the analysis octave tensors (st['gin'])."""
         plan = self._bwd_plan(st)
+        if self.cu_partition and st.get("part_slot") is not None:
+            self._retag_by_type(plan, self._part_streams[st["part_slot"]][1])
         for g in st["gzero"]:
             g.zero_()
         self.CQTransform.synthesis_adjoint(gYsum, st["gout"])
@@ -1434,8 +1473,10 @@ class Unet_CQT_oct_with_attention(nn.Module):
             lo, hi = bounds[i], bounds[i + 1]
             streams[i].wait_stream(cur)
             with torch.cuda.stream(streams[i]):
+                sti = self._state(hi - lo, i, (B, n))
+                sti["part_slot"] = i if self.cu_partition else None
                 self._denoise_guided_one(x[lo:hi], cnoise[lo:hi], cin[lo:hi], cskip[lo:hi], cout[lo:hi], hpf, y[lo:hi],
-                                         None if m is None else (m[lo:hi] if m.shape[0] > 1 else m), degradation, self._state(hi - lo, i, (B, n)),
+                                         None if m is None else (m[lo:hi] if m.shape[0] > 1 else m), degradation, sti,
                                          outs=(x_hat[lo:hi], grads[lo:hi], norm[lo:hi]), nk=nk)
         for st_ in streams:
             cur.wait_stream(st_)

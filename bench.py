@@ -249,6 +249,8 @@ def main():
     ap.add_argument("--lanes-max-batch", type=int, default=-1, help="A/B: run the two lanes of the launch plans on two streams for (sub-)batches up to this size (network.lanes_max_batch; default 3)")
     ap.add_argument("--lanes-in-sub-batches", action="store_true", help="A/B: two-lane launch plans inside the sub-batch streams too (network.lanes_in_sub_batches)")
     ap.add_argument("--split", default="", help="A/B: explicit sub-batch sizes, e.g. 5,3 (network.split_sizes; implies --streams = their count)")
+    ap.add_argument("--cu-partition", type=int, default=0, help="EXPERIMENT (A/B): spatial partition of the chip inside every sub-batch -- MFMA-bound kernels on 256 - N CUs, HBM-bound passes "
+                    "on the last N / 8 CUs of every XCD, on CU-masked streams (network.cu_partition, streams.py); 0 = free-running sub-batch streams (the product schedule)")
     ap.add_argument("--conv-table", action="store_true", help="print per-shape conv kernel times (stderr)")
     a = ap.parse_args()
 
@@ -291,6 +293,8 @@ def main():
         net.w2d_min_channels = a.w2d_min_channels
     if a.w2d_force_max_t:
         net.w2d_force_max_T = a.w2d_force_max_t
+    if a.cu_partition:
+        net.cu_partition = a.cu_partition
     if a.no_epilogue_stats:
         net.epilogue_stats = False
     if a.no_fin:
@@ -403,9 +407,11 @@ def main():
     ranks = D.gather_objects(D.rank_report(rank, local, wall_s=wall_rank, bcast_s=t_bcast, ms_per_step=1e3 * wall_rank / a.steps,
                                            single_stream_ms_per_step=1e3 * wall_serial, segments=[lo, hi]))
     if rank == 0:
-        if world > 1 and world <= torch.cuda.device_count():
-            assert not shared, "ranks share a GPU although the node has one per rank (AID_SHARED_GPU / AID_DIST_BACKEND left set?)"
-            assert len({r["gpu"] for r in ranks}) == world, "two ranks report the same GPU: %r" % [(r["rank"], r["gpu"]) for r in ranks]
+        problems = D.placement_problems(ranks, shared=bool(shared), shared_requested=bool(int(os.environ.get("AID_SHARED_GPU", "0"))),
+                                        visible_gpus=torch.cuda.device_count())
+        for msg in problems["warnings"]:
+            print("bench: WARNING: " + msg, file=sys.stderr)
+        assert not problems["errors"], "; ".join(problems["errors"])
         fams = family_table(timing)
         kerns = family_table(timing, by_kernel=True)
         dom_name = next(iter(kerns)) if kerns else None
@@ -430,7 +436,7 @@ def main():
                        "network": "unet_cqt_oct_with_attention %s, %.1f M params, random-init (seeded)" % ("44.1 kHz 8-octave" if a.workload == "musicnet44k" else "7-octave", sum(p.numel() for p in net.parameters()) / 1e6),
                        "parallelism": "segments sharded %d-way, one process per GPU, weights broadcast once in place (%.0f MB in %.3f s, %s), no collective in the loop"
                                       % (world, nbytes / 1e6, t_bcast, (torch.distributed.get_backend() if world > 1 else "single process")),
-                       "sub_batch_streams": n_split, "hip_graph_replay": graphs, "functional_shared_gpu": bool(shared),
+                       "sub_batch_streams": n_split, "cu_partition": a.cu_partition, "hip_graph_replay": graphs, "functional_shared_gpu": bool(shared),
                        "backend": (torch.distributed.get_backend() if world > 1 else "single process"), "rccl_version": D.rccl_version(),
                        "visible_gpus": torch.cuda.device_count()},
             "ranks": ranks,
@@ -491,7 +497,7 @@ def _traffic_fields(dom_name, dom):
 
 def _profile_traffic():
     """HBM bytes per launch of the conv kernels from the newest committed PMC passes of this command (profiles/), or null."""
-    for name in ("r05_conv_traffic.json", "r04_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json"):
+    for name in ("r06_conv_traffic.json", "r05_conv_traffic.json", "r04_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json"):
         tr = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tr):
             try:

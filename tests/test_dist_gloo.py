@@ -121,3 +121,65 @@ def test_rank_binding_on_a_faked_8_gpu_2_node_tree(tmp_path):
     rep = D.rank_report(0, 0, wall_s=1.23456789, bcast_s=0.5)
     assert rep["rank"] == 0 and rep["wall_s"] == 1.2346 and "binding_fallback" in rep and "cpu_threads" in rep
     assert D.gather_objects({"a": 1}) == [{"a": 1}]
+
+
+def test_eight_gpus_visible_and_rccl_init_raises_is_loud_not_gloo(monkeypatch):
+    """on a node that shows one GPU per rank, a failing RCCL bring-up must abort with a diagnostic -- never continue on gloo.
+    Both failure points: init_process_group itself, and the first collective (RCCL creates its communicator lazily)."""
+    import pytest
+    from audio_inpainting_diffusion_amd import dist as D
+    calls = []
+    monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("RANK", "3"); monkeypatch.setenv("LOCAL_RANK", "3"); monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    monkeypatch.delenv("AID_DIST_BACKEND", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: calls.append(("set_device", d)))
+    monkeypatch.setattr(dist, "is_initialized", lambda: False)
+
+    def init_raises(backend=None, **kw):
+        calls.append(("init", backend))
+        raise dist.DistBackendError("ncclUnhandledCudaError: hipIpcGetMemHandle: invalid argument")
+    monkeypatch.setattr(dist, "init_process_group", init_raises)
+    with pytest.raises(RuntimeError, match="NOT falling back to gloo") as ei:
+        D.init_distributed()
+    assert "rank 3/8" in str(ei.value) and "8 GPUs visible" in str(ei.value) and "hipIpcGetMemHandle" in str(ei.value)
+    assert calls == [("set_device", 3), ("init", "nccl")]            # one attempt, on RCCL, nothing after it
+
+    calls.clear()
+    monkeypatch.setattr(dist, "init_process_group", lambda backend=None, **kw: calls.append(("init", backend)))
+
+    def contact_raises(local):
+        calls.append(("first_contact", local))
+        raise RuntimeError("NCCL error: unhandled system error (xGMI link down)")
+    monkeypatch.setattr(D, "_rccl_first_contact", contact_raises)
+    with pytest.raises(RuntimeError, match="xGMI link down"):
+        D.init_distributed()
+    assert calls == [("set_device", 3), ("init", "nccl"), ("first_contact", 3)]
+
+    # fewer GPUs than ranks and no explicit backend: refused before any process group exists (launch_ranks sets AID_DIST_BACKEND=gloo itself)
+    calls.clear()
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(RuntimeError, match="one GPU per rank"):
+        D.init_distributed()
+    assert calls == []
+
+
+def test_placement_problems_keys_gpus_by_host_and_pci():
+    from audio_inpainting_diffusion_amd.dist import placement_problems
+    rep = lambda rank, host, gpu, pci: {"rank": rank, "host": host, "gpu": gpu, "pci": pci}
+    eight = [rep(r, "n0", r, "0000:%02x:00.0" % (5 + 16 * r)) for r in range(8)]
+    assert placement_problems(eight, False, False, 8) == {"errors": [], "warnings": []}
+    # two nodes x four ranks on 8-GPU hosts: local indices repeat across hosts -- legitimate (ADVICE r5)
+    two_nodes = [rep(r, "n%d" % (r // 4), r % 4, "0000:%02x:00.0" % (5 + 16 * (r % 4))) for r in range(8)]
+    assert placement_problems(two_nodes, False, False, 8) == {"errors": [], "warnings": []}
+    # two ranks of ONE host on one GPU while the host has a GPU each: error
+    bad = [dict(r) for r in eight]
+    bad[5]["gpu"], bad[5]["pci"] = bad[4]["gpu"], bad[4]["pci"]
+    assert placement_problems(bad, False, False, 8)["errors"]
+    # a deliberately shared functional run on a multi-GPU box: warning only; the same with nobody having asked for it: error
+    sh = [rep(r, "n0", 0, "0000:05:00.0") for r in range(2)]
+    assert placement_problems(sh, True, True, 8) == {"errors": [], "warnings": [placement_problems(sh, True, True, 8)["warnings"][0]]}
+    assert placement_problems(sh, True, False, 8)["errors"]
+    # a 1-GPU box running 8 functional ranks: nothing to complain about
+    assert placement_problems([rep(r, "n0", 0, "0000:05:00.0") for r in range(8)], True, True, 1) == {"errors": [], "warnings": []}
+    assert placement_problems(eight[:1], False, False, 8) == {"errors": [], "warnings": []}

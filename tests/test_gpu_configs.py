@@ -73,50 +73,63 @@ def test_config4_cfgB_batch4_guided_evaluation_vs_oracle_autograd():
     assert e1 < 1e-4 and e2 < 1e-4 and abs(float(nrm[b].cpu()) - float(norm)) < 1e-4 * float(norm)
 
 
-def test_config1_batch8_teacher_forced_heun_steps_vs_oracle():
-    """BASELINE.json configs[1] at FULL size and batch 8, guided branch: two Heun steps (four denoiser evaluations) of the
-    GPU sampler; every evaluation's projected x_hat is compared, teacher-forced (the oracle is fed the GPU trajectory's own
-    inputs), with the CPU oracle for one of the eight items at the first evaluation of each step (two different items).  Covers the sampler <-> network plumbing at the benchmarked
-    batch size (per-item guidance norms, schedule scalars, projection) that single-evaluation tests do not."""
-    from audio_inpainting_diffusion_amd.config import make_args
+def test_config1_batch8_eight_free_running_heun_steps_vs_oracle_fixture():
+    """SURVEY 8d parity gate (3) at the BENCHMARKED size: BASELINE.json configs[1] at full size and batch 8, guided branch, the
+    first EIGHT Heun steps (16 guided evaluations) of the real loop -- prior draw, churn noise of the tester's schedule, Heun corrections
+    (edm_sampler_inpainting.py:201-251) -- FREE-RUNNING on the GPU, item 5 (second sub-batch stream) against tests/golden/config1_traj.npz, which the
+    CPU oracle sampler wrote in the build container for that item alone (make_config_golden.py --traj; per-item generator seeded 100 + item):
+      * the state after every step and the projected x_hat of all 16 evaluations, free-running (errors chain through the trajectory): <= 1e-4;
+      * teacher-forced: entering steps 3 and 6 the item's state is REPLACED by the oracle's own fp32 state (stored in full: a chaotic trajectory cannot
+        be rebuilt from seeds), one Heun step is taken from it with the same churn draw, and both evaluations + the resulting state are compared.
+    Supersedes round 5's two-step test that ran the oracle ON the GPU box (65 s of host time for two evaluations)."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from config_cases import build, compare
     from audio_inpainting_diffusion_amd.edm import EDM
-    from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
-    from audio_inpainting_diffusion_amd.masks import mask_from_args
+    from audio_inpainting_diffusion_amd.init import seeded_init_
     from audio_inpainting_diffusion_amd.network import Unet_CQT_oct_with_attention
     from audio_inpainting_diffusion_amd.sampler import Sampler
-    from oracle.edm import OracleEDM
-    from oracle.nsgt_cqt import OracleCQT
-    from oracle.sampler import OracleSampler, smooth_mask_rows
-    from oracle.unet import OracleUnet
-    args = make_args("maestro22k", T=36, gap_ms=300.0, xi=0.25)
-    net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(DEV)), 0, gate_scale=10.0, affine_scale=10.0)
-    B, Ls = 8, args.exp.audio_len
-    mask = mask_from_args(args)
-    assert int((mask == 0).sum()) == 6615
-    y = torch.stack([torch.from_numpy(seeded_normal(51, b, Ls)) for b in range(B)]) * 0.063 * mask
+    z = np.load(os.path.join(GOLDEN, "config1_traj.npz"))
+    item, steps, seed = int(z["item"]), int(z["steps"]), int(z["seed"])
+    c = build("config1")
+    args, B, Ls = c["args"], c["B"], c["L"]
+    assert B == 8 and steps == 8 and seed == 100 + item
+    net = seeded_init_(Unet_CQT_oct_with_attention(args, torch.device(DEV)), c["net_seed"], gate_scale=10.0, affine_scale=10.0)
+    assert net._n_split(B) == 2                                  # the product schedule: two sub-batch streams
     smp = Sampler(model=net, diff_params=EDM(args), args=args)
-    smp.seeds = list(range(70, 70 + B))
-    smp.setup_inpainting(y.to(DEV), mask)
-    smp.trace, smp.trace_in = [], []
+    smp.seeds = [100 + b for b in range(B)]
+    smp.setup_inpainting(c["y"].to(DEV), c["mask"])
+    smp.trace = []
     state = smp.begin((B, Ls), torch.device(DEV))
-    for i in range(2):
+    worst = {"free": 0.0, "forced": 0.0}
+
+    def check(v, key, stream, bar, tag):
+        ds, dp, dn = compare(v.cpu(), z[key + ".proj"], z[key + ".s"], stream)
+        print(f"configs[1] B=8 item {item} {tag} {key}: strided rel-L2 {ds:.2e}, projections {dp:.2e}, squared norm {dn:.2e}")
+        assert ds < bar and dp < 3 * bar and dn < 3 * bar, (key, tag, ds, dp, dn)
+        return ds
+    for i in range(steps):
+        if f"x{i}.full" in z.files:                              # teacher-forced restart from the oracle's own state entering step i
+            gst = [g.get_state() for g in smp._gens]
+            forced = dict(state)
+            forced["x"] = state["x"].clone()
+            forced["x"][item] = torch.from_numpy(z[f"x{i}.full"]).to(DEV)
+            ntr = len(smp.trace)
+            smp.step(forced, i)
+            worst["forced"] = max(worst["forced"], check(forced["x"][item], f"x{i + 1}", 300 + i, 2e-5, "teacher-forced"),
+                                  check(smp.trace[ntr][item], f"xhat{2 * i}", 400 + 2 * i, 2e-5, "teacher-forced"),
+                                  check(smp.trace[ntr + 1][item], f"xhat{2 * i + 1}", 400 + 2 * i + 1, 2e-5, "teacher-forced"))
+            del smp.trace[ntr:]
+            for g, st_ in zip(smp._gens, gst):                   # the free-running step below draws the SAME churn noise
+                g.set_state(st_)
         smp.step(state, i)
-    assert len(smp.trace) == len(smp.trace_in) == 4
-    orc = OracleUnet(7, 64, OracleCQT(7, 64, "oct", ("kaiser", 1), 22050, Ls)).load_state_dict(net.state_dict())
-    osmp = OracleSampler(orc, OracleEDM(), T=36, xi=0.25, hann_size=50, audio_len=Ls)
-    osmp.mask = mask
-    osmp.smask = smooth_mask_rows(mask, 50)
-    for k, ((xin, t), xh) in enumerate(zip(smp.trace_in, smp.trace)):
-        assert bool(torch.isfinite(xh).all())
-        if k in (1, 3):                                  # (each oracle item-evaluation is 30-45 s of CPU: the first evaluation of each Heun step is
-            continue                                     #  compared -- item 6 in step 0, item 1 in step 1, which run in different sub-batch streams;
-        items = [6] if k == 0 else [1]                   #  the second evaluations' inputs are already functions of the first ones' outputs)
-        osmp.y = y[items]
-        osmp.trace = []
-        osmp.get_score(xin[items].cpu(), torch.tensor(t, dtype=torch.float32))
-        e = rel_l2(xh[items].cpu(), osmp.trace[0])
-        print(f"configs[1] B=8, evaluation {k} (t={t:.4f}), items {items}: projected x_hat rel-L2 vs oracle = {e:.3e}")
-        assert e < 1e-4
+        assert bool(torch.isfinite(state["x"]).all())
+        worst["free"] = max(worst["free"], check(state["x"][item], f"x{i + 1}", 300 + i, 1e-4, "free-running"),
+                            check(smp.trace[2 * i][item], f"xhat{2 * i}", 400 + 2 * i, 1e-4, "free-running"),
+                            check(smp.trace[2 * i + 1][item], f"xhat{2 * i + 1}", 400 + 2 * i + 1, 1e-4, "free-running"))
+    assert len(smp.trace) == 2 * steps
+    print(f"configs[1] B=8, 8 Heun steps: worst free-running {worst['free']:.2e}, worst teacher-forced {worst['forced']:.2e}")
 
 
 def test_cfgB_44k_8s_368368_forward_vs_oracle():

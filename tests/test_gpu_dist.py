@@ -218,6 +218,48 @@ def test_sub_batch_streams_are_bit_identical_to_one_stream():
     net.split_streams = None
     assert net._n_split(8) == 2 and net._n_split(4) == 2 and net._n_split(2) == 1
 
+def test_cu_partitioned_sub_batch_streams_are_bit_identical_and_race_free():
+    """EXPERIMENT mode network.cu_partition (round 6): inside every sub-batch the launch plans run on two CU-masked streams, lanes by kernel TYPE (MFMA-bound
+    on 256 - N CUs, HBM-bound passes on N), with the cross-lane dependencies derived from the ops' read / write sets.  Same kernels, same launch shapes:
+    the result must equal the free-running sub-batch streams to the bit, repeatedly (a missing edge shows as a race), and Plan.check() must cover every
+    dependency of both re-tagged plans."""
+    from oracle.edm import OracleEDM
+    net, args, kw = _setup(DEV)
+    B, Ls = 6, kw["audio_len"]
+    y, _ = _segments(B, Ls)
+    g0 = torch.Generator().manual_seed(5)
+    x = (torch.randn(B, Ls, generator=g0) * 0.4).to(DEV)
+    edm = OracleEDM()
+    s = torch.rand(B, 1, generator=g0) * 0.8 + 0.05
+    v = lambda t: t.reshape(-1).to(DEV).contiguous()
+    co = (v(edm.cnoise(s)), v(edm.cin(s)), v(edm.cskip(s)), v(edm.cout(s)))
+    masks = torch.ones(B, Ls)
+    for b in range(B):
+        masks[b, 900 + 100 * b: 1300 + 100 * b] = 0
+    yd, md = (y * masks).to(DEV).contiguous(), masks.to(DEV)
+    net.split_streams = 2
+    ref = (net.denoise(x, *co, True), *net.denoise_guided(x, *co, True, yd, md))
+    torch.cuda.synchronize()
+    net._states.clear()
+    net.cu_partition = 64
+    net.cu_partition_ridge = 0.5                      # (reduced network: its convs are tiny -- make some of them count as MFMA-bound so both lanes are populated)
+    try:
+        for rep in range(4):
+            got = (net.denoise(x, *co, True), *net.denoise_guided(x, *co, True, yd, md))
+            torch.cuda.synchronize()
+            for a_, b_ in zip(ref, got):
+                assert torch.equal(a_, b_), f"repetition {rep}"
+        edges = 0
+        for st in net.states_of(B):
+            for pl in (st["plan_body"], st["plan_bwd"]):
+                assert pl.lanes == 2 and {o.lane for o in pl.ops} == {0, 1}
+                edges += pl.check()
+        assert edges > 0
+    finally:
+        net.cu_partition, net.split_streams = 0, None
+        net._states.clear()
+
+
 def test_full_size_split_vs_unsplit_agree_to_rounding():
     """Full-size network, batch 4, one guided evaluation: two sub-batches of two on concurrent streams against the unsplit batch.  The Winograd form and
     tile instance of a 5x3 layer are chosen from the launch shape (aid_conv2d_wino_form / aid_conv2d_wino2d_wanted: batch 2 and batch 4 launches of the

@@ -22,6 +22,7 @@ if os.environ.get("AID_EXPERIMENT") == "1" and os.environ.get("AID_LIB_PATH"):
     print(f"[aid] AID_EXPERIMENT=1: loading {LIB_PATH} instead of the in-tree libaid_hip.so", file=_sys.stderr)
 AID_CQT_MAX_OCT = 12
 AID_STATS_SPLIT = 32
+AID_CONV2D_SPLIT_FLAG_BYTES = 4096     # include/aid_kernels.h: leading flag region of the split-K scratch (checked against the header in tests/test_host_logic.py)
 AID_ATTN_MAX_T = 128          # aid_time_attention: one workgroup holds a whole [T, T] score tile
 
 

@@ -11,7 +11,9 @@
 //              possibly stale lines of its own L2.
 // The compiler cannot reorder across either side: `asm volatile("s_waitcnt ..." ::: "memory")` is a compiler-level fence, `__syncthreads()` carries
 // workgroup-scope release / acquire fences, and atomics on the same object are never reordered with each other.  The counters / flags are left zero by
-// every launch; a launch that FAILS may not have, so the host re-zeroes them (plan.py: Plan.zero_on_fail).
+// every launch.  Host side (plan.py): a launcher that returns an error never ran its kernel, so nothing is half-way then -- the plan still re-zeroes after
+// synchronising (Plan._fail); a run that is ABANDONED half-way for any other reason (exception, interrupt) marks the plan dirty and the next run re-zeroes
+// first (Plan.run / zero_scratch); an asynchronous device fault kills the process on this stack and needs no recovery.
 #pragma once
 #include "aid_common.h"
 

@@ -428,6 +428,7 @@ extern "C" int aid_wino2d_gemm(const aid_wino2d_gemm_params* p, void* stream) {
     }
     switch (variant) {
         case 12: return w2d_launch_gemm<2, 4, 2, 2, 16, 3, 2>(p, st, "w2d_gemm_kernel<128x256,kc16,nb3>");
+#ifdef AID_EXPERIMENT       // tile-shape probes of round 5 (tools/w2d_probe.py gemm, profiles/r05_w2d_gemm_probe1.txt): -DAID_EXPERIMENT builds only
         case 1: return w2d_launch_gemm<2, 4, 2, 2, 8, 3, 2>(p, st, "w2d_gemm_kernel<128x256,kc8,nb3>");
         case 2: return w2d_launch_gemm<2, 4, 2, 2, 16, 2, 2>(p, st, "w2d_gemm_kernel<128x256,kc16,nb2>");
         case 3: return w2d_launch_gemm<4, 2, 2, 2, 16, 3, 2>(p, st, "w2d_gemm_kernel<256x128,kc16,nb3>");
@@ -438,13 +439,15 @@ extern "C" int aid_wino2d_gemm(const aid_wino2d_gemm_params* p, void* stream) {
         case 8: return w2d_launch_gemm<2, 2, 2, 2, 8, 4, 4>(p, st, "w2d_gemm_kernel<128x128,kc8,nb4,wpc4>");
         case 9: return w2d_launch_gemm<2, 4, 2, 2, 8, 6, 2>(p, st, "w2d_gemm_kernel<128x256,kc8,nb6>");
         case 10: return w2d_launch_gemm<4, 2, 2, 2, 8, 4, 2>(p, st, "w2d_gemm_kernel<256x128,kc8,nb4>");
+        case 102: return w2d_launch_gemm_s6<2, 4, 2, 2, 2, 2>(p, st, "w2d_gemm_s6_kernel<128x256,nb2>");
+#endif
         case 11: return w2d_launch_gemm<2, 2, 2, 2, 16, 2, 4>(p, st, "w2d_gemm_kernel<128x128,kc16,nb2,wpc4>");
         case 100: return w2d_launch_gemm_s6<2, 4, 2, 2, 3, 2>(p, st, "w2d_gemm_s6_kernel<128x256,nb3>");
         case 101: return w2d_launch_gemm_s6<2, 2, 2, 2, 3, 3>(p, st, "w2d_gemm_s6_kernel<128x128,nb3,wpc3>");
-        case 102: return w2d_launch_gemm_s6<2, 4, 2, 2, 2, 2>(p, st, "w2d_gemm_s6_kernel<128x256,nb2>");
         default: break;
     }
-    aid_set_error("aid_wino2d_gemm: unknown variant");
+    aid_set_error("aid_wino2d_gemm: unknown variant (0 = automatic, 11 / 12 = the two product tilings, 100 / 101 = the labelled split-precision variant; "
+                  "the round-5 probe tilings 1-10 / 102 exist in -DAID_EXPERIMENT builds only)");
     return AID_E_BADARG;
 }
 

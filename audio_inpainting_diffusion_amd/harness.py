@@ -156,7 +156,13 @@ def _resample_one_rate(audio, f: int, fs_target: int, length_target: int) -> tor
         return audio[:, :length_target]
     if fs_target == 44100 and f == 48000:
         return resample(audio, 160, 147)[:, :length_target]
-    return resample(audio, f, fs_target)[:, :length_target]
+    if f in (44100, 48000):                                                # (:191-196: any other target, from the two rates the datasets have)
+        return resample(audio, f, fs_target)[:, :length_target]
+    # any other source rate: the reference's `(fs == 44100).all()` / `(fs == 48000).all()` tests fail, its per-item loop prints "WARNING, strange fs" and
+    # passes the row through UNRESAMPLED (:165, :186, :207) -- the same rule whether the whole batch or only some rows have that rate
+    import warnings
+    warnings.warn(f"resample_batch: strange fs {f}: rows passed through unresampled, as the reference does (call harness.resample(x, {f}, {fs_target}) to resample them)")
+    return audio[:, :length_target].float()
 
 
 def resample_batch(audio: torch.Tensor, fs, fs_target: int, length_target: int) -> torch.Tensor:
@@ -165,19 +171,17 @@ def resample_batch(audio: torch.Tensor, fs, fs_target: int, length_target: int) 
     loops ``return`` inside their first iteration, so only ITEM 0 of its result is filled; item 0 here equals it, the other items are resampled too."""
     f = fs.reshape(-1) if torch.is_tensor(fs) else torch.tensor([fs])
     if bool((f == f[0]).all()):
-        return _resample_one_rate(audio, int(f[0]), fs_target, length_target)
+        y = _resample_one_rate(audio, int(f[0]), fs_target, length_target)
+        if y.shape[1] < length_target and int(f[0]) not in (44100, 48000):
+            raise ValueError(f"resample_batch: rows at {int(f[0])} Hz passed through give {y.shape[1]} samples, fewer than length_target = {length_target}")
+        return y
     if f.numel() != audio.shape[0]:
         raise ValueError(f"fs has {f.numel()} entries for a batch of {audio.shape[0]}")
     out = torch.zeros(audio.shape[0], length_target, device=audio.device, dtype=torch.float32)
     for rate in sorted(set(int(v) for v in f.tolist())):
         rows = torch.nonzero(f.cpu() == rate).reshape(-1).to(audio.device)
         sub = audio.index_select(0, rows)
-        if rate in (44100, 48000):
-            y = _resample_one_rate(sub, rate, fs_target, length_target)
-        else:                                                  # the reference's loops print a warning and pass such a row through unchanged (:165, :186, :207)
-            import warnings
-            warnings.warn(f"resample_batch: strange fs {rate} in a mixed-rate batch: rows passed through unresampled, as the reference does")
-            y = sub[:, :length_target].float()
+        y = _resample_one_rate(sub, rate, fs_target, length_target)      # (rates other than 44100 / 48000 pass through with a warning, like the reference)
         if y.shape[1] < length_target:                         # the reference's ``proc_batch[i] = a[0:length_target]`` raises on a short row: no silent zero padding
             raise ValueError(f"resample_batch: rows at {rate} Hz give {y.shape[1]} samples at {fs_target} Hz, fewer than length_target = {length_target}")
         out[rows] = y

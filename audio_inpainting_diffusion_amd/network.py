@@ -489,12 +489,13 @@ class _Builder:
         (aid_conv2d_wino_form); ``net.wino_forms`` restricts the choice (A/B measurements, tests of the F(4,3) kernels)."""
         if wpw is None or wpw.shape[0] != 30:
             return 0
+        fb = int(self.net.form_batch or self.B)               # the batch the FORM is chosen for (network.form_batch; default: this launch's)
         if wpw2 is not None and 45 in self.net.wino_forms and _lib.lib().aid_conv2d_wino2d_supported(cin, cout, F, T, dil):
             # the non-fused 2-D form F(4,5) x F(4,3) (csrc/aid_wino2d.hip: 3.0 products per output) where the library predicts it faster than the fused
             # 1-D kernels (aid_conv2d_wino2d_wanted, a function of the launch shape); wino_forms = (45,): wherever it is supported (tests, A/B)
-            if tuple(self.net.wino_forms) == (45,) or (min(cin, cout) >= self.net.w2d_min_channels and (T <= self.net.w2d_force_max_T or _lib.lib().aid_conv2d_wino2d_wanted(self.B, cin, cout, F, T, dil))):
+            if tuple(self.net.wino_forms) == (45,) or (min(cin, cout) >= self.net.w2d_min_channels and (T <= self.net.w2d_force_max_T or _lib.lib().aid_conv2d_wino2d_wanted(fb, cin, cout, F, T, dil))):
                 return 45
-        form = int(_lib.lib().aid_conv2d_wino_form(self.B, cin, cout, F, T, dil))
+        form = int(_lib.lib().aid_conv2d_wino_form(fb, cin, cout, F, T, dil))
         if form == 8 and (wpw8 is None or 8 not in self.net.wino_forms):
             form = 4
         elif form == 4 and 4 not in self.net.wino_forms and wpw8 is not None and _lib.lib().aid_conv2d_wino8_supported(cin, cout, F, T, dil):
@@ -1141,6 +1142,25 @@ class Unet_CQT_oct_with_attention(nn.Module):
                                # last N / 8 CUs of every XCD; the cross-lane dependencies are the plan's derived ones (plan.py).  0 = free-running streams.
     cu_partition_ridge = 30.0  # FLOP per algorithmic byte above which a conv launch counts as MFMA-bound (fp32 ridge ~ 20-26 FLOP/B)
 
+    cu_split = None            # EXPERIMENT (bench.py --cu-split a,b[,c]): every sub-batch stream gets its OWN share of each XCD's 32 CUs (counts per XCD, e.g. 16,16 or
+                               # 20,12 with --split 5,3; shares may overlap when they sum to more than 32: the first starts at CU 0, the last ends at CU 31) -- no
+                               # cross-stream events at all: each sub-batch's chain runs undisturbed on its partition.  None = unmasked free-running streams.
+
+    def _split_mask_streams(self, n: int):
+        key = (tuple(self.cu_split), n)
+        if getattr(self, "_csplit_key", None) != key:
+            from .streams import cu_masked_stream, xcd_range_mask
+            shares = [int(v) for v in self.cu_split]
+            assert len(shares) == n and all(0 < v <= 32 for v in shares), "cu_split: one CU count per XCD (1..32) for every sub-batch stream"
+            total = sum(shares)
+            starts, pos = [], 0
+            for k, v in enumerate(shares):                 # spread the shares over [0, 32): disjoint when they fit, evenly overlapping when they do not
+                starts.append(0 if n == 1 else round(k * (32 - v) / (n - 1)) if total > 32 else pos)
+                pos += v
+            self._csplit_streams = [cu_masked_stream(xcd_range_mask(st, st + v)) for st, v in zip(starts, shares)]
+            self._csplit_key = key
+        return self._csplit_streams
+
     def _type_lane(self, op) -> int:
         if op.name in ("aid_conv2d_wino2d_gemm", "aid_time_attention", "aid_time_attention_bwd"):
             return 0
@@ -1184,6 +1204,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
                 bounds.append(bounds[-1] + int(k))
         if self.cu_partition:
             return n, bounds, [m for m, _ in self._partition_streams(n)]
+        if self.cu_split:
+            return n, bounds, self._split_mask_streams(n)
         if getattr(self, "_side_streams", None) is None or len(self._side_streams) < n:
             # (equal priorities: raising one or two of the three sub-batch streams measured 43.7 -> 41.6 ... 42.7 evaluations/s)
             self._side_streams = [torch.cuda.Stream() for _ in range(n)]
@@ -1262,6 +1284,11 @@ class Unet_CQT_oct_with_attention(nn.Module):
                                # where the library predicts it faster (aid_conv2d_wino2d_wanted), F(8,3) where the library prefers it (aid_conv2d_wino_form),
                                # F(4,3) otherwise; (4,) keeps every layer on the F(4,3) kernels, (45,) forces the 2-D form wherever it is supported
                                # (A/B measurements, tests; set before the first forward)
+    form_batch = None          # None: the Winograd FORM of a 5x3 layer (2-D / F(8,3) / F(4,3)) is chosen for the batch of the launch it runs in -- the fastest, and the reason
+                               # why a sub-batch split or another world size reproduces a segment to rounding (<= 5e-6 per evaluation) and not to the bit.
+                               # An int pins the choice to that batch for every launch (e.g. 1: the forms of a single-segment launch everywhere), so the FORM no longer
+                               # depends on how segments are grouped; the tile INSTANCE inside a form (K-group / split-K instances for launches with few tiles) still
+                               # follows the launch shape, so this narrows the difference, it does not promise identical bits.  Set before the first forward.
     w2d_force_max_T = 0        # A/B: layers with T up to this take the 2-D form wherever it is SUPPORTED, whatever the library's per-layer prediction says (bench.py --w2d-force-max-t)
     w2d_min_channels = 128     # A/B: 256 keeps the 2-D form off the K = 128 levels the library would give it (bench.py --w2d-min-channels)
     wgrad_wino = True          # training: F(4,3) form of the 5x3 weight gradients (aid_conv2d_wgrad wino=1)

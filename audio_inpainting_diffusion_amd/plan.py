@@ -196,21 +196,42 @@ class Plan:
         return sum(len(w) for w in waits)
 
     # ---- execution -----------------------------------------------------------------------------------------------------------
+    def zero_scratch(self):
+        """Re-establish the contract of the zero_on_fail scratch: arrival counters entirely, the flag region that leads the fp32 split-K scratch."""
+        for t in self.zero_on_fail:
+            try:
+                t.zero_() if t.dtype != torch.float32 else t[:_lib.AID_CONV2D_SPLIT_FLAG_BYTES // 4].zero_()
+            except Exception:
+                pass
+        self._dirty = False
+
     def _fail(self, op, rc):
+        """A launcher returned an error (host-side validation / launch failure -- nothing of THIS op ran, but earlier ops of the run are in flight)."""
         msg = _lib.lib().aid_last_error().decode()
-        try:                       # a failed launch may have left counters / flags half-way: the next run must not find them non-zero
+        try:                       # let the kernels already queued finish: they leave their counters / flags zero themselves
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
         except Exception:
             pass
-        for t in self.zero_on_fail:
-            try:
-                t.zero_() if t.dtype != torch.float32 else t[:1024].zero_()      # (fp32 scratch: AID_CONV2D_SPLIT_FLAG_BYTES of flags lead it)
-            except Exception:
-                pass
+        self.zero_scratch()
         raise _lib.AidError(f"{op.name} failed rc={rc}: {msg}")
 
     def run(self):
+        """Launch every op.  If ANYTHING raises while a run is under way (a launcher's error code, an asynchronous device error surfacing in a torch call
+        of the multi-lane path, an interrupt between launches), the plan is marked dirty and the NEXT run first synchronises and re-zeroes the
+        counters / flags (zero_scratch): a kernel that was cut short may have left them half-way.  A device FAULT proper (memory violation)
+        aborts the process on this stack -- there is no next run to protect."""
+        if getattr(self, "_dirty", False):
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            self.zero_scratch()
+        self._dirty = True
+        self._run()
+        self._dirty = False
+
+    def _run(self):
         cur = torch.cuda.current_stream()
         multi = self.lanes > 1 and self.timing is None and self.trace is None and any(o.lane for o in self.ops)
         if not multi:
@@ -223,7 +244,9 @@ class Plan:
                     rc = op.fn(op.addr, stream)
                     e1.record()
                     trace.append((e0, e1, op.name, op.descr, op.addr, _lib.lib().aid_last_kernel().decode() if op.name in CONV_OPS else "", op.lane))
-                elif timing is not None and op.flops > 0 and op.name in CONV_OPS:
+                elif timing is not None and op.name in CONV_OPS and (op.flops > 0 or op.name == "aid_conv2d_wino2d_output"):
+                    # (the output-transform + epilogue pass of a 2-D Winograd layer carries no FLOPs of its own but IS conv time: the fused 1-D kernels do
+                    #  that work inside the timed kernel -- ADVICE r5)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     rc = op.fn(op.addr, stream)
@@ -241,8 +264,8 @@ class Plan:
         side.wait_stream(cur)
         streams = (cur, side)
         handles = (cur.cuda_stream, side.cuda_stream)
-        ev = {}
-        for j, op in enumerate(self.ops):
+        ev = self.__dict__.setdefault("_events", {})      # one event per recording op, created once and re-recorded by every run (a wait enqueued by an earlier
+        for j, op in enumerate(self.ops):                  # run captured the event's state at that time: re-recording does not disturb it)
             s = streams[op.lane]
             for i in waits[j]:
                 s.wait_event(ev[i])
@@ -250,6 +273,8 @@ class Plan:
             if rc != 0:
                 self._fail(op, rc)
             if j in record:
-                e = ev[j] = torch.cuda.Event()
+                e = ev.get(j)
+                if e is None:
+                    e = ev[j] = torch.cuda.Event()
                 e.record(s)
         cur.wait_stream(side)

@@ -37,6 +37,16 @@ def partition_masks(n_pass: int, interleaved: bool = True) -> Tuple[List[int], L
     return words(full & ~bits_pass), words(bits_pass)
 
 
+def xcd_range_mask(lo: int, hi: int) -> List[int]:
+    """mask words selecting CUs [lo, hi) of EVERY XCD (round-robin bit order: bit = cu * 8 + xcc)"""
+    if not 0 <= lo < hi <= CUS_PER_XCC:
+        raise ValueError("CU range must lie inside [0, 32]")
+    bits = 0
+    for cu in range(lo, hi):
+        bits |= 0xFF << (cu * N_XCC)
+    return [(bits >> (32 * w)) & 0xFFFFFFFF for w in range(N_XCC * CUS_PER_XCC // 32)]
+
+
 def cu_masked_stream(words: List[int]) -> torch.cuda.ExternalStream:
     """A new HIP stream whose kernels may only run on the CUs set in ``words`` (uint32 little-endian bit mask), as a torch stream."""
     h = _hip()

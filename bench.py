@@ -251,6 +251,8 @@ def main():
     ap.add_argument("--split", default="", help="A/B: explicit sub-batch sizes, e.g. 5,3 (network.split_sizes; implies --streams = their count)")
     ap.add_argument("--cu-partition", type=int, default=0, help="EXPERIMENT (A/B): spatial partition of the chip inside every sub-batch -- MFMA-bound kernels on 256 - N CUs, HBM-bound passes "
                     "on the last N / 8 CUs of every XCD, on CU-masked streams (network.cu_partition, streams.py); 0 = free-running sub-batch streams (the product schedule)")
+    ap.add_argument("--cu-split", default="", help="EXPERIMENT (A/B): CUs per XCD for each sub-batch stream, e.g. 16,16 (disjoint halves) or 20,20 (overlapping) -- CU-masked sub-batch streams "
+                    "without any cross-stream events (network.cu_split)")
     ap.add_argument("--conv-table", action="store_true", help="print per-shape conv kernel times (stderr)")
     a = ap.parse_args()
 
@@ -295,6 +297,8 @@ def main():
         net.w2d_force_max_T = a.w2d_force_max_t
     if a.cu_partition:
         net.cu_partition = a.cu_partition
+    if a.cu_split:
+        net.cu_split = tuple(int(v) for v in a.cu_split.split(","))
     if a.no_epilogue_stats:
         net.epilogue_stats = False
     if a.no_fin:
@@ -366,6 +370,7 @@ def main():
     jlast = 0
     for i in range(a.warmup, a.warmup + a.steps):
         jlast = do_step(i)
+    host_enqueue = time.perf_counter() - t0            # the host thread's share: all launches of the timed steps are enqueued (the GPU may still be running them)
     torch.cuda.synchronize()
     D.barrier()
     wall_rank = wall = time.perf_counter() - t0
@@ -422,7 +427,7 @@ def main():
         sec = max(conv_ms * 1e-3, 1e-12)
         out = {
             "metric": "denoiser-steps/sec", "value": round(evals / wall, 3), "unit": "denoiser evaluations (one segment each) per second, whole job",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * wall / a.steps, 2),
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * wall / a.steps, 2), "host_enqueue_ms_per_step": round(1e3 * host_enqueue / a.steps, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
             "dtype": "f32" if not a.mfma_split else "VARIANT: f32 storage and accumulation; the GEMMs of the 2-D Winograd layers multiply three bf16 pieces per f32 operand (exact split), six bf16-MFMA products each; all other kernels f32",
             "config": {"workload": {"maestro22k": "BASELINE.json configs[1]: batch %d x 22.05 kHz MAESTRO-shape segments (L=184184) per GPU, %g ms gap, ",
@@ -436,13 +441,16 @@ def main():
                        "network": "unet_cqt_oct_with_attention %s, %.1f M params, random-init (seeded)" % ("44.1 kHz 8-octave" if a.workload == "musicnet44k" else "7-octave", sum(p.numel() for p in net.parameters()) / 1e6),
                        "parallelism": "segments sharded %d-way, one process per GPU, weights broadcast once in place (%.0f MB in %.3f s, %s), no collective in the loop"
                                       % (world, nbytes / 1e6, t_bcast, (torch.distributed.get_backend() if world > 1 else "single process")),
-                       "sub_batch_streams": n_split, "cu_partition": a.cu_partition, "hip_graph_replay": graphs, "functional_shared_gpu": bool(shared),
+                       "sub_batch_streams": n_split, "cu_partition": a.cu_partition, "cu_split": a.cu_split or None, "hip_graph_replay": graphs, "functional_shared_gpu": bool(shared),
                        "backend": (torch.distributed.get_backend() if world > 1 else "single process"), "rccl_version": D.rccl_version(),
                        "visible_gpus": torch.cuda.device_count()},
             "ranks": ranks,
             "roofline": {"bound": "mfma", "kernel": dom_name, "measured_in": roofline_pass,
                          "definition": "achieved = MFMA FLOPs issued by ALL launches of the dominant kernel (by device-kernel name, every template instance / tile kind) "
-                                       "/ their summed duration (HIP events around each launch); Winograd F(4,3) issues 1/2, F(8,3) 5/12 and the 2-D form F(4,5) x F(4,3) (w2d_gemm_kernel, the K = 256 layers) 1/5 of the direct-form FLOPs; "
+                                       "/ their summed duration (HIP events around each launch); Winograd F(4,3) issues 1/2, F(8,3) 5/12 and the 2-D form F(4,5) x F(4,3) (w2d_gemm_kernel: every 5x3 layer "
+                                       "of the C >= 128 levels 3-6 and the bottleneck that the library gives it) 1/5 of the direct-form FLOPs; the 2-D form's output-transform + epilogue pass "
+                                       "(w2d_output_kernel, HBM-bound, no FLOPs of its own) is timed as a conv launch too and counts in all_conv / conv_time_fraction_of_wall -- the fused 1-D kernels do that "
+                                       "work inside the timed kernel -- its input-transform pass is the counterpart of the fused kernels' aid_scale_act pre-pass and, like it, is not; "
                                        "algorithmic_tflops = direct-form FLOPs / the same time; step_executed_frac = issued MFMA FLOPs of all conv / GEMM launches "
                                        "of one step / ms_per_step of the timed region / peak; non_winograd_conv_time_fraction_single_stream = 1 - (time of ALL 5x3 Winograd MFMA kernels: "
                                        "the fused 1-D kernels and the 2-D form's GEMM) / single-stream step time",

@@ -651,6 +651,9 @@ def test_polyphase_resampler_vs_oracle(L, ratio):
         with pytest.warns(UserWarning, match="strange fs"):
             odd = resample_batch(a.to(DEV), torch.tensor([32000, 44100]), 22050, 65536).cpu()
         assert torch.equal(odd[0], a[0, :65536]) and torch.equal(odd[1], mix[1])
+        with pytest.warns(UserWarning, match="strange fs"):          # the SAME rule when the whole batch has that rate (the reference's all()-tests fail there too: ADVICE r5)
+            odd2 = resample_batch(a.to(DEV), torch.tensor([32000, 32000]), 22050, 65536).cpu()
+        assert torch.equal(odd2, a[:, :65536])
 
 
 WGRAD_CASES = [

@@ -527,6 +527,33 @@ def test_failed_launch_re_zeroes_the_scratch_that_must_be_found_zero():
     with pytest.raises(_lib.AidError, match="aid_conv2d failed rc=2"):
         pl._fail(pl.ops[0], 2)
     assert int(cnt.abs().sum()) == 0 and float(flags[:1024].abs().sum()) == 0.0 and float(flags[1024:].sum()) == 3072.0
+    # the flag region's size is the header's constant, not a literal of plan.py
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "aid_kernels.h")).read()
+    assert int(re.search(r"#define AID_CONV2D_SPLIT_FLAG_BYTES (\d+)", hdr).group(1)) == _lib.AID_CONV2D_SPLIT_FLAG_BYTES == 4096
+    # a run ABANDONED half-way for any other reason (an exception between launches) marks the plan dirty: the next run re-zeroes before its first launch
+    pl2 = Plan()
+    cnt2 = torch.zeros(4, dtype=torch.int32)
+    pl2.zero_on_fail.append(cnt2)
+    seen = []
+
+    def first(addr, stream):
+        cnt2.fill_(7)                                     # "a kernel left its counter half-way"
+        return 0
+
+    def boom(addr, stream):
+        raise KeyboardInterrupt
+    pl2.ops.append(Op(first, C.addressof(holder), "aid_add2", 0, 0, "fake", 0, [], [], holder))
+    pl2.ops.append(Op(boom, C.addressof(holder), "aid_add2", 0, 0, "fake", 0, [], [], holder))
+    import unittest.mock as mock
+    with mock.patch("torch.cuda.current_stream", lambda: type("S", (), {"cuda_stream": 0})()), mock.patch("torch.cuda.synchronize", lambda: None):
+        with pytest.raises(KeyboardInterrupt):
+            pl2.run()
+        assert pl2._dirty and int(cnt2.sum()) == 28
+        pl2.ops[0] = Op(lambda addr, stream: seen.append(int(cnt2.sum())) or 0, C.addressof(holder), "aid_add2", 0, 0, "fake", 0, [], [], holder)
+        pl2.ops.pop()
+        pl2.run()
+    assert seen == [0] and not pl2._dirty                 # zeroed BEFORE the first launch of the next run
 
 
 def test_bench_reports_pmc_traffic_only_for_the_same_build_and_names_kernels_as_rocprof_does():

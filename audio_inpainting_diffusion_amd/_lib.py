@@ -200,7 +200,7 @@ class PackConvWeightParams(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("wpT", C.c_void_p), ("wpw", C.c_void_p), ("wpwT", C.c_void_p),
                 ("Cout", C.c_int), ("Cin", C.c_int), ("KH", C.c_int), ("KW", C.c_int),
                 ("Cin_pad", C.c_int), ("Cout_pad", C.c_int), ("Cin_padT", C.c_int), ("Cout_padT", C.c_int),
-                ("wpw8", C.c_void_p), ("wpw8T", C.c_void_p), ("wpw2", C.c_void_p), ("wpw2T", C.c_void_p)]
+                ("wpw8", C.c_void_p), ("wpw8T", C.c_void_p), ("wpw2", C.c_void_p), ("wpw2T", C.c_void_p), ("wpw3", C.c_void_p), ("wpw3T", C.c_void_p)]
 
 
 class WgradReduceParams(C.Structure):
@@ -259,7 +259,7 @@ EXPORTS = ["aid_abi_version", "aid_last_error", "aid_last_kernel", "aid_group_st
            "aid_time_attention_bwd", "aid_guidance_seed", "aid_guidance_step", "aid_set_rows", "aid_row_norm", "aid_scale_act", "aid_fft_pass",
            "aid_stft_frames", "aid_stft_ola", "aid_resample_poly", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino8_supported", "aid_conv2d_wino_split_ws_bytes", "aid_conv2d_fin_supported",
            "aid_conv2d_wgrad", "aid_wgrad_reduce", "aid_channel_dot", "aid_relpos_bwd", "aid_scale_bwd", "aid_modulation_bwd", "aid_embed_bwd",
-           "aid_adam", "aid_ema", "aid_sumsq", "aid_wino2d_gemm", "aid_wino2d_set_split", "aid_conv2d_wino2d_gemm", "aid_conv2d_wino2d_output", "aid_conv2d_wino2d_supported", "aid_conv2d_wino2d_positions", "aid_conv2d_wino2d_wanted"]
+           "aid_adam", "aid_ema", "aid_sumsq", "aid_wino2d_gemm", "aid_wino2d_set_split", "aid_conv2d_wino2d_gemm", "aid_conv2d_wino2d_output", "aid_conv2d_wino2d_supported", "aid_conv2d_wino2d_positions", "aid_conv2d_wino2d_wanted", "aid_conv2d_wino2d_tform"]
 
 _lib = None
 
@@ -306,16 +306,18 @@ def lib():
         L.aid_conv2d_wino2d_supported.restype = C.c_int
         L.aid_conv2d_wino2d_wanted.argtypes = [C.c_int] * 6
         L.aid_conv2d_wino2d_wanted.restype = C.c_int
+        L.aid_conv2d_wino2d_tform.argtypes = [C.c_int] * 6
+        L.aid_conv2d_wino2d_tform.restype = C.c_int
         L.aid_conv2d_wino2d_positions.argtypes = [C.c_int] * 4
         L.aid_conv2d_wino2d_positions.restype = C.c_int64
         L.aid_wino2d_set_split.argtypes = [C.c_int]
         L.aid_wino2d_set_split.restype = C.c_int
         for name in EXPORTS[3:]:
             if name not in ("aid_conv2d_pack_dims", "aid_conv2d_wino_input_supported", "aid_conv2d_dot_partials", "aid_conv2d_x2_supported", "aid_conv2d_dot_partials_1x1", "aid_conv2d_wino_input_ok", "aid_conv2d_wino_form", "aid_conv2d_wino8_supported", "aid_conv2d_wino_split_ws_bytes", "aid_conv2d_fin_supported",
-                            "aid_conv2d_stat_partials", "aid_conv2d_wgrad_tiles", "aid_conv2d_wino2d_supported", "aid_conv2d_wino2d_positions", "aid_conv2d_wino2d_wanted", "aid_wino2d_set_split"):
+                            "aid_conv2d_stat_partials", "aid_conv2d_wgrad_tiles", "aid_conv2d_wino2d_supported", "aid_conv2d_wino2d_positions", "aid_conv2d_wino2d_wanted", "aid_conv2d_wino2d_tform", "aid_wino2d_set_split"):
                 getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, name).restype = C.c_int
-        if L.aid_abi_version() != 13:
+        if L.aid_abi_version() != 14:
             raise AidError("ABI version mismatch")
         _lib = L
     return _lib
@@ -455,6 +457,22 @@ def pack_conv_weight_wino2d(w: torch.Tensor, transpose: bool = False) -> torch.T
     U = torch.einsum("fh,tk,oihk->ftio", GF, GT, w).reshape(48, ci, co)
     cip, cop = pack_dims(ci, co)
     out = torch.zeros(48, cip, cop, device=w.device, dtype=torch.float32)
+    out[:, :ci, :co] = U.float()
+    return out
+
+
+def pack_conv_weight_wino2d8(w: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+    """[Cout,Cin,5,3] -> pack of the 2-D form with F(8,3) along T [80, Cin_pad, Cout_pad]: U[xf*10 + xt] = GF w G8^T (float64, stored fp32)."""
+    w = w.detach().double()
+    if transpose:
+        w = w.flip(2, 3).permute(1, 0, 2, 3)
+    co, ci, kh, kw = w.shape
+    assert (kh, kw) == (5, 3)
+    GF = torch.from_numpy(wino45_matrices()[1]).to(w.device)
+    G8 = torch.from_numpy(wino8_matrices()[1]).to(w.device)
+    U = torch.einsum("fh,tk,oihk->ftio", GF, G8, w).reshape(80, ci, co)
+    cip, cop = pack_dims(ci, co)
+    out = torch.zeros(80, cip, cop, device=w.device, dtype=torch.float32)
     out[:, :ci, :co] = U.float()
     return out
 

@@ -491,7 +491,7 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     AID_REQUIRE(p && p->x.p && p->y.p && p->wp, "aid_conv2d: null pointer");
     AID_REQUIRE(p->B > 0 && p->Cin > 0 && p->Cout > 0 && p->F > 0 && p->T > 0, "aid_conv2d: empty shape");
     AID_REQUIRE((p->T % 4) == 0, "aid_conv2d: T must be a multiple of 4");
-    AID_REQUIRE(p->x_wino == 3 || ((p->x.sB % 4) == 0 && (p->x.sC % 4) == 0 && (p->x.sF % 4) == 0), "aid_conv2d: input view strides % 4 == 0");
+    AID_REQUIRE(p->x_wino == 3 || p->x_wino == 4 || ((p->x.sB % 4) == 0 && (p->x.sC % 4) == 0 && (p->x.sF % 4) == 0), "aid_conv2d: input view strides % 4 == 0");
     AID_REQUIRE((((uintptr_t)p->x.p) & 15) == 0, "aid_conv2d: input view must be 16-byte aligned");
     int cip, cop;
     aid_conv2d_pack_dims(p->Cin, p->Cout, &cip, &cop);
@@ -500,7 +500,7 @@ extern "C" int aid_conv2d(const aid_conv2d_params* p, void* stream) {
     AID_REQUIRE((int64_t)p->B * p->in_scale_ld < (1LL << 31), "aid_conv2d: in_scale too large");
     AID_REQUIRE(!p->x_wino || (p->KH == 5 && p->KW == 3 && p->wp_wino), "aid_conv2d: x_wino is a 5x3 Winograd-path input layout");
     AID_REQUIRE(!p->fin_mode || (p->x_wino && p->KH == 5 && p->KW == 3), "aid_conv2d: fin_mode is an option of the row-shared 5x3 Winograd kernels (aid_conv2d_fin_supported)");
-    if (p->x_wino == 3) return aid_conv53_wino2d(p, st);              // non-fused 2-D Winograd form: batched GEMM + output pass (aid_wino2d.hip)
+    if (p->x_wino == 3 || p->x_wino == 4) return aid_conv53_wino2d(p, st);              // non-fused 2-D Winograd form: batched GEMM + output pass (aid_wino2d.hip)
     if (p->x2.p) {
         AID_REQUIRE(p->KH == 1 && p->KW == 1 && !p->in_scale && p->act == 0 && p->Cin1 > 0 && p->Cin1 < p->Cin && (p->Cin1 % 16) == 0 && ((p->Cin - p->Cin1) % 16) == 0,
                     "aid_conv2d: x2 is an option of plain 1x1 convolutions with both K segments multiples of 16");

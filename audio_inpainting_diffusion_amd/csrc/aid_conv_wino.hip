@@ -1689,7 +1689,7 @@ extern "C" int aid_conv2d_wino_form(int B, int Cin, int Cout, int F, int T, int 
 }
 
 extern "C" int aid_conv2d_fin_supported(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino) {
-    if (x_wino == 3) return (B >= 1 && (Cout % 8) == 0 && aid_conv2d_wino2d_supported(Cin, Cout, F, T, dilF)) ? 1 : 0;      // (the LAST block of the output pass folds)
+    if (x_wino == 3 || x_wino == 4) return (B >= 1 && (Cout % 8) == 0 && aid_conv2d_wino2d_supported(Cin, Cout, F, T, dilF) && (x_wino == 3 || T % 32 == 0)) ? 1 : 0;      // (the LAST block of the output pass folds)
     if (B < 1 || (Cout % 8) || !wino_v_shape_ok(Cin, Cout, T)) return 0;
     if (x_wino == 2) return aid_conv2d_wino8_supported(Cin, Cout, F, T, dilF);
     if (x_wino != 1) return 0;
@@ -1745,10 +1745,10 @@ extern "C" int aid_conv2d_wino_input_ok(int B, int Cin, int Cout, int F, int T, 
 }
 
 // partials per (sample, group) of the forward (sum, sum of squares) option: the row-shared kernel only
-int aid_w2d_partials(int Cout, int F, int T, int dilF);              // aid_wino2d.hip
+int aid_w2d_partials(int Cout, int F, int T, int dilF, int TF);      // aid_wino2d.hip
 
 extern "C" int aid_conv2d_stat_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino) {
-    if (x_wino == 3) return aid_conv2d_wino2d_supported(Cin, Cout, F, T, dilF) ? aid_w2d_partials(Cout, F, T, dilF) : 0;
+    if (x_wino == 3 || x_wino == 4) return (aid_conv2d_wino2d_supported(Cin, Cout, F, T, dilF) && (x_wino == 3 || T % 32 == 0)) ? aid_w2d_partials(Cout, F, T, dilF, x_wino == 4 ? 8 : 4) : 0;
     int cip, cop;
     aid_conv2d_pack_dims(Cin, Cout, &cip, &cop);
     if (!x_wino || (Cout % 8) || !wino_v_shape_ok(Cin, Cout, T)) return 0;
@@ -1766,7 +1766,7 @@ extern "C" int aid_conv2d_stat_partials(int B, int Cin, int Cout, int F, int T, 
 
 // tiles per sample of the F(4,3) kernels (64|96 x 512 tiles) when the per-tile <y, aux> partials are well defined
 extern "C" int aid_conv2d_dot_partials(int B, int Cin, int Cout, int F, int T, int dilF, int x_wino) {
-    if (x_wino == 3) return aid_conv2d_wino2d_supported(Cin, Cout, F, T, dilF) ? aid_w2d_partials(Cout, F, T, dilF) : 0;
+    if (x_wino == 3 || x_wino == 4) return (aid_conv2d_wino2d_supported(Cin, Cout, F, T, dilF) && (x_wino == 3 || T % 32 == 0)) ? aid_w2d_partials(Cout, F, T, dilF, x_wino == 4 ? 8 : 4) : 0;
     int cip, cop;
     aid_conv2d_pack_dims(Cin, Cout, &cip, &cop);
     if ((Cin % 4) || Cout < 64 || (Cout % 8) || (T % 4) || aid_pow2ceil(T) < 8) return 0;

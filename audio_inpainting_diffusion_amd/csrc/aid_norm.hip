@@ -550,7 +550,7 @@ int aid_w2d_input(const aid_scale_act_params* p, hipStream_t st);      // aid_wi
 extern "C" int aid_scale_act(const aid_scale_act_params* p, void* stream) {
     AID_REQUIRE(p && p->x.p && p->y.p, "aid_scale_act: null pointer");
     AID_REQUIRE((p->T % 4) == 0, "aid_scale_act: T must be a multiple of 4");
-    if (p->wino == 3) return aid_w2d_input(p, (hipStream_t)stream);       // 2-D form F(4,5) x F(4,3): V [48][C][N]
+    if (p->wino == 3 || p->wino == 4) return aid_w2d_input(p, (hipStream_t)stream);       // 2-D form F(4,5) x F(4,3): V [48][C][N]; wino = 4: F(4,5) x F(8,3), V [80][C][N]
     SaDev a;
     a.p = *p;
     if (p->wino == 2) {

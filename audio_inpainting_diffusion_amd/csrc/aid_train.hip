@@ -1025,11 +1025,12 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const aid_pack_co
     const int64_t n2 = p.wpw ? (int64_t)30 * p.Cin_pad * p.Cout_pad : 0, n3 = p.wpwT ? (int64_t)30 * p.Cin_padT * p.Cout_padT : 0;
     const int64_t n4 = p.wpw8 ? (int64_t)50 * p.Cin_pad * p.Cout_pad : 0, n5 = p.wpw8T ? (int64_t)50 * p.Cin_padT * p.Cout_padT : 0;
     const int64_t n6 = p.wpw2 ? (int64_t)48 * p.Cin_pad * p.Cout_pad : 0, n7 = p.wpw2T ? (int64_t)48 * p.Cin_padT * p.Cout_padT : 0;
+    const int64_t n8 = p.wpw3 ? (int64_t)80 * p.Cin_pad * p.Cout_pad : 0, n9 = p.wpw3T ? (int64_t)80 * p.Cin_padT * p.Cout_padT : 0;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n0 + n1 + n2 + n3 + n4 + n5 + n6 + n7) return;
+    if (i >= n0 + n1 + n2 + n3 + n4 + n5 + n6 + n7 + n8 + n9) return;
     int mode = 0;
     if (i >= n0) { i -= n0; mode = 1; if (i >= n1) { i -= n1; mode = 2; if (i >= n2) { i -= n2; mode = 3; if (i >= n3) { i -= n3; mode = 4; if (i >= n4) { i -= n4; mode = 5;
-        if (i >= n5) { i -= n5; mode = 6; if (i >= n6) { i -= n6; mode = 7; } } } } } } }
+        if (i >= n5) { i -= n5; mode = 6; if (i >= n6) { i -= n6; mode = 7; if (i >= n7) { i -= n7; mode = 8; if (i >= n8) { i -= n8; mode = 9; } } } } } } } } }
     const bool tr = mode & 1;
     const int cip = tr ? p.Cin_padT : p.Cin_pad, cop = tr ? p.Cout_padT : p.Cout_pad;
     const int co = (int)(i % cop);                          // output channel of THIS operator (transposed: the layer's input channel)
@@ -1045,6 +1046,14 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const aid_pack_co
         };
         if (mode < 2) {
             v = W(t / p.KW, t % p.KW);
+        } else if (mode >= 8) {                             // 2-D form with F(8,3) along T: plane t = xf * 10 + xt, U = GF w G8^T (aid_wino45.h rows, aid_wino8.h samples)
+            constexpr double GF[8][5] = AID_W45_GF;
+            constexpr double G8[10][3] = AID_W8_G;
+            const int xf = t / 10, xt = t - 10 * xf;
+            double u = 0.0;
+            for (int kh = 0; kh < 5; ++kh)
+                u += GF[xf][kh] * (G8[xt][0] * (double)W(kh, 0) + G8[xt][1] * (double)W(kh, 1) + G8[xt][2] * (double)W(kh, 2));
+            v = (float)u;
         } else if (mode >= 6) {                             // 2-D form: plane t = xf * 6 + xt, U = GF w GT^T (aid_wino45.h)
             constexpr double GF[8][5] = AID_W45_GF;
             constexpr double GT[6][3] = AID_W45_GT;
@@ -1072,7 +1081,7 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const aid_pack_co
             v = (float)u;
         }
     }
-    float* out = mode == 0 ? p.wp : (mode == 1 ? p.wpT : (mode == 2 ? p.wpw : (mode == 3 ? p.wpwT : (mode == 4 ? p.wpw8 : (mode == 5 ? p.wpw8T : (mode == 6 ? p.wpw2 : p.wpw2T))))));
+    float* out = mode == 0 ? p.wp : (mode == 1 ? p.wpT : (mode == 2 ? p.wpw : (mode == 3 ? p.wpwT : (mode == 4 ? p.wpw8 : (mode == 5 ? p.wpw8T : (mode == 6 ? p.wpw2 : (mode == 7 ? p.wpw2T : (mode == 8 ? p.wpw3 : p.wpw3T))))))));
     out[i] = v;
 }
 
@@ -1083,12 +1092,13 @@ extern "C" int aid_pack_conv_weight(const aid_pack_conv_weight_params* p, void* 
     aid_conv2d_pack_dims(p->Cin, p->Cout, &cip, &cop);
     aid_conv2d_pack_dims(p->Cout, p->Cin, &cipT, &copT);
     AID_REQUIRE(p->Cin_pad == cip && p->Cout_pad == cop && (!p->wpT || (p->Cin_padT == cipT && p->Cout_padT == copT)), "aid_pack_conv_weight: padded dims != aid_conv2d_pack_dims()");
-    AID_REQUIRE((!p->wpw && !p->wpwT && !p->wpw8 && !p->wpw8T && !p->wpw2 && !p->wpw2T) || (p->KH == 5 && p->KW == 3), "aid_pack_conv_weight: the Winograd packs are for 5x3 layers");
-    AID_REQUIRE((!p->wpwT && !p->wpw8T && !p->wpw2T) || p->wpT, "aid_pack_conv_weight: wpwT / wpw8T / wpw2T need wpT's dims");
+    AID_REQUIRE((!p->wpw && !p->wpwT && !p->wpw8 && !p->wpw8T && !p->wpw2 && !p->wpw2T && !p->wpw3 && !p->wpw3T) || (p->KH == 5 && p->KW == 3), "aid_pack_conv_weight: the Winograd packs are for 5x3 layers");
+    AID_REQUIRE((!p->wpwT && !p->wpw8T && !p->wpw2T && !p->wpw3T) || p->wpT, "aid_pack_conv_weight: wpwT / wpw8T / wpw2T / wpw3T need wpT's dims");
     const int K = p->KH * p->KW;
     const int64_t n = (int64_t)K * cip * cop + (p->wpT ? (int64_t)K * cipT * copT : 0) + (p->wpw ? (int64_t)30 * cip * cop : 0) + (p->wpwT ? (int64_t)30 * cipT * copT : 0)
                     + (p->wpw8 ? (int64_t)50 * cip * cop : 0) + (p->wpw8T ? (int64_t)50 * cipT * copT : 0)
-                    + (p->wpw2 ? (int64_t)48 * cip * cop : 0) + (p->wpw2T ? (int64_t)48 * cipT * copT : 0);
+                    + (p->wpw2 ? (int64_t)48 * cip * cop : 0) + (p->wpw2T ? (int64_t)48 * cipT * copT : 0)
+                    + (p->wpw3 ? (int64_t)80 * cip * cop : 0) + (p->wpw3T ? (int64_t)80 * cipT * copT : 0);
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
     AID_CHECK_LAUNCH();
     return AID_OK;

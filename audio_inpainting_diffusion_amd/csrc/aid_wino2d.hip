@@ -10,8 +10,15 @@
 // Position index n = b * NB + (j * dil + r) * (T/4) + g:  4 x 4 output block of rows r + dil (4j .. 4j+3), samples 4g .. 4g+3 of sample b.
 // Error (tools/wino2d_fm5_error.py, profiles/r04_wino2d_fm5_error.txt): 2.2e-6 .. 4.3e-6 rel-L2 per layer, below the shipped F(8,3) kernel.
 // Matrices: tools/gen_wino45.py -> aid_wino45.h.
+//
+// Round 6: the T axis may also take F(8,3) (x_wino = 4; the ten-point transform of aid_wino8.h, the one the fused F(8,3) kernel uses): F(4,5) x F(8,3) has
+// 8 x 10 = 80 products per 4 x 8 outputs = 2.5 per output (-17 % MFMAs) and its Winograd-domain tensors are 80 / 32 = 2.5 x the activation instead of 3 x
+// (-17 % of the GEMM's bytes, -12 % / -9 % of the passes').  Same three kernels, templated on the T form TF = 4 | 8: NTP = TF + 2 planes along T,
+// groups of TF samples (TG = T / TF), xi = xf * NTP + xt, position index as above with T/TF groups per row.  fp32 error 1.0e-5 (K = 128) / 1.3e-5 (K = 256)
+// per layer (tools/wino2d_fm5_error.py --tf 8, profiles/r06_wino2d_f45x83_error.txt) against 2.8 / 4.3e-6 for F(4,5) x F(4,3).
 #include "aid_common.h"
 #include "aid_wino45.h"
+#include "aid_wino8.h"
 #include "aid_fin.h"
 #include <type_traits>
 #include <utility>
@@ -392,7 +399,8 @@ extern "C" int aid_wino2d_set_split(int pieces) {
 }
 
 template <int MT, int NT, int WGM, int WGN, int KC, int NBUF, int WPC>
-static int w2d_launch_gemm(const aid_wino2d_gemm_params* p, hipStream_t st, const char* name) {
+static int w2d_launch_gemm(const aid_wino2d_gemm_params* p, hipStream_t st, const char* name, const char* name8 = nullptr) {
+    if (!name8) name8 = name;
     using S = W2dGemmShape<MT, NT, WGM, WGN, KC, NBUF>;
     AID_REQUIRE(p->Cin % KC == 0, "aid_wino2d_gemm: Cin must be a multiple of the K chunk");
     AID_REQUIRE(p->Cout_pad % S::M_BLK == 0, "aid_wino2d_gemm: Cout_pad must be a multiple of the M tile");
@@ -407,7 +415,7 @@ static int w2d_launch_gemm(const aid_wino2d_gemm_params* p, hipStream_t st, cons
     a.per_xcd = aid_cdiv(a.ntiles, 8);
     hipLaunchKernelGGL((w2d_gemm_kernel<MT, NT, WGM, WGN, KC, NBUF, WPC>), dim3((unsigned)(8 * a.per_xcd)), dim3(64 * S::NW), 0, st, a);
     AID_CHECK_LAUNCH();
-    aid_note_kernel(name);
+    aid_note_kernel(p->nxi == 80 ? name8 : name);          // (bench.py prices the launch by the form: 48 planes = 1/5, 80 planes = 1/6 of the direct-form FLOPs)
     return AID_OK;
 }
 
@@ -427,7 +435,7 @@ extern "C" int aid_wino2d_gemm(const aid_wino2d_gemm_params* p, void* stream) {
         variant = tiles < 1600 ? 11 : 12;
     }
     switch (variant) {
-        case 12: return w2d_launch_gemm<2, 4, 2, 2, 16, 3, 2>(p, st, "w2d_gemm_kernel<128x256,kc16,nb3>");
+        case 12: return w2d_launch_gemm<2, 4, 2, 2, 16, 3, 2>(p, st, "w2d_gemm_kernel<128x256,kc16,nb3>", "w2d_gemm_kernel<128x256,kc16,nb3>+t8");
 #ifdef AID_EXPERIMENT       // tile-shape probes of round 5 (tools/w2d_probe.py gemm, profiles/r05_w2d_gemm_probe1.txt): -DAID_EXPERIMENT builds only
         case 1: return w2d_launch_gemm<2, 4, 2, 2, 8, 3, 2>(p, st, "w2d_gemm_kernel<128x256,kc8,nb3>");
         case 2: return w2d_launch_gemm<2, 4, 2, 2, 16, 2, 2>(p, st, "w2d_gemm_kernel<128x256,kc16,nb2>");
@@ -441,7 +449,7 @@ extern "C" int aid_wino2d_gemm(const aid_wino2d_gemm_params* p, void* stream) {
         case 10: return w2d_launch_gemm<4, 2, 2, 2, 8, 4, 2>(p, st, "w2d_gemm_kernel<256x128,kc8,nb4>");
         case 102: return w2d_launch_gemm_s6<2, 4, 2, 2, 2, 2>(p, st, "w2d_gemm_s6_kernel<128x256,nb2>");
 #endif
-        case 11: return w2d_launch_gemm<2, 2, 2, 2, 16, 2, 4>(p, st, "w2d_gemm_kernel<128x128,kc16,nb2,wpc4>");
+        case 11: return w2d_launch_gemm<2, 2, 2, 2, 16, 2, 4>(p, st, "w2d_gemm_kernel<128x128,kc16,nb2,wpc4>", "w2d_gemm_kernel<128x128,kc16,nb2,wpc4>+t8");
         case 100: return w2d_launch_gemm_s6<2, 4, 2, 2, 3, 2>(p, st, "w2d_gemm_s6_kernel<128x256,nb3>");
         case 101: return w2d_launch_gemm_s6<2, 2, 2, 2, 3, 3>(p, st, "w2d_gemm_s6_kernel<128x128,nb3,wpc3>");
         default: break;
@@ -456,11 +464,12 @@ extern "C" int aid_wino2d_gemm(const aid_wino2d_gemm_params* p, void* stream) {
 // NB = J * dil * TG positions per sample, N = B * NB.  Position n' = (j * dil + r) * TG + g.
 // =====================================================================================================================================
 struct W2dGeo { int R, J, TG, NB; int64_t N; };
-static inline W2dGeo w2d_geo(int B, int F, int T, int dil) {
+static inline W2dGeo w2d_geo(int B, int F, int T, int dil, int TF = 4) {
     W2dGeo g;
-    g.R = F / dil; g.J = (g.R + 3) / 4; g.TG = T / 4; g.NB = g.J * dil * g.TG; g.N = (int64_t)B * g.NB;
+    g.R = F / dil; g.J = (g.R + 3) / 4; g.TG = T / TF; g.NB = g.J * dil * g.TG; g.N = (int64_t)B * g.NB;
     return g;
 }
+static inline int w2d_tf_of(int x_wino) { return x_wino == 4 ? 8 : 4; }          // aid_conv2d_params::x_wino / aid_scale_act_params::wino: 3 -> F(4,3), 4 -> F(8,3) along T
 static inline bool w2d_shape_ok(int Cin, int Cout, int F, int T, int dil) {
     return dil >= 1 && (F % dil) == 0 && (T % 16) == 0 && T >= 16 && T <= 2048 && (Cin % 16) == 0 && (Cout % 128) == 0 && Cin >= 64;
 }
@@ -484,7 +493,9 @@ struct W2dInDev {
     int64_t N;
 };
 
+template <int TF>
 __global__ __launch_bounds__(256) void w2d_input_kernel(const W2dInDev a) {
+    constexpr int NTP = TF + 2;                           // planes along T: 6 (F(4,3)) or 10 (F(8,3))
     extern __shared__ __attribute__((aligned(16))) float w2d_slab[];
     int rest = blockIdx.x;
     const int jbk = rest % a.njb; rest /= a.njb;
@@ -521,36 +532,40 @@ __global__ __launch_bounds__(256) void w2d_input_kernel(const W2dInDev a) {
     for (int tl = tid; tl < ntile; tl += 256) {
         const int jl = tl / per_j, rem = tl - jl * per_j;
         const int rl = rem / a.TG, g = rem - rl * a.TG;
-        const float* sp = w2d_slab + (4 * jl) * a.rowf + rl * a.T + 4 * g;
-        float W[8][6];
+        const float* sp = w2d_slab + (4 * jl) * a.rowf + rl * a.T + TF * g;
+        float W[8][NTP];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float* row = sp + i * a.rowf;
-            const float4 v = *reinterpret_cast<const float4*>(row);
-            float d[6];
+            float d[NTP];
             d[0] = g > 0 ? row[-1] : 0.f;
-            d[1] = v.x; d[2] = v.y; d[3] = v.z; d[4] = v.w;
-            d[5] = g < a.TG - 1 ? row[4] : 0.f;
-            aid_w45_input_t(d, W[i]);
+#pragma unroll
+            for (int q = 0; q < TF / 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(row + 4 * q);
+                d[1 + 4 * q] = v.x; d[2 + 4 * q] = v.y; d[3 + 4 * q] = v.z; d[4 + 4 * q] = v.w;
+            }
+            d[TF + 1] = g < a.TG - 1 ? row[TF] : 0.f;
+            if constexpr (TF == 4) aid_w45_input_t(d, W[i]); else aid_wino8_input(d, W[i]);
         }
         float* vp = a.V + (int64_t)c * a.N + (int64_t)b * a.NB + (int64_t)((j0 + jl) * a.dil + r0 + rl) * a.TG + g;
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
+        for (int t = 0; t < NTP; ++t) {
             float d[8], Vo[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) d[i] = W[i][t];
             aid_w45_input_f(d, Vo);
 #pragma unroll
-            for (int f = 0; f < 8; ++f) vp[(int64_t)(f * 6 + t) * pstride] = Vo[f];
+            for (int f = 0; f < 8; ++f) vp[(int64_t)(f * NTP + t) * pstride] = Vo[f];
         }
     }
 }
 
-// called by aid_scale_act (aid_norm.hip) for wino == 3
+// called by aid_scale_act (aid_norm.hip) for wino == 3 (F(4,3) along T) and wino == 4 (F(8,3) along T)
 int aid_w2d_input(const aid_scale_act_params* p, hipStream_t st) {
-    AID_REQUIRE(p->dilF >= 1 && (p->F % p->dilF) == 0 && (p->T % 16) == 0 && p->T <= 2048, "aid_scale_act(wino=3): F % dilF == 0, T % 16 == 0, T <= 2048");
+    const int TF = w2d_tf_of(p->wino);
+    AID_REQUIRE(p->dilF >= 1 && (p->F % p->dilF) == 0 && (p->T % 16) == 0 && p->T <= 2048, "aid_scale_act(wino=3|4): F % dilF == 0, T % 16 == 0, T <= 2048");
     AID_REQUIRE((p->x.sB % 4) == 0 && (p->x.sC % 4) == 0 && (p->x.sF % 4) == 0 && (((uintptr_t)p->x.p) & 15) == 0, "aid_scale_act(wino=3): 16-byte aligned input rows");
-    const W2dGeo ge = w2d_geo(p->B, p->F, p->T, p->dilF);
+    const W2dGeo ge = w2d_geo(p->B, p->F, p->T, p->dilF, TF);
     AID_REQUIRE(ge.N < (1LL << 31), "aid_scale_act(wino=3): too many positions");
     W2dInDev a;
     a.x = p->x; a.scale = p->scale; a.scale_ld = p->scale_ld; a.V = p->y.p;
@@ -571,7 +586,8 @@ int aid_w2d_input(const aid_scale_act_params* p, hipStream_t st) {
     const int64_t nblk = (int64_t)p->B * p->C * a.nrb * a.njb;
     AID_REQUIRE(nblk < (1LL << 31), "aid_scale_act(wino=3): grid too large");
     const size_t lds = (size_t)(4 * JB + 4) * a.rowf * 4;
-    hipLaunchKernelGGL(w2d_input_kernel, dim3((unsigned)nblk), dim3(256), lds, st, a);
+    if (TF == 8) hipLaunchKernelGGL(w2d_input_kernel<8>, dim3((unsigned)nblk), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(w2d_input_kernel<4>, dim3((unsigned)nblk), dim3(256), lds, st, a);
     AID_CHECK_LAUNCH();
     return AID_OK;
 }
@@ -597,14 +613,20 @@ struct W2dOutDev {
 // T planes and applies the T transform first (6 -> 4 samples per group), then accumulates the four output rows with the row-axis coefficients
 // (the +- pairs of AF^T: s = a + b, t = a - b) -- 32 accumulators instead of the 96 of a row-transform-first order, ~90 registers, so that eight
 // waves per SIMD keep loads in flight and the pass's waves fit beside the two resident GEMM workgroups of another stream.
+// TF = 8 (F(8,3) along T): ONE group of eight samples per thread (GP = 1; 4-byte loads of the 80 planes): the two-group form needs 240 registers.
+#define W2D_GP(TF) ((TF) == 8 ? 1 : 2)
+template <int TF>
 __global__ __launch_bounds__(256) void w2d_output_kernel(const W2dOutDev a) {
+    constexpr int NTP = TF + 2;                           // planes along T
+    constexpr int GP = W2D_GP(TF);                        // groups per thread
+    constexpr int NS = GP * TF;                           // output samples per row of this thread
     const aid_conv2d_params& p = a.p;
     int rest = blockIdx.x;
     const int blk = rest % a.nblk; rest /= a.nblk;
     const int co = rest % p.Cout;
     const int b = rest / p.Cout;
     const int tid = threadIdx.x;
-    const int np = (blk * 256 + tid) * 2;                 // first of this thread's 2 positions within the sample
+    const int np = (blk * 256 + tid) * GP;                // first of this thread's GP positions within the sample
     const bool live = np < a.NB;
     float s1 = 0.f, s2 = 0.f, sd = 0.f;
     if (live) {
@@ -612,36 +634,43 @@ __global__ __launch_bounds__(256) void w2d_output_kernel(const W2dOutDev a) {
         const int j = q / p.dilF, r = q - j * p.dilF;
         const float* mp = a.M + ((int64_t)co * a.N + (int64_t)b * a.NB + np);
         const int64_t pstride = (int64_t)p.Cout * a.N;
-        float Y[4][8];
-        auto plane = [&](int f, float* o) {                // T transform of row-axis plane f: 2 groups x 4 samples
-            float2 m[6];
+        float Y[4][NS];
+        auto plane = [&](int f, float* o) {                // T transform of row-axis plane f: GP groups x TF samples
+            if constexpr (GP == 2) {
+                float2 m[NTP];
 #pragma unroll
-            for (int t = 0; t < 6; ++t) m[t] = *reinterpret_cast<const float2*>(mp + (int64_t)(f * 6 + t) * pstride);
-            float Mt[6];
+                for (int t = 0; t < NTP; ++t) m[t] = *reinterpret_cast<const float2*>(mp + (int64_t)(f * NTP + t) * pstride);
+                float Mt[NTP];
 #pragma unroll
-            for (int t = 0; t < 6; ++t) Mt[t] = m[t].x;
-            aid_w45_output_t(Mt, o);
+                for (int t = 0; t < NTP; ++t) Mt[t] = m[t].x;
+                if constexpr (TF == 4) aid_w45_output_t(Mt, o); else aid_wino8_output(Mt, o);
 #pragma unroll
-            for (int t = 0; t < 6; ++t) Mt[t] = m[t].y;
-            aid_w45_output_t(Mt, o + 4);
+                for (int t = 0; t < NTP; ++t) Mt[t] = m[t].y;
+                if constexpr (TF == 4) aid_w45_output_t(Mt, o + TF); else aid_wino8_output(Mt, o + TF);
+            } else {
+                float Mt[NTP];
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) Mt[t] = mp[(int64_t)(f * NTP + t) * pstride];
+                if constexpr (TF == 4) aid_w45_output_t(Mt, o); else aid_wino8_output(Mt, o);
+            }
         };
         {
-            float a0[8], a1[8], a2[8];
+            float a0[NS], a1[NS], a2[NS];
             plane(0, a0); plane(1, a1); plane(2, a2);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float s = a1[e] + a2[e], t = a1[e] - a2[e]; Y[0][e] = a0[e] + s; Y[1][e] = t; Y[2][e] = s; Y[3][e] = t; }
+            for (int e = 0; e < NS; ++e) { const float s = a1[e] + a2[e], t = a1[e] - a2[e]; Y[0][e] = a0[e] + s; Y[1][e] = t; Y[2][e] = s; Y[3][e] = t; }
         }
         {
-            float a1[8], a2[8];
+            float a1[NS], a2[NS];
             plane(3, a1); plane(4, a2);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float s = a1[e] + a2[e], t = a1[e] - a2[e]; Y[0][e] += s; Y[1][e] += 2.0f * t; Y[2][e] += 4.0f * s; Y[3][e] += 8.0f * t; }
+            for (int e = 0; e < NS; ++e) { const float s = a1[e] + a2[e], t = a1[e] - a2[e]; Y[0][e] += s; Y[1][e] += 2.0f * t; Y[2][e] += 4.0f * s; Y[3][e] += 8.0f * t; }
         }
         {
-            float a1[8], a2[8], a7[8];
+            float a1[NS], a2[NS], a7[NS];
             plane(5, a1); plane(6, a2); plane(7, a7);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float s = a1[e] + a2[e], t = a1[e] - a2[e]; Y[0][e] += s; Y[1][e] += 0.5f * t; Y[2][e] += 0.25f * s; Y[3][e] += 0.125f * t + a7[e]; }
+            for (int e = 0; e < NS; ++e) { const float s = a1[e] + a2[e], t = a1[e] - a2[e]; Y[0][e] += s; Y[1][e] += 0.5f * t; Y[2][e] += 0.25f * s; Y[3][e] += 0.125f * t + a7[e]; }
         }
         const float sv = p.out_scale ? p.out_scale[(int64_t)b * p.out_scale_ld + co] : 1.f;
         const float as = p.epi == 1 ? p.aux_scale[(int64_t)b * p.aux_scale_ld + co] : 0.f;
@@ -650,28 +679,34 @@ __global__ __launch_bounds__(256) void w2d_output_kernel(const W2dOutDev a) {
             const int jj = 4 * j + i;
             if (jj >= a.R) continue;
             const int f = r + jj * p.dilF;
-            const int t0 = 4 * g0;
+            const int t0 = TF * g0;
             float* yp = p.y.p + (int64_t)b * p.y.sB + (int64_t)co * p.y.sC + (int64_t)f * p.y.sF + t0;
-            float rr[8], uu[8];
+            float rr[NS], uu[NS];
             if (p.res.p) {
                 const float* rp = p.res.p + (int64_t)b * p.res.sB + (int64_t)co * p.res.sC + (int64_t)f * p.res.sF + t0;
-                const float4 v0 = *reinterpret_cast<const float4*>(rp), v1 = *reinterpret_cast<const float4*>(rp + 4);
-                rr[0] = v0.x; rr[1] = v0.y; rr[2] = v0.z; rr[3] = v0.w; rr[4] = v1.x; rr[5] = v1.y; rr[6] = v1.z; rr[7] = v1.w;
+#pragma unroll
+                for (int v4 = 0; v4 < NS / 4; ++v4) {
+                    const float4 v = *reinterpret_cast<const float4*>(rp + 4 * v4);
+                    rr[4 * v4] = v.x; rr[4 * v4 + 1] = v.y; rr[4 * v4 + 2] = v.z; rr[4 * v4 + 3] = v.w;
+                }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) rr[e] = 0.f;
+                for (int e = 0; e < NS; ++e) rr[e] = 0.f;
             }
             if (p.aux.p) {
                 const float* up = p.aux.p + (int64_t)b * p.aux.sB + (int64_t)co * p.aux.sC + (int64_t)f * p.aux.sF + t0;
-                const float4 v0 = *reinterpret_cast<const float4*>(up), v1 = *reinterpret_cast<const float4*>(up + 4);
-                uu[0] = v0.x; uu[1] = v0.y; uu[2] = v0.z; uu[3] = v0.w; uu[4] = v1.x; uu[5] = v1.y; uu[6] = v1.z; uu[7] = v1.w;
+#pragma unroll
+                for (int v4 = 0; v4 < NS / 4; ++v4) {
+                    const float4 v = *reinterpret_cast<const float4*>(up + 4 * v4);
+                    uu[4 * v4] = v.x; uu[4 * v4 + 1] = v.y; uu[4 * v4 + 2] = v.z; uu[4 * v4 + 3] = v.w;
+                }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) uu[e] = 0.f;
+                for (int e = 0; e < NS; ++e) uu[e] = 0.f;
             }
-            float y[8];
+            float y[NS];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < NS; ++e) {
                 float v = Y[i][e] * sv;
                 if (p.epi == 1) v *= aid_dgelu(uu[e] * as);
                 v += p.res_scale * rr[e];
@@ -679,8 +714,8 @@ __global__ __launch_bounds__(256) void w2d_output_kernel(const W2dOutDev a) {
                 y[e] = v;
                 s1 += v; s2 += v * v; sd += v * uu[e];
             }
-            *reinterpret_cast<float4*>(yp) = make_float4(y[0], y[1], y[2], y[3]);
-            *reinterpret_cast<float4*>(yp + 4) = make_float4(y[4], y[5], y[6], y[7]);
+#pragma unroll
+            for (int v4 = 0; v4 < NS / 4; ++v4) *reinterpret_cast<float4*>(yp + 4 * v4) = make_float4(y[4 * v4], y[4 * v4 + 1], y[4 * v4 + 2], y[4 * v4 + 3]);
         }
     }
     if (!p.stat_ws && !p.dot_ws) return;
@@ -725,7 +760,7 @@ __global__ __launch_bounds__(256) void w2d_output_kernel(const W2dOutDev a) {
     }
 }
 
-static inline int w2d_nblk(int NB) { return (NB / 4 + 127) / 128; }
+static inline int w2d_nblk(int NB, int TF) { return (NB + 256 * W2D_GP(TF) - 1) / (256 * W2D_GP(TF)); }      // blocks of 256 threads x GP positions per sample and channel
 
 extern "C" int aid_conv2d_wino2d_supported(int Cin, int Cout, int F, int T, int dilF) { return w2d_shape_ok(Cin, Cout, F, T, dilF) ? 1 : 0; }
 // Which launches take the 2-D form instead of the fused 1-D kernels.  Measured per layer (tools/w2d_probe.py layer, profiles/r05_w2d_passes_ab.txt,
@@ -747,13 +782,23 @@ extern "C" int aid_conv2d_wino2d_wanted(int B, int Cin, int Cout, int F, int T, 
     if (T <= 256) return 1;
     return (int64_t)B * F * T <= 2 * 65536 ? 1 : 0;
 }
+extern "C" int aid_conv2d_wino2d_wanted(int B, int Cin, int Cout, int F, int T, int dilF);
 extern "C" int64_t aid_conv2d_wino2d_positions(int B, int F, int T, int dilF) { return (dilF >= 1 && F % dilF == 0 && T % 4 == 0) ? w2d_geo(B, F, T, dilF).N : 0; }
 // per-(sample, group) partial count of stat_ws / dot_ws for x_wino = 3
-int aid_w2d_partials(int Cout, int F, int T, int dilF) { return (Cout >> 3) * w2d_nblk(w2d_geo(1, F, T, dilF).NB); }
+int aid_w2d_partials(int Cout, int F, int T, int dilF, int TF) { return (Cout >> 3) * w2d_nblk(w2d_geo(1, F, T, dilF, TF).NB, TF); }
+
+// Which T form the 2-D form of a launch should take: 0 = the launch is not for the 2-D form at all (aid_conv2d_wino2d_wanted == 0), 4 = F(4,5) x F(4,3)
+// (x_wino = 3, 48 planes), 8 = F(4,5) x F(8,3) (x_wino = 4, 80 planes: 2.5 instead of 3.0 products per output and 2.5 x instead of 3 x the activation in V / M).
+// F(8,3) wherever a row has at least two groups of eight per ... [measured: profiles/r06_w2d_tf8_layer_ab.txt]; a function of the launch shape.
+extern "C" int aid_conv2d_wino2d_tform(int B, int Cin, int Cout, int F, int T, int dilF) {
+    if (!aid_conv2d_wino2d_wanted(B, Cin, Cout, F, T, dilF)) return 0;
+    return (T % 32) == 0 ? 8 : 4;                            // (T / 8 groups per row, a multiple of 4: the GEMM's N % 4 == 0)
+}
 
 // aid_conv2d with x_wino = 3: x.p = V [48][Cin][N], wp_wino = U [48][Cin_pad][Cout_pad], ws = scratch for M [48][Cout][N]
 static int w2d_check(const aid_conv2d_params* p) {
-    AID_REQUIRE(p->KH == 5 && p->KW == 3 && p->wp_wino && p->wino_taps == 48, "aid_conv2d(x_wino=3): needs the 48-plane pack (aid_pack_conv_weight wpw2)");
+    const int TF = w2d_tf_of(p->x_wino), NXI = 8 * (TF + 2);
+    AID_REQUIRE(p->KH == 5 && p->KW == 3 && p->wp_wino && p->wino_taps == NXI, "aid_conv2d(x_wino=3|4): needs the 48- / 80-plane pack (aid_pack_conv_weight wpw2 / wpw3)");
     AID_REQUIRE(w2d_shape_ok(p->Cin, p->Cout, p->F, p->T, p->dilF), "aid_conv2d(x_wino=3): shape not supported (aid_conv2d_wino2d_supported)");
     AID_REQUIRE(!p->in_scale && p->act == 0 && !p->x2.p, "aid_conv2d(x_wino=3): no in-kernel prologue, no x2");
     if (p->fin_mode) {                                       // the last block of a sample folds the partials (aid_conv2d_fin_supported(.., 3) == 1)
@@ -764,30 +809,33 @@ static int w2d_check(const aid_conv2d_params* p) {
     }
     AID_REQUIRE(!(p->stat_ws && p->dot_ws), "aid_conv2d(x_wino=3): stat_ws and dot_ws are exclusive");
     AID_REQUIRE(!p->dot_ws || p->epi == 1, "aid_conv2d(x_wino=3): dot_ws goes with the dGELU epilogue");
-    const W2dGeo ge = w2d_geo(p->B, p->F, p->T, p->dilF);
-    AID_REQUIRE(p->ws && p->ws_bytes >= (int64_t)48 * p->Cout * ge.N * 4 && (((uintptr_t)p->ws) & 15) == 0, "aid_conv2d(x_wino=3): ws must hold 48 * Cout * N floats");
+    const W2dGeo ge = w2d_geo(p->B, p->F, p->T, p->dilF, TF);
+    AID_REQUIRE(p->ws && p->ws_bytes >= (int64_t)NXI * p->Cout * ge.N * 4 && (((uintptr_t)p->ws) & 15) == 0, "aid_conv2d(x_wino=3|4): ws must hold 48 (80) * Cout * N floats");
     AID_REQUIRE((p->y.sB % 4) == 0 && (p->y.sC % 4) == 0 && (p->y.sF % 4) == 0 && (((uintptr_t)p->y.p) & 15) == 0, "aid_conv2d(x_wino=3): 16-byte aligned output rows");
     AID_REQUIRE(!p->res.p || ((p->res.sB % 4) == 0 && (p->res.sC % 4) == 0 && (p->res.sF % 4) == 0 && (((uintptr_t)p->res.p) & 15) == 0), "aid_conv2d(x_wino=3): 16-byte aligned residual rows");
     AID_REQUIRE(!p->aux.p || ((p->aux.sB % 4) == 0 && (p->aux.sC % 4) == 0 && (p->aux.sF % 4) == 0 && (((uintptr_t)p->aux.p) & 15) == 0), "aid_conv2d(x_wino=3): 16-byte aligned aux rows");
-    const int npart = aid_w2d_partials(p->Cout, p->F, p->T, p->dilF);
+    const int npart = aid_w2d_partials(p->Cout, p->F, p->T, p->dilF, TF);
     AID_REQUIRE(!p->stat_ws || p->stat_n == npart, "aid_conv2d(x_wino=3): stat_n != aid_conv2d_stat_partials()");
     AID_REQUIRE(!p->dot_ws || p->dot_n == npart, "aid_conv2d(x_wino=3): dot_n != aid_conv2d_dot_partials()");
     return AID_OK;
 }
 static int w2d_gemm_of(const aid_conv2d_params* p, hipStream_t st) {
-    const W2dGeo ge = w2d_geo(p->B, p->F, p->T, p->dilF);
+    const int TF = w2d_tf_of(p->x_wino);
+    const W2dGeo ge = w2d_geo(p->B, p->F, p->T, p->dilF, TF);
     aid_wino2d_gemm_params gp;
     gp.U = p->wp_wino; gp.V = p->x.p; gp.M = p->ws;
-    gp.nxi = 48; gp.Cin = p->Cin; gp.Cout = p->Cout; gp.Cin_pad = p->Cin_pad; gp.Cout_pad = p->Cout_pad; gp.N = ge.N; gp.variant = 0;
+    gp.nxi = 8 * (TF + 2); gp.Cin = p->Cin; gp.Cout = p->Cout; gp.Cin_pad = p->Cin_pad; gp.Cout_pad = p->Cout_pad; gp.N = ge.N; gp.variant = 0;
     return aid_wino2d_gemm(&gp, st);
 }
 static int w2d_output_of(const aid_conv2d_params* p, hipStream_t st) {
-    const W2dGeo ge = w2d_geo(p->B, p->F, p->T, p->dilF);
+    const int TF = w2d_tf_of(p->x_wino);
+    const W2dGeo ge = w2d_geo(p->B, p->F, p->T, p->dilF, TF);
     W2dOutDev a;
     a.p = *p; a.M = p->ws;
-    a.R = ge.R; a.J = ge.J; a.TG = ge.TG; a.NB = ge.NB; a.N = ge.N; a.nblk = w2d_nblk(ge.NB);
+    a.R = ge.R; a.J = ge.J; a.TG = ge.TG; a.NB = ge.NB; a.N = ge.N; a.nblk = w2d_nblk(ge.NB, TF);
     a.fin_total = p->Cout * a.nblk;
-    hipLaunchKernelGGL(w2d_output_kernel, dim3((unsigned)((int64_t)p->B * p->Cout * a.nblk)), dim3(256), 0, st, a);
+    if (TF == 8) hipLaunchKernelGGL(w2d_output_kernel<8>, dim3((unsigned)((int64_t)p->B * p->Cout * a.nblk)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(w2d_output_kernel<4>, dim3((unsigned)((int64_t)p->B * p->Cout * a.nblk)), dim3(256), 0, st, a);
     AID_CHECK_LAUNCH();
     return AID_OK;
 }
@@ -801,12 +849,12 @@ int aid_conv53_wino2d(const aid_conv2d_params* p, hipStream_t st) {
 // The two launches of aid_conv2d(x_wino = 3) as separate calls on the same parameter block (a launch plan that wants the MFMA-bound GEMM and the
 // HBM-bound output pass as separate nodes: per-kernel timing, different streams).  _gemm then _output on one stream == aid_conv2d(p).
 extern "C" int aid_conv2d_wino2d_gemm(const aid_conv2d_params* p, void* stream) {
-    AID_REQUIRE(p && p->x.p && p->y.p && p->x_wino == 3, "aid_conv2d_wino2d_gemm: x_wino = 3 parameters");
+    AID_REQUIRE(p && p->x.p && p->y.p && (p->x_wino == 3 || p->x_wino == 4), "aid_conv2d_wino2d_gemm: x_wino = 3 | 4 parameters");
     const int rc = w2d_check(p);
     return rc != AID_OK ? rc : w2d_gemm_of(p, (hipStream_t)stream);
 }
 extern "C" int aid_conv2d_wino2d_output(const aid_conv2d_params* p, void* stream) {
-    AID_REQUIRE(p && p->x.p && p->y.p && p->x_wino == 3, "aid_conv2d_wino2d_output: x_wino = 3 parameters");
+    AID_REQUIRE(p && p->x.p && p->y.p && (p->x_wino == 3 || p->x_wino == 4), "aid_conv2d_wino2d_output: x_wino = 3 | 4 parameters");
     const int rc = w2d_check(p);
     if (rc != AID_OK) return rc;
     aid_note_kernel("w2d_output_kernel");

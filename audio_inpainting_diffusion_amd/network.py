@@ -30,6 +30,10 @@ import torch.nn as nn
 from . import _lib
 from .cqt import CQTransform
 
+# Winograd forms of a 5x3 layer -> aid_conv2d_params::x_wino / aid_scale_act_params::wino.  4 = F(4,3), 8 = F(8,3) (fused 1-D kernels); the non-fused 2-D forms:
+# 45 = F(4,5) x F(4,3) (48 planes), 85 = F(4,5) x F(8,3) (80 planes over groups of eight samples: round 6)
+XW_CODE = {0: 0, 4: 1, 8: 2, 45: 3, 85: 4}
+W2D_PLANES = {45: 48, 85: 80}
 RSQRT2 = 1.0 / math.sqrt(2.0)
 SQRT2 = math.sqrt(2.0)
 _CUBIC = (-0.01171875, -0.03515625, 0.11328125, 0.43359375, 0.43359375, 0.11328125, -0.03515625, -0.01171875)
@@ -323,7 +327,7 @@ class _Builder:
         """The output pass of the 2-D form has thousands of short blocks per sample, each of which would publish its partial past the L2 and bump the
         sample's arrival counter: measured neutral at batch 1 and -0.4 % at batch 8 (profiles/r05_fin2d_ab.txt) -- taken for launches of at most two
         samples, where the fold launch it removes is a larger share of the evaluation; the row-shared kernels (few large tiles) always take it."""
-        return x_wino != 3 or B <= 2
+        return x_wino not in (3, 4) or B <= 2
 
     def _fin_count(self, lane):
         """arrival counters of the fused finalisation (aid_kernels.h: fin_count): one zeroed word per sample and lane (launches of a lane are serial and
@@ -410,11 +414,12 @@ class _Builder:
         """``x_wino``: 0 plain activations, 4 / 8: ``x`` is the F(4,3) / F(8,3) input transform and ``wpw`` the matching 30- / 50-tap pack."""
         B, _, F, T = y.shape
         x_wino = int(x_wino)
-        xw_code = {0: 0, 4: 1, 8: 2, 45: 3}[x_wino]          # aid_conv2d_params::x_wino
+        xw_code = XW_CODE[x_wino]                            # aid_conv2d_params::x_wino
         p = _lib.Conv2dParams()
-        if x_wino == 45:                                     # 2-D form: x is the flat V [48][cin][N] of aid_scale_act(wino = 3)
-            npos = int(_lib.lib().aid_conv2d_wino2d_positions(B, F, T, dil))
-            assert x.dim() == 1 and x.numel() == 48 * cin * npos and x2 is None and in_scale is None and not act
+        nxi = W2D_PLANES.get(x_wino, 0)
+        if nxi:                                              # 2-D form: x is the flat V [48 | 80][cin][N] of aid_scale_act(wino = 3 | 4)
+            npos = self._w2d_positions(x_wino, B, F, T, dil)
+            assert x.dim() == 1 and x.numel() == nxi * cin * npos and x2 is None and in_scale is None and not act
             p.x = _lib.View(x.data_ptr(), 0, 0, 0)
         else:
             assert x.shape[1] + (0 if x2 is None else x2.shape[1]) == cin and y.shape[1] == cout and x.shape[0] == B and x.shape[2] == F
@@ -445,8 +450,8 @@ class _Builder:
         if F == 1 and kh == 1 and epi == 0:              # qk projections: few columns, long K -> split-K scratch (aid_kernels.h)
             ws = self._scratch(("ws", 8 * B * cout * T))
             p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
-        elif x_wino == 45:                               # the GEMM's output M [48][cout][N], read back by the output-transform pass of the same call
-            ws = self._scratch(("m45", 48 * cout * npos))
+        elif nxi:                                        # the GEMM's output M [48 | 80][cout][N], read back by the output-transform pass of the same call
+            ws = self._scratch(("m45", nxi * cout * npos))
             p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
         elif x_wino == 4 and B == 1 and self.whole_batch:     # a WHOLE batch of one (never a sub-batch: a segment's bits must not depend on the split):
                                                          # launches with few tiles share the K axis of a tile between two workgroups
@@ -454,16 +459,16 @@ class _Builder:
             if need:
                 ws = self._split_ws(need)
                 p.ws, p.ws_bytes = ws.data_ptr(), ws.numel() * 4
-        assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] == {8: 50, 45: 48}.get(x_wino, 30) and wpw.shape[1:] == wp.shape[1:]))
+        assert wp.shape[0] == kh * kw and (wpw is None or (wpw.shape[0] == {8: 50, 45: 48, 85: 80}.get(x_wino, 30) and wpw.shape[1:] == wp.shape[1:]))
         # algorithmic HBM bytes: x once, residual / aux once, y once, weights once
         nb = 4 * (B * F * T * (cin + cout * (1 + (res is not None) + (aux is not None))) + cin * cout * kh * kw)
         dws = None if dot is None else dot[0]
-        if x_wino == 45:
+        if nxi:
             # two plan nodes on one parameter block: the MFMA-bound batched GEMM M = U V (its FLOPs and the bytes of V + M are booked here) and the
             # HBM-bound output-transform pass with the epilogue (reads M, residual / aux; writes y and the partials)
-            self._add("aid_conv2d_wino2d_gemm", p, x, wpw, ws, flops=2 * B * F * T * cin * cout * kh * kw, nbytes=4 * 48 * npos * (cin + cout), writes=(ws,))
+            self._add("aid_conv2d_wino2d_gemm", p, x, wpw, ws, flops=2 * B * F * T * cin * cout * kh * kw, nbytes=4 * nxi * npos * (cin + cout), writes=(ws,))
             op = self._add("aid_conv2d_wino2d_output", p, ws, y, res, out_scale, aux, aux_scale, dws, fin_stats, cnt,
-                           nbytes=4 * (48 * npos * cout + B * F * T * cout * (1 + (res is not None) + (aux is not None))), writes=(y, dws, cnt))
+                           nbytes=4 * (nxi * npos * cout + B * F * T * cout * (1 + (res is not None) + (aux is not None))), writes=(y, dws, cnt))
         else:
             op = self._add("aid_conv2d", p, x, x2, y, res, wp, in_scale, out_scale, aux, aux_scale, wpw, ws, dws, fin_stats, cnt, flops=2 * B * F * T * cin * cout * kh * kw,
                            nbytes=nb, writes=(y, ws, dws, cnt))
@@ -483,24 +488,36 @@ class _Builder:
             self.nbytes += t.numel() * 8
         return t
 
-    def _wino_input(self, cin, cout, T, wp, wpw, F=0, dil=1, wpw8=None, wpw2=None):
+    @staticmethod
+    def _w2d_positions(form, B, F, T, dil):
+        """positions per transform plane of a 2-D-form launch: groups of 4 samples (form 45) or 8 (form 85)"""
+        n = int(_lib.lib().aid_conv2d_wino2d_positions(B, F, T, dil))
+        return n // 2 if form == 85 else n
+
+    def _wino_input(self, cin, cout, T, wp, wpw, F=0, dil=1, wpw8=None, wpw2=None, wpw3=None):
         """The Winograd form the pre-pass should write for this 5x3 layer (aid_scale_act wino = 1 / 2 -> aid_conv2d x_wino = 1 / 2): 8 = F(8,3)
         (10 MFMAs per 8 outputs; needs the 50-tap pack), 4 = F(4,3), 0 = plain activations.  The library answers from the launch shape
         (aid_conv2d_wino_form); ``net.wino_forms`` restricts the choice (A/B measurements, tests of the F(4,3) kernels)."""
         if wpw is None or wpw.shape[0] != 30:
             return 0
         fb = int(self.net.form_batch or self.B)               # the batch the FORM is chosen for (network.form_batch; default: this launch's)
-        if wpw2 is not None and 45 in self.net.wino_forms and _lib.lib().aid_conv2d_wino2d_supported(cin, cout, F, T, dil):
+        if wpw2 is not None and (45 in self.net.wino_forms or 85 in self.net.wino_forms) and _lib.lib().aid_conv2d_wino2d_supported(cin, cout, F, T, dil):
             # the non-fused 2-D form F(4,5) x F(4,3) (csrc/aid_wino2d.hip: 3.0 products per output) where the library predicts it faster than the fused
             # 1-D kernels (aid_conv2d_wino2d_wanted, a function of the launch shape); wino_forms = (45,): wherever it is supported (tests, A/B)
-            if tuple(self.net.wino_forms) == (45,) or (min(cin, cout) >= self.net.w2d_min_channels and (T <= self.net.w2d_force_max_T or _lib.lib().aid_conv2d_wino2d_wanted(fb, cin, cout, F, T, dil))):
-                return 45
+            if tuple(self.net.wino_forms) in ((45,), (85,), (45, 85)) or (min(cin, cout) >= self.net.w2d_min_channels and (T <= self.net.w2d_force_max_T or _lib.lib().aid_conv2d_wino2d_wanted(fb, cin, cout, F, T, dil))):
+                # ... and which T form: F(8,3) along T (85: 2.5 products per output, 2.5 x the activation in V / M) where the library says so
+                # (aid_conv2d_wino2d_tform), F(4,3) (45) otherwise; wino_forms without 85 / 45 restricts the choice
+                if wpw3 is not None and 85 in self.net.wino_forms and T % 32 == 0 and (45 not in self.net.wino_forms or tuple(self.net.wino_forms) == (85,)
+                                                                                     or int(_lib.lib().aid_conv2d_wino2d_tform(fb, cin, cout, F, T, dil)) == 8):
+                    return 85
+                if 45 in self.net.wino_forms:
+                    return 45
         form = int(_lib.lib().aid_conv2d_wino_form(fb, cin, cout, F, T, dil))
         if form == 8 and (wpw8 is None or 8 not in self.net.wino_forms):
             form = 4
         elif form == 4 and 4 not in self.net.wino_forms and wpw8 is not None and _lib.lib().aid_conv2d_wino8_supported(cin, cout, F, T, dil):
             form = 8                                          # wino_forms = (8,): F(8,3) wherever its tiles fit (tests, A/B)
-        if form == 4 and not ((4 in self.net.wino_forms or tuple(self.net.wino_forms) == (45,)) and bool(_lib.lib().aid_conv2d_wino_input_ok(self.B, cin, cout, F, T, dil))):
+        if form == 4 and not ((4 in self.net.wino_forms or tuple(self.net.wino_forms) in ((45,), (85,), (45, 85))) and bool(_lib.lib().aid_conv2d_wino_input_ok(self.B, cin, cout, F, T, dil))):
             form = 0
         return form
 
@@ -510,8 +527,8 @@ class _Builder:
 
     def _wino_scratch(self, tag, form, B, C, F, T, dil):
         """scratch for the conv input the pre-pass writes: [B, C, F, cols] (plain / 1-D Winograd domain) or the flat V [48][C][N] of the 2-D form"""
-        if form == 45:
-            return self._scratch((tag + "45", 48 * C * int(_lib.lib().aid_conv2d_wino2d_positions(B, F, T, dil))))
+        if form in W2D_PLANES:
+            return self._scratch((tag + "45", W2D_PLANES[form] * C * self._w2d_positions(form, B, F, T, dil)))
         return self._scratch((tag, B, C, F, self._wino_cols(form, T)))
 
     @staticmethod
@@ -521,17 +538,17 @@ class _Builder:
 
     def conv(self, x, y, wp, cin, cout, kh=1, kw=1, dil=1, in_scale=None, act=0, out_scale=None, res=None,
              res_scale=1.0, alpha=1.0, wpT=None, norm_stats=None, wpw=None, wpwT=None, res_nograd=False, wname=None, wpw8=None, wpw8T=None,
-             wpw2=None, wpw2T=None):
+             wpw2=None, wpw2T=None, wpw3=None, wpw3T=None):
         """Forward conv + registration of its input-VJP.  ``norm_stats``: the (mean, 1/(std+eps)) buffer when
         ``in_scale`` was produced by ``stats`` from this same ``x`` (the scale then depends on x)."""
         if act and kh > 1:
             # evaluate norm*mod -> GELU once per element into a scratch tensor; the conv stages plain copies
-            xw = self._wino_input(cin, cout, x.shape[3], wp, wpw, x.shape[2], dil, wpw8, wpw2)
+            xw = self._wino_input(cin, cout, x.shape[3], wp, wpw, x.shape[2], dil, wpw8, wpw2, wpw3)
             hbuf = self._wino_scratch("h", xw, x.shape[0], cin, x.shape[2], x.shape[3], dil)
             sp = _lib.ScaleActParams(_lib.view4(x), self._sa_out(hbuf), in_scale.data_ptr(), in_scale.stride(0), x.shape[0], cin,
-                                     x.shape[2], x.shape[3], 1, {0: 0, 4: 1, 8: 2, 45: 3}[xw], dil)
+                                     x.shape[2], x.shape[3], 1, XW_CODE[xw], dil)
             self._add("aid_scale_act", sp, x, hbuf, in_scale, writes=(hbuf,))
-            self._conv_raw(hbuf, y, wp, cin, cout, kh, kw, dil, None, 0, out_scale, res, res_scale, alpha, wpw={8: wpw8, 45: wpw2}.get(xw, wpw), x_wino=xw)
+            self._conv_raw(hbuf, y, wp, cin, cout, kh, kw, dil, None, 0, out_scale, res, res_scale, alpha, wpw={8: wpw8, 45: wpw2, 85: wpw3}.get(xw, wpw), x_wino=xw)
         else:
             self._conv_raw(x, y, wp, cin, cout, kh, kw, dil, in_scale, act, out_scale, res, res_scale, alpha)
         if wpT is None:
@@ -551,7 +568,7 @@ class _Builder:
             if kh > 1 and out_scale is not None:
                 # 5x3 dgrad: apply the gate in a copy pass so the conv input needs no in-kernel prologue
                 # (keeps it on the direct-to-LDS kernel)
-                gw = self._wino_input(cout, cin, gy.shape[3], wpT, wpwT, gy.shape[2], dil, wpw8T, wpw2T) if norm_stats is not None else 0
+                gw = self._wino_input(cout, cin, gy.shape[3], wpT, wpwT, gy.shape[2], dil, wpw8T, wpw2T, wpw3T) if norm_stats is not None else 0
                 gin = self._wino_scratch("g", gw, gy.shape[0], cout, gy.shape[2], gy.shape[3], dil)
                 nb = self._nb_src.pop(self._vkey(gy), None) if (gw in (4, 8) and self.net.fuse_norm_bwd_wino) else None
                 if nb is not None and nb[1] > self._g_last.get(gin.data_ptr(), -1) and nb[3].lane == self.lane:
@@ -562,7 +579,7 @@ class _Builder:
                     nb[3].also_writes(gin)
                 else:
                     sp = _lib.ScaleActParams(_lib.view4(gy), self._sa_out(gin), out_scale.data_ptr(), out_scale.stride(0), gy.shape[0],
-                                             cout, gy.shape[2], gy.shape[3], 0, {0: 0, 4: 1, 8: 2, 45: 3}[gw], dil)
+                                             cout, gy.shape[2], gy.shape[3], 0, XW_CODE[gw], dil)
                     self._add("aid_scale_act", sp, gy, gin, out_scale, writes=(gin,))
                 self._g_last[gin.data_ptr()] = len(self.plan.ops)      # (the dgrad conv below reads it)
                 gsc = None
@@ -571,15 +588,15 @@ class _Builder:
                 # <gd, x> per (sample, group): folded into the dgrad conv's epilogue when it runs on the F(4,3) kernels
                 nd = 0
                 if act and kh == 5 and gsc is None and wpwT is not None and wpwT.shape[0] == 30:
-                    nd = int(_lib.lib().aid_conv2d_dot_partials(B, cout, cin, F, T, dil, {0: 0, 4: 1, 8: 2, 45: 3}[gw]))
+                    nd = int(_lib.lib().aid_conv2d_dot_partials(B, cout, cin, F, T, dil, XW_CODE[gw]))
                 elif act and kh == 1 and kw == 1 and self.net.fuse_dot_1x1:        # 1x1 steps (init / out blocks): the direct-to-LDS kernel's epilogue
                     nd = int(_lib.lib().aid_conv2d_dot_partials_1x1(B, cout, cin, F, T))
                 dws = self._dot_ws(nd) if nd else self.stats_ws
                 # the last tile of each sample also folds the partials into the normalisation-backward coefficients (aid_kernels.h: fin_mode = 2)
-                fin = bool(nd and kh == 5 and gw in (4, 8, 45) and self.net.fuse_fin and self._fin_wanted(B, {4: 1, 8: 2, 45: 3}[gw])
-                           and _lib.lib().aid_conv2d_fin_supported(B, cout, cin, F, T, dil, {4: 1, 8: 2, 45: 3}[gw]))
+                fin = bool(nd and kh == 5 and gw in (4, 8, 45, 85) and self.net.fuse_fin and self._fin_wanted(B, XW_CODE[gw])
+                           and _lib.lib().aid_conv2d_fin_supported(B, cout, cin, F, T, dil, XW_CODE[gw]))
                 self._conv_raw(gin, gd, wpT, cout, cin, kh, kw, dil, gsc, 0, in_scale, None, 1.0, alpha,
-                               epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None, wpw={8: wpw8T, 45: wpw2T}.get(gw, wpwT), x_wino=gw,
+                               epi=1 if act else 0, aux=x if act else None, aux_scale=in_scale if act else None, wpw={8: wpw8T, 45: wpw2T, 85: wpw3T}.get(gw, wpwT), x_wino=gw,
                                dot=(dws, nd) if nd else None, fin_stats=norm_stats if fin else None)
                 if not nd:
                     dp = _lib.GroupDotParams(_lib.view4(gd), _lib.view4(x), B, cin, F, T, 8, self.stats_ws.data_ptr())
@@ -831,13 +848,15 @@ class Unet_CQT_oct_with_attention(nn.Module):
                     wd = wd.float().contiguous()
                 (cip, cop), (cipT, copT) = _lib.pack_dims(ci, co), _lib.pack_dims(co, ci)
                 w8 = wino and 8 in self.wino_forms                                            # F(8,3) packs (50 taps)
-                w2 = wino and 45 in self.wino_forms and co % 128 == 0 and ci % 128 == 0       # 2-D F(4,5) x F(4,3) packs (48 planes; C >= 128 layers)
+                w2 = wino and (45 in self.wino_forms or 85 in self.wino_forms) and co % 128 == 0 and ci % 128 == 0       # 2-D F(4,5) x F(4,3) packs (48 planes; C >= 128 layers)
+                w3 = w2 and 85 in self.wino_forms                                              # ... and its F(8,3)-along-T variant (80 planes)
                 bufs = [ensure(name, (kh * kw, cip, cop)), ensure(name + "#T", (kh * kw, cipT, copT)),
                         ensure(name + "#W", (30, cip, cop)) if wino else None, ensure(name + "#WT", (30, cipT, copT)) if wino else None,
                         ensure(name + "#W8", (50, cip, cop)) if w8 else None, ensure(name + "#W8T", (50, cipT, copT)) if w8 else None,
-                        ensure(name + "#W2", (48, cip, cop)) if w2 else None, ensure(name + "#W2T", (48, cipT, copT)) if w2 else None]
+                        ensure(name + "#W2", (48, cip, cop)) if w2 else None, ensure(name + "#W2T", (48, cipT, copT)) if w2 else None,
+                        ensure(name + "#W3", (80, cip, cop)) if w3 else None, ensure(name + "#W3T", (80, cipT, copT)) if w3 else None]
                 pp = _lib.PackConvWeightParams(wd.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr(), _lib.ptr(bufs[2]), _lib.ptr(bufs[3]),
-                                               co, ci, kh, kw, cip, cop, cipT, copT, _lib.ptr(bufs[4]), _lib.ptr(bufs[5]), _lib.ptr(bufs[6]), _lib.ptr(bufs[7]))
+                                               co, ci, kh, kw, cip, cop, cipT, copT, _lib.ptr(bufs[4]), _lib.ptr(bufs[5]), _lib.ptr(bufs[6]), _lib.ptr(bufs[7]), _lib.ptr(bufs[8]), _lib.ptr(bufs[9]))
                 _lib.call("aid_pack_conv_weight", pp)       # all layouts of this weight in one launch (same values as _lib.pack_conv_weight*)
             elif leaf == "gamma":
                 put(name, w.detach().reshape(-1).float())
@@ -947,7 +966,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
                     out_scale=self._mod(st, pfx + f"gate.{k}"), res=x, alpha=RSQRT2, wpT=W[pfx + f"H.{k}.weight#T"],
                     norm_stats=stb, wpw=W.get(pfx + f"H.{k}.weight#W"), wpwT=W.get(pfx + f"H.{k}.weight#WT"), wname=pfx + f"H.{k}.weight",
                     wpw8=W.get(pfx + f"H.{k}.weight#W8"), wpw8T=W.get(pfx + f"H.{k}.weight#W8T"),
-                    wpw2=W.get(pfx + f"H.{k}.weight#W2"), wpw2T=W.get(pfx + f"H.{k}.weight#W2T"))
+                    wpw2=W.get(pfx + f"H.{k}.weight#W2"), wpw2T=W.get(pfx + f"H.{k}.weight#W2T"),
+                    wpw3=W.get(pfx + f"H.{k}.weight#W3"), wpw3T=W.get(pfx + f"H.{k}.weight#W3T"))
             x = xn
         if blk.proj_place == "after":
             assert hasattr(blk, "proj_out") and hasattr(blk, "res_conv")
@@ -1280,7 +1300,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
                                # sub-batch streams; a second lane INSIDE each sub-batch stream measured -19 % at batch 8 (six streams competing)
     param_grads_in_train_mode = False   # True: a train()-mode call whose INPUT requires grad also yields parameter gradients (TrainFn) instead of
                                         # the input-only VJP; off by default because the reference's tester samples with the network in train() mode
-    wino_forms = (4, 8, 45)    # Winograd forms the 5x3 layers may use: 45 = the non-fused 2-D form F(4,5) x F(4,3) (csrc/aid_wino2d.hip) on the C >= 128 layers
+    wino_forms = (4, 8, 45, 85)    # 85 (round 6) = the 2-D form with F(8,3) along T, F(4,5) x F(8,3): 80 products per 4 x 8 outputs (2.5 per output), where the library
+                               # prefers it over 45 (aid_conv2d_wino2d_tform).  Winograd forms the 5x3 layers may use: 45 = the non-fused 2-D form F(4,5) x F(4,3) (csrc/aid_wino2d.hip) on the C >= 128 layers
                                # where the library predicts it faster (aid_conv2d_wino2d_wanted), F(8,3) where the library prefers it (aid_conv2d_wino_form),
                                # F(4,3) otherwise; (4,) keeps every layer on the F(4,3) kernels, (45,) forces the 2-D form wherever it is supported
                                # (A/B measurements, tests; set before the first forward)

@@ -186,6 +186,14 @@ def cpu_baseline(net, args, guided: bool, spectral: bool = False, n_timed: int =
                       f"on the fastest ({best[1]}, {cores} threads; median {dt:.2f} s, min {min(times):.2f} s; value = 1 / median), torch {torch.__version__} CPU fp32"}
 
 
+def exec_fraction(kn: str) -> float:
+    """MFMA FLOPs a conv launch ISSUES as a fraction of its direct-form FLOPs, from the kernel name aid_last_kernel reported: the 2-D form's GEMM over 80 planes
+    (F(4,5) x F(8,3), names ending in +t8) issues 80 products per 4 x 8 outputs x 15 taps = 1/6, over 48 planes 1/5; the fused 1-D kernels 1/2 and 5/12"""
+    if kn.startswith("w2d_gemm") and kn.endswith("+t8"):
+        return 80.0 / 480.0
+    return WINO_EXEC.get(kernel_base(kn), 1.0)
+
+
 def kernel_base(kn: str) -> str:
     """device-kernel name as rocprofv3 lists it, without the tile kind / template instance aid_last_kernel appends"""
     return kn.split("(")[0].split("+")[0].split("<")[0]
@@ -201,7 +209,7 @@ def family_table(timing, by_kernel=False):
         r["launches"] += 1
         r["ms"] += e0.elapsed_time(e1)
         r["alg"] += fl
-        r["exe"] += fl * WINO_EXEC.get(base, 1.0)
+        r["exe"] += fl * exec_fraction(kn)
         r["bytes"] += nb
     out = {}
     for kn, r in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
@@ -241,7 +249,8 @@ def main():
     ap.add_argument("--no-fused-norm-bwd", action="store_true", help="A/B: separate gate / Winograd-transform pre-pass before every dgrad conv")
     ap.add_argument("--no-fin", action="store_true", help="A/B: separate aid_group_stats / coefficient launches instead of the last tile of a sample folding the epilogue partials")
     ap.add_argument("--no-epilogue-stats", action="store_true", help="A/B: group statistics by their own read pass instead of the conv epilogue")
-    ap.add_argument("--wino-forms", default="4,8,45", help="A/B: Winograd forms the 5x3 layers may use (default 4,8,45: the 2-D form F(4,5) x F(4,3) and F(8,3) where the library prefers them; 4,8: the fused 1-D kernels only; 4: F(4,3) everywhere)")
+    ap.add_argument("--wino-forms", default="4,8,45,85", help="A/B: Winograd forms the 5x3 layers may use (default 4,8,45,85: the 2-D forms F(4,5) x F(8,3) / F(4,5) x F(4,3) and the fused F(8,3) where the library prefers them; "
+                    "4,8,45: round 5's set; 4,8: the fused 1-D kernels only; 4: F(4,3) everywhere)")
     ap.add_argument("--mfma-split", type=int, default=0, choices=[0, 6], help="LABELLED VARIANT (never the default): 6 = the 2-D Winograd form's GEMMs on three bf16 pieces per fp32 operand, "
                     "six bf16 MFMA products, fp32 accumulation (aid_wino2d_set_split); the JSON's dtype says so")
     ap.add_argument("--w2d-min-channels", type=int, default=0, help="A/B: 256 keeps the 2-D Winograd form off the K = 128 levels (network.w2d_min_channels)")
@@ -423,7 +432,7 @@ def main():
         dom = kerns.get(dom_name, {})
         conv_ms = sum(v["time_ms"] for v in fams.values())
         alg = sum(t[2] for t in timing)
-        exe = sum(t[2] * WINO_EXEC.get(kernel_base(t[5]), 1.0) for t in timing)
+        exe = sum(t[2] * exec_fraction(t[5]) for t in timing)
         sec = max(conv_ms * 1e-3, 1e-12)
         out = {
             "metric": "denoiser-steps/sec", "value": round(evals / wall, 3), "unit": "denoiser evaluations (one segment each) per second, whole job",
@@ -447,8 +456,8 @@ def main():
             "ranks": ranks,
             "roofline": {"bound": "mfma", "kernel": dom_name, "measured_in": roofline_pass,
                          "definition": "achieved = MFMA FLOPs issued by ALL launches of the dominant kernel (by device-kernel name, every template instance / tile kind) "
-                                       "/ their summed duration (HIP events around each launch); Winograd F(4,3) issues 1/2, F(8,3) 5/12 and the 2-D form F(4,5) x F(4,3) (w2d_gemm_kernel: every 5x3 layer "
-                                       "of the C >= 128 levels 3-6 and the bottleneck that the library gives it) 1/5 of the direct-form FLOPs; the 2-D form's output-transform + epilogue pass "
+                                       "/ their summed duration (HIP events around each launch); Winograd F(4,3) issues 1/2, F(8,3) 5/12 and the 2-D forms (w2d_gemm_kernel: every 5x3 layer "
+                                       "of the C >= 128 levels 3-6 and the bottleneck that the library gives it) F(4,5) x F(4,3) 1/5 and F(4,5) x F(8,3) (instances named +t8) 1/6 of the direct-form FLOPs; the 2-D form's output-transform + epilogue pass "
                                        "(w2d_output_kernel, HBM-bound, no FLOPs of its own) is timed as a conv launch too and counts in all_conv / conv_time_fraction_of_wall -- the fused 1-D kernels do that "
                                        "work inside the timed kernel -- its input-transform pass is the counterpart of the fused kernels' aid_scale_act pre-pass and, like it, is not; "
                                        "algorithmic_tflops = direct-form FLOPs / the same time; step_executed_frac = issued MFMA FLOPs of all conv / GEMM launches "

@@ -28,7 +28,7 @@ extern "C" {
 #define AID_E_BADARG (-1)   /* unsupported shape / null pointer / misaligned stride */
 #define AID_E_LAUNCH (-2)   /* hipLaunchKernel reported an error                    */
 
-#define AID_ABI_VERSION 13
+#define AID_ABI_VERSION 14
 int aid_abi_version(void);
 /* last HIP error string seen by a launcher in this process (never NULL) */
 const char* aid_last_error(void);
@@ -115,7 +115,11 @@ typedef struct {
                                  aid_scale_act(wino = 3) (x's strides are not used), wp_wino the 48-plane pack U = GF w GT^T (aid_pack_conv_weight wpw2),
                                  wino_taps = 48, and `ws` MUST hold 48 * Cout * N floats for M = U V: aid_wino2d_gemm, then the output-transform pass with the
                                  epilogue below; needs aid_conv2d_wino2d_supported(...) != 0 (Cout % 128 == 0, Cin % 16 == 0, F % dilF == 0, T % 16 == 0).
-                                 fp32 error 2-4e-6 rel-L2 per layer (profiles/r04_wino2d_fm5_error.txt). */
+                                 fp32 error 2-4e-6 rel-L2 per layer (profiles/r04_wino2d_fm5_error.txt).
+                                 4: the same three passes with F(8,3) along T -- F(4,5) x F(8,3), 80 planes, 2.5 products per output, V / M 2.5 x the activation:
+                                 x.p is V [80][Cin][N/2] written by aid_scale_act(wino = 4), wp_wino the 80-plane pack (aid_pack_conv_weight wpw3), wino_taps = 80,
+                                 `ws` holds 80 * Cout * (N/2) floats (N = aid_conv2d_wino2d_positions: groups of 8 samples halve it); additionally T % 32 == 0.
+                                 fp32 error 1.0e-5 (Cin = 128) / 1.3e-5 (Cin = 256) rel-L2 per layer (profiles/r06_wino2d_f45x83_error.txt). */
     float* ws; int64_t ws_bytes; /* optional scratch (the library never allocates): lets grid-starved 1x1 GEMMs (the qk projections:
                                  B*T columns only, K of several thousand) split K over up to 8 workgroups per tile; partial sums
                                  go to ws[S][B][Cout][F][T] and a second kernel reduces them in a FIXED order (deterministic) and
@@ -182,6 +186,9 @@ int aid_conv2d_wino2d_supported(int Cin, int Cout, int F, int T, int dilF);
 int64_t aid_conv2d_wino2d_positions(int B, int F, int T, int dilF);
 /* 1 when a launch of this shape SHOULD take the 2-D form (measured per layer against the fused 1-D kernels; a function of the launch shape) */
 int aid_conv2d_wino2d_wanted(int B, int Cin, int Cout, int F, int T, int dilF);
+/* the T form the 2-D form of such a launch should take: 0 = not a 2-D launch (aid_conv2d_wino2d_wanted == 0), 4 = F(4,5) x F(4,3) (x_wino = 3), 8 = F(4,5) x F(8,3)
+   (x_wino = 4; T % 32 == 0).  A function of the launch shape.  (ABI 14) */
+int aid_conv2d_wino2d_tform(int B, int Cin, int Cout, int F, int T, int dilF);
 /* padded dims the packed weight buffer must have for a given (Cin, Cout) */
 void aid_conv2d_pack_dims(int Cin, int Cout, int* Cin_pad, int* Cout_pad);
 
@@ -189,7 +196,7 @@ void aid_conv2d_pack_dims(int Cin, int Cout, int* Cin_pad, int* Cout_pad);
  * aid_wino2d_gemm -- the batched fp32-MFMA GEMM at the centre of the 2-D Winograd form F(4,5) x F(4,3) of the dilated 5x3 convolution
  *   (aid_conv2d x_wino = 3 runs it followed by the output-transform pass; exposed on its own for tests and measurements).
  *   replaces: the multiply-accumulate work of Conv2d.forward / F.conv2d(dilation=(d,1)) (unet...py:79-88, :433-436, :472-482) on the C >= 128 layers.
- *   For every transform index xi < nxi (48):   M[xi][co][n] = sum_ci U[xi][ci][co] * V[xi][ci][n]
+ *   For every transform index xi < nxi (48; 80 for the F(4,5) x F(8,3) form):   M[xi][co][n] = sum_ci U[xi][ci][co] * V[xi][ci][n]
  *   U [nxi][Cin_pad][Cout_pad] (aid_pack_conv_weight wpw2 / wpw2T), V [nxi][Cin][N] (aid_scale_act wino = 3), M [nxi][Cout][N]; N % 4 == 0,
  *   Cin a multiple of 16, Cout_pad a multiple of 128, every plane below 4 GiB.
  * ------------------------------------------------------------------------------------------------- */
@@ -515,8 +522,10 @@ typedef struct {
                                  3: the 2-D input transform F(4,5) x F(4,3) for aid_conv2d x_wino = 3 (matrices: csrc/aid_wino45.h, tools/gen_wino45.py):
                                  y.p is V [48][C][N] (y's strides are not used), N = aid_conv2d_wino2d_positions(B, F, T, dilF),
                                  V[xf*6 + xt][c][b*NB + (j*dilF + r)*(T/4) + g] = (BF^T h BT)[xf][xt] of the 8 x 6 patch of rows r + dilF*(4j-2 .. 4j+5),
-                                 samples 4g-1 .. 4g+4 (zero outside the tensor); F % dilF == 0, T % 16 == 0 */
-    int dilF;                 /* wino = 3 only: the dilation of the 5x3 layer that will read V */
+                                 samples 4g-1 .. 4g+4 (zero outside the tensor); F % dilF == 0, T % 16 == 0
+                                 4: the 2-D input transform F(4,5) x F(8,3) for aid_conv2d x_wino = 4: y.p is V [80][C][N/2],
+                                 V[xf*10 + xt][c][b*NB + (j*dilF + r)*(T/8) + g] of the 8 x 10 patch of rows r + dilF*(4j-2 .. 4j+5), samples 8g-1 .. 8g+8; T % 32 == 0 */
+    int dilF;                 /* wino = 3 | 4 only: the dilation of the 5x3 layer that will read V */
 } aid_scale_act_params;
 int aid_scale_act(const aid_scale_act_params* p, void* stream);
 
@@ -581,7 +590,8 @@ int aid_wino_gy(const aid_wino_gy_params* p, void* stream);
  *   wpT [KH*KW][Cin_padT][Cout_padT]       the input-gradient operator: taps flipped, channel roles swapped (pack dims of (Cout, Cin)); NULL: skip
  *   wpw / wpwT [30][...]                   F(4,3) packs U = G w of both (5x3 only; fp64 arithmetic, rounded once); NULL: skip
  *   wpw8 / wpw8T [50][...]                 F(8,3) packs of both (5x3 only; G of csrc/aid_wino8.h); NULL: skip
- *   wpw2 / wpw2T [48][...]                 F(4,5) x F(4,3) packs of both (5x3 only; csrc/aid_wino45.h); NULL: skip */
+ *   wpw2 / wpw2T [48][...]                 F(4,5) x F(4,3) packs of both (5x3 only; csrc/aid_wino45.h); NULL: skip
+ *   wpw3 / wpw3T [80][...]                 F(4,5) x F(8,3) packs of both (5x3 only; rows: aid_wino45.h, samples: aid_wino8.h); NULL: skip */
 typedef struct {
     const float* w;
     float* wp; float* wpT; float* wpw; float* wpwT;
@@ -589,6 +599,7 @@ typedef struct {
     int Cin_pad, Cout_pad, Cin_padT, Cout_padT;
     float* wpw8; float* wpw8T;
     float* wpw2; float* wpw2T;   /* 2-D packs U[xf*6 + xt] = GF w GT^T of both operators, [48][...] (5x3 only; G of csrc/aid_wino45.h); NULL: skip */
+    float* wpw3; float* wpw3T;   /* 2-D packs with F(8,3) along T, U[xf*10 + xt] = GF w G8^T, [80][...] (ABI 14); NULL: skip */
 } aid_pack_conv_weight_params;
 int aid_pack_conv_weight(const aid_pack_conv_weight_params* p, void* stream);
 

@@ -54,11 +54,12 @@ def test_unet_small_batch_items_independent():
     assert rel_l2(one.cpu(), both[1:2].cpu()) < 1e-6
 
 
-@pytest.mark.parametrize("forms", [(4, 8, 45), (45,), (4, 8), (8,), (4,)])
+@pytest.mark.parametrize("forms", [(4, 8, 45, 85), (85,), (4, 8, 45), (45,), (4, 8), (8,), (4,)])
 def test_unet_full_cfgA_vs_reference_golden(forms):
     """Full-size 22.05 kHz network (186 M parameters, L=184184), seeded weights with O(1) gates, against the REFERENCE's output.  forms = (4, 8): the
     library's choice for a batch of one (F(8,3) K-group instances where a launch is at most one 512-position tile per CU, F(4,3) elsewhere); (8,): Winograd F(8,3) on every 5x3 layer its tiles fit (what batches >= 4 mostly run) --
-    the whole-network error of the larger transform; (4,): F(4,3) only."""
+    the whole-network error of the larger transform; (4,): F(4,3) only; (4, 8, 45, 85): the library's choice (the default: the 2-D form with F(8,3) along T where the
+    library prefers it); (85,): F(4,5) x F(8,3) on every layer it supports (T % 32 == 0: all of the C >= 128 levels here) -- the whole-network error of that form."""
     from audio_inpainting_diffusion_amd import _lib
     from audio_inpainting_diffusion_amd.config import make_args
     from audio_inpainting_diffusion_amd.init import seeded_init_, seeded_normal
@@ -77,10 +78,13 @@ def test_unet_full_cfgA_vs_reference_golden(forms):
     n8 = sum(1 for k in st["plan_body"].keep if isinstance(k, _lib.Conv2dParams) and k.x_wino == 2)
     n4 = sum(1 for k in st["plan_body"].keep if isinstance(k, _lib.Conv2dParams) and k.x_wino == 1)
     n2 = sum(1 for o in st["plan_body"].ops if o.name == "aid_conv2d_wino2d_gemm")          # (GEMM and output pass are two plan nodes on one parameter block)
-    assert n2 == sum(1 for o in st["plan_body"].ops if o.name == "aid_conv2d_wino2d_output") == sum(1 for k in st["plan_body"].keep if isinstance(k, _lib.Conv2dParams) and k.x_wino == 3) // 2
-    print(f"unet_full_cfgA (wino_forms {forms}: {n2} F(4,5)xF(4,3) + {n8} F(8,3) + {n4} F(4,3) layers): rel-L2 vs reference golden = {e:.3e}; algorithmic GFLOP/eval = {net.flops_per_eval(1) / 1e9:.1f}")
+    n28 = sum(1 for o in st["plan_body"].ops if o.name == "aid_conv2d_wino2d_gemm" and o.params.x_wino == 4)
+    assert n2 == sum(1 for o in st["plan_body"].ops if o.name == "aid_conv2d_wino2d_output") == sum(1 for k in st["plan_body"].keep if isinstance(k, _lib.Conv2dParams) and k.x_wino in (3, 4)) // 2
+    print(f"unet_full_cfgA (wino_forms {forms}: {n2 - n28} F(4,5)xF(4,3) + {n28} F(4,5)xF(8,3) + {n8} F(8,3) + {n4} F(4,3) layers): rel-L2 vs reference golden = {e:.3e}; algorithmic GFLOP/eval = {net.flops_per_eval(1) / 1e9:.1f}")
     # (6 rows per residue class -- dil 64 on level 5, dil 32 on level 4 -- have no F(8,3) tile: with F(4,3) input excluded those four layers transform in the kernel)
-    if 45 in forms:      # (45,): the 2-D form on every C >= 128 layer (52 of the 75); the default: where the library predicts it faster (a batch of one: every C >= 128 layer but the 4/3-padded one)
+    if 85 in forms:
+        assert n2 + n8 + n4 == 75 and (n2 == n28 == 52 if forms == (85,) else (n2 >= 20 and n28 >= 1))
+    elif 45 in forms:      # (45,): the 2-D form on every C >= 128 layer (52 of the 75); the default: where the library predicts it faster (a batch of one: every C >= 128 layer but the 4/3-padded one)
         assert n2 + n8 + n4 == 75 and (n2 == 52 if forms == (45,) else n2 >= 20)
     else:
         assert n2 == 0 and ((n8 >= 60 and n4 == 0) if forms == (8,) else ((n8 == 0 and n4 == 75) if forms == (4,) else (n8 >= 20 and n8 + n4 == 75)))

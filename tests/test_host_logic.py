@@ -33,7 +33,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in aid_kernels.h but not exported"
     lib.aid_abi_version.restype = ctypes.c_int
-    assert lib.aid_abi_version() == int(re.search(r"#define AID_ABI_VERSION (\d+)", hdr).group(1)) == 13
+    assert lib.aid_abi_version() == int(re.search(r"#define AID_ABI_VERSION (\d+)", hdr).group(1)) == 14
     from audio_inpainting_diffusion_amd import _lib
     assert set(_lib.EXPORTS) == declared
     a, b = _lib.pack_dims(2, 96)

@@ -576,12 +576,16 @@ int aid_w2d_input(const aid_scale_act_params* p, hipStream_t st) {
     if (RB > p->dilF) RB = p->dilF;
     while (p->dilF % RB) --RB;
     a.RB = RB; a.nrb = p->dilF / RB; a.rowf = RB * p->T;
-    // JB row tiles per workgroup: 8 (activations 1.125 x), fewer when the slab would pass 64 KB or the launch would have too few workgroups
-    int JB = 16384 / a.rowf / 4 - 1;
+    // JB row tiles per workgroup: 8 (activations 1.125 x), fewer when the slab would pass 40 KB (four workgroups per CU; round 6: the F(8,3) form doubles RB at
+    // the same T, and a 64-KB slab left two workgroups per CU -- 248 instead of 138 us on [128, 256, 256] d8) or the launch would have too few workgroups;
+    // then BALANCED over the row tiles (J = 8 as 7 + 1 loaded 32 + 8 rows for 8 tiles: now 4 + 4)
+    int JB = 10240 / a.rowf / 4 - 1;
+    if (JB < 1) JB = 16384 / a.rowf / 4 - 1;               // (very long rows: up to 64 KB)
     if (JB > 8) JB = 8;
     if (JB > ge.J) JB = ge.J;
     while (JB > 2 && (int64_t)p->B * p->C * a.nrb * aid_cdiv(ge.J, JB) < 2048) JB >>= 1;
     AID_REQUIRE(JB >= 1, "aid_scale_act(wino=3): T too long for the LDS slab");
+    JB = aid_cdiv(ge.J, aid_cdiv(ge.J, JB));
     a.JB = JB; a.njb = aid_cdiv(ge.J, JB);
     const int64_t nblk = (int64_t)p->B * p->C * a.nrb * a.njb;
     AID_REQUIRE(nblk < (1LL << 31), "aid_scale_act(wino=3): grid too large");
@@ -613,12 +617,15 @@ struct W2dOutDev {
 // T planes and applies the T transform first (6 -> 4 samples per group), then accumulates the four output rows with the row-axis coefficients
 // (the +- pairs of AF^T: s = a + b, t = a - b) -- 32 accumulators instead of the 96 of a row-transform-first order, ~90 registers, so that eight
 // waves per SIMD keep loads in flight and the pass's waves fit beside the two resident GEMM workgroups of another stream.
-// TF = 8 (F(8,3) along T): ONE group of eight samples per thread (GP = 1; 4-byte loads of the 80 planes): the two-group form needs 240 registers.
-#define W2D_GP(TF) ((TF) == 8 ? 1 : 2)
-template <int TF>
+// Groups per thread GP: TF = 4 two (one float2 of every plane, 135 registers); TF = 8 (F(8,3) along T) ONE group of eight samples (4-byte loads of the 80
+// planes; the two-group form needs 240 registers) -- W2D_GP8_TWO (experiment builds, tools/w2d_tf_probe.py) gives rows of at least that many groups two.
+#ifndef W2D_GP8_TWO
+#define W2D_GP8_TWO 0
+#endif
+static inline int w2d_gp(int TF, int TG) { return TF == 4 ? 2 : ((W2D_GP8_TWO > 0 && TG >= W2D_GP8_TWO && (TG % 2) == 0) ? 2 : 1); }
+template <int TF, int GP>
 __global__ __launch_bounds__(256) void w2d_output_kernel(const W2dOutDev a) {
     constexpr int NTP = TF + 2;                           // planes along T
-    constexpr int GP = W2D_GP(TF);                        // groups per thread
     constexpr int NS = GP * TF;                           // output samples per row of this thread
     const aid_conv2d_params& p = a.p;
     int rest = blockIdx.x;
@@ -760,7 +767,7 @@ __global__ __launch_bounds__(256) void w2d_output_kernel(const W2dOutDev a) {
     }
 }
 
-static inline int w2d_nblk(int NB, int TF) { return (NB + 256 * W2D_GP(TF) - 1) / (256 * W2D_GP(TF)); }      // blocks of 256 threads x GP positions per sample and channel
+static inline int w2d_nblk(int NB, int TF, int TG) { return (NB + 256 * w2d_gp(TF, TG) - 1) / (256 * w2d_gp(TF, TG)); }      // blocks of 256 threads x GP positions per sample and channel
 
 extern "C" int aid_conv2d_wino2d_supported(int Cin, int Cout, int F, int T, int dilF) { return w2d_shape_ok(Cin, Cout, F, T, dilF) ? 1 : 0; }
 // Which launches take the 2-D form instead of the fused 1-D kernels.  Measured per layer (tools/w2d_probe.py layer, profiles/r05_w2d_passes_ab.txt,
@@ -785,7 +792,7 @@ extern "C" int aid_conv2d_wino2d_wanted(int B, int Cin, int Cout, int F, int T, 
 extern "C" int aid_conv2d_wino2d_wanted(int B, int Cin, int Cout, int F, int T, int dilF);
 extern "C" int64_t aid_conv2d_wino2d_positions(int B, int F, int T, int dilF) { return (dilF >= 1 && F % dilF == 0 && T % 4 == 0) ? w2d_geo(B, F, T, dilF).N : 0; }
 // per-(sample, group) partial count of stat_ws / dot_ws for x_wino = 3
-int aid_w2d_partials(int Cout, int F, int T, int dilF, int TF) { return (Cout >> 3) * w2d_nblk(w2d_geo(1, F, T, dilF, TF).NB, TF); }
+int aid_w2d_partials(int Cout, int F, int T, int dilF, int TF) { const W2dGeo g = w2d_geo(1, F, T, dilF, TF); return (Cout >> 3) * w2d_nblk(g.NB, TF, g.TG); }
 
 // Which T form the 2-D form of a launch should take: 0 = the launch is not for the 2-D form at all (aid_conv2d_wino2d_wanted == 0), 4 = F(4,5) x F(4,3)
 // (x_wino = 3, 48 planes), 8 = F(4,5) x F(8,3) (x_wino = 4, 80 planes: 2.5 instead of 3.0 products per output and 2.5 x instead of 3 x the activation in V / M).
@@ -832,10 +839,12 @@ static int w2d_output_of(const aid_conv2d_params* p, hipStream_t st) {
     const W2dGeo ge = w2d_geo(p->B, p->F, p->T, p->dilF, TF);
     W2dOutDev a;
     a.p = *p; a.M = p->ws;
-    a.R = ge.R; a.J = ge.J; a.TG = ge.TG; a.NB = ge.NB; a.N = ge.N; a.nblk = w2d_nblk(ge.NB, TF);
+    a.R = ge.R; a.J = ge.J; a.TG = ge.TG; a.NB = ge.NB; a.N = ge.N; a.nblk = w2d_nblk(ge.NB, TF, ge.TG);
     a.fin_total = p->Cout * a.nblk;
-    if (TF == 8) hipLaunchKernelGGL(w2d_output_kernel<8>, dim3((unsigned)((int64_t)p->B * p->Cout * a.nblk)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(w2d_output_kernel<4>, dim3((unsigned)((int64_t)p->B * p->Cout * a.nblk)), dim3(256), 0, st, a);
+    const dim3 grid((unsigned)((int64_t)p->B * p->Cout * a.nblk));
+    if (TF == 8 && w2d_gp(8, ge.TG) == 2) hipLaunchKernelGGL((w2d_output_kernel<8, 2>), grid, dim3(256), 0, st, a);
+    else if (TF == 8) hipLaunchKernelGGL((w2d_output_kernel<8, 1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((w2d_output_kernel<4, 2>), grid, dim3(256), 0, st, a);
     AID_CHECK_LAUNCH();
     return AID_OK;
 }

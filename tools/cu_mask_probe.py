@@ -119,5 +119,49 @@ def main():
               f"(max of the two alone {1e3 * max(g, h):.0f}; unmasked serial {1e3 * (g0 + h0):.0f}, unmasked free streams {1e3 * both0:.0f})")
 
 
+def launch_cost():
+    """== 4. what a LAUNCH costs on a CU-masked stream: 2000 back-to-back tiny kernels (one workgroup, no work) per stream kind, and the same kernels
+    alternating between two streams with an event edge per launch (the type-lane schedule of network.cu_partition)"""
+    print("== 4. per-launch cost: 2000 empty one-workgroup kernels ==")
+    out = torch.zeros(64, dtype=torch.int32, device=dev)
+    n = 2000
+
+    def chain(s):
+        def run(reps):
+            for _ in range(reps):
+                for _ in range(n):
+                    probe.cu_where(out.data_ptr(), 1, 0, s.cuda_stream)
+        return run
+    plain = torch.cuda.Stream()
+    masked = cu_masked_stream(partition_masks(64)[0])
+    full_mask = cu_masked_stream([0xFFFFFFFF] * 8)
+    for label, s in (("unmasked stream", plain), ("CU-masked stream (192 CUs)", masked), ("CU-masked stream, all 256 bits set", full_mask)):
+        chain(s)(1)
+        ms = timeit(chain(s), [s], reps=3)
+        print(f"  {label:40s} {1e3 * ms / n:6.2f} us per launch")
+
+    def pingpong(sa, sb):
+        evs = [torch.cuda.Event() for _ in range(n)]
+
+        def run(reps):
+            for _ in range(reps):
+                for k in range(n):
+                    s, o = (sa, sb) if k & 1 else (sb, sa)
+                    if k:
+                        s.wait_event(evs[k - 1])
+                    probe.cu_where(out.data_ptr(), 1, 0, s.cuda_stream)
+                    evs[k].record(s)
+        return run
+    for label, sa, sb in (("two unmasked streams, event per launch", plain, torch.cuda.Stream()),
+                          ("two CU-masked streams (192 / 64), event per launch", masked, cu_masked_stream(partition_masks(64)[1]))):
+        pingpong(sa, sb)(1)
+        ms = timeit(pingpong(sa, sb), [sa, sb], reps=3)
+        print(f"  {label:52s} {1e3 * ms / n:6.2f} us per launch")
+
+
 if __name__ == "__main__":
-    main()
+    if "--launch-cost" in sys.argv:
+        sys.argv.remove("--launch-cost")
+        launch_cost()
+    else:
+        main()

@@ -141,7 +141,7 @@ class NormBwdParams(C.Structure):
     _fields_ = [("gd", View), ("x", View), ("gy", View), ("out", View),
                 ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("groups", C.c_int),
                 ("stats", C.c_void_p), ("ws", C.c_void_p), ("eps", C.c_float), ("a", C.c_float), ("accumulate", C.c_int),
-                ("ws_n", C.c_int), ("wout", View), ("wscale", C.c_void_p), ("wscale_ld", C.c_int64), ("wform", C.c_int), ("coef_ready", C.c_int)]
+                ("ws_n", C.c_int), ("wout", View), ("wscale", C.c_void_p), ("wscale_ld", C.c_int64), ("wform", C.c_int), ("coef_ready", C.c_int), ("wdil", C.c_int)]
 
 
 class AttentionBwdParams(C.Structure):

@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256) void norm_bwd_wino8_kernel(const NbDev a) {
     }
 }
 
+int aid_w2d_input_nb(const aid_norm_bwd_params* p, const float* coef, hipStream_t st);      // aid_wino2d.hip
 extern "C" int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream) {
     AID_REQUIRE(p && p->gd.p && p->x.p && p->out.p && p->stats && p->ws, "aid_norm_bwd: null pointer");
     AID_REQUIRE(p->groups > 0 && p->C % p->groups == 0 && (p->T % 4) == 0, "aid_norm_bwd: bad shape");
@@ -387,6 +388,8 @@ extern "C" int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream) {
         hipLaunchKernelGGL(norm_bwd_coef, dim3(p->B * p->groups), dim3(64), 0, (hipStream_t)stream, a);
         AID_CHECK_LAUNCH();
     }
+    if (p->wout.p && (p->wform == 3 || p->wform == 4))     // the 2-D forms: this pass IS the input pass of the layer below (aid_wino2d.hip), V [48 | 80][C][N]
+        return aid_w2d_input_nb(p, a.coef, (hipStream_t)stream);
     if (p->wout.p && p->wform == 2) {
         AID_REQUIRE((p->T % 16) == 0 && !p->accumulate, "aid_norm_bwd: wout needs T % 16 == 0 and accumulate = 0 (neighbour samples are recomputed)");
         AID_REQUIRE(p->wout.sF >= 10 * (p->T / 8) && (p->wout.sB % 4) == 0 && (p->wout.sC % 4) == 0 && (p->wout.sF % 4) == 0 && (((uintptr_t)p->wout.p) & 15) == 0,

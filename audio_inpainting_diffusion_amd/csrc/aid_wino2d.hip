@@ -486,6 +486,9 @@ static inline bool w2d_shape_ok(int Cin, int Cout, int F, int T, int dil) {
 struct W2dInDev {
     aid_view x; const float* scale; int64_t scale_ld;
     float* V;
+    // NB mode (the normalisation backward folded into this pass, aid_norm_bwd wform = 3 | 4): the element is gd - coef[b,g] (x - mean[b,g]) + nb_a gy,
+    // written to gx for the rows this workgroup owns, and times scale[b,c] into the transform
+    aid_view gd, gy, gx; const float* coef; const float* stats; float nb_a; int cg;
     int B, C, F, T, act, dil;
     int R, J, TG, NB;
     int RB, JB, nrb, njb;      // residue classes / row tiles per workgroup, workgroups along each
@@ -493,7 +496,7 @@ struct W2dInDev {
     int64_t N;
 };
 
-template <int TF>
+template <int TF, bool NB>
 __global__ __launch_bounds__(256) void w2d_input_kernel(const W2dInDev a) {
     constexpr int NTP = TF + 2;                           // planes along T: 6 (F(4,3)) or 10 (F(8,3))
     extern __shared__ __attribute__((aligned(16))) float w2d_slab[];
@@ -518,7 +521,20 @@ __global__ __launch_bounds__(256) void w2d_input_kernel(const W2dInDev a) {
         const int jj = 4 * j0 - 2 + jl;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (jj >= 0 && jj < a.R) {
-            v = *reinterpret_cast<const float4*>(xb + (int64_t)(r0 + rl + jj * a.dil) * a.x.sF + 4 * t4);
+            const int f = r0 + rl + jj * a.dil;
+            v = *reinterpret_cast<const float4*>(xb + (int64_t)f * a.x.sF + 4 * t4);
+            if constexpr (NB) {                           // aid_norm_bwd's arithmetic (norm_bwd_kernel), element by element
+                const int bg = b * (a.C / a.cg) + c / a.cg;
+                const float coef = a.coef[bg], mean = a.stats[2 * bg];
+                const float4 g = *reinterpret_cast<const float4*>(a.gd.p + (int64_t)b * a.gd.sB + (int64_t)c * a.gd.sC + (int64_t)f * a.gd.sF + 4 * t4);
+                v = make_float4(g.x - coef * (v.x - mean), g.y - coef * (v.y - mean), g.z - coef * (v.z - mean), g.w - coef * (v.w - mean));
+                if (a.gy.p) {
+                    const float4 y = *reinterpret_cast<const float4*>(a.gy.p + (int64_t)b * a.gy.sB + (int64_t)c * a.gy.sC + (int64_t)f * a.gy.sF + 4 * t4);
+                    v.x += a.nb_a * y.x; v.y += a.nb_a * y.y; v.z += a.nb_a * y.z; v.w += a.nb_a * y.w;
+                }
+                if (jl >= 2 && jl < 2 + 4 * jbe)          // the rows of THIS workgroup's row tiles (the halo rows belong to its neighbours)
+                    *reinterpret_cast<float4*>(a.gx.p + (int64_t)b * a.gx.sB + (int64_t)c * a.gx.sC + (int64_t)f * a.gx.sF + 4 * t4) = v;
+            }
             v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
             if (a.act == 1) { v.x = aid_gelu(v.x); v.y = aid_gelu(v.y); v.z = aid_gelu(v.z); v.w = aid_gelu(v.w); }      // (gelu(0) = 0: the padding stays zero)
         }
@@ -560,40 +576,65 @@ __global__ __launch_bounds__(256) void w2d_input_kernel(const W2dInDev a) {
     }
 }
 
-// called by aid_scale_act (aid_norm.hip) for wino == 3 (F(4,3) along T) and wino == 4 (F(8,3) along T)
-int aid_w2d_input(const aid_scale_act_params* p, hipStream_t st) {
-    const int TF = w2d_tf_of(p->wino);
-    AID_REQUIRE(p->dilF >= 1 && (p->F % p->dilF) == 0 && (p->T % 16) == 0 && p->T <= 2048, "aid_scale_act(wino=3|4): F % dilF == 0, T % 16 == 0, T <= 2048");
-    AID_REQUIRE((p->x.sB % 4) == 0 && (p->x.sC % 4) == 0 && (p->x.sF % 4) == 0 && (((uintptr_t)p->x.p) & 15) == 0, "aid_scale_act(wino=3): 16-byte aligned input rows");
-    const W2dGeo ge = w2d_geo(p->B, p->F, p->T, p->dilF, TF);
-    AID_REQUIRE(ge.N < (1LL << 31), "aid_scale_act(wino=3): too many positions");
-    W2dInDev a;
-    a.x = p->x; a.scale = p->scale; a.scale_ld = p->scale_ld; a.V = p->y.p;
-    a.B = p->B; a.C = p->C; a.F = p->F; a.T = p->T; a.act = p->act; a.dil = p->dilF;
+// geometry / blocking of the input pass for a prefilled W2dInDev (x, scale, V, B, C, F, T, act, dil [, the NB fields]) and its launch
+static int w2d_input_launch(W2dInDev& a, int TF, bool nb, hipStream_t st) {
+    AID_REQUIRE(a.dil >= 1 && (a.F % a.dil) == 0 && (a.T % 16) == 0 && a.T <= 2048, "2-D Winograd input pass: F % dilF == 0, T % 16 == 0, T <= 2048");
+    AID_REQUIRE(TF == 4 || (a.T % 32) == 0, "2-D Winograd input pass with F(8,3) along T: T % 32 == 0");
+    AID_REQUIRE((a.x.sB % 4) == 0 && (a.x.sC % 4) == 0 && (a.x.sF % 4) == 0 && (((uintptr_t)a.x.p) & 15) == 0, "2-D Winograd input pass: 16-byte aligned input rows");
+    const W2dGeo ge = w2d_geo(a.B, a.F, a.T, a.dil, TF);
+    AID_REQUIRE(ge.N < (1LL << 31), "2-D Winograd input pass: too many positions");
     a.R = ge.R; a.J = ge.J; a.TG = ge.TG; a.NB = ge.NB; a.N = ge.N;
     // RB classes per workgroup: 64 positions (256 bytes) per row tile where the dilation has that many classes; the largest divisor of dil below that otherwise
     int RB = ge.TG >= 64 ? 1 : 64 / ge.TG;
-    if (RB > p->dilF) RB = p->dilF;
-    while (p->dilF % RB) --RB;
-    a.RB = RB; a.nrb = p->dilF / RB; a.rowf = RB * p->T;
+    if (RB > a.dil) RB = a.dil;
+    while (a.dil % RB) --RB;
+    a.RB = RB; a.nrb = a.dil / RB; a.rowf = RB * a.T;
     // JB row tiles per workgroup: 8 (activations 1.125 x), fewer when the slab would pass 40 KB (four workgroups per CU; round 6: the F(8,3) form doubles RB at
     // the same T, and a 64-KB slab left two workgroups per CU -- 248 instead of 138 us on [128, 256, 256] d8) or the launch would have too few workgroups;
     // then BALANCED over the row tiles (J = 8 as 7 + 1 loaded 32 + 8 rows for 8 tiles: now 4 + 4)
-    int JB = 10240 / a.rowf / 4 - 1;
-    if (JB < 1) JB = 16384 / a.rowf / 4 - 1;               // (very long rows: up to 64 KB)
-    if (JB > 8) JB = 8;
+    // and MORE than 8 where a row tile has few positions (RB TG < 32: T = 32 .. 64 at small dilations), so that phase 2 has a tile for every thread
+    // (F(8,3) on [256, 448, 32] d1: 4 positions per row tile left 32 of 256 threads busy -- 63 us against 44 for the F(4,3) form's 64)
+    int JBmax = 10240 / a.rowf / 4 - 1;
+    if (JBmax < 1) JBmax = 16384 / a.rowf / 4 - 1;         // (very long rows: up to 64 KB)
+    int JB = aid_cdiv(256, RB * ge.TG);
+    if (JB < 8) JB = 8;
+    if (JB > JBmax) JB = JBmax;
     if (JB > ge.J) JB = ge.J;
-    while (JB > 2 && (int64_t)p->B * p->C * a.nrb * aid_cdiv(ge.J, JB) < 2048) JB >>= 1;
-    AID_REQUIRE(JB >= 1, "aid_scale_act(wino=3): T too long for the LDS slab");
+    while (JB > 2 && (int64_t)a.B * a.C * a.nrb * aid_cdiv(ge.J, JB) < 2048) JB >>= 1;
+    AID_REQUIRE(JB >= 1, "2-D Winograd input pass: T too long for the LDS slab");
     JB = aid_cdiv(ge.J, aid_cdiv(ge.J, JB));
     a.JB = JB; a.njb = aid_cdiv(ge.J, JB);
-    const int64_t nblk = (int64_t)p->B * p->C * a.nrb * a.njb;
-    AID_REQUIRE(nblk < (1LL << 31), "aid_scale_act(wino=3): grid too large");
+    const int64_t nblk = (int64_t)a.B * a.C * a.nrb * a.njb;
+    AID_REQUIRE(nblk < (1LL << 31), "2-D Winograd input pass: grid too large");
     const size_t lds = (size_t)(4 * JB + 4) * a.rowf * 4;
-    if (TF == 8) hipLaunchKernelGGL(w2d_input_kernel<8>, dim3((unsigned)nblk), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(w2d_input_kernel<4>, dim3((unsigned)nblk), dim3(256), lds, st, a);
+    const dim3 grid((unsigned)nblk);
+    if (TF == 8) { if (nb) hipLaunchKernelGGL((w2d_input_kernel<8, true>), grid, dim3(256), lds, st, a); else hipLaunchKernelGGL((w2d_input_kernel<8, false>), grid, dim3(256), lds, st, a); }
+    else { if (nb) hipLaunchKernelGGL((w2d_input_kernel<4, true>), grid, dim3(256), lds, st, a); else hipLaunchKernelGGL((w2d_input_kernel<4, false>), grid, dim3(256), lds, st, a); }
     AID_CHECK_LAUNCH();
     return AID_OK;
+}
+
+// called by aid_scale_act (aid_norm.hip) for wino == 3 (F(4,3) along T) and wino == 4 (F(8,3) along T)
+int aid_w2d_input(const aid_scale_act_params* p, hipStream_t st) {
+    W2dInDev a = {};
+    a.x = p->x; a.scale = p->scale; a.scale_ld = p->scale_ld; a.V = p->y.p;
+    a.B = p->B; a.C = p->C; a.F = p->F; a.T = p->T; a.act = p->act; a.dil = p->dilF;
+    return w2d_input_launch(a, w2d_tf_of(p->wino), false, st);
+}
+
+// called by aid_norm_bwd (aid_norm.hip) for wform == 3 | 4: the normalisation backward AND the 2-D input transform of (its result times wscale[b,c]) for the
+// dgrad conv of the layer below in one pass -- reads gd, x, gy once (1.125 x with the halo rows), writes out (= dL/dx) and V
+int aid_w2d_input_nb(const aid_norm_bwd_params* p, const float* coef, hipStream_t st) {
+    AID_REQUIRE(!p->accumulate && p->wdil >= 1, "aid_norm_bwd(wform=3|4): accumulate = 0 and wdil = the dilation of the layer that reads V");
+    AID_REQUIRE((p->gd.sB % 4) == 0 && (p->gd.sC % 4) == 0 && (p->gd.sF % 4) == 0 && (((uintptr_t)p->gd.p) & 15) == 0 &&
+                (p->out.sB % 4) == 0 && (p->out.sC % 4) == 0 && (p->out.sF % 4) == 0 && (((uintptr_t)p->out.p) & 15) == 0 &&
+                (!p->gy.p || ((p->gy.sB % 4) == 0 && (p->gy.sC % 4) == 0 && (p->gy.sF % 4) == 0 && (((uintptr_t)p->gy.p) & 15) == 0)),
+                "aid_norm_bwd(wform=3|4): 16-byte aligned rows");
+    W2dInDev a = {};
+    a.x = p->x; a.scale = p->wscale; a.scale_ld = p->wscale_ld; a.V = p->wout.p;
+    a.B = p->B; a.C = p->C; a.F = p->F; a.T = p->T; a.act = 0; a.dil = p->wdil;
+    a.gd = p->gd; a.gy = p->gy; a.gx = p->out; a.coef = coef; a.stats = p->stats; a.nb_a = p->a; a.cg = p->C / p->groups;
+    return w2d_input_launch(a, p->wform == 4 ? 8 : 4, true, st);
 }
 
 // =====================================================================================================================================
@@ -796,10 +837,14 @@ int aid_w2d_partials(int Cout, int F, int T, int dilF, int TF) { const W2dGeo g 
 
 // Which T form the 2-D form of a launch should take: 0 = the launch is not for the 2-D form at all (aid_conv2d_wino2d_wanted == 0), 4 = F(4,5) x F(4,3)
 // (x_wino = 3, 48 planes), 8 = F(4,5) x F(8,3) (x_wino = 4, 80 planes: 2.5 instead of 3.0 products per output and 2.5 x instead of 3 x the activation in V / M).
-// F(8,3) wherever a row has at least two groups of eight per ... [measured: profiles/r06_w2d_tf8_layer_ab.txt]; a function of the launch shape.
+// A function of the launch shape, B included.
 extern "C" int aid_conv2d_wino2d_tform(int B, int Cin, int Cout, int F, int T, int dilF) {
     if (!aid_conv2d_wino2d_wanted(B, Cin, Cout, F, T, dilF)) return 0;
-    return (T % 32) == 0 ? 8 : 4;                            // (T / 8 groups per row, a multiple of 4: the GEMM's N % 4 == 0)
+    if (T % 32) return 4;                                    // (T / 8 groups per row, a multiple of 4: the GEMM's N % 4 == 0)
+    // per layer (tools/w2d_tf_probe.py, profiles/r06_w2d_tf8_layer_ab.txt): the three passes of the F(8,3) form take 0.81-0.92 of the F(4,3) form's time at
+    // batch 4 and 8 on every level, 0.87-0.91 on level 5 at batch 1; a launch with fewer than 512 positions per plane (level 6 at batch 1: 448, the last GEMM
+    // column tile 7/8 empty) ties (0.98-1.03) and keeps the more accurate form
+    return w2d_geo(B, F, T, dilF, 8).N >= 512 ? 8 : 4;
 }
 
 // aid_conv2d with x_wino = 3: x.p = V [48][Cin][N], wp_wino = U [48][Cin_pad][Cout_pad], ws = scratch for M [48][Cout][N]

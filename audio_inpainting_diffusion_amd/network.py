@@ -570,11 +570,12 @@ class _Builder:
                 # (keeps it on the direct-to-LDS kernel)
                 gw = self._wino_input(cout, cin, gy.shape[3], wpT, wpwT, gy.shape[2], dil, wpw8T, wpw2T, wpw3T) if norm_stats is not None else 0
                 gin = self._wino_scratch("g", gw, gy.shape[0], cout, gy.shape[2], gy.shape[3], dil)
-                nb = self._nb_src.pop(self._vkey(gy), None) if (gw in (4, 8) and self.net.fuse_norm_bwd_wino) else None
+                nb = self._nb_src.pop(self._vkey(gy), None) if (gw in (4, 8, 45, 85) and self.net.fuse_norm_bwd_wino) else None
                 if nb is not None and nb[1] > self._g_last.get(gin.data_ptr(), -1) and nb[3].lane == self.lane:
-                    # gy was written last by an aid_norm_bwd and nothing used this scratch since: that pass also writes gin
-                    nb[0].wout, nb[0].wscale, nb[0].wscale_ld = _lib.view4(gin), out_scale.data_ptr(), out_scale.stride(0)
-                    nb[0].wform = 2 if gw == 8 else 1
+                    # gy was written last by an aid_norm_bwd and nothing used this scratch since: that pass also writes gin (for the 2-D forms it then
+                    # IS this layer's input pass: the normalisation backward folded into the transform, one read of gd / x / gy instead of two passes)
+                    nb[0].wout, nb[0].wscale, nb[0].wscale_ld = self._sa_out(gin), out_scale.data_ptr(), out_scale.stride(0)
+                    nb[0].wform, nb[0].wdil = {4: 1, 8: 2, 45: 3, 85: 4}[gw], dil
                     self.plan.keep.extend((gin, out_scale))
                     nb[3].also_writes(gin)
                 else:

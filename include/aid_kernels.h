@@ -417,9 +417,13 @@ typedef struct {
     aid_view wout;                /* optional second output (T % 16 == 0): the F(4,3) input transform [B, C, F, 6, T/4] of out * wscale[b,c] -- what
                                      aid_scale_act(wino=1) would write for the dgrad conv of the layer below (its gate pre-pass folded into this pass) */
     const float* wscale; int64_t wscale_ld;   /* [B, wscale_ld] or NULL (-> 1) */
-    int wform;                    /* Winograd form of wout: 0 / 1 = F(4,3) as above; 2 = F(8,3), wout rows [10][T/8] (aid_scale_act wino = 2) */
+    int wform;                    /* Winograd form of wout: 0 / 1 = F(4,3) as above; 2 = F(8,3), wout rows [10][T/8] (aid_scale_act wino = 2);
+                                     3 / 4 (ABI 14): the 2-D forms -- wout.p is V [48 | 80][C][N] (wout's strides unused), exactly what aid_scale_act(wino = 3 | 4,
+                                     act = 0, scale = wscale, dilF = wdil) would write from `out`: this pass then IS the input pass of the dgrad conv of the layer
+                                     below (reads gd, x, gy once -- 1.125 x with the halo rows -- writes out and V); accumulate must be 0 */
     int coef_ready;               /* 1: the B*groups coefficients behind the partials in `ws` were already written by the conv that produced the partials
                                      (aid_conv2d fin_mode = 2): the coefficient kernel is not launched */
+    int wdil;                     /* wform = 3 | 4 only: the dilation of the 5x3 layer that will read V */
 } aid_norm_bwd_params;
 int aid_norm_bwd(const aid_norm_bwd_params* p, void* stream);
 

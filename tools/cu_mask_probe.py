@@ -13,6 +13,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audio_inpainting_diffusion_amd import _lib as L
 from audio_inpainting_diffusion_amd.streams import cu_masked_stream, partition_masks
 
+LAUNCH_COST = "--launch-cost" in sys.argv
+if LAUNCH_COST:
+    sys.argv.remove("--launch-cost")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 Cc, F, T, dil = (int(v) for v in sys.argv[2:6]) if len(sys.argv) > 5 else (256, 384, 64, 2)
 dev = "cuda"
@@ -160,8 +163,7 @@ def launch_cost():
 
 
 if __name__ == "__main__":
-    if "--launch-cost" in sys.argv:
-        sys.argv.remove("--launch-cost")
+    if LAUNCH_COST:
         launch_cost()
     else:
         main()

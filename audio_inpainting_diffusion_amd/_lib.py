@@ -124,7 +124,7 @@ class Add2Params(C.Structure):
 
 class ScaleActParams(C.Structure):
     _fields_ = [("x", View), ("y", View), ("scale", C.c_void_p), ("scale_ld", C.c_int64),
-                ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("act", C.c_int), ("wino", C.c_int), ("dilF", C.c_int)]
+                ("B", C.c_int), ("C", C.c_int), ("F", C.c_int), ("T", C.c_int), ("act", C.c_int), ("wino", C.c_int), ("dilF", C.c_int), ("mul", C.c_float)]
 
 
 class FftPassParams(C.Structure):

@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void scale_act_kernel(const SaDev a) {
     const int bc = row / p.F;
     const int c = bc % p.C;
     const int b = bc / p.C;
-    const float sc = p.scale ? p.scale[(int64_t)b * p.scale_ld + c] : 1.f;
+    const float sc = (p.scale ? p.scale[(int64_t)b * p.scale_ld + c] : 1.f) * (p.mul != 0.f ? p.mul : 1.f);
     float4 v = *reinterpret_cast<const float4*>(p.x.p + (int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)f * p.x.sF + o4);
     v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
     if (p.act == 1) { v.x = aid_gelu(v.x); v.y = aid_gelu(v.y); v.z = aid_gelu(v.z); v.w = aid_gelu(v.w); }
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void scale_act_wino_kernel(const SaDev a) {
     const int bc = row / p.F;
     const int c = bc % p.C;
     const int b = bc / p.C;
-    const float sc = p.scale ? p.scale[(int64_t)b * p.scale_ld + c] : 1.f;
+    const float sc = (p.scale ? p.scale[(int64_t)b * p.scale_ld + c] : 1.f) * (p.mul != 0.f ? p.mul : 1.f);
     const float* xr = p.x.p + (int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)f * p.x.sF;
     float h[18];                                         // h[0] = sample o16-1 ... h[17] = sample o16+16
 #pragma unroll
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void scale_act_wino8_kernel(const SaDev a) {
         const int bc = row / p.F;
         const int c = bc % p.C;
         const int b = bc / p.C;
-        const float sc = p.scale ? p.scale[(int64_t)b * p.scale_ld + c] : 1.f;
+        const float sc = (p.scale ? p.scale[(int64_t)b * p.scale_ld + c] : 1.f) * (p.mul != 0.f ? p.mul : 1.f);
         const float* xr = p.x.p + (int64_t)b * p.x.sB + (int64_t)c * p.x.sC + (int64_t)f * p.x.sF;
         float h[18];                                     // h[0] = sample o16-1 ... h[17] = sample o16+16
 #pragma unroll

@@ -484,7 +484,7 @@ static inline bool w2d_shape_ok(int Cin, int Cout, int F, int T, int dil) {
 // Activations per element: (4 JB + 4) / (4 JB) = 1.125 at JB = 8.  ~90 registers: its waves fit beside the two resident GEMM workgroups of another stream.
 // =====================================================================================================================================
 struct W2dInDev {
-    aid_view x; const float* scale; int64_t scale_ld;
+    aid_view x; const float* scale; int64_t scale_ld; float mul;      // element = act(x * scale[b,c] * mul)
     float* V;
     // NB mode (the normalisation backward folded into this pass, aid_norm_bwd wform = 3 | 4): the element is gd - coef[b,g] (x - mean[b,g]) + nb_a gy,
     // written to gx for the rows this workgroup owns, and times scale[b,c] into the transform
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void w2d_input_kernel(const W2dInDev a) {
     const int j0 = jbk * a.JB, r0 = rbk * a.RB;
     const int jbe = min(a.JB, a.J - j0);                  // row tiles of this workgroup
     const int nrows = 4 * jbe + 4;                        // sub-lattice indices 4 j0 - 2 .. 4 (j0 + jbe) + 1
-    const float sc = a.scale ? a.scale[(int64_t)b * a.scale_ld + c] : 1.f;
+    const float sc = (a.scale ? a.scale[(int64_t)b * a.scale_ld + c] : 1.f) * a.mul;
     const float* const xb = a.x.p + (int64_t)b * a.x.sB + (int64_t)c * a.x.sC;
     const int T4 = a.T >> 2, per_row = a.RB * T4;         // float4s per row group
     // ---- phase 1: HBM -> activation -> LDS -------------------------------------------------------------------------------------------
@@ -617,7 +617,7 @@ static int w2d_input_launch(W2dInDev& a, int TF, bool nb, hipStream_t st) {
 // called by aid_scale_act (aid_norm.hip) for wino == 3 (F(4,3) along T) and wino == 4 (F(8,3) along T)
 int aid_w2d_input(const aid_scale_act_params* p, hipStream_t st) {
     W2dInDev a = {};
-    a.x = p->x; a.scale = p->scale; a.scale_ld = p->scale_ld; a.V = p->y.p;
+    a.x = p->x; a.scale = p->scale; a.scale_ld = p->scale_ld; a.V = p->y.p; a.mul = p->mul != 0.f ? p->mul : 1.f;
     a.B = p->B; a.C = p->C; a.F = p->F; a.T = p->T; a.act = p->act; a.dil = p->dilF;
     return w2d_input_launch(a, w2d_tf_of(p->wino), false, st);
 }
@@ -631,7 +631,7 @@ int aid_w2d_input_nb(const aid_norm_bwd_params* p, const float* coef, hipStream_
                 (!p->gy.p || ((p->gy.sB % 4) == 0 && (p->gy.sC % 4) == 0 && (p->gy.sF % 4) == 0 && (((uintptr_t)p->gy.p) & 15) == 0)),
                 "aid_norm_bwd(wform=3|4): 16-byte aligned rows");
     W2dInDev a = {};
-    a.x = p->x; a.scale = p->wscale; a.scale_ld = p->wscale_ld; a.V = p->wout.p;
+    a.x = p->x; a.scale = p->wscale; a.scale_ld = p->wscale_ld; a.V = p->wout.p; a.mul = 1.f;
     a.B = p->B; a.C = p->C; a.F = p->F; a.T = p->T; a.act = 0; a.dil = p->wdil;
     a.gd = p->gd; a.gy = p->gy; a.gx = p->out; a.coef = coef; a.stats = p->stats; a.nb_a = p->a; a.cg = p->C / p->groups;
     return w2d_input_launch(a, p->wform == 4 ? 8 : 4, true, st);

@@ -188,15 +188,50 @@ class _Builder:
         self.gstate = {}       # storage data_ptr -> 'full' (first contribution overwrites the whole tensor: no zero fill,
                                #   no read-modify-write) | 'zero' (touched through partial views: zero-filled, accumulated)
         self.scratch = {}      # shape -> scratch tensor for dgrad outputs awaiting the normalisation backward
+        self.galias = {}       # (reverse sweep) storage data_ptr of a gradient tensor -> [(view key, gradient view, source view, multiplier)]: a PENDING scaled
+                               #   copy "gradient = multiplier * source" that has not been launched -- see _defer_copy / Gsrc
 
     # ---- gradient storage: one flat buffer per activation storage, views share strides/offsets ------------
-    def G(self, t):
+    def G(self, t, _peek=False):
         st = t.untyped_storage()
         g = self.gmap.get(st.data_ptr())
         if g is None:
             g = self.gmap[st.data_ptr()] = torch.zeros(st.nbytes() // 4, device=self.device, dtype=torch.float32)
             self.nbytes += g.numel() * 4
-        return g.as_strided(t.size(), t.stride(), t.storage_offset())
+        gv = g.as_strided(t.size(), t.stride(), t.storage_offset())
+        if self.galias and not _peek:                     # anybody who asks for this gradient the ordinary way needs it in memory: launch what was deferred
+            self._materialise(st.data_ptr())
+        return gv
+
+    # ---- deferred scaled copies of the reverse sweep (round 6) -------------------------------------------------------------------
+    # "dL/dres = c * dL/dy" as the FIRST contribution to dL/dres is a pure scaled copy (8 bytes per element and a launch: 56 of them per guided evaluation,
+    # 1.6 % of the GPU time at batch 8 and 61 launches of ~10 us at batch 1).  Where the only readers of dL/dres are the gate pre-pass and the normalisation
+    # backward of the LAST dilated step of a block, those read dL/dy through the pending copy instead (aid_scale_act mul, aid_norm_bwd a) and the copy is
+    # never launched; any other access (G) launches it first.
+    def _defer_copy(self, src, dst, c):
+        """dst = c * src, to be launched only if somebody needs dst in memory (both gradient views)"""
+        if not self.net.fold_grad_copies or self.train or not self._in_bwd:
+            self.add2_raw(src, None, dst, c, 0.0)
+            return
+        key = dst.untyped_storage().data_ptr()
+        self._materialise(key)                             # (an older pending copy into the same storage would be overwritten in the wrong order)
+        self.galias.setdefault(key, []).append((self._vkey(dst), dst, src, float(c)))
+
+    def _materialise(self, storage_ptr=None):
+        for key in ([storage_ptr] if storage_ptr is not None else list(self.galias)):
+            for _vk, dst, src, c in self.galias.pop(key, ()):
+                self.add2_raw(src, None, dst, c, 0.0)
+
+    def Gsrc(self, t):
+        """(gradient view to READ, multiplier): the source of a pending scaled copy into dL/dt when exactly that view is pending (the copy is then dropped),
+        else (G(t), 1.0)"""
+        gv = self.G(t, _peek=True)
+        key = t.untyped_storage().data_ptr()
+        pend = self.galias.get(key)
+        if pend and len(pend) == 1 and pend[0][0] == self._vkey(gv):
+            _vk, _dst, src, c = self.galias.pop(key)[0]
+            return src, c
+        return self.G(t), 1.0
 
     def _gacc(self, t) -> bool:
         """Decide, at plan-build time, whether the next gradient contribution to activation ``t`` must accumulate
@@ -268,6 +303,7 @@ class _Builder:
             self.lane = lane
             emit()
         self.lane = 0
+        self._materialise()                                # (pending copies nobody read through: the caller reads the gradients from memory)
         self._in_bwd = False
         self.bplan, self.plan = self.plan, fwd_plan
         return self.bplan
@@ -555,9 +591,11 @@ class _Builder:
             return
 
         def bw():
-            gy = self.G(y)
-            B, _, F, T = x.shape
             fused_res = (norm_stats is not None) and (res is x)
+            # the last dilated step of a block may read dL/dy THROUGH a pending scaled copy (see _defer_copy): its only readers here are the gate pre-pass
+            # (aid_scale_act mul) and the normalisation backward's skip term (a)
+            gy, gmul = self.Gsrc(y) if (kh > 1 and out_scale is not None and norm_stats is not None and fused_res and not self.train) else (self.G(y), 1.0)
+            B, _, F, T = x.shape
             if res is not None and not fused_res and not res_nograd:
                 gr = self.G(res)
                 if self._gacc(res):
@@ -570,7 +608,7 @@ class _Builder:
                 # (keeps it on the direct-to-LDS kernel)
                 gw = self._wino_input(cout, cin, gy.shape[3], wpT, wpwT, gy.shape[2], dil, wpw8T, wpw2T, wpw3T) if norm_stats is not None else 0
                 gin = self._wino_scratch("g", gw, gy.shape[0], cout, gy.shape[2], gy.shape[3], dil)
-                nb = self._nb_src.pop(self._vkey(gy), None) if (gw in (4, 8, 45, 85) and self.net.fuse_norm_bwd_wino) else None
+                nb = self._nb_src.pop(self._vkey(gy), None) if (gw in (4, 8, 45, 85) and self.net.fuse_norm_bwd_wino and gmul == 1.0) else None
                 if nb is not None and nb[1] > self._g_last.get(gin.data_ptr(), -1) and nb[3].lane == self.lane:
                     # gy was written last by an aid_norm_bwd and nothing used this scratch since: that pass also writes gin (for the 2-D forms it then
                     # IS this layer's input pass: the normalisation backward folded into the transform, one read of gd / x / gy instead of two passes)
@@ -580,7 +618,7 @@ class _Builder:
                     nb[3].also_writes(gin)
                 else:
                     sp = _lib.ScaleActParams(_lib.view4(gy), self._sa_out(gin), out_scale.data_ptr(), out_scale.stride(0), gy.shape[0],
-                                             cout, gy.shape[2], gy.shape[3], 0, XW_CODE[gw], dil)
+                                             cout, gy.shape[2], gy.shape[3], 0, XW_CODE[gw], dil, 0.0 if gmul == 1.0 else gmul)
                     self._add("aid_scale_act", sp, gy, gin, out_scale, writes=(gin,))
                 self._g_last[gin.data_ptr()] = len(self.plan.ops)      # (the dgrad conv below reads it)
                 gsc = None
@@ -606,7 +644,7 @@ class _Builder:
                     self._train_conv(x, gy, gd, wname, cin, cout, kh, kw, dil, in_scale, act, out_scale, alpha, wpw=wpw)
                 npar = _lib.NormBwdParams(_lib.view4(gd), _lib.view4(x), _lib.view4(gy if fused_res else None), _lib.view4(self.G(x)),
                                           B, cin, F, T, 8, norm_stats.data_ptr(), dws.data_ptr(), 1e-7,
-                                          alpha * res_scale, 1 if self._gacc(x) else 0, nd)
+                                          alpha * res_scale * gmul, 1 if self._gacc(x) else 0, nd)
                 npar.coef_ready = 1 if fin else 0
                 gxv = self.G(x)
                 nop = self._add("aid_norm_bwd", npar, gd, x, gy, norm_stats, dws, gxv, writes=(gxv,))
@@ -636,11 +674,12 @@ class _Builder:
     def res_grad(self, res, y, c):
         """Register dL/dres (+)= c * dL/dy (the residual input of a conv whose own input gradient is taken elsewhere)."""
         def bw():
-            gy, gr = self.G(y), self.G(res)
+            gy = self.G(y)
             if self._gacc(res):
+                gr = self.G(res)
                 self.add2_raw(gr, gy, gr, 1.0, c)
             else:
-                self.add2_raw(gy, None, gr, c, 0.0)
+                self._defer_copy(gy, self.G(res, _peek=True), c)
         self._reg_bwd(bw)
 
     def add2_raw(self, u, v, y, a, b):
@@ -654,12 +693,13 @@ class _Builder:
         self.add2_raw(u, v, y, a, b)
 
         def bw():
-            gy, gu, gv = self.G(y), self.G(u), self.G(v)
-            for tt, gt, c in ((u, gu, a), (v, gv, b)):
+            gy = self.G(y)
+            for tt, c in ((u, a), (v, b)):
                 if self._gacc(tt):
+                    gt = self.G(tt)
                     self.add2_raw(gt, gy, gt, 1.0, c)
                 else:
-                    self.add2_raw(gy, None, gt, c, 0.0)
+                    self._defer_copy(gy, self.G(tt, _peek=True), c)
         self._reg_bwd(bw)
 
     def copy(self, u, y):
@@ -1316,6 +1356,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
     wgrad_wino = True          # training: F(4,3) form of the 5x3 weight gradients (aid_conv2d_wgrad wino=1)
     fuse_fin = True            # the last tile of a sample folds the conv epilogue's statistics / dot partials itself (aid_conv2d fin_mode): no aid_group_stats
                                # launch after such a conv and no coefficient kernel in aid_norm_bwd (A/B: bench.py --no-fin)
+    fold_grad_copies = True    # reverse sweep: a first-contribution scaled copy dL/dres = c dL/dy is not launched where the last dilated step of a block can read
+                               # dL/dy through it (aid_scale_act mul / aid_norm_bwd a): _Builder._defer_copy (A/B: bench.py --no-fold-copies)
     fuse_norm_bwd_wino = True  # reverse sweep: aid_norm_bwd also writes the Winograd-domain, gated copy that the dgrad conv below stages
     epilogue_stats = True      # forward group statistics from the epilogue of the conv that produces the tensor (row-shared F(4,3) kernel)
     GRAPH_MAX_B = 3

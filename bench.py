@@ -247,6 +247,7 @@ def main():
     ap.add_argument("--no-pair-merge", action="store_true", help="A/B: separate input-gradient convs for proj_in and res_conv")
     ap.add_argument("--no-lanes", action="store_true", help="A/B: single-stream launch plans at small batches (plan.py lanes off)")
     ap.add_argument("--no-fused-norm-bwd", action="store_true", help="A/B: separate gate / Winograd-transform pre-pass before every dgrad conv")
+    ap.add_argument("--no-fold-copies", action="store_true", help="A/B: launch every first-contribution scaled gradient copy of the reverse sweep (network.fold_grad_copies = False)")
     ap.add_argument("--no-fin", action="store_true", help="A/B: separate aid_group_stats / coefficient launches instead of the last tile of a sample folding the epilogue partials")
     ap.add_argument("--no-epilogue-stats", action="store_true", help="A/B: group statistics by their own read pass instead of the conv epilogue")
     ap.add_argument("--wino-forms", default="4,8,45,85", help="A/B: Winograd forms the 5x3 layers may use (default 4,8,45,85: the 2-D forms F(4,5) x F(8,3) / F(4,5) x F(4,3) and the fused F(8,3) where the library prefers them; "
@@ -312,6 +313,8 @@ def main():
         net.epilogue_stats = False
     if a.no_fin:
         net.fuse_fin = False
+    if a.no_fold_copies:
+        net.fold_grad_copies = False
     if a.no_fused_norm_bwd:
         net.fuse_norm_bwd_wino = False
     if a.streams:

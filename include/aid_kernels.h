@@ -530,6 +530,8 @@ typedef struct {
                                  4: the 2-D input transform F(4,5) x F(8,3) for aid_conv2d x_wino = 4: y.p is V [80][C][N/2],
                                  V[xf*10 + xt][c][b*NB + (j*dilF + r)*(T/8) + g] of the 8 x 10 patch of rows r + dilF*(4j-2 .. 4j+5), samples 8g-1 .. 8g+8; T % 32 == 0 */
     int dilF;                 /* wino = 3 | 4 only: the dilation of the 5x3 layer that will read V */
+    float mul;                /* (ABI 14) optional scalar on top of scale[b,c]: h = act(x * scale[b,c] * mul); 0 = none.  The reverse sweep reads a gradient
+                                 tensor THROUGH a pending scaled copy (dL/dres = c * dL/dy) instead of materialising the copy first */
 } aid_scale_act_params;
 int aid_scale_act(const aid_scale_act_params* p, void* stream);
 

@@ -200,7 +200,7 @@ class _Builder:
             self.nbytes += g.numel() * 4
         gv = g.as_strided(t.size(), t.stride(), t.storage_offset())
         if self.galias and not _peek:                     # anybody who asks for this gradient the ordinary way needs it in memory: launch what was deferred
-            self._materialise(st.data_ptr())
+            self._materialise(g.untyped_storage().data_ptr())      # (galias is keyed by the GRADIENT buffer's storage)
         return gv
 
     # ---- deferred scaled copies of the reverse sweep (round 6) -------------------------------------------------------------------
@@ -226,7 +226,7 @@ class _Builder:
         """(gradient view to READ, multiplier): the source of a pending scaled copy into dL/dt when exactly that view is pending (the copy is then dropped),
         else (G(t), 1.0)"""
         gv = self.G(t, _peek=True)
-        key = t.untyped_storage().data_ptr()
+        key = gv.untyped_storage().data_ptr()
         pend = self.galias.get(key)
         if pend and len(pend) == 1 and pend[0][0] == self._vkey(gv):
             _vk, _dst, src, c = self.galias.pop(key)[0]

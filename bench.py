@@ -361,6 +361,12 @@ def main():
     # batches of segments does.  Two positions stay in reserve for the single-stream roofline pass.
     ROOF_STEPS = max(1, a.roof_steps)                  # Heun steps of the single-stream roofline pass (after one warm-up step)
     span = T - 2 - (ROOF_STEPS + 1)
+    if a.cu_split or a.cu_partition:
+        # hipExtStreamCreateWithCUMask makes BLOCKING streams: they synchronise implicitly with the NULL stream, which is torch's default stream -- every
+        # element-wise launch of the sampler between two evaluations then drains and gates both masked streams through the runtime's legacy-stream path
+        # (first A/B of the round: 16 + 16 CUs per XCD 29 evaluations/s; the same two evaluations without null-stream launches in between: level with
+        # free-running streams, profiles/r06_cu_mask_e2e_probe.txt).  The experiment therefore runs its main stream on a non-blocking pool stream.
+        torch.cuda.set_stream(torch.cuda.Stream())
     state = smp.begin((B, L), dev)
 
     def do_step(i):

@@ -68,6 +68,9 @@ template <int N> struct W2dVec;
 template <> struct W2dVec<1> { typedef float type; };
 template <> struct W2dVec<2> { typedef float2 type; };
 template <> struct W2dVec<4> { typedef float4 type; };
+struct w2d_float3 { float x, y, z; };                                  // (three interleaved rows of the 96-channel levels: 12-byte aligned, read as b32 / b64 pieces)
+template <> struct W2dVec<3> { typedef w2d_float3 type; };
+__device__ __forceinline__ float w2d_get(const w2d_float3& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 __device__ __forceinline__ float w2d_get(const float& v, int) { return v; }
 __device__ __forceinline__ float w2d_get(const float2& v, int i) { return i ? v.y : v.x; }
 __device__ __forceinline__ float w2d_get(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
@@ -426,6 +429,10 @@ extern "C" int aid_wino2d_gemm(const aid_wino2d_gemm_params* p, void* stream) {
     AID_REQUIRE(((uintptr_t)p->U & 15) == 0 && ((uintptr_t)p->V & 15) == 0 && ((uintptr_t)p->M & 15) == 0 && (p->Cout_pad % 4) == 0, "aid_wino2d_gemm: 16-byte alignment");
     AID_REQUIRE(p->Cin_pad >= p->Cin && p->Cout_pad >= p->Cout, "aid_wino2d_gemm: padded dims");
     int variant = p->variant;
+    if (variant == 0 && (p->Cout_pad % 128) != 0) {                    // the 96-channel levels: 96 x 128 tiles on two waves (three interleaved 32-row fragments per lane),
+        AID_REQUIRE((p->Cout_pad % 96) == 0, "aid_wino2d_gemm: Cout_pad must be a multiple of 128 or of 96");      // three workgroups per CU (round 5's patch, kept out of the
+        return w2d_launch_gemm<3, 2, 1, 2, 16, 3, 3>(p, st, "w2d_gemm_kernel<96x128,kc16,nb3,wpc3>", "w2d_gemm_kernel<96x128,kc16,nb3,wpc3>+t8");     // product then: with 48 planes it lost 0.6-1.2 %)
+    }
     if (variant == 0 && g_w2d_split == 6) variant = ((int64_t)p->nxi * aid_cdiv(p->N, 256) * aid_cdiv(p->Cout, 128) < 1600) ? 101 : 100;
     if (variant == 0) {
         // 128 x 256 tiles (two workgroups per CU) while the launch has a few rounds of them; 128 x 128 tiles at four workgroups per CU for the short ones
@@ -471,7 +478,7 @@ static inline W2dGeo w2d_geo(int B, int F, int T, int dil, int TF = 4) {
 }
 static inline int w2d_tf_of(int x_wino) { return x_wino == 4 ? 8 : 4; }          // aid_conv2d_params::x_wino / aid_scale_act_params::wino: 3 -> F(4,3), 4 -> F(8,3) along T
 static inline bool w2d_shape_ok(int Cin, int Cout, int F, int T, int dil) {
-    return dil >= 1 && (F % dil) == 0 && (T % 16) == 0 && T >= 16 && T <= 2048 && (Cin % 16) == 0 && (Cout % 128) == 0 && Cin >= 64;
+    return dil >= 1 && (F % dil) == 0 && (T % 16) == 0 && T >= 16 && T <= 2048 && (Cin % 16) == 0 && ((Cout % 128) == 0 || (Cout % 96) == 0) && Cin >= 64;
 }
 
 // =====================================================================================================================================

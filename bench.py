@@ -256,6 +256,7 @@ def main():
                     "six bf16 MFMA products, fp32 accumulation (aid_wino2d_set_split); the JSON's dtype says so")
     ap.add_argument("--w2d-min-channels", type=int, default=0, help="A/B: 256 keeps the 2-D Winograd form off the K = 128 levels (network.w2d_min_channels)")
     ap.add_argument("--w2d-force-max-t", type=int, default=0, help="A/B: the 2-D Winograd form on every SUPPORTED layer with T up to this (network.w2d_force_max_T)")
+    ap.add_argument("--w2d-c96-max-t", type=int, default=-1, help="A/B: the 96-channel levels with T up to this take the 2-D Winograd form (network.w2d_c96_max_T)")
     ap.add_argument("--lanes-max-batch", type=int, default=-1, help="A/B: run the two lanes of the launch plans on two streams for (sub-)batches up to this size (network.lanes_max_batch; default 3)")
     ap.add_argument("--lanes-in-sub-batches", action="store_true", help="A/B: two-lane launch plans inside the sub-batch streams too (network.lanes_in_sub_batches)")
     ap.add_argument("--split", default="", help="A/B: explicit sub-batch sizes, e.g. 5,3 (network.split_sizes; implies --streams = their count)")
@@ -305,6 +306,8 @@ def main():
         net.w2d_min_channels = a.w2d_min_channels
     if a.w2d_force_max_t:
         net.w2d_force_max_T = a.w2d_force_max_t
+    if a.w2d_c96_max_t >= 0:
+        net.w2d_c96_max_T = a.w2d_c96_max_t
     if a.cu_partition:
         net.cu_partition = a.cu_partition
     if a.cu_split:

@@ -30,7 +30,7 @@ def _rand(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
-@pytest.mark.parametrize("shape", [(128, 128, 256), (64, 128, 1000), (256, 256, 2052), (32, 128, 4)])
+@pytest.mark.parametrize("shape", [(128, 128, 256), (64, 128, 1000), (256, 256, 2052), (32, 128, 4), (96, 96, 1000), (64, 192, 260)])
 def test_wino2d_gemm_vs_torch(L, shape):
     """M[xi] = U[xi]^T V[xi] for 48 planes; ragged last column tile, K of 2 .. 16 chunks"""
     cin, cout, N = shape
@@ -85,6 +85,8 @@ W2D_CASES = [
     (2, 128, 24, 32, 8),         # R = 3: a single ragged tile per class
     (1, 256, 12, 48, 2),         # two Cout tiles, T = 48 (TG = 12)
     (3, 128, 8, 528, 1),         # TG = 132 > 64 lanes: neighbour samples across wave boundaries
+    (2, 96, 24, 64, 2),          # the 96-channel levels: 96 x 128 GEMM tiles (three interleaved row fragments per lane), K = 6 chunks
+    (1, 192, 16, 32, 1),         # two 96-row tiles
 ]
 
 
@@ -113,6 +115,7 @@ W2D8_CASES = [
     (2, 128, 24, 32, 8),         # R = 3: a single ragged tile per class
     (1, 256, 12, 96, 2),         # two Cout tiles, TG = 12
     (3, 128, 8, 544, 1),         # TG = 68 > 64 lanes: neighbour samples across wave boundaries
+    (2, 96, 24, 64, 2),          # 96-channel level
 ]
 
 

@@ -507,7 +507,7 @@ def test_two_dimensional_winograd_choice_is_a_function_of_the_launch_shape():
         assert L.aid_conv2d_wino2d_wanted(B, 128, 128, 320, 128, 4) == L.aid_conv2d_wino2d_wanted(B, 128, 128, 320, 128, 4)
         assert L.aid_conv2d_wino2d_positions(B, 448, 32, 64) == B * 2 * 64 * 8 and L.aid_conv2d_wino2d_positions(B, 384, 64, 1) == B * 96 * 16
     assert L.aid_conv2d_wino2d_supported(256, 256, 448, 32, 1) == 1 and L.aid_conv2d_wino2d_supported(128, 128, 256, 256, 16) == 1
-    assert L.aid_conv2d_wino2d_supported(96, 96, 192, 512, 2) == 0 and L.aid_conv2d_wino2d_supported(256, 256, 448, 24, 1) == 0      # Cout % 128, T % 16
+    assert L.aid_conv2d_wino2d_supported(96, 96, 192, 512, 2) == 1 and L.aid_conv2d_wino2d_supported(64, 64, 64, 2048, 1) == 0 and L.aid_conv2d_wino2d_supported(256, 256, 448, 24, 1) == 0      # Cout % 128 or % 96, T % 16
     assert L.aid_conv2d_wino2d_supported(256, 256, 450, 32, 4) == 0 and L.aid_conv2d_wino2d_supported(128, 128, 64, 4096, 1) == 0    # F % dil, T <= 2048
 
 

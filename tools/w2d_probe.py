@@ -75,6 +75,9 @@ def gemm(variants):
 
 # (label, C, F, T, dilations) -- the C >= 128 levels of the 22.05 kHz network (level geometry)
 LAYER_SHAPES = [
+    ("L1 C96 F128 T1024", 96, 128, 1024, (1, 4)),
+    ("L2 C96 F192 T512", 96, 192, 512, (1, 2, 4, 8)),
+    ("L3d C96 F256 T256", 96, 256, 256, (1, 4)),
     ("L3 C128 F256 T256", 128, 256, 256, (1, 2, 4, 8, 16)),
     ("L4 C128 F320 T128", 128, 320, 128, (1, 2, 4, 8, 16, 32)),
     ("L5 C256 F384 T64", 256, 384, 64, (1, 2, 4, 8, 16, 32, 64)),
@@ -102,16 +105,19 @@ def layer(batches):
             y = torch.empty_like(x)
             w = (torch.randn(C, C, 5, 3, generator=g) / (C * 15) ** 0.5).to(dev)
             isc, osc = torch.ones(B, C, device=dev), torch.ones(B, C, device=dev)
-            wp, w2, w4, w8 = _lib.pack_conv_weight(w), _lib.pack_conv_weight_wino2d(w), _lib.pack_conv_weight_wino(w), _lib.pack_conv_weight_wino8(w)
+            TF = int(os.environ.get("PROBE_TF", "4"))            # 8: the F(4,5) x F(8,3) form (x_wino = 4, 80 planes)
+            NXI, XW = (80, 4) if TF == 8 else (48, 3)
+            wp, w4, w8 = _lib.pack_conv_weight(w), _lib.pack_conv_weight_wino(w), _lib.pack_conv_weight_wino8(w)
+            w2 = _lib.pack_conv_weight_wino2d8(w) if TF == 8 else _lib.pack_conv_weight_wino2d(w)
             el = B * C * Fd * T
             for dil in dils:
-                if not lib.aid_conv2d_wino2d_supported(C, C, Fd, T, dil):
+                if not lib.aid_conv2d_wino2d_supported(C, C, Fd, T, dil) or (TF == 8 and T % 32):
                     continue
-                N = int(lib.aid_conv2d_wino2d_positions(B, Fd, T, dil))
-                V = torch.empty(48 * C * N, device=dev)
-                ws = torch.empty(48 * C * N, device=dev)
-                sp = _lib.ScaleActParams(_lib.view4(x), _lib.View(V.data_ptr(), 0, 0, 0), isc.data_ptr(), isc.stride(0), B, C, Fd, T, 1, 3, dil)
-                gp = _lib.Wino2dGemmParams(w2.data_ptr(), V.data_ptr(), ws.data_ptr(), 48, C, C, wp.shape[1], wp.shape[2], N, 0)
+                N = int(lib.aid_conv2d_wino2d_positions(B, Fd, T, dil)) * 4 // TF
+                V = torch.empty(NXI * C * N, device=dev)
+                ws = torch.empty(NXI * C * N, device=dev)
+                sp = _lib.ScaleActParams(_lib.view4(x), _lib.View(V.data_ptr(), 0, 0, 0), isc.data_ptr(), isc.stride(0), B, C, Fd, T, 1, XW, dil)
+                gp = _lib.Wino2dGemmParams(w2.data_ptr(), V.data_ptr(), ws.data_ptr(), NXI, C, C, wp.shape[1], wp.shape[2], N, 0)
 
                 def cpar(xin, xw, wpw, taps):
                     p = _lib.Conv2dParams()
@@ -123,7 +129,7 @@ def layer(batches):
                     p.KH, p.KW, p.dilF, p.act, p.epi = 5, 3, dil, 0, 0
                     p.alpha, p.res_scale = 0.7071, 1.0
                     return p
-                p3 = cpar(_lib.View(V.data_ptr(), 0, 0, 0), 3, w2, 48)
+                p3 = cpar(_lib.View(V.data_ptr(), 0, 0, 0), XW, w2, NXI)
                 p3.ws, p3.ws_bytes = ws.data_ptr(), ws.numel() * 4
                 t_in = time_call(lambda: _lib.call("aid_scale_act", sp))
                 t_g = time_call(lambda: _lib.call("aid_wino2d_gemm", gp))
@@ -137,7 +143,7 @@ def layer(batches):
                 gp.variant = 0
                 t_c = time_call(lambda: _lib.call("aid_conv2d", p3))
                 t_out = t_c - t_g
-                nfl = 2.0 * 48 * C * C * N
+                nfl = 2.0 * NXI * C * C * N
                 # the 1-D path as the library picks it
                 form = int(lib.aid_conv2d_wino_form(B, C, C, Fd, T, dil))
                 cols = {4: 6 * (T // 4), 8: 10 * (T // 8)}.get(form)
@@ -149,9 +155,9 @@ def layer(batches):
                 p1 = cpar(_lib.view4(xv), {4: 1, 8: 2}[form], {4: w4, 8: w8}[form], {4: 30, 8: 50}[form])
                 t_p1 = time_call(lambda: _lib.call("aid_scale_act", sp1))
                 t_c1 = time_call(lambda: _lib.call("aid_conv2d", p1))
-                pad = N * 16 / (B * Fd * T)
-                print(f"{label} d{dil:<2d} B{B} | {t_in * 1e6:6.1f} ({(el * 4 + 48 * C * N * 4) / t_in / 1e12:4.2f})  {t_g * 1e6:6.1f} ({nfl / t_g / PEAK:5.3f})  "
-                      f"{t_out * 1e6:6.1f} ({(48 * C * N * 4 + 3 * el * 4) / t_out / 1e12:4.2f})  {(t_in + t_c) * 1e6:7.1f} | F({form},3) {t_p1 * 1e6:6.1f} {t_c1 * 1e6:7.1f} "
+                pad = N * 4 * TF / (B * Fd * T)
+                print(f"{label} d{dil:<2d} B{B} | {t_in * 1e6:6.1f} ({(el * 4 + NXI * C * N * 4) / t_in / 1e12:4.2f})  {t_g * 1e6:6.1f} ({nfl / t_g / PEAK:5.3f})  "
+                      f"{t_out * 1e6:6.1f} ({(NXI * C * N * 4 + 3 * el * 4) / t_out / 1e12:4.2f})  {(t_in + t_c) * 1e6:7.1f} | F({form},3) {t_p1 * 1e6:6.1f} {t_c1 * 1e6:7.1f} "
                       f"{(t_p1 + t_c1) * 1e6:7.1f} | {(t_in + t_c) / (t_p1 + t_c1):5.3f}  pad {pad:4.2f}  " + " ".join(tv), flush=True)
                 del V, ws, xv
             del x, res, y

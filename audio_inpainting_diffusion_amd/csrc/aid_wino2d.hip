@@ -499,7 +499,9 @@ struct W2dInDev {
     int B, C, F, T, act, dil;
     int R, J, TG, NB;
     int RB, JB, nrb, njb;      // residue classes / row tiles per workgroup, workgroups along each
-    int rowf;                  // floats per LDS row group = RB * T
+    int rowf;                  // floats per LDS row group = RB * roww
+    int TS, nts, hal, roww;    // T segments (round 6: long rows -- T = 512 / 1024 on the 96-channel levels -- no longer force JB = 1 .. 4): a workgroup takes TS samples
+                               // of a row plus `hal` float4 of halo on either side (one sample of each is used); roww = TS + 8 hal floats per class row
     int64_t N;
 };
 
@@ -508,6 +510,7 @@ __global__ __launch_bounds__(256) void w2d_input_kernel(const W2dInDev a) {
     constexpr int NTP = TF + 2;                           // planes along T: 6 (F(4,3)) or 10 (F(8,3))
     extern __shared__ __attribute__((aligned(16))) float w2d_slab[];
     int rest = blockIdx.x;
+    const int ts = rest % a.nts; rest /= a.nts;
     const int jbk = rest % a.njb; rest /= a.njb;
     const int rbk = rest % a.nrb; rest /= a.nrb;
     const int c = rest % a.C;
@@ -518,16 +521,18 @@ __global__ __launch_bounds__(256) void w2d_input_kernel(const W2dInDev a) {
     const int nrows = 4 * jbe + 4;                        // sub-lattice indices 4 j0 - 2 .. 4 (j0 + jbe) + 1
     const float sc = (a.scale ? a.scale[(int64_t)b * a.scale_ld + c] : 1.f) * a.mul;
     const float* const xb = a.x.p + (int64_t)b * a.x.sB + (int64_t)c * a.x.sC;
-    const int T4 = a.T >> 2, per_row = a.RB * T4;         // float4s per row group
+    const int T4 = a.T >> 2, W4 = a.roww >> 2, per_row = a.RB * W4;         // float4s per row / per slab row / per row group
+    const int t4base = ts * (a.TS >> 2) - a.hal;          // first float4 of the slab row within the tensor row (the halo float4 first)
     // ---- phase 1: HBM -> activation -> LDS -------------------------------------------------------------------------------------------
     const int n4 = nrows * per_row;
 #pragma unroll 4
     for (int e = tid; e < n4; e += 256) {
         const int jl = e / per_row, rem = e - jl * per_row;
-        const int rl = rem / T4, t4 = rem - rl * T4;
+        const int rl = rem / W4, q4 = rem - rl * W4;
+        const int t4 = t4base + q4;
         const int jj = 4 * j0 - 2 + jl;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (jj >= 0 && jj < a.R) {
+        if (jj >= 0 && jj < a.R && t4 >= 0 && t4 < T4) {
             const int f = r0 + rl + jj * a.dil;
             v = *reinterpret_cast<const float4*>(xb + (int64_t)f * a.x.sF + 4 * t4);
             if constexpr (NB) {                           // aid_norm_bwd's arithmetic (norm_bwd_kernel), element by element
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(256) void w2d_input_kernel(const W2dInDev a) {
                     const float4 y = *reinterpret_cast<const float4*>(a.gy.p + (int64_t)b * a.gy.sB + (int64_t)c * a.gy.sC + (int64_t)f * a.gy.sF + 4 * t4);
                     v.x += a.nb_a * y.x; v.y += a.nb_a * y.y; v.z += a.nb_a * y.z; v.w += a.nb_a * y.w;
                 }
-                if (jl >= 2 && jl < 2 + 4 * jbe)          // the rows of THIS workgroup's row tiles (the halo rows belong to its neighbours)
+                if (jl >= 2 && jl < 2 + 4 * jbe && q4 >= a.hal && q4 < W4 - a.hal)      // the rows / samples of THIS workgroup's tiles (the halo belongs to its neighbours)
                     *reinterpret_cast<float4*>(a.gx.p + (int64_t)b * a.gx.sB + (int64_t)c * a.gx.sC + (int64_t)f * a.gx.sF + 4 * t4) = v;
             }
             v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
@@ -549,25 +554,27 @@ __global__ __launch_bounds__(256) void w2d_input_kernel(const W2dInDev a) {
     }
     __syncthreads();
     // ---- phase 2: tiles ----------------------------------------------------------------------------------------------------------------
-    const int per_j = a.RB * a.TG;
+    const int TGs = a.TS / TF;                            // groups of this segment
+    const int per_j = a.RB * TGs;
     const int ntile = jbe * per_j;
     const int64_t pstride = (int64_t)a.C * a.N;
     for (int tl = tid; tl < ntile; tl += 256) {
         const int jl = tl / per_j, rem = tl - jl * per_j;
-        const int rl = rem / a.TG, g = rem - rl * a.TG;
-        const float* sp = w2d_slab + (4 * jl) * a.rowf + rl * a.T + TF * g;
+        const int rl = rem / TGs, gl = rem - rl * TGs;
+        const int g = ts * TGs + gl;
+        const float* sp = w2d_slab + (4 * jl) * a.rowf + rl * a.roww + 4 * a.hal + TF * gl;
         float W[8][NTP];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float* row = sp + i * a.rowf;
             float d[NTP];
-            d[0] = g > 0 ? row[-1] : 0.f;
+            d[0] = (gl > 0 || a.hal) ? row[-1] : 0.f;          // (a halo float4 outside the tensor row was stored as zeros)
 #pragma unroll
             for (int q = 0; q < TF / 4; ++q) {
                 const float4 v = *reinterpret_cast<const float4*>(row + 4 * q);
                 d[1 + 4 * q] = v.x; d[2 + 4 * q] = v.y; d[3 + 4 * q] = v.z; d[4 + 4 * q] = v.w;
             }
-            d[TF + 1] = g < a.TG - 1 ? row[TF] : 0.f;
+            d[TF + 1] = (gl < TGs - 1 || a.hal) ? row[TF] : 0.f;
             if constexpr (TF == 4) aid_w45_input_t(d, W[i]); else aid_wino8_input(d, W[i]);
         }
         float* vp = a.V + (int64_t)c * a.N + (int64_t)b * a.NB + (int64_t)((j0 + jl) * a.dil + r0 + rl) * a.TG + g;
@@ -591,11 +598,17 @@ static int w2d_input_launch(W2dInDev& a, int TF, bool nb, hipStream_t st) {
     const W2dGeo ge = w2d_geo(a.B, a.F, a.T, a.dil, TF);
     AID_REQUIRE(ge.N < (1LL << 31), "2-D Winograd input pass: too many positions");
     a.R = ge.R; a.J = ge.J; a.TG = ge.TG; a.NB = ge.NB; a.N = ge.N;
+    // T segments of 256 samples for rows longer than that (one float4 of halo on either side)
+    a.TS = (a.T > 256 && (a.T % 256) == 0) ? 256 : a.T;
+    a.nts = a.T / a.TS; a.hal = a.nts > 1 ? 1 : 0; a.roww = a.TS + 8 * a.hal;
+    const int TGs = a.TS / TF;
     // RB classes per workgroup: 64 positions (256 bytes) per row tile where the dilation has that many classes; the largest divisor of dil below that otherwise
-    int RB = ge.TG >= 64 ? 1 : 64 / ge.TG;
+    // (and fewer while a row group would pass 384 floats: the slab must hold at least six row tiles)
+    int RB = TGs >= 64 ? 1 : 64 / TGs;
     if (RB > a.dil) RB = a.dil;
     while (a.dil % RB) --RB;
-    a.RB = RB; a.nrb = a.dil / RB; a.rowf = RB * a.T;
+    while (RB > 1 && RB * a.roww > 384) { --RB; while (a.dil % RB) --RB; }
+    a.RB = RB; a.nrb = a.dil / RB; a.rowf = RB * a.roww;
     // JB row tiles per workgroup: 8 (activations 1.125 x), fewer when the slab would pass 40 KB (four workgroups per CU; round 6: the F(8,3) form doubles RB at
     // the same T, and a 64-KB slab left two workgroups per CU -- 248 instead of 138 us on [128, 256, 256] d8) or the launch would have too few workgroups;
     // then BALANCED over the row tiles (J = 8 as 7 + 1 loaded 32 + 8 rows for 8 tiles: now 4 + 4)
@@ -603,15 +616,15 @@ static int w2d_input_launch(W2dInDev& a, int TF, bool nb, hipStream_t st) {
     // (F(8,3) on [256, 448, 32] d1: 4 positions per row tile left 32 of 256 threads busy -- 63 us against 44 for the F(4,3) form's 64)
     int JBmax = 10240 / a.rowf / 4 - 1;
     if (JBmax < 1) JBmax = 16384 / a.rowf / 4 - 1;         // (very long rows: up to 64 KB)
-    int JB = aid_cdiv(256, RB * ge.TG);
+    int JB = aid_cdiv(256, RB * TGs);
     if (JB < 8) JB = 8;
     if (JB > JBmax) JB = JBmax;
     if (JB > ge.J) JB = ge.J;
-    while (JB > 2 && (int64_t)a.B * a.C * a.nrb * aid_cdiv(ge.J, JB) < 2048) JB >>= 1;
+    while (JB > 2 && (int64_t)a.B * a.C * a.nrb * a.nts * aid_cdiv(ge.J, JB) < 2048) JB >>= 1;
     AID_REQUIRE(JB >= 1, "2-D Winograd input pass: T too long for the LDS slab");
     JB = aid_cdiv(ge.J, aid_cdiv(ge.J, JB));
     a.JB = JB; a.njb = aid_cdiv(ge.J, JB);
-    const int64_t nblk = (int64_t)a.B * a.C * a.nrb * a.njb;
+    const int64_t nblk = (int64_t)a.B * a.C * a.nrb * a.njb * a.nts;
     AID_REQUIRE(nblk < (1LL << 31), "2-D Winograd input pass: grid too large");
     const size_t lds = (size_t)(4 * JB + 4) * a.rowf * 4;
     const dim3 grid((unsigned)nblk);
@@ -832,6 +845,10 @@ extern "C" int aid_conv2d_wino2d_wanted(int B, int Cin, int Cout, int F, int T, 
     if (!w2d_shape_ok(Cin, Cout, F, T, dilF)) return 0;
     const W2dGeo ge = w2d_geo(B, F, T, dilF);
     const double pad = (double)ge.J * 4.0 / (double)ge.R;
+    // round 6: the 96-channel levels (1, 2 and the decoder of 3) on the 80-plane form with 96 x 128 GEMM tiles -- with 48 planes this lost 0.6-1.2 % end to end (round 5),
+    // with 80 it is 0.87-0.94 of the fused F(8,3) path per layer at T <= 512 and ties at T = 1024 (profiles/r06_w2d_c96_tf8_probe.txt: batch 1 0.77-0.98), and end to end
+    // 60.5 / 60.7 -> 62.1 / 61.6 evaluations/s at batch 8, 38.4 -> 39.8 at batch 1, 48.2 -> 49.9 at batch 2 (profiles/r06_w2d_c96_bench_ab.txt)
+    if ((Cout % 128) != 0) return (Cin >= 96 && (T % 32) == 0 && T <= 1024 && pad <= 1.21) ? 1 : 0;
     if (Cin >= 256 && Cout >= 256) return pad <= 1.34 ? 1 : 0;
     if (Cin < 128 || Cout < 128 || pad > 1.21) return 0;
     if (T <= 256) return 1;

@@ -540,8 +540,8 @@ class _Builder:
         if wpw2 is not None and (45 in self.net.wino_forms or 85 in self.net.wino_forms) and _lib.lib().aid_conv2d_wino2d_supported(cin, cout, F, T, dil):
             # the non-fused 2-D form F(4,5) x F(4,3) (csrc/aid_wino2d.hip: 3.0 products per output) where the library predicts it faster than the fused
             # 1-D kernels (aid_conv2d_wino2d_wanted, a function of the launch shape); wino_forms = (45,): wherever it is supported (tests, A/B)
-            if tuple(self.net.wino_forms) in ((45,), (85,), (45, 85)) or (min(cin, cout) >= self.net.w2d_min_channels and (T <= self.net.w2d_force_max_T or _lib.lib().aid_conv2d_wino2d_wanted(fb, cin, cout, F, T, dil))) \
-                    or (cout % 128 != 0 and T <= self.net.w2d_c96_max_T):
+            if tuple(self.net.wino_forms) in ((45,), (85,), (45, 85)) or (min(cin, cout) >= self.net.w2d_min_channels and (T <= self.net.w2d_force_max_T or _lib.lib().aid_conv2d_wino2d_wanted(fb, cin, cout, F, T, dil))
+                                                                            and (cout % 128 == 0 or T <= self.net.w2d_c96_max_T)):
                 # ... and which T form: F(8,3) along T (85: 2.5 products per output, 2.5 x the activation in V / M) where the library says so
                 # (aid_conv2d_wino2d_tform), F(4,3) (45) otherwise; wino_forms without 85 / 45 restricts the choice
                 if wpw3 is not None and 85 in self.net.wino_forms and T % 32 == 0 and (45 not in self.net.wino_forms or tuple(self.net.wino_forms) == (85,) or cout % 128 != 0
@@ -1352,7 +1352,8 @@ class Unet_CQT_oct_with_attention(nn.Module):
                                # An int pins the choice to that batch for every launch (e.g. 1: the forms of a single-segment launch everywhere), so the FORM no longer
                                # depends on how segments are grouped; the tile INSTANCE inside a form (K-group / split-K instances for launches with few tiles) still
                                # follows the launch shape, so this narrows the difference, it does not promise identical bits.  Set before the first forward.
-    w2d_c96_max_T = 0          # A/B (set before the first forward): the 96-channel levels with T up to this take the 2-D form too (96 x 128 GEMM tiles; bench.py --w2d-c96-max-t)
+    w2d_c96_max_T = 1024       # the 96-channel levels with T up to this take the 2-D form where the library wants it (96 x 128 GEMM tiles, 80 planes; round 6);
+                               # 0: never (A/B, bench.py --w2d-c96-max-t 0; set before the first forward: it also decides which packs are built)
     w2d_force_max_T = 0        # A/B: layers with T up to this take the 2-D form wherever it is SUPPORTED, whatever the library's per-layer prediction says (bench.py --w2d-force-max-t)
     w2d_min_channels = 128     # A/B: 256 keeps the 2-D form off the K = 128 levels the library would give it (bench.py --w2d-min-channels)
     wgrad_wino = True          # training: F(4,3) form of the 5x3 weight gradients (aid_conv2d_wgrad wino=1)

@@ -83,9 +83,9 @@ def test_unet_full_cfgA_vs_reference_golden(forms):
     print(f"unet_full_cfgA (wino_forms {forms}: {n2 - n28} F(4,5)xF(4,3) + {n28} F(4,5)xF(8,3) + {n8} F(8,3) + {n4} F(4,3) layers): rel-L2 vs reference golden = {e:.3e}; algorithmic GFLOP/eval = {net.flops_per_eval(1) / 1e9:.1f}")
     # (6 rows per residue class -- dil 64 on level 5, dil 32 on level 4 -- have no F(8,3) tile: with F(4,3) input excluded those four layers transform in the kernel)
     if 85 in forms:
-        assert n2 + n8 + n4 == 75 and (n2 == n28 == 52 if forms == (85,) else (n2 >= 20 and n28 >= 1))
-    elif 45 in forms:      # (45,): the 2-D form on every C >= 128 layer (52 of the 75); the default: where the library predicts it faster (a batch of one: every C >= 128 layer but the 4/3-padded one)
-        assert n2 + n8 + n4 == 75 and (n2 == 52 if forms == (45,) else n2 >= 20)
+        assert n2 + n8 + n4 == 75 and (n2 == n28 == 68 if forms == (85,) else (n2 >= 20 and n28 >= 1))      # (68 = the 52 layers of the C >= 128 levels + the 16 of the 96-channel levels)
+    elif 45 in forms:      # (45,): the 2-D form on every C >= 96 layer (68 of the 75); the default: where the library predicts it faster (a batch of one: every C >= 128 layer but the 4/3-padded one)
+        assert n2 + n8 + n4 == 75 and (n2 == 68 if forms == (45,) else n2 >= 20)
     else:
         assert n2 == 0 and ((n8 >= 60 and n4 == 0) if forms == (8,) else ((n8 == 0 and n4 == 75) if forms == (4,) else (n8 >= 20 and n8 + n4 == 75)))
     assert e < TOL

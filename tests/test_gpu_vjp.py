@@ -389,7 +389,7 @@ def test_norm_bwd_with_winograd_domain_copy(L, shape, with_gy, wform):
 
 @pytest.mark.parametrize("wform", [3, 4])
 @pytest.mark.parametrize("shape,dil,with_gy", [((2, 16, 24, 64), 2, True), ((1, 64, 20, 32), 4, False), ((2, 8, 28, 96), 1, True), ((1, 8, 8, 544), 1, True),
-                                                ((2, 16, 24, 32), 8, True)])
+                                                ((2, 16, 24, 32), 8, True), ((1, 8, 12, 512), 2, True)])
 def test_norm_bwd_folded_into_the_2d_input_pass(L, shape, dil, with_gy, wform):
     """aid_norm_bwd(wform = 3 | 4): ONE pass that is both the normalisation backward (out = what the plain call writes, to rounding: the two kernels'
     FMA contraction differs) and the 2-D Winograd input pass of the layer below -- V [48 | 80][C][N] = what aid_scale_act(wino = 3 | 4, scale = wscale,

@@ -87,6 +87,7 @@ W2D_CASES = [
     (3, 128, 8, 528, 1),         # TG = 132 > 64 lanes: neighbour samples across wave boundaries
     (2, 96, 24, 64, 2),          # the 96-channel levels: 96 x 128 GEMM tiles (three interleaved row fragments per lane), K = 6 chunks
     (1, 192, 16, 32, 1),         # two 96-row tiles
+    (1, 128, 12, 512, 2),        # T = 512: the input pass works in two T segments of 256 samples with a float4 of halo on either side
 ]
 
 
@@ -116,6 +117,8 @@ W2D8_CASES = [
     (1, 256, 12, 96, 2),         # two Cout tiles, TG = 12
     (3, 128, 8, 544, 1),         # TG = 68 > 64 lanes: neighbour samples across wave boundaries
     (2, 96, 24, 64, 2),          # 96-channel level
+    (1, 96, 8, 1024, 4),         # T = 1024: four T segments in the input pass, four residue classes
+    (2, 128, 20, 512, 1),        # T = 512, ragged row tiles
 ]
 
 

@@ -503,7 +503,7 @@ def test_two_dimensional_winograd_choice_is_a_function_of_the_launch_shape():
             assert L.aid_conv2d_wino2d_wanted(B, 128, 128, 320, 128, d) == 1                 # (d = 32: 10 rows per class -> 12, padding 1.2)
         assert L.aid_conv2d_wino2d_wanted(B, 128, 128, 384, 64, 64) == 0                    # 6 rows per class -> 8: 1.33 does not pay at K = 128
         assert L.aid_conv2d_wino2d_wanted(B, 128, 128, 256, 256, 2) == 1 and L.aid_conv2d_wino2d_wanted(B, 128, 128, 128, 512, 2) == (1 if B <= 2 else 0)
-        assert L.aid_conv2d_wino2d_wanted(B, 96, 96, 192, 512, 2) == 0 and L.aid_conv2d_wino2d_wanted(B, 64, 64, 64, 2048, 1) == 0
+        assert L.aid_conv2d_wino2d_wanted(B, 96, 96, 192, 512, 2) == 1 and L.aid_conv2d_wino2d_wanted(B, 96, 96, 64, 2048, 1) == 0 and L.aid_conv2d_wino2d_wanted(B, 64, 64, 64, 2048, 1) == 0
         assert L.aid_conv2d_wino2d_wanted(B, 128, 128, 320, 128, 4) == L.aid_conv2d_wino2d_wanted(B, 128, 128, 320, 128, 4)
         assert L.aid_conv2d_wino2d_positions(B, 448, 32, 64) == B * 2 * 64 * 8 and L.aid_conv2d_wino2d_positions(B, 384, 64, 1) == B * 96 * 16
     assert L.aid_conv2d_wino2d_supported(256, 256, 448, 32, 1) == 1 and L.aid_conv2d_wino2d_supported(128, 128, 256, 256, 16) == 1

@@ -598,8 +598,9 @@ static int w2d_input_launch(W2dInDev& a, int TF, bool nb, hipStream_t st) {
     const W2dGeo ge = w2d_geo(a.B, a.F, a.T, a.dil, TF);
     AID_REQUIRE(ge.N < (1LL << 31), "2-D Winograd input pass: too many positions");
     a.R = ge.R; a.J = ge.J; a.TG = ge.TG; a.NB = ge.NB; a.N = ge.N;
-    // T segments of 256 samples for rows longer than that (one float4 of halo on either side)
-    a.TS = (a.T > 256 && (a.T % 256) == 0) ? 256 : a.T;
+    // T segments of 512 samples for rows longer than that (one float4 of halo on either side): T = 1024 on level 1 left one row tile per workgroup (eight slab
+    // rows for four of output: 3.2 TB/s); segments of 256 measured 4.0 TB/s there but cost T = 512 its 256-byte store runs (4.4 -> 4.0), so 512 it is
+    a.TS = (a.T > 512 && (a.T % 512) == 0) ? 512 : a.T;
     a.nts = a.T / a.TS; a.hal = a.nts > 1 ? 1 : 0; a.roww = a.TS + 8 * a.hal;
     const int TGs = a.TS / TF;
     // RB classes per workgroup: 64 positions (256 bytes) per row tile where the dilation has that many classes; the largest divisor of dil below that otherwise

@@ -1355,7 +1355,7 @@ class Unet_CQT_oct_with_attention(nn.Module):
     w2d_c96_max_T = 1024       # the 96-channel levels with T up to this take the 2-D form where the library wants it (96 x 128 GEMM tiles, 80 planes; round 6);
                                # 0: never (A/B, bench.py --w2d-c96-max-t 0; set before the first forward: it also decides which packs are built)
     w2d_force_max_T = 0        # A/B: layers with T up to this take the 2-D form wherever it is SUPPORTED, whatever the library's per-layer prediction says (bench.py --w2d-force-max-t)
-    w2d_min_channels = 128     # A/B: 256 keeps the 2-D form off the K = 128 levels the library would give it (bench.py --w2d-min-channels)
+    w2d_min_channels = 96      # A/B: 256 keeps the 2-D form off the K = 128 levels the library would give it (bench.py --w2d-min-channels)
     wgrad_wino = True          # training: F(4,3) form of the 5x3 weight gradients (aid_conv2d_wgrad wino=1)
     fuse_fin = True            # the last tile of a sample folds the conv epilogue's statistics / dot partials itself (aid_conv2d fin_mode): no aid_group_stats
                                # launch after such a conv and no coefficient kernel in aid_norm_bwd (A/B: bench.py --no-fin)

@@ -392,6 +392,188 @@ static int w2d_launch_gemm_s6(const aid_wino2d_gemm_params* p, hipStream_t st, c
     return AID_OK;
 }
 
+// =====================================================================================================================================
+// 2b. the batched GEMM with the ROW-AXIS OUTPUT TRANSFORM FOLDED IN (round 6; the HBM-bound launches: Cin <= 128 on the 80-plane form).
+// "halve M".  A workgroup owns one T-axis index xt and one (Cout tile, column tile) and walks the EIGHT row-axis planes
+// xf = 0 .. 7 of it one after the other through the same three-buffer direct-to-LDS pipeline (the chunk stream is continuous: chunk c is K-chunk
+// c % nch of plane c / nch); when a plane's K loop ends its accumulators are folded into the four output-row accumulators with the column of AF^T
+// (Y[j] += AF^T[j][xf] * acc) and cleared.  It writes M'[j * NTP + xt][co][n], 4 NTP planes instead of 8 NTP: the GEMM's writes and the output
+// pass's reads of M halve (these launches sit below the fp32 ridge at 24-32 FLOP/B), the output pass keeps only its T transform.
+// Five accumulator sets per tile: 64-column tiles (one 32 x 32 fragment column pair per wave), two workgroups per CU.
+// =====================================================================================================================================
+__constant__ float w2d_atf[8][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f}, {1.f, 2.f, 4.f, 8.f}, {1.f, -2.f, 4.f, -8.f},
+                                    {1.f, 0.5f, 0.25f, 0.125f}, {1.f, -0.5f, 0.25f, -0.125f}, {0.f, 0.f, 0.f, 1.f}};      // [xf][j] = AF^T[j][xf] (aid_wino45.h)
+
+template <int MT, int NT, int WGM, int WGN, int KC, int NBUF, int WPC>
+__global__ __launch_bounds__(64 * WGM * WGN, (WPC * WGM * WGN + 3) / 4) void w2d_gemm_fold_kernel(const W2dGemmDev a, const int ntp) {
+    using S = W2dGemmShape<MT, NT, WGM, WGN, KC, NBUF>;
+    constexpr int NW = S::NW, M_BLK = S::M_BLK, N_BLK = S::N_BLK, XSZ = S::XSZ, BUFSZ = S::BUFSZ;
+    constexpr int NXP = S::NXP, PPW = S::PPW, NSTEP = S::NSTEP;
+    constexpr int ISTEPS = NSTEP < PPW ? NSTEP : PPW;
+    typedef typename W2dVec<MT>::type avec;
+    typedef typename W2dVec<NT>::type bvec;
+    __shared__ __attribute__((aligned(16))) float smem[S::LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int half = lane >> 5;
+
+    const int Lt = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);      // XCD-aware order: (xt, n tile, m tile), m fastest
+    if (Lt >= a.ntiles) return;
+    int rest = Lt;
+    const int by = rest % a.ntm; rest /= a.ntm;
+    const int bn = rest % a.ntn;
+    const int xt = rest / a.ntn;
+    const int m0 = by * M_BLK, n0 = bn * N_BLK;
+
+    unsigned poff[PPW];
+    int plds[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int pc = wave + i * NW;
+        plds[i] = pc * 256;
+        if (pc < NXP) {
+            const int e = pc * 256 + 4 * lane;
+            const int k = e / N_BLK, nl = e % N_BLK;
+            poff[i] = (unsigned)(4 * ((int64_t)k * a.N + min(n0 + nl, a.N - 4)));
+        } else {
+            const int e = (pc - NXP) * 256 + 4 * lane;
+            const int k = e / M_BLK, col = e % M_BLK;
+            poff[i] = (unsigned)(4 * ((int64_t)k * a.Cout_pad + m0 + col));
+        }
+    }
+    const int nch = a.nchunks, nct = 8 * nch;                // chunks per plane, chunks of the whole stream
+    const int64_t xstep = (int64_t)KC * a.N * 4, wstep = (int64_t)KC * a.Cout_pad * 4;          // bytes per chunk
+    const int64_t xplane = (int64_t)ntp * a.Cin * a.N * 4, wplane = (int64_t)ntp * a.Cin_pad * a.Cout_pad * 4;      // bytes from plane (xf, xt) to (xf + 1, xt)
+    const char* const xbase = reinterpret_cast<const char*>(a.V + (int64_t)xt * a.Cin * a.N);
+    const char* const wbase = reinterpret_cast<const char*>(a.U + (int64_t)xt * a.Cin_pad * a.Cout_pad);
+
+    const int vB = half * N_BLK + wn * (32 * NT) + NT * (lane & 31);
+    const int vA = XSZ + half * M_BLK + wm * (32 * MT) + MT * (lane & 31);
+
+    f32x16 acc[MT][NT];
+    f32x16 Y[4][MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; Y[0][i][j][r] = 0.f; Y[1][i][j][r] = 0.f; Y[2][i][j][r] = 0.f; Y[3][i][j][r] = 0.f; }
+
+    auto issue_piece = [&](auto ic, const char* xs, const char* ws, float* buf) {
+        constexpr int i = decltype(ic)::value;
+        const char* base = (wave + i * NW < NXP) ? xs : ws;          // (scalar)
+        const unsigned la = W2D_LDS_ADDR(buf + plds[i]);
+        const unsigned off = poff[i];
+        W2D_DMA16_SBASE(off, base, la);
+    };
+    auto src_of = [&](int c, const char*& xs, const char*& ws) {      // (scalar) sources of stream chunk c
+        const int xf = c / nch, kc = c - xf * nch;
+        xs = xbase + xf * xplane + kc * xstep;
+        ws = wbase + xf * wplane + kc * wstep;
+    };
+    constexpr int AHEAD = NBUF - 1;
+    w2d_static_for<AHEAD>([&](auto qc) {
+        const char *xs, *ws;
+        src_of(decltype(qc)::value, xs, ws);
+        w2d_static_for<PPW>([&](auto ic) { issue_piece(ic, xs, ws, smem + decltype(qc)::value * BUFSZ); });
+    });
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+
+    auto chunk = [&](auto curc, int ch) {
+        constexpr int cur = decltype(curc)::value;
+        const float* Bf = smem + cur * BUFSZ;
+        float* Nx = smem + ((cur + AHEAD) % NBUF) * BUFSZ;
+        const bool more = (ch + AHEAD) < nct;
+        const char *xs = xbase, *ws = wbase;
+        if (more) src_of(ch + AHEAD, xs, ws);
+        bvec bv[2];
+        avec av[2];
+        auto load_step = [&](int s_, int q) {
+            bv[q] = *reinterpret_cast<const bvec*>(Bf + vB + 2 * s_ * N_BLK);
+            av[q] = *reinterpret_cast<const avec*>(Bf + vA + 2 * s_ * M_BLK);
+        };
+        load_step(0, 0);
+        w2d_static_for<NSTEP>([&](auto sc) {
+            constexpr int s_ = decltype(sc)::value;
+            if (more) w2d_static_for<PPW>([&](auto ic) {
+                if constexpr (s_ < ISTEPS && decltype(ic)::value % ISTEPS == s_) issue_piece(ic, xs, ws, Nx);
+            });
+            if (s_ + 1 < NSTEP) load_step(s_ + 1, (s_ + 1) & 1);
+            constexpr int q = s_ & 1;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2d_get(av[q], i), w2d_get(bv[q], j), acc[i][j], 0, 0, 0);
+        });
+        asm volatile("" ::: "memory");
+        if (NBUF >= 3 && more) __builtin_amdgcn_s_waitcnt(W2D_VMCNT(PPW * (AHEAD - 1)));
+        else if (NBUF >= 4 && (ch + AHEAD - 1) < nct) __builtin_amdgcn_s_waitcnt(W2D_VMCNT(PPW * (AHEAD - 2)));
+        else __builtin_amdgcn_s_waitcnt(W2D_VMCNT(0));
+        __builtin_amdgcn_s_waitcnt(W2D_LGKMCNT0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int xf = ch / nch;
+        if (ch - xf * nch == nch - 1) {                       // (wave-uniform) the K loop of plane xf is complete: fold it into the four output rows
+            const float c0 = w2d_atf[xf][0], c1 = w2d_atf[xf][1], c2 = w2d_atf[xf][2], c3 = w2d_atf[xf][3];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][j][r];
+                        Y[0][i][j][r] += c0 * v; Y[1][i][j][r] += c1 * v; Y[2][i][j][r] += c2 * v; Y[3][i][j][r] += c3 * v;
+                        acc[i][j][r] = 0.f;
+                    }
+        }
+    };
+    for (int ch = 0; ch < nct; ch += NBUF)
+        w2d_static_for<NBUF>([&](auto qc) { if (ch + decltype(qc)::value < nct) chunk(qc, ch + decltype(qc)::value); });
+
+    // ---- epilogue: the four output-row planes j * ntp + xt ---------------------------------------------------------------------------------
+    const int n = n0 + wn * (32 * NT) + NT * (lane & 31);
+    if (n >= a.N) return;
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr) {
+        float* const cb = a.Mo + (int64_t)(jr * ntp + xt) * a.Cout * a.N + n;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (32 * MT) + MT * (4 * half + (r & 3) + 8 * (r >> 2)) + i;
+                if (m >= a.Cout) continue;
+                float* q = cb + (int64_t)m * a.N;
+                if constexpr (NT == 4) *reinterpret_cast<float4*>(q) = make_float4(Y[jr][i][0][r], Y[jr][i][1][r], Y[jr][i][2][r], Y[jr][i][3][r]);
+                else if constexpr (NT == 2) *reinterpret_cast<float2*>(q) = make_float2(Y[jr][i][0][r], Y[jr][i][1][r]);
+                else *q = Y[jr][i][0][r];
+            }
+    }
+}
+
+template <int MT, int NT, int WGM, int WGN, int KC, int NBUF, int WPC>
+static int w2d_launch_gemm_fold(const aid_wino2d_gemm_params* p, int ntp, hipStream_t st, const char* name) {
+    using S = W2dGemmShape<MT, NT, WGM, WGN, KC, NBUF>;
+    AID_REQUIRE(p->Cin % KC == 0 && p->Cout_pad % S::M_BLK == 0 && p->nxi == 8 * ntp, "w2d gemm (folded): Cin % KC, Cout_pad % M tile, nxi = 8 ntp");
+    AID_REQUIRE((int64_t)p->Cin * p->N * 4 * p->nxi < (1LL << 40) && (int64_t)p->Cin * p->N * 4 < (1LL << 32), "w2d gemm (folded): plane size");
+    W2dGemmDev a;
+    a.U = p->U; a.V = p->V; a.Mo = p->M;
+    a.Cin = p->Cin; a.Cout = p->Cout; a.Cin_pad = p->Cin_pad; a.Cout_pad = p->Cout_pad; a.N = (int)p->N;
+    a.nchunks = p->Cin / KC;
+    a.ntn = aid_cdiv(p->N, S::N_BLK);
+    a.ntm = aid_cdiv(p->Cout, S::M_BLK);
+    a.ntiles = ntp * a.ntn * a.ntm;
+    a.per_xcd = aid_cdiv(a.ntiles, 8);
+    hipLaunchKernelGGL((w2d_gemm_fold_kernel<MT, NT, WGM, WGN, KC, NBUF, WPC>), dim3((unsigned)(8 * a.per_xcd)), dim3(64 * S::NW), 0, st, a, ntp);
+    AID_CHECK_LAUNCH();
+    aid_note_kernel(name);
+    return AID_OK;
+}
+
 // the split-precision variant as a process-wide switch of aid_conv2d(x_wino = 3) (0: the fp32-MFMA product kernel; 6: the six-product bf16 split): set
 // by bench.py --mfma-split 6 and the variant's tests only
 static int g_w2d_split = 0;
@@ -685,7 +867,8 @@ struct W2dOutDev {
 #define W2D_GP8_TWO 0
 #endif
 static inline int w2d_gp(int TF, int TG) { return TF == 4 ? 2 : ((W2D_GP8_TWO > 0 && TG >= W2D_GP8_TWO && (TG % 2) == 0) ? 2 : 1); }
-template <int TF, int GP>
+// FOLD: M holds the 4 NTP planes j * NTP + xt the folded GEMM wrote (w2d_gemm_fold_kernel): only the T transform is left.
+template <int TF, int GP, bool FOLD>
 __global__ __launch_bounds__(256) void w2d_output_kernel(const W2dOutDev a) {
     constexpr int NTP = TF + 2;                           // planes along T
     constexpr int NS = GP * TF;                           // output samples per row of this thread
@@ -723,6 +906,9 @@ __global__ __launch_bounds__(256) void w2d_output_kernel(const W2dOutDev a) {
                 if constexpr (TF == 4) aid_w45_output_t(Mt, o); else aid_wino8_output(Mt, o);
             }
         };
+        if constexpr (FOLD) {
+            plane(0, Y[0]); plane(1, Y[1]); plane(2, Y[2]); plane(3, Y[3]);
+        } else {
         {
             float a0[NS], a1[NS], a2[NS];
             plane(0, a0); plane(1, a1); plane(2, a2);
@@ -740,6 +926,7 @@ __global__ __launch_bounds__(256) void w2d_output_kernel(const W2dOutDev a) {
             plane(5, a1); plane(6, a2); plane(7, a7);
 #pragma unroll
             for (int e = 0; e < NS; ++e) { const float s = a1[e] + a2[e], t = a1[e] - a2[e]; Y[0][e] += s; Y[1][e] += 0.5f * t; Y[2][e] += 0.25f * s; Y[3][e] += 0.125f * t + a7[e]; }
+        }
         }
         const float sv = p.out_scale ? p.out_scale[(int64_t)b * p.out_scale_ld + co] : 1.f;
         const float as = p.epi == 1 ? p.aux_scale[(int64_t)b * p.aux_scale_ld + co] : 0.f;
@@ -896,12 +1083,25 @@ static int w2d_check(const aid_conv2d_params* p) {
     AID_REQUIRE(!p->dot_ws || p->dot_n == npart, "aid_conv2d(x_wino=3): dot_n != aid_conv2d_dot_partials()");
     return AID_OK;
 }
+// Which launches fold the row-axis output transform into the GEMM (M' with 4 NTP planes): the HBM-bound ones -- Cin <= 128 on the 80-plane form.
+// A function of the layer shape; the GEMM and the output pass of a launch both ask it.  (W2D_FOLD_M = 0: never -- experiment builds for the A/B.)
+#ifndef W2D_FOLD_M
+#define W2D_FOLD_M 1
+#endif
+static inline bool w2d_fold_m(const aid_conv2d_params* p) {
+    return W2D_FOLD_M && p->x_wino == 4 && p->Cin <= 128 && (p->Cin % 16) == 0 && ((p->Cout_pad % 128) == 0 || (p->Cout_pad % 96) == 0);
+}
 static int w2d_gemm_of(const aid_conv2d_params* p, hipStream_t st) {
     const int TF = w2d_tf_of(p->x_wino);
     const W2dGeo ge = w2d_geo(p->B, p->F, p->T, p->dilF, TF);
     aid_wino2d_gemm_params gp;
     gp.U = p->wp_wino; gp.V = p->x.p; gp.M = p->ws;
     gp.nxi = 8 * (TF + 2); gp.Cin = p->Cin; gp.Cout = p->Cout; gp.Cin_pad = p->Cin_pad; gp.Cout_pad = p->Cout_pad; gp.N = ge.N; gp.variant = 0;
+    if (w2d_fold_m(p)) {
+        AID_REQUIRE((gp.N % 4) == 0, "aid_conv2d(x_wino=4): N % 4 == 0");
+        if ((p->Cout_pad % 128) == 0) return w2d_launch_gemm_fold<1, 2, 4, 1, 16, 3, 2>(&gp, TF + 2, st, "w2d_gemm_kernel<128x64,foldM,kc16,nb3>+t8");
+        return w2d_launch_gemm_fold<3, 1, 1, 2, 16, 3, 2>(&gp, TF + 2, st, "w2d_gemm_kernel<96x64,foldM,kc16,nb3>+t8");
+    }
     return aid_wino2d_gemm(&gp, st);
 }
 static int w2d_output_of(const aid_conv2d_params* p, hipStream_t st) {
@@ -912,9 +1112,10 @@ static int w2d_output_of(const aid_conv2d_params* p, hipStream_t st) {
     a.R = ge.R; a.J = ge.J; a.TG = ge.TG; a.NB = ge.NB; a.N = ge.N; a.nblk = w2d_nblk(ge.NB, TF, ge.TG);
     a.fin_total = p->Cout * a.nblk;
     const dim3 grid((unsigned)((int64_t)p->B * p->Cout * a.nblk));
-    if (TF == 8 && w2d_gp(8, ge.TG) == 2) hipLaunchKernelGGL((w2d_output_kernel<8, 2>), grid, dim3(256), 0, st, a);
-    else if (TF == 8) hipLaunchKernelGGL((w2d_output_kernel<8, 1>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((w2d_output_kernel<4, 2>), grid, dim3(256), 0, st, a);
+    if (TF == 8 && w2d_gp(8, ge.TG) == 2) hipLaunchKernelGGL((w2d_output_kernel<8, 2, false>), grid, dim3(256), 0, st, a);
+    else if (TF == 8 && w2d_fold_m(p)) hipLaunchKernelGGL((w2d_output_kernel<8, 1, true>), grid, dim3(256), 0, st, a);
+    else if (TF == 8) hipLaunchKernelGGL((w2d_output_kernel<8, 1, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((w2d_output_kernel<4, 2, false>), grid, dim3(256), 0, st, a);
     AID_CHECK_LAUNCH();
     return AID_OK;
 }

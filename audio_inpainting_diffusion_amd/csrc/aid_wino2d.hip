@@ -1088,8 +1088,18 @@ static int w2d_check(const aid_conv2d_params* p) {
 #ifndef W2D_FOLD_M
 #define W2D_FOLD_M 1
 #endif
+#ifndef W2D_FOLD_MIN_WGS
+#define W2D_FOLD_MIN_WGS 768
+#endif
 static inline bool w2d_fold_m(const aid_conv2d_params* p) {
-    return W2D_FOLD_M && p->x_wino == 4 && p->Cin <= 128 && (p->Cin % 16) == 0 && ((p->Cout_pad % 128) == 0 || (p->Cout_pad % 96) == 0);
+    if (!(W2D_FOLD_M && p->x_wino == 4 && p->Cin <= 128 && (p->Cin % 16) == 0 && ((p->Cout_pad % 128) == 0 || (p->Cout_pad % 96) == 0))) return false;
+    // the folded GEMM has an eighth of the workgroups (each walks eight planes) on 64-column tiles: it needs a launch that still fills the chip a few times --
+    // per layer it wins 4-9 % at >= 1280 workgroups (level 3 at the product's sub-batch of four), ties at 800 and loses 10-50 % below 650 (batch 1;
+    // profiles/r06_w2d_foldm_layer_ab.txt); end to end (profiles/r06_w2d_foldm_threshold_ab.txt, configs[1], alternating runs): no fold 61.48 / 61.52,
+    // threshold 1900 61.63 / 61.41, 1024 62.38 / 62.04, 768 62.89 / 62.55 evaluations/s; batch 1 / 2 and configs[4] unchanged under 768
+    const W2dGeo ge = w2d_geo(p->B, p->F, p->T, p->dilF, 8);
+    const int64_t wgs = (int64_t)10 * aid_cdiv(ge.N, 64) * aid_cdiv(p->Cout, (p->Cout_pad % 128) == 0 ? 128 : 96);
+    return wgs >= W2D_FOLD_MIN_WGS;
 }
 static int w2d_gemm_of(const aid_conv2d_params* p, hipStream_t st) {
     const int TF = w2d_tf_of(p->x_wino);

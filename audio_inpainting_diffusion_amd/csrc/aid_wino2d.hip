@@ -1088,11 +1088,17 @@ static int w2d_check(const aid_conv2d_params* p) {
 #ifndef W2D_FOLD_M
 #define W2D_FOLD_M 1
 #endif
+#ifndef W2D_FOLD_MAX_CIN
+#define W2D_FOLD_MAX_CIN 128
+#endif
+#ifndef W2D_FOLD_WPC
+#define W2D_FOLD_WPC 2
+#endif
 #ifndef W2D_FOLD_MIN_WGS
 #define W2D_FOLD_MIN_WGS 768
 #endif
 static inline bool w2d_fold_m(const aid_conv2d_params* p) {
-    if (!(W2D_FOLD_M && p->x_wino == 4 && p->Cin <= 128 && (p->Cin % 16) == 0 && ((p->Cout_pad % 128) == 0 || (p->Cout_pad % 96) == 0))) return false;
+    if (!(W2D_FOLD_M && p->x_wino == 4 && p->Cin <= W2D_FOLD_MAX_CIN && (p->Cin % 16) == 0 && ((p->Cout_pad % 128) == 0 || (p->Cout_pad % 96) == 0))) return false;
     // the folded GEMM has an eighth of the workgroups (each walks eight planes) on 64-column tiles: it needs a launch that still fills the chip a few times --
     // per layer it wins 4-9 % at >= 1280 workgroups (level 3 at the product's sub-batch of four), ties at 800 and loses 10-50 % below 650 (batch 1;
     // profiles/r06_w2d_foldm_layer_ab.txt); end to end (profiles/r06_w2d_foldm_threshold_ab.txt, configs[1], alternating runs): no fold 61.48 / 61.52,
@@ -1109,7 +1115,7 @@ static int w2d_gemm_of(const aid_conv2d_params* p, hipStream_t st) {
     gp.nxi = 8 * (TF + 2); gp.Cin = p->Cin; gp.Cout = p->Cout; gp.Cin_pad = p->Cin_pad; gp.Cout_pad = p->Cout_pad; gp.N = ge.N; gp.variant = 0;
     if (w2d_fold_m(p)) {
         AID_REQUIRE((gp.N % 4) == 0, "aid_conv2d(x_wino=4): N % 4 == 0");
-        if ((p->Cout_pad % 128) == 0) return w2d_launch_gemm_fold<1, 2, 4, 1, 16, 3, 2>(&gp, TF + 2, st, "w2d_gemm_kernel<128x64,foldM,kc16,nb3>+t8");
+        if ((p->Cout_pad % 128) == 0) return w2d_launch_gemm_fold<1, 2, 4, 1, 16, 3, W2D_FOLD_WPC>(&gp, TF + 2, st, "w2d_gemm_kernel<128x64,foldM,kc16,nb3>+t8");
         return w2d_launch_gemm_fold<3, 1, 1, 2, 16, 3, 2>(&gp, TF + 2, st, "w2d_gemm_kernel<96x64,foldM,kc16,nb3>+t8");
     }
     return aid_wino2d_gemm(&gp, st);

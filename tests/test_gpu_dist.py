@@ -126,25 +126,6 @@ def test_flat_parameter_storage_survives_load_and_repack():
         assert torch.equal(net(x, cn), y_other)
 
 
-def test_bench_self_launches_two_ranks_on_one_gpu():
-    """`python bench.py --gpus 2` started as a plain process must spawn its own ranks (functional mode on a 1-GPU box)."""
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "1", "--no-cpu-baseline"]
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak"
-    assert j["config"]["functional_shared_gpu"] == (torch.cuda.device_count() < 2)
-    assert j["roofline"]["frac"] is not None and 0 < j["roofline"]["frac"] < 1.0
-    # the per-rank table a bad SCALE line is read from: one row per rank in rank order, where it ran and its own clocks
-    assert [x["rank"] for x in j["ranks"]] == [0, 1] and all(x["wall_s"] > 0 and x["bcast_s"] >= 0 and x["cpu_threads"] >= 1 and x["pci"] for x in j["ranks"])
-    assert [x["segments"] for x in j["ranks"]] == [[0, 1], [1, 2]] and j["config"]["backend"] in ("gloo", "nccl") and j["config"]["visible_gpus"] == torch.cuda.device_count()
-    assert max(x["wall_s"] for x in j["ranks"]) * 1e3 <= j["ms_per_step"] * j["steps"] * 1.001 + 1e-6
-    print("bench --gpus 2 (self-launched):", j["value"], "evals/s;", j["config"]["parallelism"], "| ranks:", [(x["rank"], x["gpu"], x["numa_node"], x["cpu_threads"], x["wall_s"]) for x in j["ranks"]])
-
-
 @pytest.mark.parametrize("xi,dctype", [(0.25, "end"), (0.0, "end"), (0.25, "always")])
 def test_sampler_data_consistency_types_vs_oracle(xi, dctype):
     """data_consistency.type on the GPU sampler against the oracle (itself pinned by tests/golden/sampler_dc.npz)."""
@@ -445,35 +426,6 @@ def _worker_full(rank, world, port, q):
     torch.distributed.destroy_process_group()
 
 
-def test_full_size_two_ranks_on_one_gpu_equal_one_process():
-    """BASELINE configs[2] at its real shapes on ONE GPU: the full-size 22.05 kHz network (186 M parameters, L = 184184), 2 ranks sharing
-    cuda:0 with 2 segments each (collectives on gloo), ONE 745 MB weight broadcast, one guided Heun step (two evaluations with the
-    hand-written input-VJP), output gather == the single-process batch-4 run (which itself runs as 2 sub-batch streams)."""
-    from audio_inpainting_diffusion_amd import dist as D
-    net, args, y, mask = _full_setup(DEV, seed=0)
-    ref = _full_step(net, args, y, mask, D.item_seeds(700, 0, 4), DEV).cpu()
-    del net
-    torch.cuda.empty_cache()
-    world, port = 2, _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_full, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted((q.get(timeout=1200) for _ in range(world)), key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=300)
-        assert p.exitcode == 0
-    assert [r[2] for r in res] == [(0, 2), (2, 4)]
-    for rank, nbytes, _, allout in res:
-        e = rel_l2(allout, ref)
-        print(f"full size, rank {rank}: gathered 2x2 segments vs single-process B=4 after one guided Heun step: rel-L2 = {e:.2e} ({nbytes / 1e6:.0f} MB broadcast)")
-        # (not 0: the Winograd form / tile instance of a 5x3 layer is a function of the LAUNCH shape, batch included -- a rank's batch of two and the
-        #  single process's batch of four may take different instances, which differ in summation order)
-        assert allout.shape == tuple(ref.shape) and nbytes > 700e6 and e < 5e-6
-    assert np.array_equal(res[0][3], res[1][3])
-
-
 def test_full_size_eight_ranks_on_one_gpu_equal_one_process():
     """Dress rehearsal of BASELINE configs[2]'s WORLD SIZE before the driver's first 8-GPU run: eight processes sharing cuda:0 (gloo; RCCL refuses
     two ranks on one device), the full-size 22.05 kHz network in each, ranks start from two different weight sets, ONE in-place 745 MB broadcast
@@ -573,7 +525,10 @@ def test_bench_self_launches_eight_ranks_rank0_only_json():
     ranks = re.findall(r"\[aid dist\] rank (\d+)/8 \(local \d+\): backend (\w+), device (cuda:\d+)", r.stderr)     # (the ranks' lines may interleave)
     assert sorted(int(k[0]) for k in ranks) == list(range(8)), r.stderr[-2000:]
     assert [x["rank"] for x in j["ranks"]] == list(range(8)) and [x["segments"] for x in j["ranks"]] == [[i, i + 1] for i in range(8)]
-    assert all(x["wall_s"] > 0 and x["cpu_threads"] >= 1 for x in j["ranks"])
+    assert all(x["wall_s"] > 0 and x["bcast_s"] >= 0 and x["cpu_threads"] >= 1 and x["pci"] for x in j["ranks"])      # the per-rank table a bad SCALE line is read from
+    assert j["roofline"]["frac"] is not None and 0 < j["roofline"]["frac"] < 1.0
+    assert j["config"]["backend"] in ("gloo", "nccl") and j["config"]["visible_gpus"] == torch.cuda.device_count()
+    assert max(x["wall_s"] for x in j["ranks"]) * 1e3 <= j["ms_per_step"] * j["steps"] * 1.001 + 1e-6
     print("bench --gpus 8 (self-launched):", j["value"], "evals/s;", j["config"]["parallelism"])
 
 

@@ -440,7 +440,7 @@ def main():
         assert not problems["errors"], "; ".join(problems["errors"])
         fams = family_table(timing)
         kerns = family_table(timing, by_kernel=True)
-        dom_name = next(iter(kerns)) if kerns else None
+        dom_name = next((k for k, v in kerns.items() if v["executed_mfma_tflops"] > 0), None)      # the MFMA kernel with the most GPU time (the 2-D form's output pass is timed as conv time but issues no MFMA)
         dom = kerns.get(dom_name, {})
         conv_ms = sum(v["time_ms"] for v in fams.values())
         alg = sum(t[2] for t in timing)
@@ -467,7 +467,7 @@ def main():
                        "visible_gpus": torch.cuda.device_count()},
             "ranks": ranks,
             "roofline": {"bound": "mfma", "kernel": dom_name, "measured_in": roofline_pass,
-                         "definition": "achieved = MFMA FLOPs issued by ALL launches of the dominant kernel (by device-kernel name, every template instance / tile kind) "
+                         "definition": "achieved = MFMA FLOPs issued by ALL launches of the dominant kernel (the MFMA-issuing conv / GEMM kernel with the most GPU time, by device-kernel name, every template instance / tile kind) "
                                        "/ their summed duration (HIP events around each launch); Winograd F(4,3) issues 1/2, F(8,3) 5/12 and the 2-D forms (w2d_gemm_kernel: every 5x3 layer "
                                        "of the C >= 128 levels 3-6 and the bottleneck that the library gives it) F(4,5) x F(4,3) 1/5 and F(4,5) x F(8,3) (instances named +t8) 1/6 of the direct-form FLOPs; the 2-D form's output-transform + epilogue pass "
                                        "(w2d_output_kernel, HBM-bound, no FLOPs of its own) is timed as a conv launch too and counts in all_conv / conv_time_fraction_of_wall -- the fused 1-D kernels do that "

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WPC * WGM * WGN + 3) / 4) void w2d
         } else {
             const int e = (pc - NXP) * 256 + 4 * lane;
             const int k = e / M_BLK, col = e % M_BLK;
-            poff[i] = (unsigned)(4 * ((int64_t)k * a.Cout_pad + m0 + col));
+            poff[i] = (unsigned)(4 * ((int64_t)k * a.Cout_pad + min(m0 + col, a.Cout_pad - 4)));      // a 96-channel panel on the 128-wide tile: columns past Cout_pad re-read the last four (never stored)
         }
     }
     const int nch = a.nchunks, nct = 8 * nch;                // chunks per plane, chunks of the whole stream
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WPC * WGM * WGN + 3) / 4) void w2d
 template <int MT, int NT, int WGM, int WGN, int KC, int NBUF, int WPC>
 static int w2d_launch_gemm_fold(const aid_wino2d_gemm_params* p, int ntp, hipStream_t st, const char* name) {
     using S = W2dGemmShape<MT, NT, WGM, WGN, KC, NBUF>;
-    AID_REQUIRE(p->Cin % KC == 0 && p->Cout_pad % S::M_BLK == 0 && p->nxi == 8 * ntp, "w2d gemm (folded): Cin % KC, Cout_pad % M tile, nxi = 8 ntp");
+    AID_REQUIRE(p->Cin % KC == 0 && p->Cout_pad % 32 == 0 && p->nxi == 8 * ntp, "w2d gemm (folded): Cin % KC, Cout_pad % 32, nxi = 8 ntp");
     AID_REQUIRE((int64_t)p->Cin * p->N * 4 * p->nxi < (1LL << 40) && (int64_t)p->Cin * p->N * 4 < (1LL << 32), "w2d gemm (folded): plane size");
     W2dGemmDev a;
     a.U = p->U; a.V = p->V; a.Mo = p->M;
@@ -1097,14 +1097,23 @@ static int w2d_check(const aid_conv2d_params* p) {
 #ifndef W2D_FOLD_MIN_WGS
 #define W2D_FOLD_MIN_WGS 768
 #endif
+#ifndef W2D_FOLD_KC
+#define W2D_FOLD_KC 16
+#endif
+#ifndef W2D_FOLD_NBUF
+#define W2D_FOLD_NBUF 3
+#endif
+#define W2D_STR2(x) #x
+#define W2D_STR(x) W2D_STR2(x)
+#define W2D_FOLD_TAG ",foldM,kc" W2D_STR(W2D_FOLD_KC) ",nb" W2D_STR(W2D_FOLD_NBUF) ">+t8"
 static inline bool w2d_fold_m(const aid_conv2d_params* p) {
-    if (!(W2D_FOLD_M && p->x_wino == 4 && p->Cin <= W2D_FOLD_MAX_CIN && (p->Cin % 16) == 0 && ((p->Cout_pad % 128) == 0 || (p->Cout_pad % 96) == 0))) return false;
+    if (!(W2D_FOLD_M && p->x_wino == 4 && p->Cin <= W2D_FOLD_MAX_CIN && (p->Cin % W2D_FOLD_KC) == 0 && ((p->Cout_pad % 128) == 0 || (p->Cout_pad % 96) == 0))) return false;
     // the folded GEMM has an eighth of the workgroups (each walks eight planes) on 64-column tiles: it needs a launch that still fills the chip a few times --
     // per layer it wins 4-9 % at >= 1280 workgroups (level 3 at the product's sub-batch of four), ties at 800 and loses 10-50 % below 650 (batch 1;
     // profiles/r06_w2d_foldm_layer_ab.txt); end to end (profiles/r06_w2d_foldm_threshold_ab.txt, configs[1], alternating runs): no fold 61.48 / 61.52,
     // threshold 1900 61.63 / 61.41, 1024 62.38 / 62.04, 768 62.89 / 62.55 evaluations/s; batch 1 / 2 and configs[4] unchanged under 768
     const W2dGeo ge = w2d_geo(p->B, p->F, p->T, p->dilF, 8);
-    const int64_t wgs = (int64_t)10 * aid_cdiv(ge.N, 64) * aid_cdiv(p->Cout, (p->Cout_pad % 128) == 0 ? 128 : 96);
+    const int64_t wgs = (int64_t)10 * aid_cdiv(ge.N, 64) * aid_cdiv(p->Cout, 128);
     return wgs >= W2D_FOLD_MIN_WGS;
 }
 static int w2d_gemm_of(const aid_conv2d_params* p, hipStream_t st) {
@@ -1115,8 +1124,13 @@ static int w2d_gemm_of(const aid_conv2d_params* p, hipStream_t st) {
     gp.nxi = 8 * (TF + 2); gp.Cin = p->Cin; gp.Cout = p->Cout; gp.Cin_pad = p->Cin_pad; gp.Cout_pad = p->Cout_pad; gp.N = ge.N; gp.variant = 0;
     if (w2d_fold_m(p)) {
         AID_REQUIRE((gp.N % 4) == 0, "aid_conv2d(x_wino=4): N % 4 == 0");
-        if ((p->Cout_pad % 128) == 0) return w2d_launch_gemm_fold<1, 2, 4, 1, 16, 3, W2D_FOLD_WPC>(&gp, TF + 2, st, "w2d_gemm_kernel<128x64,foldM,kc16,nb3>+t8");
-        return w2d_launch_gemm_fold<3, 1, 1, 2, 16, 3, 2>(&gp, TF + 2, st, "w2d_gemm_kernel<96x64,foldM,kc16,nb3>+t8");
+        if ((p->Cout_pad % 128) == 0) return w2d_launch_gemm_fold<1, 2, 4, 1, W2D_FOLD_KC, W2D_FOLD_NBUF, W2D_FOLD_WPC>(&gp, TF + 2, st, "w2d_gemm_kernel<128x64" W2D_FOLD_TAG);
+        // 96-channel panels ride the same four-wave 128 x 64 instance (the fourth wave multiplies clamped columns and stores nothing): 500 -> 437 us per launch against the
+        // two-wave 96 x 64 tiles it replaced -- a quarter of the MFMAs wasted, but four waves hide the LDS latency two could not (profiles/r06_w2d_c96wide_ab.txt)
+#ifdef W2D_FOLD96_W3          // (experiment builds: three waves on exact 96 x 64 tiles, K chunks of 24 so that the 1-KiB pieces divide evenly)
+        if ((p->Cin % 24) == 0) return w2d_launch_gemm_fold<1, 2, 3, 1, 24, W2D_FOLD96_W3, W2D_FOLD_WPC>(&gp, TF + 2, st, "w2d_gemm_kernel<96x64w3,foldM,kc24,nb" W2D_STR(W2D_FOLD96_W3) ">+t8");
+#endif
+        return w2d_launch_gemm_fold<1, 2, 4, 1, W2D_FOLD_KC, W2D_FOLD_NBUF, W2D_FOLD_WPC>(&gp, TF + 2, st, "w2d_gemm_kernel<128x64(96)" W2D_FOLD_TAG);
     }
     return aid_wino2d_gemm(&gp, st);
 }

@@ -502,7 +502,7 @@ class _Builder:
         if nxi:
             # (bookkeeping only: the launches whose GEMM folds the row-axis output transform write and re-read HALF of M -- the rule of w2d_fold_m in
             #  csrc/aid_wino2d.hip, restated here for the algorithmic byte counts bench.py reports; the library decides on its own)
-            mxi = nxi // 2 if (x_wino == 85 and cin <= 128 and 10 * (-(-npos // 64)) * (-(-cout // (128 if wp.shape[2] % 128 == 0 else 96))) >= 768) else nxi
+            mxi = nxi // 2 if (x_wino == 85 and cin <= 128 and 10 * (-(-npos // 64)) * (-(-cout // 128)) >= 768) else nxi
             # two plan nodes on one parameter block: the MFMA-bound batched GEMM M = U V (its FLOPs and the bytes of V + M are booked here) and the
             # HBM-bound output-transform pass with the epilogue (reads M, residual / aux; writes y and the partials)
             self._add("aid_conv2d_wino2d_gemm", p, x, wpw, ws, flops=2 * B * F * T * cin * cout * kh * kw, nbytes=4 * npos * (nxi * cin + mxi * cout), writes=(ws,))

@@ -1097,17 +1097,16 @@ static int w2d_check(const aid_conv2d_params* p) {
 #ifndef W2D_FOLD_MIN_WGS
 #define W2D_FOLD_MIN_WGS 768
 #endif
-#ifndef W2D_FOLD_KC
-#define W2D_FOLD_KC 16
+#ifndef W2D_FOLD96_KC          // (experiment builds: K chunk and buffer count of the three-wave 96 x 64 instance)
+#define W2D_FOLD96_KC 24
 #endif
-#ifndef W2D_FOLD_NBUF
-#define W2D_FOLD_NBUF 3
+#ifndef W2D_FOLD96_NBUF
+#define W2D_FOLD96_NBUF 3
 #endif
 #define W2D_STR2(x) #x
 #define W2D_STR(x) W2D_STR2(x)
-#define W2D_FOLD_TAG ",foldM,kc" W2D_STR(W2D_FOLD_KC) ",nb" W2D_STR(W2D_FOLD_NBUF) ">+t8"
 static inline bool w2d_fold_m(const aid_conv2d_params* p) {
-    if (!(W2D_FOLD_M && p->x_wino == 4 && p->Cin <= W2D_FOLD_MAX_CIN && (p->Cin % W2D_FOLD_KC) == 0 && ((p->Cout_pad % 128) == 0 || (p->Cout_pad % 96) == 0))) return false;
+    if (!(W2D_FOLD_M && p->x_wino == 4 && p->Cin <= W2D_FOLD_MAX_CIN && (p->Cin % 16) == 0 && ((p->Cout_pad % 128) == 0 || (p->Cout_pad % 96) == 0))) return false;
     // the folded GEMM has an eighth of the workgroups (each walks eight planes) on 64-column tiles: it needs a launch that still fills the chip a few times --
     // per layer it wins 4-9 % at >= 1280 workgroups (level 3 at the product's sub-batch of four), ties at 800 and loses 10-50 % below 650 (batch 1;
     // profiles/r06_w2d_foldm_layer_ab.txt); end to end (profiles/r06_w2d_foldm_threshold_ab.txt, configs[1], alternating runs): no fold 61.48 / 61.52,
@@ -1124,13 +1123,16 @@ static int w2d_gemm_of(const aid_conv2d_params* p, hipStream_t st) {
     gp.nxi = 8 * (TF + 2); gp.Cin = p->Cin; gp.Cout = p->Cout; gp.Cin_pad = p->Cin_pad; gp.Cout_pad = p->Cout_pad; gp.N = ge.N; gp.variant = 0;
     if (w2d_fold_m(p)) {
         AID_REQUIRE((gp.N % 4) == 0, "aid_conv2d(x_wino=4): N % 4 == 0");
-        if ((p->Cout_pad % 128) == 0) return w2d_launch_gemm_fold<1, 2, 4, 1, W2D_FOLD_KC, W2D_FOLD_NBUF, W2D_FOLD_WPC>(&gp, TF + 2, st, "w2d_gemm_kernel<128x64" W2D_FOLD_TAG);
-        // 96-channel panels ride the same four-wave 128 x 64 instance (the fourth wave multiplies clamped columns and stores nothing): 500 -> 437 us per launch against the
-        // two-wave 96 x 64 tiles it replaced -- a quarter of the MFMAs wasted, but four waves hide the LDS latency two could not (profiles/r06_w2d_c96wide_ab.txt)
-#ifdef W2D_FOLD96_W3          // (experiment builds: three waves on exact 96 x 64 tiles, K chunks of 24 so that the 1-KiB pieces divide evenly)
-        if ((p->Cin % 24) == 0) return w2d_launch_gemm_fold<1, 2, 3, 1, 24, W2D_FOLD96_W3, W2D_FOLD_WPC>(&gp, TF + 2, st, "w2d_gemm_kernel<96x64w3,foldM,kc24,nb" W2D_STR(W2D_FOLD96_W3) ">+t8");
-#endif
-        return w2d_launch_gemm_fold<1, 2, 4, 1, W2D_FOLD_KC, W2D_FOLD_NBUF, W2D_FOLD_WPC>(&gp, TF + 2, st, "w2d_gemm_kernel<128x64(96)" W2D_FOLD_TAG);
+        // The instances (profiles/r06_w2d_fold_tiles_ab.txt, per launch in the evaluation): 128-channel panels on four waves x (32 x 64), K chunks of 32 where Cin allows
+        // (276 -> 264 us against chunks of 16: half the barriers; more buffers of 16 measured nothing, the loads are not what it waits for); 96-channel panels on THREE
+        // waves with K chunks of 24 (exact 96 x 64 tiles, 15 one-KiB pieces per chunk = 5 per wave): 409 us against 437 on the four-wave instance with a quarter
+        // of its columns clamped and 500 on two waves x (96 x 32).  Other Cin (multiples of 16) keep the four-wave instance with chunks of 16.
+        const bool p96 = (p->Cout_pad % 128) != 0;
+        if (p96 && (p->Cin % W2D_FOLD96_KC) == 0)
+            return w2d_launch_gemm_fold<1, 2, 3, 1, W2D_FOLD96_KC, W2D_FOLD96_NBUF, W2D_FOLD_WPC>(&gp, TF + 2, st, "w2d_gemm_kernel<96x64,foldM,kc" W2D_STR(W2D_FOLD96_KC) ",nb" W2D_STR(W2D_FOLD96_NBUF) ">+t8");
+        if ((p->Cin % 32) == 0)
+            return w2d_launch_gemm_fold<1, 2, 4, 1, 32, 3, W2D_FOLD_WPC>(&gp, TF + 2, st, p96 ? "w2d_gemm_kernel<128x64(96),foldM,kc32,nb3>+t8" : "w2d_gemm_kernel<128x64,foldM,kc32,nb3>+t8");
+        return w2d_launch_gemm_fold<1, 2, 4, 1, 16, 3, W2D_FOLD_WPC>(&gp, TF + 2, st, p96 ? "w2d_gemm_kernel<128x64(96),foldM,kc16,nb3>+t8" : "w2d_gemm_kernel<128x64,foldM,kc16,nb3>+t8");
     }
     return aid_wino2d_gemm(&gp, st);
 }

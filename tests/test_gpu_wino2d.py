@@ -272,24 +272,28 @@ def test_conv2d_wino2d(L, case):
     assert rel_l2(outs[2].cpu(), wpw.cpu()) < 1e-7 and rel_l2(outs[3].cpu(), wpwT.cpu()) < 1e-7
 
 
-@pytest.mark.parametrize("case", [(4, 128, 80, 512, 1), (4, 96, 96, 512, 2)])
+@pytest.mark.parametrize("case", [(4, 128, 128, 80, 512, 1, "<128x64,foldM,kc32"), (4, 96, 96, 96, 512, 2, "<96x64,foldM,kc24"),
+                                  (4, 112, 128, 80, 512, 1, "<128x64,foldM,kc16"), (4, 96, 128, 80, 512, 1, "<128x64,foldM,kc32"),
+                                  (4, 112, 96, 96, 512, 2, "<128x64(96),foldM,kc16"), (4, 128, 96, 96, 512, 1, "<128x64(96),foldM,kc32")])
 def test_conv2d_wino2d_folded_gemm_on_large_launches(L, case):
     """Launches with >= 768 folded workgroups and Cin <= 128 on the 80-plane form take w2d_gemm_fold_kernel (the row-axis output transform folded into the GEMM: M has
     40 planes) and the FOLD output pass -- the per-shape cases above are too small for it.  Forward with gate + residual and the (sum, sum of squares) partials, through
-    aid_conv2d and through the two separate entry points, against the fp64 convolution on the CPU; the kernel that ran is asserted by name."""
-    B, C, Fd, T, dil = case
+    aid_conv2d and through the two separate entry points, against the fp64 convolution on the CPU; the kernel that ran is asserted by name: 128-channel panels on
+    the four-wave instance with K chunks of 32 (16 where Cin is no multiple of 32), 96-channel panels on the three-wave instance with chunks of 24 or, for other Cin,
+    on the four-wave instance with clamped weight columns."""
+    B, Ci, C, Fd, T, dil, inst = case
     N = int(L.lib().aid_conv2d_wino2d_positions(B, Fd, T, dil)) // 2
     assert 10 * ((N + 63) // 64) >= 768
-    x = _rand(B, C, Fd, T, seed=70)
-    w = _rand(C, C, 5, 3, seed=71, scale=1.0 / math.sqrt(C * 15))
-    in_scale, out_scale, res = 1.0 + 0.5 * _rand(B, C, seed=72), _rand(B, C, seed=73), _rand(B, C, Fd, T, seed=74)
+    x = _rand(B, Ci, Fd, T, seed=70)
+    w = _rand(C, Ci, 5, 3, seed=71, scale=1.0 / math.sqrt(Ci * 15))
+    in_scale, out_scale, res = 1.0 + 0.5 * _rand(B, Ci, seed=72), _rand(B, C, seed=73), _rand(B, C, Fd, T, seed=74)
     alpha, res_scale = 1 / math.sqrt(2), 1.5
     xd, wd, isd, osd, resd = x.to(DEV), w.to(DEV), in_scale.to(DEV), out_scale.to(DEV), res.to(DEV)
-    V = torch.empty(80 * C * N, device=DEV)
-    L.call("aid_scale_act", L.ScaleActParams(L.view4(xd), L.View(V.data_ptr(), 0, 0, 0), isd.data_ptr(), isd.stride(0), B, C, Fd, T, 1, 4, dil))
+    V = torch.empty(80 * Ci * N, device=DEV)
+    L.call("aid_scale_act", L.ScaleActParams(L.view4(xd), L.View(V.data_ptr(), 0, 0, 0), isd.data_ptr(), isd.stride(0), B, Ci, Fd, T, 1, 4, dil))
     wp, wpw = L.pack_conv_weight(wd), L.pack_conv_weight_wino2d8(wd)
     ws = torch.full((80 * C * N + 16,), 7.0, device=DEV)
-    nst = int(L.lib().aid_conv2d_stat_partials(B, C, C, Fd, T, dil, 4))
+    nst = int(L.lib().aid_conv2d_stat_partials(B, Ci, C, Fd, T, dil, 4))
     sws = torch.zeros(B * 8 * nst * 2, device=DEV, dtype=torch.float64)
     ys = []
     for split_calls in (False, True):
@@ -298,7 +302,7 @@ def test_conv2d_wino2d_folded_gemm_on_large_launches(L, case):
         p.x, p.y, p.res, p.aux = L.View(V.data_ptr(), 0, 0, 0), L.view4(y), L.view4(resd), L.view4(None)
         p.wp, p.wp_wino, p.wino_taps, p.x_wino = wp.data_ptr(), wpw.data_ptr(), 80, 4
         p.out_scale, p.out_scale_ld = osd.data_ptr(), osd.stride(0)
-        p.B, p.Cin, p.Cout, p.F, p.T = B, C, C, Fd, T
+        p.B, p.Cin, p.Cout, p.F, p.T = B, Ci, C, Fd, T
         p.Cin_pad, p.Cout_pad = wp.shape[1], wp.shape[2]
         p.KH, p.KW, p.dilF, p.act, p.epi = 5, 3, dil, 0, 0
         p.alpha, p.res_scale = alpha, res_scale
@@ -306,7 +310,7 @@ def test_conv2d_wino2d_folded_gemm_on_large_launches(L, case):
         p.stat_ws, p.stat_n = sws.data_ptr(), nst
         if split_calls:
             L.call("aid_conv2d_wino2d_gemm", p)
-            assert "foldM" in L.lib().aid_last_kernel().decode()
+            assert inst in L.lib().aid_last_kernel().decode(), L.lib().aid_last_kernel().decode()
             L.call("aid_conv2d_wino2d_output", p)
         else:
             L.call("aid_conv2d", p)
